@@ -1,0 +1,324 @@
+"""CPU ORACLE for the CMHSE embedding-and-ranking hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-NumPy restatement of the reference's algorithm for the path named in
+BASELINE.json (`north_star`) and mapped in SURVEY.md §8(a).  It is the checker: only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.  The product
+(`cmhse_amd`) never imports it and has no CPU fallback.
+
+Parity status: PINNED.  The reference ships no tests or golden vectors of its own,
+so the oracle is pinned against outputs of the reference itself, run in the build container by
+`tools/make_golden.py` (reference imported read-only from /root/reference with in-memory shims,
+torch 2.10.0 CPU / numpy 2.2.6) and committed as `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks every function below against those vectors.
+
+The arithmetic of the reference lives in un-vendored third-party code:
+  * `torch.nn.GRU` (PyTorch >= 0.4 per /root/reference/README.md:10; fixtures made with 2.10.0):
+        r = sigmoid(W_ir x + b_ir + W_hr h + b_hr)
+        z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
+        n = tanh(W_in x + b_in + r * (W_hn h + b_hn))
+        h' = (1 - z) * n + z * h            gate row order in weight_ih_l0/weight_hh_l0: r, z, n
+  * `torch.nn.functional.normalize`:  x / max(||x||_2, 1e-12)
+  * `numpy.dot`, `numpy.argsort`
+restated here from their published definitions and anchored on the reference's call sites.
+
+Every function takes `dtype` (default float32, the reference's arithmetic type); float64 gives a
+higher-precision yardstick for tolerance tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+POOL_LAST, POOL_ATTN, POOL_MAX = 0, 1, 2
+POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}
+
+
+def _sigmoid(x):
+  return 1.0 / (1.0 + np.exp(-x))
+
+
+# --------------------------------------------------------------------------------------------
+# GRU (torch.nn.GRU, 1 layer, unidirectional, batch_first) over ragged sequences.
+# Call sites: /root/reference/layers.py:31-34,54-56 (Seq2Seq), :75-79,98-102 (Attention),
+# :169-172,192-194 (Maxout).  pack_padded_sequence (layers.py:52,97,190) only reorders the
+# sequences; each sequence is independent, so the oracle masks by `t < len` instead of sorting.
+# --------------------------------------------------------------------------------------------
+def gru_forward(x, lens, w_ih, w_hh, b_ih, b_hh, h0=None, dtype=np.float32):
+  """x [S,T,I] zero-padded, lens [S] ints (>=1).  Returns hs [S,T,H] (zeros at t >= len, like
+  pad_packed_sequence, layers.py:103) and h_last [S,H] (= h at t = len-1)."""
+  x = np.asarray(x, dtype=dtype)
+  lens = np.asarray(lens).astype(np.int64)
+  w_ih = np.asarray(w_ih, dtype=dtype); w_hh = np.asarray(w_hh, dtype=dtype)
+  b_ih = np.asarray(b_ih, dtype=dtype); b_hh = np.asarray(b_hh, dtype=dtype)
+  S, T, I = x.shape
+  H = w_hh.shape[1]
+  Tmax = int(lens.max())
+  h = np.zeros((S, H), dtype=dtype) if h0 is None else np.array(h0, dtype=dtype)
+  hs = np.zeros((S, T, H), dtype=dtype)
+  # input projection for every (s,t) at once: gi = x W_ih^T + b_ih
+  gi = (x[:, :Tmax].reshape(S * Tmax, I) @ w_ih.T + b_ih).reshape(S, Tmax, 3 * H)
+  for t in range(Tmax):
+    act = np.nonzero(lens > t)[0]
+    gh = h[act] @ w_hh.T + b_hh
+    g = gi[act, t]
+    r = _sigmoid(g[:, :H] + gh[:, :H])
+    z = _sigmoid(g[:, H:2 * H] + gh[:, H:2 * H])
+    n = np.tanh(g[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn = ((1.0 - z) * n + z * h[act]).astype(dtype)
+    h[act] = hn
+    hs[act, t] = hn
+  return hs, h
+
+
+def seq2seq_forward(x, lens, p, h0=None, dtype=np.float32):
+  """layers.Seq2Seq.forward, /root/reference/layers.py:47-66: final hidden state."""
+  _, h_last = gru_forward(x, lens, p['rnn.rnn.weight_ih_l0'], p['rnn.rnn.weight_hh_l0'],
+                          p['rnn.rnn.bias_ih_l0'], p['rnn.rnn.bias_hh_l0'], h0, dtype)
+  return h_last
+
+
+def maxout_forward(x, lens, p, h0=None, dtype=np.float32):
+  """layers.Maxout.forward, /root/reference/layers.py:185-204: per-sequence max over valid
+  steps (F.max_pool1d over outputs[i,:len_i], :201-202)."""
+  hs, _ = gru_forward(x, lens, p['rnn.rnn.weight_ih_l0'], p['rnn.rnn.weight_hh_l0'],
+                      p['rnn.rnn.bias_ih_l0'], p['rnn.rnn.bias_hh_l0'], h0, dtype)
+  lens = np.asarray(lens).astype(np.int64)
+  T = hs.shape[1]
+  mask = (np.arange(T)[None, :] < lens[:, None])[:, :, None]
+  return np.where(mask, hs, -np.inf).max(axis=1).astype(dtype)
+
+
+def attention_energies(hs, p, dtype=np.float32):
+  """e = att_w(tanh(lin(h))), /root/reference/layers.py:105-106."""
+  S, T, H = hs.shape
+  w_lin = np.asarray(p['rnn.lin.weight'], dtype=dtype)
+  b_lin = np.asarray(p['rnn.lin.bias'], dtype=dtype)
+  w_att = np.asarray(p['rnn.att_w.weight'], dtype=dtype).reshape(-1)
+  emb_h = np.tanh(hs.reshape(S * T, H) @ w_lin.T + b_lin)
+  return (emb_h @ w_att).reshape(S, T).astype(dtype)
+
+
+def attention_forward(x, lens, p, h0=None, dtype=np.float32):
+  """layers.Attention.forward, /root/reference/layers.py:93-119.
+  Masked softmax without max-subtraction and with +1e-4 in the denominator (:158-162)."""
+  hs, _ = gru_forward(x, lens, p['rnn.rnn.weight_ih_l0'], p['rnn.rnn.weight_hh_l0'],
+                      p['rnn.rnn.bias_ih_l0'], p['rnn.rnn.bias_hh_l0'], h0, dtype)
+  lens = np.asarray(lens).astype(np.int64)
+  Tmax = int(lens.max())
+  hs = hs[:, :Tmax]                      # pad_packed_sequence pads to the batch maximum
+  e = attention_energies(hs, p, dtype)
+  mask = (np.arange(Tmax)[None, :] < lens[:, None]).astype(dtype)
+  ex = np.exp(e) * mask
+  att = ex / (ex.sum(axis=1, keepdims=True) + dtype(0.0001))
+  return (att[:, :, None] * hs).sum(axis=1).astype(dtype)
+
+
+def pooled_gru_forward(rnn_type, x, lens, p, h0=None, dtype=np.float32):
+  """Dispatch on `rnn_type` as model.EncoderImage/EncoderSequence do,
+  /root/reference/model.py:27-34,50-57."""
+  if rnn_type == 'attention':
+    return attention_forward(x, lens, p, h0, dtype)
+  if rnn_type == 'seq2seq':
+    return seq2seq_forward(x, lens, p, h0, dtype)
+  if rnn_type == 'maxout':
+    return maxout_forward(x, lens, p, h0, dtype)
+  raise ValueError('Unsupported RNN type')    # model.py:34
+
+
+def encoder_text_forward(rnn_type, tokens, lens, p, dtype=np.float32):
+  """model.EncoderText.forward, /root/reference/model.py:92-99: embed(x) then rnn.
+  Returns (outputs, word_embeddings)."""
+  table = np.asarray(p['embed.weight'], dtype=dtype)
+  cap_emb = table[np.asarray(tokens)]
+  return pooled_gru_forward(rnn_type, cap_emb, lens, p, None, dtype), cap_emb
+
+
+def l2_normalize(x, dtype=np.float32):
+  """torch.nn.functional.normalize(x) (p=2, dim=1, eps=1e-12); call sites
+  /root/reference/model.py:333-343, evaluation.py:111-116."""
+  x = np.asarray(x, dtype=dtype)
+  nrm = np.sqrt((x * x).sum(axis=1, keepdims=True))
+  return (x / np.maximum(nrm, dtype(1e-12))).astype(dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# Similarity + contrastive loss, /root/reference/loss.py:12-13, 74-118
+# --------------------------------------------------------------------------------------------
+def cosine_sim(im, s, dtype=np.float32):
+  """loss.cosine_sim, /root/reference/loss.py:12-13 (inputs are pre-normalised by callers)."""
+  return np.asarray(im, dtype=dtype) @ np.asarray(s, dtype=dtype).T
+
+
+def contrastive_loss(im, s, margin=0.0, max_violation=False, norm=True, dtype=np.float32):
+  """loss.ContrastiveLoss.forward, /root/reference/loss.py:86-117."""
+  scores = cosine_sim(im, s, dtype)
+  n, m = scores.shape
+  diag = np.diag(scores).reshape(n, 1)
+  cost_s = np.maximum(dtype(margin) + scores - diag, 0)         # :94  row-wise (caption retrieval)
+  cost_im = np.maximum(dtype(margin) + scores - diag.T, 0)      # :97  column-wise (image retrieval)
+  eye = np.eye(n, dtype=bool)
+  cost_s = np.where(eye, 0, cost_s)                             # :100-106
+  cost_im = np.where(eye, 0, cost_im)
+  if max_violation:                                             # :109-111
+    cost_s = cost_s.max(axis=1)
+    cost_im = cost_im.max(axis=0)
+  loss = cost_s.sum(dtype=dtype) + cost_im.sum(dtype=dtype)
+  if norm:                                                      # :114-115  divides by n*m
+    loss = loss / dtype(n * m)
+  return dtype(loss)
+
+
+def euclidean_loss(a, b, norm=True, dtype=np.float32):
+  """decoder.loss.EuclideanLoss, /root/reference/decoder/loss.py:17-26."""
+  d = np.asarray(a, dtype=dtype) - np.asarray(b, dtype=dtype)
+  sub = np.sqrt((d * d).sum(axis=1))
+  return dtype(sub.mean() if norm else sub.sum())
+
+
+# --------------------------------------------------------------------------------------------
+# Ranking, /root/reference/evaluation.py:160-213
+# --------------------------------------------------------------------------------------------
+def rank_rows(d):
+  """Per-row rank of the diagonal element and arg-max column.
+
+  The reference sorts each row with `numpy.argsort(d[i])[::-1]` (evaluation.py:167,195), which is
+  only well-defined when no score ties with d[i,i]; on such rows it equals
+      rank_i = #{ j != i : d_ij > d_ii },   top1_i = argmax_j d_ij.
+  Documented tie rule of the build (ties are implementation-defined upstream):
+  strict '>' for the rank, smallest column index for top1."""
+  n = d.shape[0]
+  diag = d[np.arange(n), np.arange(n)][:, None]
+  gt = d > diag
+  gt[np.arange(n), np.arange(n)] = False
+  return gt.sum(axis=1).astype(np.int64), d.argmax(axis=1).astype(np.int64)
+
+
+def recall_report(ranks):
+  """evaluation.py:173-184: note 'r10' is Recall@50 (`ranks < 50`, :175)."""
+  ranks = np.asarray(ranks, dtype=np.float64)
+  r1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
+  r5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
+  r10 = 100.0 * len(np.where(ranks < 50)[0]) / len(ranks)
+  medr = np.floor(np.median(ranks)) + 1
+  meanr = ranks.mean() + 1
+  return {'r1': r1, 'r5': r5, 'r10': r10, 'medr': medr, 'meanr': meanr, 'sum': r1 + r5 + r10}
+
+
+def i2t(images, captions, dtype=np.float32):
+  """evaluation.i2t, /root/reference/evaluation.py:160-185."""
+  d = np.dot(np.asarray(images, dtype=dtype), np.asarray(captions, dtype=dtype).T)
+  ranks, top1 = rank_rows(d)
+  return recall_report(ranks), top1.astype(np.float64), ranks.astype(np.float64)
+
+
+def t2i(images, captions, dtype=np.float32):
+  """evaluation.t2i, /root/reference/evaluation.py:188-213."""
+  d = np.dot(np.asarray(captions, dtype=dtype), np.asarray(images, dtype=dtype).T)
+  ranks, top1 = rank_rows(d)
+  return recall_report(ranks), top1.astype(np.float64), ranks.astype(np.float64)
+
+
+# --------------------------------------------------------------------------------------------
+# Model orchestration, /root/reference/model.py:222-255 and evaluation.py:80-158
+# `params` is the reference's state-dict list [clip_enc, txt_enc, vid_seq_enc, txt_seq_enc]
+# (model.py:166-168) with numpy values.
+# --------------------------------------------------------------------------------------------
+def forward_emb(rnn_type, params, clips, captions, lengths_clip, lengths_cap, dtype=np.float32):
+  """VSE.forward_emb, /root/reference/model.py:222-236.  Returns (clip_emb, cap_emb, word)."""
+  clip_emb = pooled_gru_forward(rnn_type, clips, lengths_clip, params[0], None, dtype)
+  cap_emb, word = encoder_text_forward(rnn_type, captions, lengths_cap, params[1], dtype)
+  return clip_emb, cap_emb, word
+
+
+def scatter_rows(emb, counts, dtype=np.float32):
+  """model.py:239-250: consecutive rows of `emb` -> zero-padded [B, max(counts), H]."""
+  B, H = len(counts), emb.shape[1]
+  out = np.zeros((B, max(counts), H), dtype=dtype)
+  pos = 0
+  for i, c in enumerate(counts):
+    out[i, :c] = emb[pos:pos + c]
+    pos += c
+  return out
+
+
+def structure_emb(rnn_type, params, clip_emb, cap_emb, num_clips, num_caps,
+                  vid_context=None, para_context=None, dtype=np.float32):
+  """VSE.structure_emb, /root/reference/model.py:238-255: level-2 GRUs with h0 = context."""
+  x_v = scatter_rows(clip_emb, num_clips, dtype)
+  x_p = scatter_rows(cap_emb, num_caps, dtype)
+  vid_emb = pooled_gru_forward(rnn_type, x_v, num_clips, params[2], vid_context, dtype)
+  para_emb = pooled_gru_forward(rnn_type, x_p, num_caps, params[3], para_context, dtype)
+  return vid_emb, para_emb
+
+
+def encode_batch(rnn_type, params, batch, contextual_model=True, dtype=np.float32):
+  """One loader batch of evaluation.encode_data, /root/reference/evaluation.py:97-116.
+  Returns the six L2-normalised embedding matrices in the order encode_data returns them."""
+  (clips, captions, videos, paragraphs, lengths_clip, lengths_cap, lengths_video,
+   lengths_paragraph, num_clips, num_caps) = [np.asarray(b) if not isinstance(b, tuple) else b
+                                              for b in batch[:10]]
+  clip_emb, cap_emb, _ = forward_emb(rnn_type, params, clips, captions, lengths_clip,
+                                     lengths_cap, dtype)
+  vid_ctx, para_ctx, _ = forward_emb(rnn_type, params, videos, paragraphs, lengths_video,
+                                     lengths_paragraph, dtype)
+  if contextual_model:
+    vid_emb, para_emb = structure_emb(rnn_type, params, clip_emb, cap_emb, num_clips, num_caps,
+                                      vid_ctx, para_ctx, dtype)
+  else:
+    vid_emb, para_emb = structure_emb(rnn_type, params, clip_emb, cap_emb, num_clips, num_caps,
+                                      None, None, dtype)
+  n = lambda a: l2_normalize(a, dtype)
+  return n(vid_emb), n(para_emb), n(clip_emb), n(cap_emb), n(vid_ctx), n(para_ctx)
+
+
+def encode_data(rnn_type, params, batches, margin=0.2, max_violation=False, norm=False,
+                contextual_model=True, dtype=np.float32):
+  """evaluation.encode_data, /root/reference/evaluation.py:80-158.
+  Returns the reference's 8-tuple plus the list of per-batch 'Letest' losses (:129)."""
+  outs = [[] for _ in range(6)]
+  num_clips_total, cur_vid_total, test_losses = [], [], []
+  for batch in batches:
+    embs = encode_batch(rnn_type, params, batch, contextual_model, dtype)
+    for o, e in zip(outs, embs):
+      o.append(e)
+    num_clips_total.extend(batch[8])
+    cur_vid_total.extend(batch[11])
+    test_losses.append(float(contrastive_loss(embs[0], embs[1], margin, max_violation, norm,
+                                              dtype)))
+  cat = [np.concatenate(o, 0) for o in outs]
+  return (cat[0], cat[1], cat[2], cat[3], cat[4], cat[5], num_clips_total, cur_vid_total,
+          test_losses)
+
+
+def train_losses(rnn_type, params, batch, margin=0.2, max_violation=False, norm=False,
+                 low_level_loss=False, dtype=np.float32):
+  """Forward half of VSE.train_emb, /root/reference/model.py:319-343 (no reconstruction, no weak
+  loss): the (name, value, n) triples `forward_loss` sends to the logger (model.py:291), in call
+  order, and the total loss (model.py:336,344)."""
+  (clips, captions, videos, paragraphs, lengths_clip, lengths_cap, lengths_video,
+   lengths_paragraph, num_clips, num_caps) = batch[:10]
+  clip_emb, cap_emb, _ = forward_emb(rnn_type, params, clips, captions, lengths_clip,
+                                     lengths_cap, dtype)
+  vid_ctx, para_ctx, _ = forward_emb(rnn_type, params, videos, paragraphs, lengths_video,
+                                     lengths_paragraph, dtype)
+  vid_emb, para_emb = structure_emb(rnn_type, params, clip_emb, cap_emb, num_clips, num_caps,
+                                    vid_ctx, para_ctx, dtype)
+  n = lambda a: l2_normalize(a, dtype)
+  cl = lambda a, b: contrastive_loss(a, b, margin, max_violation, norm, dtype)
+  log = []
+
+  def fl(a, b, name):
+    v = cl(a, b)
+    log.append(('Le' + name, float(v), a.shape[0]))
+    return v
+
+  loss_1 = fl(n(vid_emb), n(para_emb), '_vid')
+  loss_3 = fl(n(vid_ctx), n(para_ctx), '_ctx_low_lvel')
+  loss_5 = (fl(n(vid_emb), n(vid_emb), '_vid_inloss') +
+            fl(n(para_emb), n(para_emb), '_para_inloss')) / 2
+  loss = loss_1 + loss_3 + loss_5
+  if low_level_loss:
+    loss_2 = fl(n(clip_emb), n(cap_emb), '_low_lvel')
+    loss_6 = (fl(n(clip_emb), n(clip_emb), '_clip_inloss') +
+              fl(n(cap_emb), n(cap_emb), '_cap_inloss')) / 2
+    loss = loss + loss_2 + loss_6
+  return log, float(loss)

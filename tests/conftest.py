@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+  sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+  config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+  return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def golden_state_dicts(g):
+  """Rebuild the reference's state-dict list [clip_enc, txt_enc, vid_seq_enc, txt_seq_enc]."""
+  sds = [dict() for _ in range(4)]
+  for k in g.files:
+    if k.startswith('sd'):
+      i, key = k[2:].split('.', 1)
+      sds[int(i)][key] = g[k]
+  return sds
+
+
+def golden_batches(g):
+  out = []
+  for bi in range(int(g['n_batches'])):
+    p = 'batch%d.' % bi
+    out.append((g[p + 'clips'], g[p + 'captions'], g[p + 'videos'], g[p + 'paragraphs'],
+                g[p + 'lengths_clip'], g[p + 'lengths_cap'], g[p + 'lengths_video'],
+                g[p + 'lengths_paragraph'], tuple(int(c) for c in g[p + 'num_clips']),
+                tuple(int(c) for c in g[p + 'num_caps']), tuple(range(len(g[p + 'num_clips']))),
+                tuple('v%d_%d' % (bi, j) for j in range(len(g[p + 'num_clips'])))))
+  return out
+
+
+@pytest.fixture(scope='session')
+def oracle():
+  sys.path.insert(0, os.path.join(REPO, 'oracle'))
+  import cmhse_oracle
+  return cmhse_oracle

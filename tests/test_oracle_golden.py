@@ -1,0 +1,105 @@
+"""Pins the CPU oracle (oracle/cmhse_oracle.py) to outputs of the reference itself
+(tests/golden/*.npz, produced by tools/make_golden.py from /root/reference)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_state_dicts, golden_batches
+
+TOL = 2e-6   # fp32 restatement vs fp32 reference: summation-order noise only
+
+
+@pytest.mark.parametrize('cls,fn', [('Attention', 'attention_forward'),
+                                    ('Maxout', 'maxout_forward'),
+                                    ('Seq2Seq', 'seq2seq_forward')])
+@pytest.mark.parametrize('tag', ['ragged', 'equal', 'one'])
+def test_layers_forward(oracle, cls, fn, tag):
+  g = load_golden('layers.npz')
+  p = {k[len(cls) + 4:]: g[k] for k in g.files if k.startswith(cls + '.sd.')}
+  key = '%s.%s' % (cls, tag)
+  x, lens, h0 = g[key + '.x'], g[key + '.lens'], g[key + '.h0']
+  y = getattr(oracle, fn)(x, lens, p)
+  y_h0 = getattr(oracle, fn)(x, lens, p, h0)
+  np.testing.assert_allclose(y, g[key + '.out'], atol=TOL, rtol=0)
+  np.testing.assert_allclose(y_h0, g[key + '.out_h0'], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('n', [5, 16, 37])
+def test_normalize_and_contrastive(oracle, n):
+  g = load_golden('loss.npz')
+  a, b = g['n%d.a' % n], g['n%d.b' % n]
+  an, bn = oracle.l2_normalize(a), oracle.l2_normalize(b)
+  np.testing.assert_allclose(an, g['n%d.a_norm' % n], atol=1e-7, rtol=0)
+  np.testing.assert_allclose(oracle.cosine_sim(an, bn), g['n%d.scores' % n], atol=1e-6, rtol=0)
+  for mv in (0, 1):
+    for nm in (0, 1):
+      tag = 'n%d.mv%d.norm%d' % (n, mv, nm)
+      ab = oracle.contrastive_loss(an, bn, 0.2, bool(mv), bool(nm))
+      aa = oracle.contrastive_loss(an, an, 0.2, bool(mv), bool(nm))
+      np.testing.assert_allclose(ab, g[tag + '.ab'], rtol=2e-6, atol=1e-6)
+      np.testing.assert_allclose(aa, g[tag + '.aa'], rtol=2e-6, atol=1e-6)
+
+
+def test_normalize_zero_rows_and_euclid(oracle):
+  g = load_golden('loss.npz')
+  np.testing.assert_array_equal(oracle.l2_normalize(g['normalize.zero_rows.x']),
+                                g['normalize.zero_rows.y'])
+  np.testing.assert_allclose(oracle.euclidean_loss(g['euclid.a'], g['euclid.b'], True),
+                             g['euclid.norm1'], rtol=1e-6)
+  np.testing.assert_allclose(oracle.euclidean_loss(g['euclid.a'], g['euclid.b'], False),
+                             g['euclid.norm0'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('n', [50, 203])
+def test_rank_bit_exact(oracle, n):
+  g = load_golden('rank.npz')
+  a, b = g['n%d.images' % n], g['n%d.captions' % n]
+  for nm, fn in [('i2t', oracle.i2t), ('t2i', oracle.t2i)]:
+    rep, top1, ranks = fn(a, b)
+    np.testing.assert_array_equal(ranks, g['n%d.%s.ranks' % (n, nm)])
+    np.testing.assert_array_equal(top1, g['n%d.%s.top1' % (n, nm)])
+    want = g['n%d.%s.report' % (n, nm)]
+    got = np.array([rep[k] for k in ['r1', 'r5', 'r10', 'medr', 'meanr', 'sum']])
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_model_forward_and_encode(oracle, rnn_type):
+  g = load_golden('model_%s.npz' % rnn_type)
+  sds = golden_state_dicts(g)
+  batches = golden_batches(g)
+  b = batches[0]
+  clip_emb, cap_emb, word = oracle.forward_emb(rnn_type, sds, b[0], b[1], b[4], b[5])
+  vid_ctx, para_ctx, _ = oracle.forward_emb(rnn_type, sds, b[2], b[3], b[6], b[7])
+  vid_emb, para_emb = oracle.structure_emb(rnn_type, sds, clip_emb, cap_emb, b[8], b[9],
+                                           vid_ctx, para_ctx)
+  vid_nc, para_nc = oracle.structure_emb(rnn_type, sds, clip_emb, cap_emb, b[8], b[9])
+  for nm, v in [('clip_emb', clip_emb), ('cap_emb', cap_emb), ('word', word),
+                ('vid_context', vid_ctx), ('para_context', para_ctx), ('vid_emb', vid_emb),
+                ('para_emb', para_emb), ('vid_emb_noctx', vid_nc), ('para_emb_noctx', para_nc)]:
+    np.testing.assert_allclose(v, g['fwd.' + nm], atol=TOL, rtol=0, err_msg=nm)
+
+  res = oracle.encode_data(rnn_type, sds, batches, margin=0.2, max_violation=False, norm=False)
+  for i, nm in enumerate(['vid_embs', 'para_embs', 'clip_embs', 'cap_embs', 'vid_contexts',
+                          'para_contexts']):
+    np.testing.assert_allclose(res[i], g['enc.' + nm], atol=TOL, rtol=0, err_msg=nm)
+  assert list(res[6]) == list(g['enc.num_clips_total'])
+  np.testing.assert_allclose(res[8], g['enc.test_losses'], rtol=1e-5, atol=1e-6)
+  for nm, fn in [('i2t', oracle.i2t), ('t2i', oracle.t2i)]:
+    rep, top1, ranks = fn(res[0], res[1])
+    np.testing.assert_array_equal(ranks, g['enc.%s.ranks' % nm])
+    np.testing.assert_array_equal(top1, g['enc.%s.top1' % nm])
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_train_loss_meters(oracle, rnn_type):
+  g = load_golden('model_%s.npz' % rnn_type)
+  sds = golden_state_dicts(g)
+  batch = golden_batches(g)[1]
+  for mv in (0, 1):
+    for nm in (0, 1):
+      tag = 'train.mv%d.norm%d' % (mv, nm)
+      log, _ = oracle.train_losses(rnn_type, sds, batch, margin=0.2, max_violation=bool(mv),
+                                   norm=bool(nm), low_level_loss=True)
+      assert [l[0] for l in log] == [str(s) for s in g[tag + '.names']]
+      np.testing.assert_allclose([l[1] for l in log], g[tag + '.values'], rtol=1e-5, atol=2e-6)
+      assert [l[2] for l in log] == list(g[tag + '.n'])
