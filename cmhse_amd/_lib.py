@@ -1,0 +1,77 @@
+"""ctypes binding of libcmhse_hip.so (include/cmhse_hip.h).
+
+This is the binding a maintainer of the reference would add.  There is no CPU
+fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcmhse_hip.so')
+
+POOL_LAST, POOL_ATTN, POOL_MAX = 0, 1, 2
+POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}
+
+c_void_p, c_int32, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                  ctypes.c_size_t, ctypes.c_float)
+
+
+class GruWeights(ctypes.Structure):
+  _fields_ = [('w_ih', c_void_p), ('w_hh', c_void_p), ('b_ih', c_void_p), ('b_hh', c_void_p),
+              ('w_lin', c_void_p), ('b_lin', c_void_p), ('w_att', c_void_p)]
+
+
+class SeqBatch(ctypes.Structure):
+  _fields_ = [('S', c_int32), ('Tmax', c_int32), ('I', c_int32), ('H', c_int32),
+              ('x_rows', c_void_p), ('tok_rows', c_void_p), ('emb_table', c_void_p),
+              ('vocab', c_int32), ('h0_rows', c_void_p), ('lens', c_void_p),
+              ('out_row', c_void_p), ('step_off', c_void_p), ('step_count_host', c_void_p)]
+
+
+# every symbol include/cmhse_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32]),
+    'cmhse_gru_pool_fwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),
+                                          c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
+    'cmhse_gather_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                         c_void_p]),
+    'cmhse_sim_rank_workspace': (c_size_t, [c_int32]),
+    'cmhse_sim_rank': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                      c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_cosine_sim': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                        c_void_p]),
+    'cmhse_contrastive_workspace': (c_size_t, [c_int32]),
+    'cmhse_contrastive_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float,
+                                             c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                             c_size_t, c_void_p]),
+    'cmhse_strerror': (ctypes.c_char_p, [ctypes.c_int]),
+    'cmhse_version': (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+  """Load the HIP library (after torch, so both share one HIP runtime).  Fails loudly."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  import torch  # noqa: F401  torch's bundled libamdhip64.so.7 must be the runtime we bind to
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        'cmhse_amd: %s is missing. Build it with `python -m cmhse_amd.build` (needs hipcc); '
+        'there is no CPU fallback for the hot path.' % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)   # AttributeError if the library does not export the symbol
+    fn.restype = res
+    fn.argtypes = args
+  _lib = lib
+  return lib
+
+
+def check(rc, what):
+  if rc != 0:
+    msg = load().cmhse_strerror(rc).decode()
+    raise RuntimeError('cmhse_hip: %s failed: %s (%d)' % (what, msg, rc))

@@ -1,0 +1,475 @@
+// gru.hip — hierarchical-encoder hot path: packed GRU steps + last / attention / max pooling.
+//
+// Replaces the bodies of layers.Seq2Seq / Attention / Maxout .forward of the reference
+// (/root/reference/layers.py:47-66, 93-119, 185-204), i.e. torch.nn.GRU over a
+// pack_padded_sequence batch followed by the pooling, with hand-written gfx950 kernels.
+//
+// Data layout in HBM
+//   * inputs are consumed in place through one base pointer per sequence (cmhse_seq_batch);
+//   * hidden states live in ONE time-major packed buffer hs[sumT][H] — exactly the order of
+//     pack_padded_sequence: step t occupies rows step_off[t] .. step_off[t]+S_t-1, where the
+//     S_t still-active sequences are a prefix of the length-sorted batch.  h_{t-1} of the active
+//     prefix is therefore a contiguous row block: the A operand of step t is read coalesced, and
+//     the same buffer feeds the attention pooling (and a later BPTT) without any copy;
+//   * weights stay in the reference's checkpoint layout ([3H,I], [3H,H], gate rows r,z,n).
+//
+// Kernels
+//   gru_step_kernel   one launch per time step: fused [x_t | h_{t-1}] x [W_ih | W_hh]^T exact-fp32
+//                     MFMA GEMM (nt_core.hpp) over the active prefix; the r/z pre-activations
+//                     accumulate over both K phases, the two n-gate terms are kept apart; gate
+//                     math, the state update, the hs store and the last/max pooling are the
+//                     epilogue (no gate pre-activation ever goes to HBM).  Bound: fp32 MFMA.
+//   attn_energy_kernel  e = w_att . tanh(W_lin h + b_lin) for all packed rows at once
+//                     ([sumT,H] x [H,H]^T MFMA GEMM, tanh-dot epilogue, wave-shuffle row sums).
+//   attn_pool_kernel  masked exp-softmax (no max-subtraction, +1e-4: layers.py:158-162) and the
+//                     weighted sum over time; HBM-bound, one pass over hs.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/cmhse_hip.h"
+#include "nt_core.hpp"
+
+namespace cmhse {
+
+struct GruStepParams {
+  const uint64_t* x_rows;
+  const uint64_t* tok_rows;
+  const float* emb;
+  const uint64_t* h0_rows;
+  const int32_t* lens;
+  const int32_t* out_row;
+  const float* w_ih;
+  const float* w_hh;
+  const float* b_ih;
+  const float* b_hh;
+  float* hs;
+  float* out;
+  int32_t I, H, t, S_t, vocab, pool_mode, n_tiles;
+  int64_t off_prev, off_cur;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ bool aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+constexpr int kGruBM = 128;  // sequences per workgroup
+constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
+
+__global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams p) {
+  constexpr int BM = kGruBM, BU = kGruBU, BNR = 3 * BU;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // 1-D grid, N tile fastest: blocks b and b+8 land on the same XCD (round-robin dispatch), so
+  // with H/BU a multiple of 8 every XCD's L2 keeps re-serving the same two weight-row slices.
+  const int u0 = (blockIdx.x % p.n_tiles) * BU;
+  const int m0 = (blockIdx.x / p.n_tiles) * BM;
+  const int srow = tid >> 2;
+  const int I = p.I, H = p.H;
+
+  // Rows this thread stages.  A: sequences m0 + srow + 64 i.  B: gate g, unit u0 + (row % BU).
+  const float* ax[BM / 64];
+  const float* ah[BM / 64];
+  bool avx = (I % 4 == 0), avh = (H % 4 == 0);
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i) {
+    const int m = m0 + srow + 64 * i;
+    ax[i] = nullptr;
+    ah[i] = nullptr;
+    if (m < p.S_t) {
+      if (p.tok_rows != nullptr) {
+        long long tok = reinterpret_cast<const long long*>(p.tok_rows[m])[p.t];
+        if (tok < 0) tok = 0;
+        if (tok >= p.vocab) tok = p.vocab - 1;
+        ax[i] = p.emb + tok * I;
+      } else {
+        ax[i] = reinterpret_cast<const float*>(p.x_rows[m]) + static_cast<int64_t>(p.t) * I;
+      }
+      if (p.t > 0)
+        ah[i] = p.hs + (p.off_prev + m) * H;
+      else if (p.h0_rows != nullptr)
+        ah[i] = reinterpret_cast<const float*>(p.h0_rows[m]);
+      avx = avx && aligned16(ax[i]);
+      avh = avh && (ah[i] == nullptr || aligned16(ah[i]));
+    }
+  }
+  const float* bx[BNR / 64];
+  const float* bh[BNR / 64];
+  const bool bvx = (I % 4 == 0) && aligned16(p.w_ih);
+  const bool bvh = (H % 4 == 0) && aligned16(p.w_hh);
+#pragma unroll
+  for (int i = 0; i < BNR / 64; ++i) {
+    const int br = srow + 64 * i;
+    const int g = br / BU, u = u0 + (br % BU);
+    bx[i] = (u < H) ? p.w_ih + (static_cast<int64_t>(g) * H + u) * I : nullptr;
+    bh[i] = (u < H) ? p.w_hh + (static_cast<int64_t>(g) * H + u) * H : nullptr;
+  }
+
+  // accumulators per 32-sequence sub-tile: 0 = r, 1 = z, 2 = W_in x, 3 = W_hn h
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
+
+  const int a_row0 = wm * 64;
+  const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
+  nt_phase<BM, BNR, 2, 3, 4, 2>(smem, ax, bx, I, avx, bvx, a_row0, b_row0, acc);
+  const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
+  if (have_h) nt_phase<BM, BNR, 2, 3, 4, 3>(smem, ah, bh, H, avh, bvh, a_row0, b_row0, acc);
+
+  // ---- epilogue: gates, state update, pooling ----
+  const int u = u0 + wn * 32 + acc_col(lane);
+  if (u >= H) return;
+  const float b_r = p.b_ih[u] + p.b_hh[u];
+  const float b_z = p.b_ih[H + u] + p.b_hh[H + u];
+  const float b_in = p.b_ih[2 * H + u];
+  const float b_hn = p.b_hh[2 * H + u];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
+      if (m >= p.S_t) continue;
+      float hp = 0.f;
+      if (p.t > 0)
+        hp = p.hs[(p.off_prev + m) * H + u];
+      else if (p.h0_rows != nullptr)
+        hp = reinterpret_cast<const float*>(p.h0_rows[m])[u];
+      const float rg = sigmoidf_(acc[ms][0][r] + b_r);
+      const float zg = sigmoidf_(acc[ms][1][r] + b_z);
+      const float ng = tanhf(acc[ms][2][r] + b_in + rg * (acc[ms][3][r] + b_hn));
+      const float hn = (1.0f - zg) * ng + zg * hp;
+      p.hs[(p.off_cur + m) * H + u] = hn;
+      if (p.pool_mode == CMHSE_POOL_MAX) {
+        float* o = p.out + static_cast<int64_t>(p.out_row[m]) * H + u;
+        *o = (p.t == 0) ? hn : fmaxf(*o, hn);
+      } else if (p.pool_mode == CMHSE_POOL_LAST) {
+        if (p.t == p.lens[m] - 1) p.out[static_cast<int64_t>(p.out_row[m]) * H + u] = hn;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
+// ---------------------------------------------------------------------------------------------
+struct AttnEnergyParams {
+  const float* hs;     // [rows, H]
+  const float* w_lin;  // [H, H]
+  const float* b_lin;
+  const float* w_att;
+  float* e_part;  // [n_tiles, rows]
+  int64_t rows;
+  int32_t H, n_tiles;
+};
+
+constexpr int kAttBM = 128;
+constexpr int kAttBN = 256;
+
+__global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyParams p) {
+  constexpr int BM = kAttBM, BN = kAttBN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = blockIdx.x % p.n_tiles;
+  const int n0 = nt * BN;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
+  const int srow = tid >> 2;
+  const int H = p.H;
+
+  const float* ar[BM / 64];
+  const float* br[BN / 64];
+  const bool vec = (H % 4 == 0) && aligned16(p.hs) && aligned16(p.w_lin);
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i) {
+    const int64_t m = m0 + srow + 64 * i;
+    ar[i] = (m < p.rows) ? p.hs + m * H : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 64; ++i) {
+    const int n = n0 + srow + 64 * i;
+    br[i] = (n < H) ? p.w_lin + static_cast<int64_t>(n) * H : nullptr;
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
+  const int b_row0[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
+  nt_phase<BM, BN, 2, 4, 4, 3>(smem, ar, br, H, vec, vec, wm * 64, b_row0, acc);
+
+  // epilogue: per-row partial dot over this wave's 128 columns, then the two N-waves via LDS
+  float wa[4], bl[4];
+#pragma unroll
+  for (int ns = 0; ns < 4; ++ns) {
+    const int n = n0 + b_row0[ns] + acc_col(lane);
+    wa[ns] = (n < H) ? p.w_att[n] : 0.f;
+    bl[ns] = (n < H) ? p.b_lin[n] : 0.f;
+  }
+  float* red = smem;  // [2 (wn)][BM]; main loop ended with a barrier
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) s += wa[ns] * tanhf(acc[ms][ns][r] + bl[ns]);
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+      if ((lane & 31) == 0) red[wn * BM + wm * 64 + ms * 32 + acc_row(r, lane)] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < BM) {
+    const int64_t m = m0 + tid;
+    if (m < p.rows) p.e_part[static_cast<int64_t>(nt) * p.rows + m] = red[tid] + red[BM + tid];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention pooling: out[s] = sum_t a_t h_t,  a_t = exp(e_t) [t < len] / (sum_t exp(e_t) + 1e-4)
+// one workgroup per sequence; reads each hidden row once (HBM-bound).
+// ---------------------------------------------------------------------------------------------
+struct AttnPoolParams {
+  const float* hs;
+  const float* e_part;
+  const int32_t* lens;
+  const int32_t* out_row;
+  const int32_t* step_off;
+  float* out;
+  int64_t rows;
+  int32_t H, n_tiles;
+};
+
+__global__ __launch_bounds__(kThreads) void attn_pool_kernel(const AttnPoolParams p) {
+  const int s = blockIdx.x;
+  const int len = p.lens[s];
+  const int tid = threadIdx.x;
+  __shared__ float s_w[kThreads];
+  __shared__ float s_den;
+  // pass 1: denominator sum_t exp(e_t) + 1e-4 (each exp evaluated by exactly one thread)
+  float part = 0.f;
+  for (int t = tid; t < len; t += kThreads) {
+    const int64_t row = static_cast<int64_t>(p.step_off[t]) + s;
+    float e = 0.f;
+    for (int q = 0; q < p.n_tiles; ++q) e += p.e_part[q * p.rows + row];
+    part += expf(e);
+  }
+  s_w[tid] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float d = 0.f;
+    for (int i = 0; i < kThreads; ++i) d += s_w[i];
+    s_den = d + 0.0001f;
+  }
+  __syncthreads();
+  const float den = s_den;
+  const int H = p.H;
+  float* o = p.out + static_cast<int64_t>(p.out_row[s]) * H;
+  // pass 2: weighted sum; the weights of 256 steps at a time are staged in LDS
+  for (int ub = 0; ub < H; ub += 4 * kThreads) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int t0 = 0; t0 < len; t0 += kThreads) {
+      __syncthreads();
+      if (t0 + tid < len) {
+        const int64_t row = static_cast<int64_t>(p.step_off[t0 + tid]) + s;
+        float e = 0.f;
+        for (int q = 0; q < p.n_tiles; ++q) e += p.e_part[q * p.rows + row];
+        s_w[tid] = expf(e) / den;
+      }
+      __syncthreads();
+      const int cnt = (len - t0 < kThreads) ? (len - t0) : kThreads;
+      for (int j = 0; j < cnt; ++j) {
+        const float* hrow = p.hs + (static_cast<int64_t>(p.step_off[t0 + j]) + s) * H;
+        const float wgt = s_w[j];
+        const int u = ub + tid;
+        if (u < H) a0 += wgt * hrow[u];
+        if (u + kThreads < H) a1 += wgt * hrow[u + kThreads];
+        if (u + 2 * kThreads < H) a2 += wgt * hrow[u + 2 * kThreads];
+        if (u + 3 * kThreads < H) a3 += wgt * hrow[u + 3 * kThreads];
+      }
+    }
+    const int u = ub + tid;
+    if (u < H) o[u] = a0;
+    if (u + kThreads < H) o[u + kThreads] = a1;
+    if (u + 2 * kThreads < H) o[u + 2 * kThreads] = a2;
+    if (u + 3 * kThreads < H) o[u + 3 * kThreads] = a3;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize: y = x / max(||x||_2, 1e-12), one workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void l2norm_rows_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ y, int cols,
+                                                               int64_t ld) {
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * ld;
+  float* yr = y + row * ld;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < cols; c += kThreads) {
+    const float v = xr[c];
+    ss += v * v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
+  __shared__ float s_part[kThreads / 64];
+  __shared__ float s_inv;
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kThreads / 64; ++i) t += s_part[i];
+    s_inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  for (int c = threadIdx.x; c < cols; c += kThreads) yr[c] = xr[c] * inv;
+}
+
+// nn.Embedding lookup as a plain row gather (only used when the caller asks for the word tensor,
+// model.py:94,98; the encoders fuse the lookup into their operand loads instead).
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table,
+                                                               const long long* __restrict__ ids,
+                                                               float* __restrict__ out, int cols,
+                                                               int vocab) {
+  const int64_t r = blockIdx.x;
+  long long id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* src = table + id * cols;
+  float* dst = out + r * cols;
+  for (int c = threadIdx.x; c < cols; c += kThreads) dst[c] = src[c];
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace cmhse
+
+using namespace cmhse;
+
+extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t H,
+                                           int32_t pool_mode) {
+  (void)S;
+  (void)Tmax;
+  if (sum_T <= 0 || H <= 0) return 0;
+  size_t bytes = align_up(static_cast<size_t>(sum_T) * H * sizeof(float), 256);
+  if (pool_mode == CMHSE_POOL_ATTN) {
+    const size_t n_tiles = (H + kAttBN - 1) / kAttBN;
+    bytes += align_up(n_tiles * static_cast<size_t>(sum_T) * sizeof(float), 256);
+  }
+  return bytes;
+}
+
+extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
+                                  int32_t pool_mode, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+  if (!b || !w || !out || !workspace) return CMHSE_ERR_ARG;
+  if (b->S <= 0 || b->Tmax <= 0 || b->I <= 0 || b->H <= 0) return CMHSE_ERR_ARG;
+  if ((b->x_rows == nullptr) == (b->tok_rows == nullptr)) return CMHSE_ERR_ARG;
+  if (b->tok_rows && (!b->emb_table || b->vocab <= 0)) return CMHSE_ERR_ARG;
+  if (!b->lens || !b->out_row || !b->step_off || !b->step_count_host) return CMHSE_ERR_ARG;
+  if (!w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh) return CMHSE_ERR_ARG;
+  if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX)
+    return CMHSE_ERR_ARG;
+  if (pool_mode == CMHSE_POOL_ATTN && (!w->w_lin || !w->b_lin || !w->w_att)) return CMHSE_ERR_ARG;
+  int64_t sum_T = 0;
+  for (int t = 0; t < b->Tmax; ++t) {
+    const int c = b->step_count_host[t];
+    if (c <= 0 || c > b->S || (t > 0 && c > b->step_count_host[t - 1])) return CMHSE_ERR_ARG;
+    sum_T += c;
+  }
+  if (b->step_count_host[0] != b->S) return CMHSE_ERR_ARG;
+  if (sum_T * b->H >= (int64_t(1) << 40)) return CMHSE_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->H, pool_mode))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+  float* hs = static_cast<float*>(workspace);
+  GruStepParams p;
+  p.x_rows = b->x_rows;
+  p.tok_rows = b->tok_rows;
+  p.emb = b->emb_table;
+  p.h0_rows = b->h0_rows;
+  p.lens = b->lens;
+  p.out_row = b->out_row;
+  p.w_ih = w->w_ih;
+  p.w_hh = w->w_hh;
+  p.b_ih = w->b_ih;
+  p.b_hh = w->b_hh;
+  p.hs = hs;
+  p.out = out;
+  p.I = b->I;
+  p.H = b->H;
+  p.vocab = b->vocab;
+  p.pool_mode = pool_mode;
+  p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
+  const size_t smem = TileSmem<kGruBM, 3 * kGruBU>::kBytes;
+  const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
+  int64_t off = 0;
+  for (int t = 0; t < b->Tmax; ++t) {
+    const int S_t = b->step_count_host[t];
+    p.t = t;
+    p.S_t = S_t;
+    p.off_prev = off - (t > 0 ? b->step_count_host[t - 1] : 0);
+    p.off_cur = off;
+    const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + kGruBM - 1) / kGruBM);
+    hipLaunchKernelGGL(gru_step_kernel, dim3(grid), dim3(kThreads), smem, stream, p);
+    off += S_t;
+  }
+  if (pool_mode == CMHSE_POOL_ATTN) {
+    const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
+    float* e_part = reinterpret_cast<float*>(
+        static_cast<char*>(workspace) + align_up(static_cast<size_t>(sum_T) * b->H * sizeof(float), 256));
+    AttnEnergyParams ep;
+    ep.hs = hs;
+    ep.w_lin = w->w_lin;
+    ep.b_lin = w->b_lin;
+    ep.w_att = w->w_att;
+    ep.e_part = e_part;
+    ep.rows = sum_T;
+    ep.H = b->H;
+    ep.n_tiles = att_tiles;
+    const int64_t m_tiles = (sum_T + kAttBM - 1) / kAttBM;
+    if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
+    const size_t att_smem = TileSmem<kAttBM, kAttBN>::kBytes;
+    hipLaunchKernelGGL(attn_energy_kernel, dim3(static_cast<unsigned>(m_tiles * att_tiles)),
+                       dim3(kThreads), att_smem, stream, ep);
+    AttnPoolParams pp;
+    pp.hs = hs;
+    pp.e_part = e_part;
+    pp.lens = b->lens;
+    pp.out_row = b->out_row;
+    pp.step_off = b->step_off;
+    pp.out = out;
+    pp.rows = sum_T;
+    pp.H = b->H;
+    pp.n_tiles = att_tiles;
+    hipLaunchKernelGGL(attn_pool_kernel, dim3(b->S), dim3(kThreads), 0, stream, pp);
+  }
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_l2norm_rows(const float* x, float* y, int32_t rows, int32_t cols, int64_t ld,
+                                 void* stream_) {
+  if (!x || !y || rows < 0 || cols <= 0 || ld < cols) return CMHSE_ERR_ARG;
+  if (rows == 0) return CMHSE_OK;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(rows), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream_), x, y, cols, ld);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_gather_rows(const float* table, const int64_t* ids, int64_t n, int32_t cols,
+                                 int32_t vocab, float* out, void* stream_) {
+  if (!table || !ids || !out || n < 0 || cols <= 0 || vocab <= 0) return CMHSE_ERR_ARG;
+  if (n == 0) return CMHSE_OK;
+  if (n > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>(n)), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream_), table,
+                     reinterpret_cast<const long long*>(ids), out, cols, vocab);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}

@@ -1,0 +1,359 @@
+// sim.hip — N x M cosine-similarity contraction with fused ranking / loss epilogues.
+//
+//   cmhse_sim_rank        evaluation.i2t / t2i  (/root/reference/evaluation.py:160-213):
+//                         numpy.dot + per-row numpy.argsort become one exact-fp32 MFMA GEMM whose
+//                         epilogue counts, per row, the columns that beat the diagonal and tracks
+//                         the arg-max column — the N x M matrix never reaches HBM.
+//   cmhse_cosine_sim      loss.cosine_sim       (/root/reference/loss.py:12-13)
+//   cmhse_contrastive_fwd loss.ContrastiveLoss.forward (/root/reference/loss.py:86-117)
+//
+// Bit-exactness of the ranks: every d[i][j] is produced by the same MFMA k-chain (nt_core.hpp:
+// the k order per output element does not depend on the tile position), so the diagonal values
+// written by the diagonal pass are bit-identical to what the counting pass recomputes, and
+// `d[i][j] > d[i][i]` is evaluated on consistently rounded fp32 values, like the reference's
+// comparison inside numpy.argsort.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/cmhse_hip.h"
+#include "nt_core.hpp"
+
+namespace cmhse {
+
+constexpr int kSimBM = 128;
+constexpr int kSimBN = 128;
+
+enum { kSimDiag = 0, kSimRank = 1, kSimStore = 2 };
+
+struct SimParams {
+  const float* A;  // [N, D]
+  const float* B;  // [M, D]
+  int32_t N, M, D, row0, nrows, n_tiles;
+  float* diag;                  // [nrows]
+  int32_t* rank;                // [nrows]
+  unsigned long long* top1key;  // [nrows]
+  float* scores;                // [nrows, M] (kSimStore)
+};
+
+__device__ __forceinline__ bool aligned16s(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// monotone map float -> uint32 (total order of non-NaN floats)
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p) {
+  constexpr int BM = kSimBM, BN = kSimBN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int srow = tid >> 2;
+  int i0, j0;  // tile origin: local stripe row, global column
+  if (MODE == kSimDiag) {
+    i0 = blockIdx.x * BM;
+    j0 = p.row0 + i0;  // the column block that holds this row block's diagonal
+  } else {
+    j0 = (blockIdx.x % p.n_tiles) * BN;
+    i0 = (blockIdx.x / p.n_tiles) * BM;
+  }
+  const float* ar[BM / 64];
+  const float* br[BN / 64];
+  const bool vec = (p.D % 4 == 0) && aligned16s(p.A) && aligned16s(p.B);
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i) {
+    const int li = i0 + srow + 64 * i;
+    ar[i] = (li < p.nrows) ? p.A + static_cast<int64_t>(p.row0 + li) * p.D : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 64; ++i) {
+    const int j = j0 + srow + 64 * i;
+    br[i] = (j < p.M) ? p.B + static_cast<int64_t>(j) * p.D : nullptr;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) acc[ms][ns] = zero16();
+  const int b_row0[2] = {wn * 64, wn * 64 + 32};
+  nt_phase<BM, BN, 2, 2, 2, 1>(smem, ar, br, p.D, vec, vec, wm * 64, b_row0, acc);
+
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int li = i0 + wm * 64 + ms * 32 + acc_row(r, lane);  // local stripe row
+      const int gi = p.row0 + li;                                  // its diagonal column
+      const bool rok = li < p.nrows;
+      if (MODE == kSimDiag) {
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+          const int j = j0 + b_row0[ns] + acc_col(lane);
+          if (rok && j == gi) p.diag[li] = acc[ms][ns][r];
+        }
+      } else if (MODE == kSimStore) {
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+          const int j = j0 + b_row0[ns] + acc_col(lane);
+          if (rok && j < p.M) p.scores[static_cast<int64_t>(li) * p.M + j] = acc[ms][ns][r];
+        }
+      } else {
+        const float dii = rok ? p.diag[li] : 0.f;
+        int cnt = 0;
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+          const int j = j0 + b_row0[ns] + acc_col(lane);
+          const float v = acc[ms][ns][r];
+          if (rok && j < p.M) {
+            cnt += (j != gi && v > dii) ? 1 : 0;
+            const unsigned long long key =
+                (static_cast<unsigned long long>(ordered_bits(v)) << 32) |
+                static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<unsigned>(j));
+            best = (key > best) ? key : best;
+          }
+        }
+        // reduce over the 32 lanes that share this row (xor masks < 32 stay inside a half-wave)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+          cnt += __shfl_xor(cnt, d, 64);
+          const unsigned long long o = __shfl_xor(best, d, 64);
+          best = (o > best) ? o : best;
+        }
+        if (rok && (lane & 31) == 0) {
+          if (cnt) atomicAdd(&p.rank[li], cnt);
+          atomicMax(&p.top1key[li], best);
+        }
+      }
+    }
+  }
+}
+
+__global__ void top1_finalize_kernel(const unsigned long long* key, int32_t* top1, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) top1[i] = static_cast<int32_t>(0xFFFFFFFFu - static_cast<unsigned>(key[i] & 0xFFFFFFFFull));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrastive loss reduction over a stored n x n score matrix (loss.py:89-117).
+// Workgroup b < nrb reduces rows [64b, 64b+64) (cost_s); workgroup nrb + c reduces columns
+// [64c, 64c+64) (cost_im).  fp64 partial sums, fixed order -> bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+struct LossParams {
+  const float* scores;  // [n, n]
+  int32_t n, nrb;
+  float margin;
+  int32_t max_violation, norm;
+  double* partial;  // [2 * nrb]
+  float* loss;
+};
+
+__global__ __launch_bounds__(kThreads) void contrastive_partial_kernel(const LossParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n;
+  const float* S = p.scores;
+  __shared__ double s_part[kThreads];
+  double total = 0.0;
+  if (static_cast<int>(blockIdx.x) < p.nrb) {
+    // rows: one wave per row, lanes stride the columns
+    const int r0 = blockIdx.x * 64;
+    for (int i = r0 + wave; i < r0 + 64 && i < n; i += kThreads / 64) {
+      const float dii = S[static_cast<int64_t>(i) * n + i];
+      double sum = 0.0;
+      float mx = 0.f;
+      for (int j = lane; j < n; j += 64) {
+        float c = fmaxf(p.margin + S[static_cast<int64_t>(i) * n + j] - dii, 0.f);
+        if (j == i) c = 0.f;
+        sum += c;
+        mx = fmaxf(mx, c);
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+      }
+      total += p.max_violation ? static_cast<double>(mx) : sum;
+    }
+    s_part[tid] = (lane == 0) ? total : 0.0;
+  } else {
+    // columns: thread c < 64 owns column j (coalesced across the wave), 4 waves split the rows
+    const int j = (blockIdx.x - p.nrb) * 64 + lane;
+    double sum = 0.0;
+    float mx = 0.f;
+    if (j < n) {
+      const float djj = S[static_cast<int64_t>(j) * n + j];
+      for (int i = wave; i < n; i += kThreads / 64) {
+        float c = fmaxf(p.margin + S[static_cast<int64_t>(i) * n + j] - djj, 0.f);
+        if (i == j) c = 0.f;
+        sum += c;
+        mx = fmaxf(mx, c);
+      }
+    }
+    // combine the 4 waves' shares of each column, then the 64 columns
+    __shared__ double c_sum[kThreads];
+    __shared__ float c_max[kThreads];
+    c_sum[tid] = sum;
+    c_max[tid] = mx;
+    __syncthreads();
+    double v = 0.0;
+    if (wave == 0) {
+      const double cs = c_sum[lane] + c_sum[64 + lane] + c_sum[128 + lane] + c_sum[192 + lane];
+      const float cm = fmaxf(fmaxf(c_max[lane], c_max[64 + lane]),
+                             fmaxf(c_max[128 + lane], c_max[192 + lane]));
+      v = p.max_violation ? static_cast<double>(cm) : cs;
+    }
+    s_part[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kThreads; ++i) t += s_part[i];
+    p.partial[blockIdx.x] = t;
+  }
+}
+
+__global__ void contrastive_final_kernel(const LossParams p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double cs = 0.0, ci = 0.0;
+    for (int b = 0; b < p.nrb; ++b) cs += p.partial[b];
+    for (int b = 0; b < p.nrb; ++b) ci += p.partial[p.nrb + b];
+    // loss.py:113-117: cost_s.sum() + cost_im.sum(), each an fp32 tensor sum
+    float loss = static_cast<float>(cs) + static_cast<float>(ci);
+    if (p.norm) loss = loss / static_cast<float>(static_cast<int64_t>(p.n) * p.n);
+    *p.loss = loss;
+  }
+}
+
+static inline size_t align_up_(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int launch_sim_store(const float* A, const float* B, int n, int m, int D, float* scores,
+                            hipStream_t stream) {
+  SimParams p;
+  p.A = A;
+  p.B = B;
+  p.N = n;
+  p.M = m;
+  p.D = D;
+  p.row0 = 0;
+  p.nrows = n;
+  p.n_tiles = (m + kSimBN - 1) / kSimBN;
+  p.diag = nullptr;
+  p.rank = nullptr;
+  p.top1key = nullptr;
+  p.scores = scores;
+  const int64_t blocks = static_cast<int64_t>(p.n_tiles) * ((n + kSimBM - 1) / kSimBM);
+  if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
+  const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
+  hipLaunchKernelGGL(sim_kernel<kSimStore>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                     smem, stream, p);
+  return CMHSE_OK;
+}
+
+}  // namespace cmhse
+
+using namespace cmhse;
+
+extern "C" size_t cmhse_sim_rank_workspace(int32_t nrows) {
+  if (nrows <= 0) return 0;
+  return align_up_(static_cast<size_t>(nrows) * sizeof(float), 256) +
+         align_up_(static_cast<size_t>(nrows) * sizeof(unsigned long long), 256);
+}
+
+extern "C" int cmhse_sim_rank(const float* A, const float* B, int32_t N, int32_t M, int32_t D,
+                              int32_t row0, int32_t nrows, int32_t* rank, int32_t* top1,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!A || !B || !rank || !top1 || !workspace) return CMHSE_ERR_ARG;
+  if (N <= 0 || M <= 0 || D <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > N) return CMHSE_ERR_ARG;
+  if (row0 + nrows > M) return CMHSE_ERR_ARG;  // diagonal d[i][i] must exist
+  if (nrows == 0) return CMHSE_OK;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_sim_rank_workspace(nrows))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SimParams p;
+  p.A = A;
+  p.B = B;
+  p.N = N;
+  p.M = M;
+  p.D = D;
+  p.row0 = row0;
+  p.nrows = nrows;
+  p.n_tiles = (M + kSimBN - 1) / kSimBN;
+  p.diag = static_cast<float*>(workspace);
+  p.top1key = reinterpret_cast<unsigned long long*>(
+      static_cast<char*>(workspace) + align_up_(static_cast<size_t>(nrows) * sizeof(float), 256));
+  p.rank = rank;
+  p.scores = nullptr;
+  const int m_tiles = (nrows + kSimBM - 1) / kSimBM;
+  const int64_t blocks = static_cast<int64_t>(p.n_tiles) * m_tiles;
+  if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
+  if (hipMemsetAsync(rank, 0, sizeof(int32_t) * nrows, stream) != hipSuccess) return CMHSE_ERR_LAUNCH;
+  if (hipMemsetAsync(p.top1key, 0, sizeof(unsigned long long) * nrows, stream) != hipSuccess)
+    return CMHSE_ERR_LAUNCH;
+  const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
+  hipLaunchKernelGGL(sim_kernel<kSimDiag>, dim3(m_tiles), dim3(kThreads), smem, stream, p);
+  hipLaunchKernelGGL(sim_kernel<kSimRank>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
+                     smem, stream, p);
+  hipLaunchKernelGGL(top1_finalize_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream,
+                     p.top1key, top1, nrows);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_cosine_sim(const float* im, const float* s, int32_t n, int32_t m, int32_t D,
+                                float* scores, void* stream_) {
+  if (!im || !s || !scores || n <= 0 || m <= 0 || D <= 0) return CMHSE_ERR_ARG;
+  const int rc = launch_sim_store(im, s, n, m, D, scores, static_cast<hipStream_t>(stream_));
+  if (rc != CMHSE_OK) return rc;
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" size_t cmhse_contrastive_workspace(int32_t n) {
+  if (n <= 0) return 0;
+  const size_t nrb = (n + 63) / 64;
+  return align_up_(static_cast<size_t>(n) * n * sizeof(float), 256) +
+         align_up_(2 * nrb * sizeof(double), 256);
+}
+
+extern "C" int cmhse_contrastive_fwd(const float* im, const float* s, int32_t n, int32_t D,
+                                     float margin, int32_t max_violation, int32_t norm,
+                                     float* loss, float* scores_out, void* workspace,
+                                     size_t workspace_bytes, void* stream_) {
+  if (!im || !s || !loss || !workspace || n <= 0 || D <= 0) return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_contrastive_workspace(n))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* scores = scores_out ? scores_out : static_cast<float*>(workspace);
+  const int rc = launch_sim_store(im, s, n, n, D, scores, stream);
+  if (rc != CMHSE_OK) return rc;
+  LossParams lp;
+  lp.scores = scores;
+  lp.n = n;
+  lp.nrb = (n + 63) / 64;
+  lp.margin = margin;
+  lp.max_violation = max_violation;
+  lp.norm = norm;
+  lp.partial = reinterpret_cast<double*>(static_cast<char*>(workspace) +
+                                         align_up_(static_cast<size_t>(n) * n * sizeof(float), 256));
+  lp.loss = loss;
+  hipLaunchKernelGGL(contrastive_partial_kernel, dim3(2 * lp.nrb), dim3(kThreads), 0, stream, lp);
+  hipLaunchKernelGGL(contrastive_final_kernel, dim3(1), dim3(64), 0, stream, lp);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" const char* cmhse_strerror(int code) {
+  switch (code) {
+    case CMHSE_OK: return "ok";
+    case CMHSE_ERR_ARG: return "invalid argument";
+    case CMHSE_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
+    case CMHSE_ERR_LAUNCH: return "HIP launch/runtime error";
+    case CMHSE_ERR_UNSUPPORTED: return "shape not supported";
+    default: return "unknown error";
+  }
+}
+
+extern "C" const char* cmhse_version(void) { return "cmhse_hip 0.1.0 gfx950"; }

@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's `evaluation.py` on the MI355X hot path.
+
+Exports the names train.py imports (train.py:10): i2t, t2i, AverageMeter, LogCollector,
+encode_data, LogReporter — with the reference's signatures and return values
+(/root/reference/evaluation.py:18-213).
+
+MI355X-first differences in HOW (not WHAT) things are computed:
+  * encode_data fuses many loader batches into one "super-batch" per encoder launch sequence
+    (clips and whole-video streams of all those batches go through `clip_enc` together, sentences
+    and paragraphs through `txt_enc` together), keeps every embedding on the device, and still
+    reports the per-loader-batch 'Letest' loss (evaluation.py:129) and returns the same 8-tuple;
+  * i2t / t2i never build the N x N matrix or sort: ranks and arg-max come out of the fused
+    similarity kernel (cmhse_sim_rank).
+"""
+from __future__ import annotations
+
+import time
+from collections import OrderedDict
+
+import numpy
+import numpy as np
+import torch
+
+from . import ops
+
+
+class AverageMeter(object):
+  """/root/reference/evaluation.py:18-45 (note avg = sum / (1e-4 + count), update(val, n=0))."""
+
+  def __init__(self):
+    self.reset()
+
+  def reset(self):
+    self.val = 0
+    self.avg = 0
+    self.sum = 0
+    self.count = 0
+
+  def update(self, val, n=0):
+    self.val = val
+    self.sum += val * n
+    self.count += n
+    self.avg = self.sum / (.0001 + self.count)
+
+  def __str__(self):
+    if self.count == 0:
+      return str(self.val)
+    return '%.4f (%.4f)' % (self.val, self.avg)
+
+
+class LogCollector(object):
+  """/root/reference/evaluation.py:48-72."""
+
+  def __init__(self):
+    self.meters = OrderedDict()
+
+  def update(self, k, v, n=0):
+    if k not in self.meters:
+      self.meters[k] = AverageMeter()
+    self.meters[k].update(v, n)
+
+  def __str__(self):
+    s = ''
+    for i, (k, v) in enumerate(self.meters.items()):
+      if i > 0:
+        s += '  '
+      s += k + ' ' + str(v)
+    return s
+
+  def tb_log(self, tb_logger, prefix='', step=None):
+    for k, v in self.meters.items():
+      tb_logger.log_value(prefix + k, v.val, step=step)
+
+
+def LogReporter(tb_logger, result, epoch, name):
+  """/root/reference/evaluation.py:74-78."""
+  for key in result:
+    tb_logger.log_value(name + key, result[key], step=epoch)
+  return
+
+
+# ---------------------------------------------------------------------------------------------
+# encode_data
+# ---------------------------------------------------------------------------------------------
+def _to_dev(t, device):
+  return t if t.is_cuda else t.to(device, non_blocking=True)
+
+
+def encode_group(model, group, contextual_model=True, device=None):
+  """Encode a list of loader batches (12-tuples) as ONE super-batch.  Returns a dict of device
+  tensors: the six un-normalised embedding matrices plus their L2-normalised versions, rows in
+  loader order.  Arithmetic per sequence is identical to per-batch encoding (sequences are
+  independent), only the launch granularity differs."""
+  device = device or torch.device('cuda', torch.cuda.current_device())
+  clips_l, caps_l, vids_l, pars_l = [], [], [], []
+  len_clip, len_cap, len_vid, len_par = [], [], [], []
+  num_clips, num_caps = [], []
+  for b in group:
+    clips_l.append(_to_dev(b[0], device).float().contiguous())
+    caps_l.append(_to_dev(b[1], device).long().contiguous())
+    vids_l.append(_to_dev(b[2], device).float().contiguous())
+    pars_l.append(_to_dev(b[3], device).long().contiguous())
+    len_clip.append(np.asarray(b[4], dtype=np.int64))
+    len_cap.append(np.asarray(b[5], dtype=np.int64))
+    len_vid.append(np.asarray(b[6], dtype=np.int64))
+    len_par.append(np.asarray(b[7], dtype=np.int64))
+    num_clips.extend(int(c) for c in b[8])
+    num_caps.extend(int(c) for c in b[9])
+  n_clip = int(sum(len(l) for l in len_clip))
+  n_cap = int(sum(len(l) for l in len_cap))
+  n_vid = len(num_clips)
+  if n_clip != sum(num_clips) or n_cap != sum(num_caps):
+    raise ValueError('batch contract violated: sum(num_clips) != number of clip rows')
+
+  clip_rnn, txt_rnn = model.clip_enc.rnn, model.txt_enc.rnn
+  H1v = clip_rnn.rnn.weight_hh_l0.shape[1]
+  H1t = txt_rnn.rnn.weight_hh_l0.shape[1]
+  img_dim = clips_l[0].shape[2]
+  table = model.txt_enc.embed.weight.detach()
+
+  # level 1, visual: clips of all batches, then whole-video streams of all batches (same weights)
+  ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
+  lens = np.concatenate(len_clip + len_vid)
+  vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs)
+  clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
+  # level 1, text: sentences, then paragraphs
+  ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
+  lens = np.concatenate(len_cap + len_par)
+  txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
+  cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
+
+  # level 2: each video's clips are consecutive rows of clip_emb -> addressed in place
+  def level2(enc, rows, counts, ctx_rows, Hin):
+    counts = np.asarray(counts, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    x_ptrs = np.uint64(rows.data_ptr()) + starts * np.uint64(Hin * 4)
+    h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
+    return enc.rnn.forward_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
+
+  vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v)
+  para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)
+  n = ops.l2norm_rows
+  return dict(vid_emb=n(vid_emb), para_emb=n(para_emb), clip_emb=n(clip_emb), cap_emb=n(cap_emb),
+              vid_ctx=n(vid_ctx), para_ctx=n(para_ctx), n_vid=n_vid,
+              batch_sizes=[len(b[8]) for b in group])
+
+
+def _group_batches(batches, max_bytes):
+  """Split the loader's batches into super-batches of at most `max_bytes` of padded features."""
+  groups, cur, cur_bytes = [], [], 0
+  for b in batches:
+    nbytes = b[0].numel() * 4 + b[2].numel() * 4
+    if cur and cur_bytes + nbytes > max_bytes:
+      groups.append(cur)
+      cur, cur_bytes = [], 0
+    cur.append(b)
+    cur_bytes += nbytes
+  if cur:
+    groups.append(cur)
+  return groups
+
+
+def encode_data_device(opt, model, data_loader, log_step=10, logging=print, contextual_model=True,
+                       superbatch_bytes=48 << 30):
+  """Device-resident core of encode_data: returns (dict of six [N,*] normalised embedding tensors
+  on the GPU, num_clips_total, cur_vid_total)."""
+  batch_time = AverageMeter()
+  val_logger = LogCollector()
+  model.val_start(opt)
+  end = time.time()
+  outs = {k: [] for k in ['vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx']}
+  num_clips_total, cur_vid_total = [], []
+  batches = list(data_loader)
+  n_loader = len(batches)
+  i = 0
+  with torch.no_grad():
+    for group in _group_batches(batches, superbatch_bytes):
+      model.logger = val_logger                     # evaluation.py:99
+      enc = encode_group(model, group, contextual_model)
+      for k in outs:
+        outs[k].append(enc[k])
+      # per-loader-batch 'Letest' loss (evaluation.py:129), all on device, one sync per group
+      losses, pos = [], 0
+      for bs in enc['batch_sizes']:
+        losses.append(model.criterion(enc['vid_emb'][pos:pos + bs], enc['para_emb'][pos:pos + bs]))
+        pos += bs
+      loss_vals = torch.stack(losses).cpu().tolist()
+      for b, bs, lv in zip(group, enc['batch_sizes'], loss_vals):
+        num_clips_total.extend(b[8])
+        cur_vid_total.extend(b[11])
+        model.logger.update('Letest', lv, bs)       # model.py:291
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i % log_step == 0:
+          logging('Test: [{0}/{1}]\t{e_log}\tTime {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                  .format(i, n_loader, batch_time=batch_time, e_log=str(model.logger)))
+        i += 1
+  cat = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in outs.items()}
+  return cat, num_clips_total, cur_vid_total
+
+
+def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_model=True):
+  """/root/reference/evaluation.py:80-158: returns (vid_embs, para_embs, clip_embs, cap_embs,
+  vid_contexts, para_contexts, num_clips_total, cur_vid_total); the six arrays are float32 NumPy
+  like the reference's."""
+  cat, num_clips_total, cur_vid_total = encode_data_device(opt, model, data_loader, log_step,
+                                                           logging, contextual_model)
+  to_np = lambda t: t.cpu().numpy()
+  return (to_np(cat['vid_emb']), to_np(cat['para_emb']), to_np(cat['clip_emb']),
+          to_np(cat['cap_emb']), to_np(cat['vid_ctx']), to_np(cat['para_ctx']),
+          num_clips_total, cur_vid_total)
+
+
+# ---------------------------------------------------------------------------------------------
+# i2t / t2i
+# ---------------------------------------------------------------------------------------------
+def report_from_ranks(ranks):
+  """evaluation.py:173-184; 'r10' is Recall@50 upstream (`ranks < 50`, :175)."""
+  r1 = 100.0 * len(numpy.where(ranks < 1)[0]) / len(ranks)
+  r5 = 100.0 * len(numpy.where(ranks < 5)[0]) / len(ranks)
+  r10 = 100.0 * len(numpy.where(ranks < 50)[0]) / len(ranks)
+  medr = numpy.floor(numpy.median(ranks)) + 1
+  meanr = ranks.mean() + 1
+  report_dict = dict()
+  report_dict['r1'] = r1
+  report_dict['r5'] = r5
+  report_dict['r10'] = r10
+  report_dict['medr'] = medr
+  report_dict['meanr'] = meanr
+  report_dict['sum'] = r1 + r5 + r10
+  return report_dict
+
+
+def _as_device(x):
+  if isinstance(x, torch.Tensor):
+    return x if x.is_cuda else x.cuda()
+  if not torch.cuda.is_available():
+    raise RuntimeError('cmhse_amd.evaluation needs an MI355X (no CPU fallback)')
+  return torch.from_numpy(numpy.ascontiguousarray(x, dtype=numpy.float32)).cuda()
+
+
+def _rank_report(queries, gallery):
+  rank, top1 = ops.sim_rank(_as_device(queries), _as_device(gallery))
+  ranks = rank.cpu().numpy().astype(numpy.float64)      # the reference stores ranks in float64
+  top1 = top1.cpu().numpy().astype(numpy.float64)
+  return report_from_ranks(ranks), top1, ranks
+
+
+def i2t(images, captions, npts=None, measure='cosine'):
+  """/root/reference/evaluation.py:160-185 (video -> paragraph).  `npts`, `measure` are ignored
+  upstream too (:161).  Accepts NumPy arrays (reference contract) or GPU tensors."""
+  return _rank_report(images, captions)
+
+
+def t2i(images, captions, npts=None, measure='cosine'):
+  """/root/reference/evaluation.py:188-213 (paragraph -> video)."""
+  return _rank_report(captions, images)

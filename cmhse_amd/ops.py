@@ -1,0 +1,220 @@
+"""Thin host-side wrappers over the C ABI (include/cmhse_hip.h): argument marshalling, the
+pack_padded_sequence-style schedule, workspaces.  No arithmetic happens here and there is no CPU
+fallback — tensors must live on the MI355X.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF  # noqa: F401
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+  if not isinstance(t, torch.Tensor) or not t.is_cuda:
+    raise RuntimeError('cmhse_amd: `%s` must be a tensor on the GPU (no CPU fallback; the HIP '
+                       'path is the only implementation)' % name)
+
+
+def _f32c(t, name):
+  _require_cuda(t, name)
+  if t.dtype != torch.float32:
+    t = t.float()
+  return t.contiguous()
+
+
+class SeqSchedule(object):
+  """Host-side schedule of one packed GRU launch sequence.
+
+  Mirrors what the reference does with `torch.sort(lengths, 0, True)` +
+  `pack_padded_sequence(..., lens.tolist())` (/root/reference/layers.py:94-97): sequences sorted
+  longest-first, so the sequences still active at step t are the prefix [0, step_count[t]).
+  All small per-sequence arrays go to the device in ONE copy.
+  """
+
+  def __init__(self, lens, device, x_ptrs=None, tok_ptrs=None, h0_ptrs=None):
+    lens = np.asarray(lens, dtype=np.int64).reshape(-1)
+    if lens.size == 0 or lens.min() < 1:
+      raise ValueError('all sequence lengths must be >= 1 (pack_padded_sequence contract)')
+    S = lens.size
+    order = np.argsort(-lens, kind='stable')
+    ls = lens[order]
+    Tmax = int(ls[0])
+    # step_count[t] = #{s : len_s > t}
+    hist = np.bincount(ls, minlength=Tmax + 1)
+    step_count = (S - np.cumsum(hist)[:Tmax]).astype(np.int32)
+    step_off = np.zeros(Tmax + 1, dtype=np.int64)
+    np.cumsum(step_count, out=step_off[1:])
+    if step_off[-1] >= 2 ** 31:
+      raise ValueError('packed batch too large for int32 row offsets')
+    self.S, self.Tmax, self.sum_T = S, Tmax, int(step_off[-1])
+    self.order = order
+    self.step_count_host = np.ascontiguousarray(step_count)
+    self.lens_sorted = ls
+
+    # one packed metadata buffer: [x_rows u64 | h0_rows u64 | lens i32 | out_row i32 | step_off i32]
+    n64 = 2 * S
+    n32 = 2 * S + (Tmax + 1)
+    buf = np.zeros(n64 * 8 + n32 * 4, dtype=np.uint8)
+    v64 = buf[:n64 * 8].view(np.uint64)
+    v32 = buf[n64 * 8:].view(np.int32)
+    src = x_ptrs if x_ptrs is not None else tok_ptrs
+    v64[:S] = np.asarray(src, dtype=np.uint64)[order]
+    if h0_ptrs is not None:
+      v64[S:2 * S] = np.asarray(h0_ptrs, dtype=np.uint64)[order]
+    v32[:S] = ls
+    v32[S:2 * S] = order
+    v32[2 * S:] = step_off
+    self.meta = torch.from_numpy(buf).to(device)
+    base = self.meta.data_ptr()
+    self.p_rows = base
+    self.p_h0 = base + S * 8 if h0_ptrs is not None else None
+    self.p_lens = base + n64 * 8
+    self.p_out_row = self.p_lens + S * 4
+    self.p_step_off = self.p_out_row + S * 4
+    self.is_tokens = x_ptrs is None
+
+
+def padded_row_ptrs(t):
+  """Base address of every sequence of a contiguous padded batch [S, T, ...]."""
+  S = t.shape[0]
+  stride = t.stride(0) * t.element_size()
+  return (np.uint64(t.data_ptr()) + np.arange(S, dtype=np.uint64) * np.uint64(stride))
+
+
+def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
+                 emb_table=None, h0_ptrs=None, out=None):
+  """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
+  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and schedule."""
+  lib = _lib.load()
+  sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs)
+  S = sched.S
+  if out is None:
+    out = torch.empty(S, H, dtype=torch.float32, device=device)
+  ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, H, pool_mode)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+
+  w = _lib.GruWeights()
+  keep = []
+  for name in ['w_ih', 'w_hh', 'b_ih', 'b_hh']:
+    t = _f32c(weights[name], name)
+    keep.append(t)
+    setattr(w, name, t.data_ptr())
+  if pool_mode == POOL_ATTN:
+    for name in ['w_lin', 'b_lin', 'w_att']:
+      t = _f32c(weights[name], name)
+      keep.append(t)
+      setattr(w, name, t.data_ptr())
+  b = _lib.SeqBatch()
+  b.S, b.Tmax, b.I, b.H = S, sched.Tmax, I, H
+  if sched.is_tokens:
+    emb_table = _f32c(emb_table, 'emb_table')
+    keep.append(emb_table)
+    b.tok_rows = sched.p_rows
+    b.emb_table = emb_table.data_ptr()
+    b.vocab = emb_table.shape[0]
+  else:
+    b.x_rows = sched.p_rows
+  b.h0_rows = sched.p_h0
+  b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
+  b.step_count_host = sched.step_count_host.ctypes.data
+  rc = lib.cmhse_gru_pool_fwd(ctypes.byref(b), ctypes.byref(w), pool_mode, out.data_ptr(),
+                              ws.data_ptr(), ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_gru_pool_fwd')
+  ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I)
+  return out, ctx
+
+
+def l2norm_rows(x, out=None):
+  """torch.nn.functional.normalize(x) on device (cmhse_l2norm_rows)."""
+  lib = _lib.load()
+  x = _f32c(x, 'x')
+  if x.dim() != 2:
+    raise ValueError('l2norm_rows expects [rows, cols]')
+  if out is None:
+    out = torch.empty_like(x)
+  rc = lib.cmhse_l2norm_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.shape[1],
+                             _stream())
+  _lib.check(rc, 'cmhse_l2norm_rows')
+  return out
+
+
+def gather_rows(table, ids):
+  """nn.Embedding lookup on device (cmhse_gather_rows): table[ids] with ids of any shape."""
+  lib = _lib.load()
+  table = _f32c(table, 'table')
+  _require_cuda(ids, 'ids')
+  ids = ids.contiguous()
+  if ids.dtype != torch.int64:
+    ids = ids.long()
+  out = torch.empty(tuple(ids.shape) + (table.shape[1],), dtype=torch.float32,
+                    device=table.device)
+  rc = lib.cmhse_gather_rows(table.data_ptr(), ids.data_ptr(), ids.numel(), table.shape[1],
+                             table.shape[0], out.data_ptr(), _stream())
+  _lib.check(rc, 'cmhse_gather_rows')
+  return out
+
+
+def sim_rank(a, b, row0=0, nrows=None):
+  """Ranks / top-1 of the stripe [row0,row0+nrows) of a @ b.T (cmhse_sim_rank).
+  Returns int32 device tensors (rank, top1)."""
+  lib = _lib.load()
+  a = _f32c(a, 'a')
+  b = _f32c(b, 'b')
+  N, D = a.shape
+  M = b.shape[0]
+  if b.shape[1] != D:
+    raise ValueError('embedding widths differ')
+  if nrows is None:
+    nrows = N - row0
+  rank = torch.empty(nrows, dtype=torch.int32, device=a.device)
+  top1 = torch.empty(nrows, dtype=torch.int32, device=a.device)
+  if nrows == 0:
+    return rank, top1
+  ws_bytes = lib.cmhse_sim_rank_workspace(nrows)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+  rc = lib.cmhse_sim_rank(a.data_ptr(), b.data_ptr(), N, M, D, row0, nrows, rank.data_ptr(),
+                          top1.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_sim_rank')
+  return rank, top1
+
+
+def cosine_sim(im, s):
+  """loss.cosine_sim on device: im @ s.T, exact fp32 (cmhse_cosine_sim)."""
+  lib = _lib.load()
+  im = _f32c(im, 'im')
+  s = _f32c(s, 's')
+  n, D = im.shape
+  m = s.shape[0]
+  out = torch.empty(n, m, dtype=torch.float32, device=im.device)
+  rc = lib.cmhse_cosine_sim(im.data_ptr(), s.data_ptr(), n, m, D, out.data_ptr(), _stream())
+  _lib.check(rc, 'cmhse_cosine_sim')
+  return out
+
+
+def contrastive_fwd(im, s, margin, max_violation, norm, want_scores=False):
+  """loss.ContrastiveLoss.forward on device (cmhse_contrastive_fwd): 0-d loss tensor
+  (and the score matrix when `want_scores`)."""
+  lib = _lib.load()
+  im = _f32c(im, 'im')
+  s = _f32c(s, 's')
+  n, D = im.shape
+  if s.shape[0] != n or s.shape[1] != D:
+    raise ValueError('ContrastiveLoss needs im and s of identical shape (diag view, loss.py:89)')
+  loss = torch.empty((), dtype=torch.float32, device=im.device)
+  scores = torch.empty(n, n, dtype=torch.float32, device=im.device) if want_scores else None
+  ws_bytes = lib.cmhse_contrastive_workspace(n)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
+  rc = lib.cmhse_contrastive_fwd(im.data_ptr(), s.data_ptr(), n, D, float(margin),
+                                 int(bool(max_violation)), int(bool(norm)), loss.data_ptr(),
+                                 scores.data_ptr() if want_scores else None, ws.data_ptr(),
+                                 ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_contrastive_fwd')
+  return (loss, scores) if want_scores else loss

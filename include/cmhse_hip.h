@@ -1,0 +1,145 @@
+/* cmhse_hip.h — C ABI of libcmhse_hip.so, the MI355X (gfx950) hot-path library.
+ *
+ * The reference (zbwglory/CMHSE) has no FFI layer: its hot path calls third-party PyTorch / NumPy
+ * operators from Python.  Each entry point below replaces one of those call sites; the citation
+ * (file:line into the reference tree) says which.  A maintainer of the reference binds these with
+ * `ctypes`; cmhse_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures (`stream` is a hipStream_t
+ *     passed as void*; NULL = the null stream);
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - all float data is IEEE fp32, row-major, 16-byte aligned rows are the fast path (feature
+ *     width and hidden size multiples of 4); indices are int32 unless stated (token ids: int64,
+ *     as torch.LongTensor);
+ *   - calls are asynchronous on `stream`, allocate nothing, keep no global state and are
+ *     re-entrant; scratch memory is an explicit caller-owned workspace whose size the matching
+ *     `*_workspace` function returns;
+ *   - return value: 0 = success, negative = error code (cmhse_strerror); no exceptions or aborts
+ *     cross the ABI.
+ */
+#ifndef CMHSE_HIP_H_
+#define CMHSE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  CMHSE_OK = 0,
+  CMHSE_ERR_ARG = -1,        /* invalid argument (null pointer, non-positive size, bad mode) */
+  CMHSE_ERR_WORKSPACE = -2,  /* workspace too small or misaligned */
+  CMHSE_ERR_LAUNCH = -3,     /* HIP launch / runtime error (hipGetLastError text via strerror) */
+  CMHSE_ERR_UNSUPPORTED = -4 /* shape outside what the kernels support */
+};
+
+/* pooling applied on top of the GRU hidden states (reference: model.py:27-34 `rnn_type`) */
+enum {
+  CMHSE_POOL_LAST = 0, /* layers.Seq2Seq.forward   layers.py:47-66   h at t = len-1            */
+  CMHSE_POOL_ATTN = 1, /* layers.Attention.forward layers.py:93-119  masked exp-softmax pooling */
+  CMHSE_POOL_MAX = 2   /* layers.Maxout.forward    layers.py:185-204 max over valid steps       */
+};
+
+/* Weights of one encoder layer, laid out exactly as the reference's state-dict tensors
+ * (layers.py:70-91; checkpoint keys rnn.rnn.weight_ih_l0 ...). */
+typedef struct cmhse_gru_weights {
+  const float* w_ih;  /* [3H, I]  rnn.rnn.weight_ih_l0, gate row order r,z,n (torch.nn.GRU) */
+  const float* w_hh;  /* [3H, H]  rnn.rnn.weight_hh_l0 */
+  const float* b_ih;  /* [3H]     rnn.rnn.bias_ih_l0 */
+  const float* b_hh;  /* [3H]     rnn.rnn.bias_hh_l0 */
+  const float* w_lin; /* [H, H]   rnn.lin.weight   (CMHSE_POOL_ATTN only, else NULL) */
+  const float* b_lin; /* [H]      rnn.lin.bias */
+  const float* w_att; /* [H]      rnn.att_w.weight ([1,H]) */
+} cmhse_gru_weights;
+
+/* A ragged batch of S sequences, already ordered by length, longest first — the order
+ * torch.nn.utils.rnn.pack_padded_sequence imposes (layers.py:94-97).  The caller (host logic in
+ * cmhse_amd/layers.py) sorts and fills these small arrays; the feature / token storage itself is
+ * never copied or re-laid-out: each sequence is addressed through its own base pointer, so padded
+ * [S,T,I] batches, several loader batches at once, and the consecutive-row inputs of
+ * VSE.structure_emb (model.py:238-255) are all consumed in place. */
+typedef struct cmhse_seq_batch {
+  int32_t S;    /* sequences */
+  int32_t Tmax; /* longest length (= lens[0]) */
+  int32_t I;    /* input width: img_dim, word_dim or first-level size */
+  int32_t H;    /* hidden size (embed_size) */
+  const uint64_t* x_rows;   /* [S] address of step 0 of sequence s: fp32 rows, stride I floats;
+                               NULL when tok_rows is used */
+  const uint64_t* tok_rows; /* [S] address of token 0 of sequence s (int64 ids, contiguous);
+                               the embedding lookup of model.EncoderText.forward (model.py:94) is
+                               fused into the operand load.  NULL when x_rows is used */
+  const float* emb_table;   /* [vocab, I] embed.weight (tok_rows only) */
+  int32_t vocab;
+  const uint64_t* h0_rows;  /* [S] address of the initial hidden row of sequence s (H floats), or
+                               NULL for h0 = 0 (layers.py:98-102 `hidden`) */
+  const int32_t* lens;      /* [S] lengths, non-increasing, all >= 1 */
+  const int32_t* out_row;   /* [S] row of `out` that receives sequence s (undoes the sort,
+                               layers.py:116-117) */
+  const int32_t* step_off;  /* [Tmax+1] step_off[t] = sum_{t'<t} #{s : lens[s] > t'}: row offset
+                               of step t in the time-major packed hidden-state buffer */
+  const int32_t* step_count_host; /* HOST [Tmax] #{s : lens[s] > t} (sizes the per-step grids) */
+} cmhse_seq_batch;
+
+/* Bytes of workspace cmhse_gru_pool_fwd needs for this batch: the time-major packed hidden states
+ * hs[sumT, H] (kept for the attention pooling and for a later backward pass) plus the attention
+ * energy partials. */
+size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t H,
+                                int32_t pool_mode);
+
+/* Replaces the body of layers.{Seq2Seq,Attention,Maxout}.forward (layers.py:47-66, 93-119,
+ * 185-204): 1-layer unidirectional GRU over the packed batch (nn.GRU, layers.py:31-34) followed
+ * by the pooling `pool_mode`.  out[out_row[s], :] (row stride H) receives the un-normalised
+ * embedding of sequence s.  The first sum_T*H floats of `workspace` hold, on return, the hidden
+ * states in pack_padded_sequence's time-major packed order. */
+int cmhse_gru_pool_fwd(const cmhse_seq_batch* seqs, const cmhse_gru_weights* w, int32_t pool_mode,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.nn.functional.normalize(x) (p=2, dim=1, eps=1e-12) — call sites model.py:333-343,
+ * evaluation.py:111-116.  y may alias x.  Rows have stride `ld` floats. */
+int cmhse_l2norm_rows(const float* x, float* y, int32_t rows, int32_t cols, int64_t ld,
+                      void* stream);
+
+/* nn.Embedding lookup (model.EncoderText.forward, model.py:94): out[r,:] = table[ids[r],:] for
+ * n ids (int64).  Only needed when the caller wants the word tensor itself (`return_word`,
+ * model.py:233); the encoders fuse the lookup into cmhse_gru_pool_fwd. */
+int cmhse_gather_rows(const float* table, const int64_t* ids, int64_t n, int32_t cols,
+                      int32_t vocab, float* out, void* stream);
+
+/* Replaces evaluation.i2t / t2i's `numpy.dot` + per-row `numpy.argsort` loop
+ * (evaluation.py:164-171, 192-199) for the row stripe [row0, row0+nrows) of the N x M score
+ * matrix d = A B^T (A [N,D], B [M,D], exact-fp32 MFMA).  The matrix is never materialised:
+ *   rank[i - row0] = #{ j != i : d[i,j] > d[i,i] }   (position of i in the descending sort)
+ *   top1[i - row0] = argmax_j d[i,j]                 (smallest j on exact ties)
+ * for i in the stripe; the diagonal convention requires row0 + nrows <= M. */
+size_t cmhse_sim_rank_workspace(int32_t nrows);
+int cmhse_sim_rank(const float* A, const float* B, int32_t N, int32_t M, int32_t D, int32_t row0,
+                   int32_t nrows, int32_t* rank, int32_t* top1, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* Replaces loss.cosine_sim (loss.py:12-13): scores[n,m] = im s^T, exact fp32. */
+int cmhse_cosine_sim(const float* im, const float* s, int32_t n, int32_t m, int32_t D,
+                     float* scores, void* stream);
+
+/* Replaces loss.ContrastiveLoss.forward (loss.py:86-117) for im [n,D], s [n,D]:
+ *   cost_s = max(0, margin + S - diag_i), cost_im = max(0, margin + S - diag_j), diagonals cleared,
+ *   max_violation: row/column maxima instead of all entries; norm: divide by n*n.
+ * Writes the scalar loss to *loss (device).  `scores_out` ([n,n], may be NULL -> kept in the
+ * workspace) receives the score matrix (needed by the backward pass). */
+size_t cmhse_contrastive_workspace(int32_t n);
+int cmhse_contrastive_fwd(const float* im, const float* s, int32_t n, int32_t D, float margin,
+                          int32_t max_violation, int32_t norm, float* loss, float* scores_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Text for an error code returned by the functions above (static storage). */
+const char* cmhse_strerror(int code);
+
+/* Library / target identification: "cmhse_hip <version> gfx950". */
+const char* cmhse_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMHSE_HIP_H_ */

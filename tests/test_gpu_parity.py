@@ -1,0 +1,346 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors produced by the
+reference (tests/golden) and against the CPU oracle on seeded inputs.
+
+Bars (BASELINE.json north_star): integer ranks / top-1 / R@K / medr bit-identical; embeddings and
+losses within 1e-4 (fp32); loss tolerance is relative for |loss| > 1 (an fp32 loss of magnitude
+5e3 has an ulp of 5e-4, so an absolute 1e-4 is not representable there).
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_state_dicts, golden_batches
+
+pytestmark = pytest.mark.gpu
+
+EMB_TOL = 1e-4
+
+
+def loss_close(got, want):
+  return abs(float(got) - float(want)) <= 1e-4 * max(1.0, abs(float(want)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+  assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+  from cmhse_amd import _lib
+  _lib.load()     # fail loudly if the HIP library is missing
+  return torch.device('cuda', 0)
+
+
+def make_layer(cls_name, I, H, sd, dev):
+  from cmhse_amd import layers
+  layer = getattr(layers, cls_name)(I, H)
+  layer.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in sd.items()})
+  return layer.to(dev)
+
+
+@pytest.mark.parametrize('cls', ['Attention', 'Maxout', 'Seq2Seq'])
+@pytest.mark.parametrize('tag', ['ragged', 'equal', 'one'])
+def test_layers_vs_golden(dev, cls, tag):
+  g = load_golden('layers.npz')
+  sd = {k[len(cls) + 4:]: g[k] for k in g.files if k.startswith(cls + '.sd.')}
+  layer = make_layer(cls, 24, 32, sd, dev)
+  key = '%s.%s' % (cls, tag)
+  x = torch.from_numpy(g[key + '.x']).to(dev)
+  lens = torch.from_numpy(g[key + '.lens'])
+  h0 = torch.from_numpy(g[key + '.h0']).to(dev)
+  with torch.no_grad():
+    y = layer(x, lens).cpu().numpy()
+    y_h0 = layer(x, lens, h0).cpu().numpy()
+  np.testing.assert_allclose(y, g[key + '.out'], atol=EMB_TOL, rtol=0)
+  np.testing.assert_allclose(y_h0, g[key + '.out_h0'], atol=EMB_TOL, rtol=0)
+
+
+@pytest.mark.parametrize('n', [5, 16, 37])
+def test_loss_vs_golden(dev, n):
+  from cmhse_amd import ops
+  from cmhse_amd.loss import ContrastiveLoss, cosine_sim
+  g = load_golden('loss.npz')
+  a = torch.from_numpy(g['n%d.a' % n]).to(dev)
+  b = torch.from_numpy(g['n%d.b' % n]).to(dev)
+  an, bn = ops.l2norm_rows(a), ops.l2norm_rows(b)
+  np.testing.assert_allclose(an.cpu().numpy(), g['n%d.a_norm' % n], atol=1e-6, rtol=0)
+  np.testing.assert_allclose(cosine_sim(an, bn).cpu().numpy(), g['n%d.scores' % n], atol=1e-5,
+                             rtol=0)
+  for mv in (0, 1):
+    for nm in (0, 1):
+      crit = ContrastiveLoss(margin=0.2, measure='cosine', max_violation=bool(mv), norm=bool(nm))
+      tag = 'n%d.mv%d.norm%d' % (n, mv, nm)
+      assert loss_close(crit(an, bn).item(), g[tag + '.ab']), tag
+      assert loss_close(crit(an, an).item(), g[tag + '.aa']), tag
+
+
+def test_normalize_zero_rows(dev):
+  from cmhse_amd import ops
+  g = load_golden('loss.npz')
+  y = ops.l2norm_rows(torch.from_numpy(g['normalize.zero_rows.x']).to(dev)).cpu().numpy()
+  np.testing.assert_allclose(y, g['normalize.zero_rows.y'], atol=1e-7, rtol=0)
+
+
+@pytest.mark.parametrize('n', [50, 203])
+def test_rank_vs_golden_bit_exact(dev, n):
+  from cmhse_amd.evaluation import i2t, t2i
+  g = load_golden('rank.npz')
+  a, b = g['n%d.images' % n], g['n%d.captions' % n]
+  for nm, fn in [('i2t', i2t), ('t2i', t2i)]:
+    rep, top1, ranks = fn(a, b)
+    np.testing.assert_array_equal(ranks, g['n%d.%s.ranks' % (n, nm)])
+    np.testing.assert_array_equal(top1, g['n%d.%s.top1' % (n, nm)])
+    got = np.array([rep[k] for k in ['r1', 'r5', 'r10', 'medr', 'meanr', 'sum']])
+    np.testing.assert_array_equal(got, g['n%d.%s.report' % (n, nm)])
+    assert ranks.dtype == np.float64 and top1.dtype == np.float64
+
+
+def golden_opt(rnn_type, **kw):
+  opt = argparse.Namespace(
+      margin=0.2, word_dim=12, embed_size=32, grad_clip=0.0, learning_rate=0.001,
+      max_violation=False, img_dim=24, measure='cosine', rnn_type=rnn_type, img_first_size=32,
+      cap_first_size=32, low_level_loss=False, weak_low_level_loss=False, reconstruct_loss=False,
+      lowest_reconstruct_loss=False, norm=False, data_name='anet_precomp', vocab_size=60)
+  for k, v in kw.items():
+    setattr(opt, k, v)
+  return opt
+
+
+def golden_model(rnn_type, g, **kw):
+  from cmhse_amd.model import VSE
+  opt = golden_opt(rnn_type, **kw)
+  model = VSE(opt)
+  sds = golden_state_dicts(g)
+  model.load_state_dict([{k: torch.from_numpy(v) for k, v in sd.items()} for sd in sds], opt)
+  return opt, model
+
+
+def torch_batches(batches):
+  return [tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in b)
+          for b in batches]
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_model_vs_golden(dev, rnn_type):
+  """VSE.forward_emb / structure_emb / encode_data / i2t / t2i against the reference's outputs."""
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import encode_data, i2t, t2i, LogCollector
+  g = load_golden('model_%s.npz' % rnn_type)
+  opt, model = golden_model(rnn_type, g)
+  batches = torch_batches(golden_batches(g))
+  b = batches[0]
+  with torch.no_grad():
+    clip_emb, cap_emb, word = model.forward_emb(b[0], b[1], b[4], b[5], return_word=True)
+    vid_ctx, para_ctx = model.forward_emb(b[2], b[3], b[6], b[7])
+    vid_emb, para_emb = model.structure_emb(clip_emb, cap_emb, b[8], b[9], vid_ctx, para_ctx)
+    vid_nc, para_nc = model.structure_emb(clip_emb, cap_emb, b[8], b[9])
+  for nm, v in [('clip_emb', clip_emb), ('cap_emb', cap_emb), ('word', word),
+                ('vid_context', vid_ctx), ('para_context', para_ctx), ('vid_emb', vid_emb),
+                ('para_emb', para_emb), ('vid_emb_noctx', vid_nc), ('para_emb_noctx', para_nc)]:
+    np.testing.assert_allclose(v.cpu().numpy(), g['fwd.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+
+  res = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  for i, nm in enumerate(['vid_embs', 'para_embs', 'clip_embs', 'cap_embs', 'vid_contexts',
+                          'para_contexts']):
+    assert res[i].dtype == np.float32
+    np.testing.assert_allclose(res[i], g['enc.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+  assert list(res[6]) == list(g['enc.num_clips_total'])
+  # per-batch 'Letest' meter: last value and running average, like the reference's LogCollector
+  want = g['enc.test_losses']
+  meter = model.logger.meters['Letest']
+  assert loss_close(meter.val, want[-1])
+  sizes = [len(b_[8]) for b_ in batches]
+  avg = sum(w * s for w, s in zip(want, sizes)) / (.0001 + sum(sizes))
+  assert abs(meter.avg - avg) < 1e-4
+  for nm, fn in [('i2t', i2t), ('t2i', t2i)]:
+    rep, top1, ranks = fn(res[0], res[1])
+    np.testing.assert_array_equal(ranks, g['enc.%s.ranks' % nm])
+    np.testing.assert_array_equal(top1, g['enc.%s.top1' % nm])
+    got = np.array([rep[k] for k in ['r1', 'r5', 'r10', 'medr', 'meanr', 'sum']])
+    np.testing.assert_array_equal(got, g['enc.%s.report' % nm])
+
+
+class MeterLog(object):
+  def __init__(self):
+    self.calls = []
+
+  def update(self, k, v, n=0):
+    self.calls.append((k, float(v), int(n)))
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_train_loss_meters_vs_golden(dev, rnn_type):
+  """Forward half of VSE.train_emb: the (name, value, n) stream sent to the logger."""
+  g = load_golden('model_%s.npz' % rnn_type)
+  batch = torch_batches(golden_batches(g))[1]
+  for mv in (0, 1):
+    for nm in (0, 1):
+      opt, model = golden_model(rnn_type, g, max_violation=bool(mv), norm=bool(nm),
+                                low_level_loss=True)
+      model.logger = MeterLog()
+      with torch.no_grad():
+        model.train_losses(opt, *batch)
+      tag = 'train.mv%d.norm%d' % (mv, nm)
+      assert [c[0] for c in model.logger.calls] == [str(s) for s in g[tag + '.names']]
+      for c, want in zip(model.logger.calls, g[tag + '.values']):
+        assert loss_close(c[1], want), (tag, c)
+      assert [c[2] for c in model.logger.calls] == list(g[tag + '.n'])
+
+
+# ------------------------------------------------------------------------------------------
+# seeded comparisons with the oracle at sizes that exercise tiling edges
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('pool', ['attention', 'maxout', 'seq2seq'])
+@pytest.mark.parametrize('S,T,I,H', [(3, 5, 10, 33),       # odd widths: scalar-load path
+                                     (150, 9, 500, 96),    # > one M tile, H not a tile multiple
+                                     (70, 17, 300, 256)])
+def test_gru_pool_vs_oracle(dev, oracle, pool, S, T, I, H):
+  from cmhse_amd import layers
+  rng = np.random.RandomState(S + T)
+  cls = {'attention': 'Attention', 'maxout': 'Maxout', 'seq2seq': 'Seq2Seq'}[pool]
+  torch.manual_seed(3)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy() for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[0] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  with torch.no_grad():
+    y = layer(torch.from_numpy(x).to(dev), torch.from_numpy(lens)).cpu().numpy()
+    y0 = layer(torch.from_numpy(x).to(dev), torch.from_numpy(lens),
+               torch.from_numpy(h0).to(dev)).cpu().numpy()
+  want = oracle.pooled_gru_forward(pool, x, lens, sd, None, np.float64)
+  want0 = oracle.pooled_gru_forward(pool, x, lens, sd, h0, np.float64)
+  np.testing.assert_allclose(y, want, atol=EMB_TOL, rtol=0)
+  np.testing.assert_allclose(y0, want0, atol=EMB_TOL, rtol=0)
+
+
+@pytest.mark.parametrize('n,m,d', [(1, 1, 8), (129, 300, 64), (515, 515, 1024), (257, 400, 30)])
+def test_sim_rank_vs_oracle(dev, oracle, n, m, d):
+  """Rectangular and non-tile-multiple shapes; ranks compared exactly on tie-free rows."""
+  from cmhse_amd import ops, synthetic
+  rng = np.random.RandomState(n + m)
+  a = rng.standard_normal((n, d)).astype(np.float32)
+  b = rng.standard_normal((m, d)).astype(np.float32)
+  k = min(n, m)
+  b[:k] += 2.0 * a[:k]
+  a /= np.linalg.norm(a, axis=1, keepdims=True)
+  b /= np.linalg.norm(b, axis=1, keepdims=True)
+  d64 = a.astype(np.float64) @ b.astype(np.float64).T
+  diag = d64[np.arange(n), np.arange(n)][:, None]
+  gap = np.abs(d64 - diag)
+  gap[np.arange(n), np.arange(n)] = 1.0
+  ok = gap.min(axis=1) > 1e-5
+  srt = np.sort(d64, axis=1)
+  ok_top = (srt[:, -1] - srt[:, -2]) > 1e-5 if m > 1 else np.ones(n, bool)
+  rank, top1 = ops.sim_rank(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+  want_rank = ((d64 > diag).sum(axis=1) - 0).astype(np.int64)
+  np.testing.assert_array_equal(rank.cpu().numpy()[ok], want_rank[ok])
+  np.testing.assert_array_equal(top1.cpu().numpy()[ok_top], d64.argmax(axis=1)[ok_top])
+  assert ok.mean() > 0.99
+
+
+def test_sim_rank_stripes_match_full(dev):
+  """Row-stripe calls (the multi-GPU sharding unit) give exactly the full-matrix ranks."""
+  from cmhse_amd import ops, synthetic
+  a, b = synthetic.correlated_embeddings(700, 256, 3.0, seed=4)
+  ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+  rank, top1 = ops.sim_rank(ta, tb)
+  for parts in (2, 3, 8):
+    bounds = np.linspace(0, 700, parts + 1).astype(int)
+    rs, ts = [], []
+    for p in range(parts):
+      r, t = ops.sim_rank(ta, tb, int(bounds[p]), int(bounds[p + 1] - bounds[p]))
+      rs.append(r)
+      ts.append(t)
+    assert torch.equal(torch.cat(rs), rank) and torch.equal(torch.cat(ts), top1)
+
+
+def test_sim_rank_tie_rule(dev):
+  """Documented tie rule: strict '>' for the rank, smallest column for top1."""
+  from cmhse_amd import ops
+  a = torch.zeros(4, 8, device=dev)
+  b = torch.zeros(4, 8, device=dev)
+  a[:, 0] = 1.0
+  b[:, 0] = 1.0          # every score equals 1.0
+  rank, top1 = ops.sim_rank(a, b)
+  assert rank.tolist() == [0, 0, 0, 0] and top1.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize('n', [1, 2, 64, 65, 300])
+def test_contrastive_vs_oracle(dev, oracle, n):
+  from cmhse_amd import ops
+  rng = np.random.RandomState(n)
+  a = rng.standard_normal((n, 128)).astype(np.float32)
+  b = (a + rng.standard_normal((n, 128))).astype(np.float32)
+  a /= np.linalg.norm(a, axis=1, keepdims=True)
+  b /= np.linalg.norm(b, axis=1, keepdims=True)
+  ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+  for mv in (False, True):
+    for nm in (False, True):
+      got = ops.contrastive_fwd(ta, tb, 0.2, mv, nm).item()
+      want = oracle.contrastive_loss(a, b, 0.2, mv, nm, np.float64)
+      assert loss_close(got, want), (n, mv, nm, got, want)
+
+
+def test_superbatch_equals_per_batch(dev):
+  """encode_data's fused super-batch gives the same embeddings as per-batch VSE calls."""
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import encode_data
+  g = load_golden('model_attention.npz')
+  opt, model = golden_model('attention', g)
+  spec = synthetic.ragged_spec(23, seed=5)
+  batches = synthetic.make_batches(spec, 6, opt.img_dim, opt.vocab_size, seed=1)
+  res = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  from cmhse_amd import ops
+  pos = 0
+  with torch.no_grad():
+    for b in batches:
+      clip_emb, cap_emb = model.forward_emb(b[0], b[1], b[4], b[5])
+      vc, pc = model.forward_emb(b[2], b[3], b[6], b[7])
+      ve, pe = model.structure_emb(clip_emb, cap_emb, b[8], b[9], vc, pc)
+      B = len(b[8])
+      np.testing.assert_allclose(ops.l2norm_rows(ve).cpu().numpy(), res[0][pos:pos + B],
+                                 atol=1e-6, rtol=0)
+      np.testing.assert_allclose(ops.l2norm_rows(pe).cpu().numpy(), res[1][pos:pos + B],
+                                 atol=1e-6, rtol=0)
+      pos += B
+
+
+def test_cpu_tensor_is_rejected_loudly(dev):
+  from cmhse_amd import ops
+  with pytest.raises(RuntimeError):
+    ops.l2norm_rows(torch.zeros(2, 4))
+  with pytest.raises(RuntimeError):
+    ops.sim_rank(torch.zeros(2, 4), torch.zeros(2, 4))
+
+
+def test_full_size_rank_properties(dev, oracle):
+  """BASELINE full-val size (4917 x 4917 x 1024): size-independent properties.
+  (1) ranks of A vs A are all zero (a row's best match is itself);
+  (2) permuting the gallery permutes top1 and leaves ranks unchanged;
+  (3) a 512-row sample of the stripe agrees exactly with the fp64 oracle on tie-free rows."""
+  from cmhse_amd import ops, synthetic
+  n = 4917
+  a, b = synthetic.correlated_embeddings(n, 1024, 3.0, seed=0)
+  ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+  r_self, t_self = ops.sim_rank(ta, ta)
+  assert int(r_self.abs().sum()) == 0
+  assert torch.equal(t_self.cpu(), torch.arange(n, dtype=torch.int32))
+  rank, top1 = ops.sim_rank(ta, tb)
+  rep = oracle.recall_report(rank.cpu().numpy())
+  assert 25.0 < rep['r1'] < 40.0          # R@1 ~ 33 %
+  sample = np.arange(0, n, n // 512)[:512]
+  d64 = a[sample].astype(np.float64) @ b.astype(np.float64).T
+  diag = d64[np.arange(len(sample)), sample][:, None]
+  gap = np.abs(d64 - diag)
+  gap[np.arange(len(sample)), sample] = 1.0
+  ok = gap.min(axis=1) > 1e-6
+  want = (d64 > diag).sum(axis=1)
+  np.testing.assert_array_equal(rank.cpu().numpy()[sample][ok], want[ok])
+  assert ok.mean() > 0.98

@@ -1,0 +1,137 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares,
+host-side schedule/meters/report logic, the synthetic batch contract, loud failure without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+  from cmhse_amd import _lib, build
+  build.build()
+  lib = _lib.load()
+  header = open(os.path.join(REPO, 'include', 'cmhse_hip.h')).read()
+  declared = set(re.findall(r'\b(cmhse_[a-z0-9_]+)\s*\(', header))
+  assert declared, 'no declarations parsed'
+  assert declared == set(_lib.SIGNATURES.keys())
+  for name in declared:
+    assert hasattr(lib, name), name
+  assert lib.cmhse_version().decode().endswith('gfx950')
+  assert lib.cmhse_strerror(-2).decode().startswith('workspace')
+  # size queries are pure host functions
+  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 32, 0) >= 10 * 32 * 4
+  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 32, 1) > lib.cmhse_gru_pool_workspace(4, 3, 10, 32, 0)
+  assert lib.cmhse_sim_rank_workspace(100) >= 100 * 12
+  assert lib.cmhse_contrastive_workspace(10) >= 400
+
+
+def test_argument_validation_without_gpu():
+  """Bad arguments are rejected with error codes before anything touches the device."""
+  from cmhse_amd import _lib
+  lib = _lib.load()
+  assert lib.cmhse_l2norm_rows(None, None, 1, 1, 1, None) == -1
+  assert lib.cmhse_sim_rank(None, None, 1, 1, 1, 0, 1, None, None, None, 0, None) == -1
+  assert lib.cmhse_contrastive_fwd(None, None, 1, 1, 0.2, 0, 0, None, None, None, 0, None) == -1
+  assert lib.cmhse_gru_pool_fwd(None, None, 0, None, None, 0, None) == -1
+
+
+def test_seq_schedule_matches_pack_padded_sequence():
+  from cmhse_amd.ops import SeqSchedule
+  from torch.nn.utils.rnn import pack_padded_sequence
+  lens = np.array([3, 7, 1, 7, 4, 2])
+  ptrs = np.arange(len(lens), dtype=np.uint64) * 1000
+  s = SeqSchedule(lens, 'cpu', x_ptrs=ptrs)
+  x = torch.zeros(len(lens), 7, 1)
+  packed = pack_padded_sequence(x[torch.from_numpy(s.order)], s.lens_sorted.tolist(),
+                                batch_first=True)
+  assert packed.batch_sizes.tolist() == s.step_count_host.tolist()
+  assert s.sum_T == lens.sum() and s.Tmax == 7
+  meta = s.meta.numpy()
+  S = len(lens)
+  rows = meta[:S * 8].view(np.uint64)
+  assert rows.tolist() == (ptrs[s.order]).tolist()
+  v32 = meta[2 * S * 8:].view(np.int32)
+  assert v32[:S].tolist() == sorted(lens.tolist(), reverse=True)
+  assert v32[S:2 * S].tolist() == s.order.tolist()
+  assert v32[2 * S:].tolist() == np.concatenate([[0], np.cumsum(s.step_count_host)]).tolist()
+  with pytest.raises(ValueError):
+    SeqSchedule(np.array([2, 0]), 'cpu', x_ptrs=ptrs[:2])
+
+
+def test_meters_follow_reference_quirks():
+  from cmhse_amd.evaluation import AverageMeter, LogCollector
+  m = AverageMeter()
+  m.update(5)                       # n defaults to 0: records val only (evaluation.py:30)
+  assert str(m) == '5' and m.count == 0
+  m.update(2.0, 4)
+  assert abs(m.avg - 8.0 / 4.0001) < 1e-12
+  lc = LogCollector()
+  lc.update('Le_vid', 1.5, 2)
+  lc.update('Eit', 3)
+  assert str(lc) == 'Le_vid 1.5000 (1.4999)  Eit 3'   # avg = 3 / 2.0001
+
+
+@pytest.mark.parametrize('n', [50, 203])
+def test_report_from_ranks_vs_golden(n):
+  from cmhse_amd.evaluation import report_from_ranks
+  g = load_golden('rank.npz')
+  for nm in ['i2t', 't2i']:
+    rep = report_from_ranks(g['n%d.%s.ranks' % (n, nm)])
+    got = np.array([rep[k] for k in ['r1', 'r5', 'r10', 'medr', 'meanr', 'sum']])
+    np.testing.assert_array_equal(got, g['n%d.%s.report' % (n, nm)])
+
+
+def test_synthetic_batches_honour_the_12_tuple_contract():
+  from cmhse_amd import synthetic
+  spec = synthetic.anet_like_spec(50, seed=0)
+  batches = synthetic.make_batches(spec, 16, 20, 100, seed=0)
+  assert len(batches) == 4
+  seen = 0
+  for b in batches:
+    clips, caps, vids, pars, lc, lcap, lv, lp, nc, ncap, ind, cur = b
+    assert clips.shape[0] == caps.shape[0] == sum(nc) == len(lc) == len(lcap)
+    assert clips.shape[1] == int(lc.max()) and caps.shape[1] == int(lcap.max())
+    assert vids.shape[0] == pars.shape[0] == len(nc) == len(ind) == len(cur)
+    assert int(lc.max()) <= 80 and int(lv.max()) <= 80 and int(lc.min()) >= 1
+    j = 0
+    for v, c in enumerate(nc):          # paragraph = concatenation of its sentences
+      want = torch.cat([caps[j + k, :lcap[j + k]] for k in range(c)])
+      assert torch.equal(pars[v, :lp[v]], want)
+      assert float(clips[j, lc[j]:].abs().sum()) == 0.0      # zero padding
+      j += c
+    seen += len(nc)
+  assert seen == 50
+  assert spec.totals()['clips'] == sum(spec.num_clips)
+
+
+def test_product_path_fails_loudly_without_gpu():
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  import argparse
+  from cmhse_amd import ops
+  from cmhse_amd.model import VSE
+  from cmhse_amd.evaluation import i2t
+  with pytest.raises(RuntimeError):
+    ops.l2norm_rows(torch.zeros(2, 4))
+  with pytest.raises(RuntimeError):
+    i2t(np.zeros((2, 4), np.float32), np.zeros((2, 4), np.float32))
+  opt = argparse.Namespace(norm=False, grad_clip=0, img_dim=8, img_first_size=8, vocab_size=10,
+                           word_dim=4, cap_first_size=8, rnn_type='maxout', embed_size=8,
+                           data_name='x', margin=0.2, measure='cosine', max_violation=False,
+                           learning_rate=1e-3)
+  with pytest.raises(RuntimeError):
+    VSE(opt)
+
+
+def test_product_never_imports_the_oracle():
+  """The oracle is test infrastructure: no file of the package may reference it."""
+  pkg = os.path.join(REPO, 'cmhse_amd')
+  for root, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.hpp', '.h')):
+        text = open(os.path.join(root, f)).read()
+        assert 'cmhse_oracle' not in text and 'import oracle' not in text, f

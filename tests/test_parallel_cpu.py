@@ -1,0 +1,87 @@
+"""World-size-2 (and 3) gloo test of the sharded validation: partitioning, the all-gather of
+unequal shards, stripe ranking and the merge — with the CPU oracle standing in for the two HIP
+calls (tests only; the product defaults have no fallback)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _worker(rank, world, port, n_videos, batch, out_dir):
+  sys.path.insert(0, REPO)
+  sys.path.insert(0, os.path.join(REPO, 'oracle'))
+  import cmhse_oracle as oracle
+  from cmhse_amd import parallel_eval, synthetic
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  a, b = synthetic.correlated_embeddings(n_videos, 48, 2.0, seed=11)
+  # fake "loader": batch k carries its slice of precomputed embeddings; num_clips in slot 8
+  batches = []
+  for k0 in range(0, n_videos, batch):
+    k1 = min(n_videos, k0 + batch)
+    bt = [None] * 12
+    bt[8] = tuple([1] * (k1 - k0))
+    bt[0] = (a[k0:k1], b[k0:k1])
+    batches.append(tuple(bt))
+
+  def encode_fn(opt, model, mine):
+    if not mine:
+      return None
+    return (torch.from_numpy(np.concatenate([m[0][0] for m in mine])),
+            torch.from_numpy(np.concatenate([m[0][1] for m in mine])))
+
+  def rank_fn(q, g, row0, nrows):
+    d = q[row0:row0 + nrows].numpy().astype(np.float64) @ g.numpy().astype(np.float64).T
+    diag = d[np.arange(nrows), row0 + np.arange(nrows)][:, None]
+    return (torch.from_numpy((d > diag).sum(1).astype(np.int32)),
+            torch.from_numpy(d.argmax(1).astype(np.int32)))
+
+  res = parallel_eval.validate_sharded(None, None, batches, encode_fn=encode_fn, rank_fn=rank_fn,
+                                       device='cpu', dim=48)
+  np.savez(os.path.join(out_dir, 'r%d.npz' % rank), ranks_i=res[2], ranks_t=res[3],
+           top1_i=res[4], top1_t=res[5], rep_i=np.array(sorted(res[0].items()), dtype=object)[:, 1]
+           .astype(np.float64))
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_videos,batch', [(2, 37, 5), (3, 10, 4), (2, 3, 4)])
+def test_sharded_validation_matches_single_process(tmp_path, oracle, world, n_videos, batch):
+  from cmhse_amd import synthetic
+  port = _free_port()
+  mp.spawn(_worker, args=(world, port, n_videos, batch, str(tmp_path)), nprocs=world, join=True)
+  a, b = synthetic.correlated_embeddings(n_videos, 48, 2.0, seed=11)
+  _, top1_i, ranks_i = oracle.i2t(a, b, np.float64)
+  _, top1_t, ranks_t = oracle.t2i(a, b, np.float64)
+  for r in range(world):
+    got = np.load(os.path.join(str(tmp_path), 'r%d.npz' % r))
+    np.testing.assert_array_equal(got['ranks_i'], ranks_i)
+    np.testing.assert_array_equal(got['ranks_t'], ranks_t)
+    np.testing.assert_array_equal(got['top1_i'], top1_i)
+    np.testing.assert_array_equal(got['top1_t'], top1_t)
+
+
+def test_shard_range_is_a_partition():
+  from cmhse_amd.parallel_eval import shard_range
+  for n in [0, 1, 7, 154]:
+    for w in [1, 2, 3, 8]:
+      pieces = [shard_range(n, r, w) for r in range(w)]
+      assert pieces[0][0] == 0 and pieces[-1][1] == n
+      assert all(pieces[i][1] == pieces[i + 1][0] for i in range(w - 1))
+      sizes = [b - a for a, b in pieces]
+      assert max(sizes) - min(sizes) <= 1
