@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: video<->paragraph pairs encoded + scored per second.
+
+One "step" = one full validation pass of the hot path over a synthetic ActivityNet-val-shaped
+split: encode every clip / sentence / whole-video stream / paragraph with the
+hierarchical GRU encoders (level 1 + level 2, L2-normalise, per-loader-batch ContrastiveLoss like
+evaluation.py:129), then score all N x N video-paragraph pairs in both directions (i2t + t2i:
+ranks, top-1, Recall@K).  pairs = N^2; inputs are resident in HBM before the timed region.
+
+Workloads (config.workload):
+  anet_c3d_val   BASELINE configs[1] model (img_dim=500, embed=1024, attention pooling, loader
+                 batch 32) over the val_1-shaped split N=4917, sumC~17.5k  [default]
+  anet_icep_val  configs[4] model (img_dim=2048) over the same split
+  plumbing       configs[0]: 64 videos x 4 clips x 10 frames, batch 16
+
+N>1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL): the SAME split is
+sharded over ranks (strong scaling): each rank encodes its slice, embeddings are all-gathered,
+each rank scores its row stripe (cmhse_amd/parallel_eval.py).
+
+The JSON line also carries
+  roofline      for the dominant kernel (gru_step_kernel): algorithmic FLOPs of the timed launches
+                (2*3H*I + 2*3H*H + 14H per sequence-step) / their HIP-event time,
+                against the exact-fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+  cpu_baseline  the NumPy oracle (oracle/, "port") timed on this host's cores on a bounded
+                sample of the same workload, extrapolated to the full split (encode ~ N,
+                scoring ~ N^2) — a reported baseline, never the thing measured as `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from cmhse_amd import ops, parallel_eval, synthetic  # noqa: E402
+from cmhse_amd.evaluation import encode_data_device  # noqa: E402
+from cmhse_amd.model import VSE  # noqa: E402
+
+WORKLOADS = {
+    'anet_c3d_val': dict(n_videos=4917, batch=32, img_dim=500, feat='normal', vocab=13058,
+                         dataset='anet'),
+    'anet_icep_val': dict(n_videos=4917, batch=32, img_dim=2048, feat='relu', vocab=13058,
+                          dataset='anet'),
+    'didemo_icep_val': dict(n_videos=1004, batch=32, img_dim=2048, feat='relu', vocab=7205,
+                            dataset='didemo'),
+    'plumbing': dict(n_videos=64, batch=16, img_dim=500, feat='normal', vocab=13058,
+                     dataset='uniform'),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+
+
+def make_opt(wl, rnn_type, embed):
+  return argparse.Namespace(
+      margin=0.2, word_dim=300, embed_size=embed, grad_clip=0.0, learning_rate=0.001,
+      max_violation=False, img_dim=wl['img_dim'], measure='cosine', rnn_type=rnn_type,
+      img_first_size=embed, cap_first_size=embed, low_level_loss=False, weak_low_level_loss=False,
+      reconstruct_loss=False, lowest_reconstruct_loss=False, norm=False,
+      data_name='anet_precomp', vocab_size=wl['vocab'])
+
+
+def device_batch(spec, b0, b1, clip_pos, img_dim, vocab, feat, gen, device):
+  """One loader batch of the 12-tuple contract, generated directly in HBM."""
+  nclips = spec.num_clips[b0:b1]
+  sumC = sum(nclips)
+  fpc = torch.tensor(spec.frames_per_clip[clip_pos:clip_pos + sumC], dtype=torch.int64)
+  wps = torch.tensor(spec.words_per_sent[clip_pos:clip_pos + sumC], dtype=torch.int64)
+  fpv = torch.tensor(spec.frames_per_video[b0:b1], dtype=torch.int64)
+  B = b1 - b0
+
+  def feats(lens):
+    T = int(lens.max())
+    x = torch.randn(len(lens), T, img_dim, generator=gen, device=device)
+    if feat == 'relu':
+      x = (0.5 * x).abs_()
+    mask = torch.arange(T, device=device)[None, :] < lens.to(device)[:, None]
+    return x * mask[:, :, None]
+
+  clips, videos = feats(fpc), feats(fpv)
+  Lc = int(wps.max())
+  caps = torch.randint(4, vocab, (sumC, Lc), generator=gen, device=device)
+  caps = caps * (torch.arange(Lc, device=device)[None, :] < wps.to(device)[:, None])
+  starts = np.concatenate([[0], np.cumsum(nclips)])
+  par_len = torch.tensor([int(wps[starts[v]:starts[v + 1]].sum()) for v in range(B)],
+                         dtype=torch.int64)
+  pars = torch.zeros(B, int(par_len.max()), dtype=torch.int64, device=device)
+  caps_h, wps_l = caps.cpu(), wps.tolist()
+  for v in range(B):
+    toks = torch.cat([caps_h[j, :wps_l[j]] for j in range(starts[v], starts[v + 1])])
+    pars[v, :len(toks)] = toks.to(device)
+  return (clips, caps, videos, pars, fpc, wps, fpv, par_len, tuple(nclips), tuple(nclips),
+          tuple(range(b0, b1)), tuple('v_%06d' % k for k in range(b0, b1)))
+
+
+def build_loader(spec, wl, device, own_lo, own_hi, seed=0):
+  """All loader batches of the split; only batches [own_lo, own_hi) are materialised (the others
+  carry just num_clips, which is all parallel_eval needs from them)."""
+  gen = torch.Generator(device=device)
+  batches, clip_pos = [], 0
+  n, bs = spec.n_videos, wl['batch']
+  for bi, b0 in enumerate(range(0, n, bs)):
+    b1 = min(n, b0 + bs)
+    nclips = spec.num_clips[b0:b1]
+    if own_lo <= bi < own_hi:
+      gen.manual_seed(seed * 100003 + bi)
+      batches.append(device_batch(spec, b0, b1, clip_pos, wl['img_dim'], wl['vocab'], wl['feat'],
+                                  gen, device))
+    else:
+      stub = [None] * 12
+      stub[8] = tuple(nclips)
+      batches.append(tuple(stub))
+    clip_pos += sum(nclips)
+  return batches
+
+
+def gru_flops_per_step(I, H):
+  """algorithmic FLOPs of one GRU (sequence, timestep)."""
+  return 2 * 3 * H * I + 2 * 3 * H * H + 14 * H
+
+
+def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full):
+  """NumPy oracle on the host cores over the first `n_sample_batches` loader batches."""
+  sys.path.insert(0, os.path.join(REPO, 'oracle'))
+  import cmhse_oracle as oracle
+  sub = synthetic.SplitSpec(spec.num_clips, spec.frames_per_clip, spec.frames_per_video,
+                            spec.words_per_sent)
+  nv = min(spec.n_videos, n_sample_batches * wl['batch'])
+  sub.num_clips = sub.num_clips[:nv]
+  nc = sum(sub.num_clips)
+  sub.frames_per_clip = sub.frames_per_clip[:nc]
+  sub.words_per_sent = sub.words_per_sent[:nc]
+  sub.frames_per_video = sub.frames_per_video[:nv]
+  batches = synthetic.make_batches(sub, wl['batch'], wl['img_dim'], wl['vocab'], seed=0,
+                                   feat=wl['feat'])
+  np_batches = [tuple(x.numpy() if hasattr(x, 'numpy') else x for x in b) for b in batches]
+  sds = [{k: v.detach().cpu().numpy() for k, v in sd.items()} for sd in model.state_dict(opt)]
+  t0 = time.time()
+  res = oracle.encode_data(opt.rnn_type, sds, np_batches, margin=opt.margin)
+  t_enc = time.time() - t0
+  t0 = time.time()
+  oracle.i2t(res[0], res[1])
+  oracle.t2i(res[0], res[1])
+  t_score = time.time() - t0
+  scale = n_full / float(nv)
+  t_full = t_enc * scale + t_score * scale * scale
+  return {
+      'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': os.cpu_count(),
+      'kind': 'port',
+      'sample': ('NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS threads = host cores) on the '
+                 'first %d videos (%d loader batches) of the same split: encode %.2f s, i2t+t2i '
+                 '%.3f s; extrapolated to N=%d with encode ~ N and scoring ~ N^2'
+                 % (nv, len(batches), t_enc, t_score, n_full)),
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=3)
+  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--workload', default='anet_c3d_val', choices=sorted(WORKLOADS))
+  ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
+  ap.add_argument('--embed', type=int, default=1024)
+  ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
+  ap.add_argument('--cpu_batches', type=int, default=8,
+                  help='loader batches in the CPU-baseline sample (0 = skip)')
+  args = ap.parse_args()
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with '
+                     'torch.distributed.run)' % (args.gpus, world))
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', device_id=device)
+
+  wl = dict(WORKLOADS[args.workload])
+  if args.n_videos:
+    wl['n_videos'] = args.n_videos
+  opt = make_opt(wl, args.rnn_type, args.embed)
+  torch.manual_seed(1)
+  model = VSE(opt)       # same seed on every rank -> replicated weights
+  if wl['dataset'] == 'uniform':
+    spec = synthetic.uniform_spec(wl['n_videos'], clips=4, frames=10, words=12)
+  else:
+    spec = synthetic.anet_like_spec(wl['n_videos'], seed=0, dataset=wl['dataset'])
+  n_batches = (spec.n_videos + wl['batch'] - 1) // wl['batch']
+  lo, hi = parallel_eval.shard_range(n_batches, rank, world)
+  batches = build_loader(spec, wl, device, lo, hi)
+  N = spec.n_videos
+  quiet = lambda *a, **k: None
+
+  def step():
+    if world == 1:
+      cat, _, _ = encode_data_device(opt, model, batches, logging=quiet)
+      r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
+      r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
+      return r_i, r_t
+    res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed)
+    return res[2], res[3]
+
+  def sync():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step()
+  sync()
+  t0 = time.perf_counter()
+  with ops.StepTimers() as timers:
+    for _ in range(args.steps):
+      ranks_i, ranks_t = step()
+    sync()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  # roofline of the dominant kernel from the HIP-event spans around the per-step GRU launches
+  spans = timers.collect()
+  flops = sum(sum_T * gru_flops_per_step(I, H) for (_, _, sum_T, I, H, _, _) in spans)
+  ms = sum(s[0] for s in spans)
+  launches = sum(s[1] for s in spans)
+  achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+  ms_per_step = elapsed / args.steps * 1e3
+  pairs = float(N) * float(N)
+
+  if rank == 0:
+    if isinstance(ranks_i, torch.Tensor):
+      ranks_i = ranks_i.cpu().numpy()
+    r1 = 100.0 * float((np.asarray(ranks_i) < 1).mean())
+    out = {
+        'metric': 'video-paragraph pairs encoded+scored per second (full hot path: hierarchical '
+                  'GRU encode + i2t + t2i)',
+        'value': pairs * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': args.workload, 'n_videos': N, 'n_clips': len(spec.frames_per_clip),
+                   'loader_batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': args.embed,
+                   'rnn_type': args.rnn_type, 'step': 'encode_data + i2t + t2i over the split',
+                   'sharding': 'videos over ranks, all-gather embeddings, row-stripe scoring'},
+        'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
+        'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
+                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'launches': launches, 'avg_launch_us': (ms * 1e3 / launches) if launches else None,
+                     'flops_per_launch': (flops / launches) if launches else None,
+                     'kernel_time_share': (ms * 1e-3) / elapsed if elapsed > 0 else None},
+    }
+    if world == 1 and args.cpu_batches > 0:
+      out['cpu_baseline'] = cpu_baseline(wl, opt, model, spec, args.cpu_batches, N)
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -25,7 +25,8 @@ class SeqBatch(ctypes.Structure):
   _fields_ = [('S', c_int32), ('Tmax', c_int32), ('I', c_int32), ('H', c_int32),
               ('x_rows', c_void_p), ('tok_rows', c_void_p), ('emb_table', c_void_p),
               ('vocab', c_int32), ('h0_rows', c_void_p), ('lens', c_void_p),
-              ('out_row', c_void_p), ('step_off', c_void_p), ('step_count_host', c_void_p)]
+              ('out_row', c_void_p), ('step_off', c_void_p), ('step_count_host', c_void_p),
+              ('step_timer', c_void_p)]
 
 
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
@@ -45,6 +46,9 @@ SIGNATURES = {
     'cmhse_contrastive_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float,
                                              c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                              c_size_t, c_void_p]),
+    'cmhse_timer_create': (c_void_p, []),
+    'cmhse_timer_destroy': (None, [c_void_p]),
+    'cmhse_timer_elapsed_ms': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float)]),
     'cmhse_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'cmhse_version': (ctypes.c_char_p, []),
 }

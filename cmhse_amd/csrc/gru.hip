@@ -27,6 +27,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <new>
+
 #include "../../include/cmhse_hip.h"
 #include "nt_core.hpp"
 
@@ -345,6 +347,10 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
   for (int c = threadIdx.x; c < cols; c += kThreads) dst[c] = src[c];
 }
 
+struct Timer {
+  hipEvent_t start, stop;
+};
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace cmhse
@@ -410,6 +416,8 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
   const size_t smem = TileSmem<kGruBM, 3 * kGruBU>::kBytes;
   const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
+  Timer* timer = static_cast<Timer*>(b->step_timer);
+  if (timer) hipEventRecord(timer->start, stream);
   int64_t off = 0;
   for (int t = 0; t < b->Tmax; ++t) {
     const int S_t = b->step_count_host[t];
@@ -421,6 +429,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     hipLaunchKernelGGL(gru_step_kernel, dim3(grid), dim3(kThreads), smem, stream, p);
     off += S_t;
   }
+  if (timer) hipEventRecord(timer->stop, stream);
   if (pool_mode == CMHSE_POOL_ATTN) {
     const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
     float* e_part = reinterpret_cast<float*>(
@@ -472,4 +481,35 @@ extern "C" int cmhse_gather_rows(const float* table, const int64_t* ids, int64_t
                      static_cast<hipStream_t>(stream_), table,
                      reinterpret_cast<const long long*>(ids), out, cols, vocab);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" void* cmhse_timer_create(void) {
+  Timer* t = new (std::nothrow) Timer;
+  if (!t) return nullptr;
+  if (hipEventCreate(&t->start) != hipSuccess) {
+    delete t;
+    return nullptr;
+  }
+  if (hipEventCreate(&t->stop) != hipSuccess) {
+    hipEventDestroy(t->start);
+    delete t;
+    return nullptr;
+  }
+  return t;
+}
+
+extern "C" void cmhse_timer_destroy(void* timer) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t) return;
+  hipEventDestroy(t->start);
+  hipEventDestroy(t->stop);
+  delete t;
+}
+
+extern "C" int cmhse_timer_elapsed_ms(void* timer, float* ms_host) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t || !ms_host) return CMHSE_ERR_ARG;
+  if (hipEventSynchronize(t->stop) != hipSuccess) return CMHSE_ERR_LAUNCH;
+  if (hipEventElapsedTime(ms_host, t->start, t->stop) != hipSuccess) return CMHSE_ERR_LAUNCH;
+  return CMHSE_OK;
 }

@@ -89,6 +89,34 @@ def padded_row_ptrs(t):
   return (np.uint64(t.data_ptr()) + np.arange(S, dtype=np.uint64) * np.uint64(stride))
 
 
+class StepTimers(object):
+  """Measurement aid for bench.py: while active, every cmhse_gru_pool_fwd call gets a
+  cmhse_timer around its per-step GRU kernels; `collect()` returns a list of
+  (elapsed_ms, n_launches, sum_T, I, H, had_h0) and frees the timers."""
+  active = None
+
+  def __init__(self):
+    self.items = []
+
+  def __enter__(self):
+    StepTimers.active = self
+    return self
+
+  def __exit__(self, *a):
+    StepTimers.active = None
+
+  def collect(self):
+    lib = _lib.load()
+    out = []
+    for handle, meta in self.items:
+      ms = ctypes.c_float(0.0)
+      _lib.check(lib.cmhse_timer_elapsed_ms(handle, ctypes.byref(ms)), 'cmhse_timer_elapsed_ms')
+      lib.cmhse_timer_destroy(handle)
+      out.append((ms.value,) + meta)
+    self.items = []
+    return out
+
+
 def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None):
   """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
@@ -125,6 +153,11 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
   b.h0_rows = sched.p_h0
   b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
   b.step_count_host = sched.step_count_host.ctypes.data
+  if StepTimers.active is not None:
+    handle = lib.cmhse_timer_create()
+    b.step_timer = handle
+    StepTimers.active.items.append((handle, (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None,
+                                             S)))
   rc = lib.cmhse_gru_pool_fwd(ctypes.byref(b), ctypes.byref(w), pool_mode, out.data_ptr(),
                               ws.data_ptr(), ws_bytes, _stream())
   _lib.check(rc, 'cmhse_gru_pool_fwd')

@@ -81,6 +81,8 @@ typedef struct cmhse_seq_batch {
   const int32_t* step_off;  /* [Tmax+1] step_off[t] = sum_{t'<t} #{s : lens[s] > t'}: row offset
                                of step t in the time-major packed hidden-state buffer */
   const int32_t* step_count_host; /* HOST [Tmax] #{s : lens[s] > t} (sizes the per-step grids) */
+  void* step_timer;         /* optional cmhse_timer (or NULL): brackets the per-step GRU kernels of
+                               this call on `stream` — measurement only, no effect on results */
 } cmhse_seq_batch;
 
 /* Bytes of workspace cmhse_gru_pool_fwd needs for this batch: the time-major packed hidden states
@@ -132,6 +134,13 @@ size_t cmhse_contrastive_workspace(int32_t n);
 int cmhse_contrastive_fwd(const float* im, const float* s, int32_t n, int32_t D, float margin,
                           int32_t max_violation, int32_t norm, float* loss, float* scores_out,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement aid (bench.py's roofline leg): a pair of HIP events owned by the handle.  A timer
+ * passed in cmhse_seq_batch.step_timer is recorded before the first and after the last GRU step
+ * kernel of that call; cmhse_timer_elapsed_ms waits for the stop event and returns the span. */
+void* cmhse_timer_create(void);
+void cmhse_timer_destroy(void* timer);
+int cmhse_timer_elapsed_ms(void* timer, float* ms_host);
 
 /* Text for an error code returned by the functions above (static storage). */
 const char* cmhse_strerror(int code);
