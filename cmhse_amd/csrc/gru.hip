@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <new>
 
@@ -60,6 +61,7 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 constexpr int kGruBM = 128;  // sequences per workgroup
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams p) {
   constexpr int BM = kGruBM, BU = kGruBU, BNR = 3 * BU;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,41 +75,40 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
   const int I = p.I, H = p.H;
 
   // Rows this thread stages.  A: sequences m0 + srow + 64 i.  B: gate g, unit u0 + (row % BU).
-  const float* ax[BM / 64];
-  const float* ah[BM / 64];
-  bool avx = (I % 4 == 0), avh = (H % 4 == 0);
+  // Out-of-range rows are clamped to a valid row and flagged invalid (read as zeros).
+  rowaddr_t ax[BM / 64];
+  rowaddr_t ah[BM / 64];
+  bool av[BM / 64];
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i) {
     const int m = m0 + srow + 64 * i;
-    ax[i] = nullptr;
-    ah[i] = nullptr;
-    if (m < p.S_t) {
-      if (p.tok_rows != nullptr) {
-        long long tok = reinterpret_cast<const long long*>(p.tok_rows[m])[p.t];
-        if (tok < 0) tok = 0;
-        if (tok >= p.vocab) tok = p.vocab - 1;
-        ax[i] = p.emb + tok * I;
-      } else {
-        ax[i] = reinterpret_cast<const float*>(p.x_rows[m]) + static_cast<int64_t>(p.t) * I;
-      }
-      if (p.t > 0)
-        ah[i] = p.hs + (p.off_prev + m) * H;
-      else if (p.h0_rows != nullptr)
-        ah[i] = reinterpret_cast<const float*>(p.h0_rows[m]);
-      avx = avx && aligned16(ax[i]);
-      avh = avh && (ah[i] == nullptr || aligned16(ah[i]));
+    av[i] = m < p.S_t;
+    const int mc = av[i] ? m : (p.S_t - 1);
+    if (p.tok_rows != nullptr) {
+      long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
+      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
+      ax[i] = row_addr(p.emb + tok * I);
+    } else {
+      ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * I * 4u;
     }
+    if (p.t > 0)
+      ah[i] = row_addr(p.hs + (p.off_prev + mc) * H);
+    else if (p.h0_rows != nullptr)
+      ah[i] = p.h0_rows[mc];
+    else
+      ah[i] = row_addr(p.w_hh);  // unused: the h phase is skipped
   }
-  const float* bx[BNR / 64];
-  const float* bh[BNR / 64];
-  const bool bvx = (I % 4 == 0) && aligned16(p.w_ih);
-  const bool bvh = (H % 4 == 0) && aligned16(p.w_hh);
+  rowaddr_t bx[BNR / 64];
+  rowaddr_t bh[BNR / 64];
+  bool bv[BNR / 64];
 #pragma unroll
   for (int i = 0; i < BNR / 64; ++i) {
     const int br = srow + 64 * i;
     const int g = br / BU, u = u0 + (br % BU);
-    bx[i] = (u < H) ? p.w_ih + (static_cast<int64_t>(g) * H + u) * I : nullptr;
-    bh[i] = (u < H) ? p.w_hh + (static_cast<int64_t>(g) * H + u) * H : nullptr;
+    bv[i] = u < H;
+    const int uc = bv[i] ? u : (H - 1);
+    bx[i] = row_addr(p.w_ih + (static_cast<int64_t>(g) * H + uc) * I);
+    bh[i] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
   }
 
   // accumulators per 32-sequence sub-tile: 0 = r, 1 = z, 2 = W_in x, 3 = W_hn h
@@ -119,9 +120,9 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
 
   const int a_row0 = wm * 64;
   const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
-  nt_phase<BM, BNR, 2, 3, 4, 2>(smem, ax, bx, I, avx, bvx, a_row0, b_row0, acc);
+  nt_phase<BM, BNR, 2, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-  if (have_h) nt_phase<BM, BNR, 2, 3, 4, 3>(smem, ah, bh, H, avh, bvh, a_row0, b_row0, acc);
+  if (have_h) nt_phase<BM, BNR, 2, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
 
   // ---- epilogue: gates, state update, pooling ----
   const int u = u0 + wn * 32 + acc_col(lane);
@@ -157,6 +158,136 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Latency-shaped GRU step for small active sets (training batches, the long ragged tails of
+// paragraphs): with S_t <= ~2k sequences the 128 x 64 tile above fills only a few CUs and every
+// launch costs one full K loop (~150 us).  Here a workgroup owns 32 sequences x 8 hidden units:
+//   * ONE MFMA per k-step computes all three gates of those 8 units: the 32 B columns of
+//     v_mfma_f32_32x32x2_f32 are [r x8 | z x8 | n x8 | 8 unused];
+//   * the x phase and the h phase accumulate into two separate 32x32 accumulators (the n gate
+//     needs W_in x and W_hn h apart), so there are 2 x 16 accumulator registers per lane;
+//   * the 4 waves split K four ways (wave w takes k-blocks w, w+4, ...), operand fragments go
+//     global -> registers directly in MFMA layout through a 4-deep register ring (no LDS, no
+//     barrier in the loop), and the partial tiles meet in LDS in a fixed order (deterministic);
+//   * H/8 x ceil(S_t/32) workgroups: 128 even for a single active sequence at H = 1024.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTinyBM = 32;
+constexpr int kTinyBU = 8;
+constexpr int kTinyRing = 4;
+constexpr int kTinyMaxSeqs = 2048;  // above this the 128 x 64 LDS-tiled kernel is faster
+
+template <bool VEC>
+__device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool bvalid, int K,
+                                           int wave, int hi, f32x16& acc) {
+  const int nkb = (K + 7) / 8;                     // k-blocks of 8 in this phase
+  const int nmine = (nkb - wave + 3) / 4;          // blocks kb = wave, wave+4, ...
+  if (nmine <= 0) return;
+  float4 ra[kTinyRing], rb[kTinyRing];
+#pragma unroll
+  for (int d = 0; d < kTinyRing; ++d) {
+    const int k = (wave + 4 * d) * 8 + 4 * hi;
+    ra[d] = issue_row4<VEC>(arow, k, K);
+    rb[d] = issue_row4<VEC>(brow, k, K);
+  }
+  for (int it = 0; it < nmine; it += kTinyRing) {
+#pragma unroll
+    for (int d = 0; d < kTinyRing; ++d) {
+      const int k = (wave + 4 * (it + d)) * 8 + 4 * hi;
+      const float4 a = finish_row4<VEC>(ra[d], true, k, K);
+      const float4 b = finish_row4<VEC>(rb[d], bvalid, k, K);
+      const int kn = k + 4 * kTinyRing * 8;
+      ra[d] = issue_row4<VEC>(arow, kn, K);
+      rb[d] = issue_row4<VEC>(brow, kn, K);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepParams p) {
+  constexpr int BM = kTinyBM, BU = kTinyBU;
+  __shared__ float red[4][2][16][64];  // [wave][x|h accumulator][register][lane], 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u_tiles = (p.H + BU - 1) / BU;
+  const int u0 = (blockIdx.x % u_tiles) * BU;  // unit tile fastest: b, b+8 share an XCD's L2
+  const int m0 = (blockIdx.x / u_tiles) * BM;
+  const int I = p.I, H = p.H;
+  const int row = lane & 31, hi = lane >> 5;
+
+  // A fragment row of this lane: sequence m0 + row (clamped; rows are independent, and rows past
+  // S_t are never stored)
+  const int m = m0 + row;
+  const int mc = (m < p.S_t) ? m : (p.S_t - 1);
+  rowaddr_t ax, ah;
+  if (p.tok_rows != nullptr) {
+    long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
+    tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
+    ax = row_addr(p.emb + tok * I);
+  } else {
+    ax = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * I * 4u;
+  }
+  const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
+  if (p.t > 0)
+    ah = row_addr(p.hs + (p.off_prev + mc) * H);
+  else if (p.h0_rows != nullptr)
+    ah = p.h0_rows[mc];
+  else
+    ah = row_addr(p.w_hh);
+  // B fragment row of this lane: column `row` of the MFMA = gate row>>3 of unit u0 + (row&7)
+  const int g = row >> 3, uu = u0 + (row & 7);
+  const bool bvalid = (g < 3) && (uu < H);
+  const int gc = (g < 3) ? g : 2, uc = (uu < H) ? uu : (H - 1);
+  const rowaddr_t bx = row_addr(p.w_ih + (static_cast<int64_t>(gc) * H + uc) * I);
+  const rowaddr_t bh = row_addr(p.w_hh + (static_cast<int64_t>(gc) * H + uc) * H);
+
+  f32x16 acc_x = zero16(), acc_h = zero16();
+  tiny_phase<VEC>(ax, bx, bvalid, I, wave, hi, acc_x);
+  if (have_h) tiny_phase<VEC>(ah, bh, bvalid, H, wave, hi, acc_h);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    red[wave][0][r][lane] = acc_x[r];
+    red[wave][1][r][lane] = acc_h[r];
+  }
+  __syncthreads();
+
+  // epilogue: one (sequence, unit) per thread; its three gate columns sit in lanes col, col+8,
+  // col+16 of the half-wave that owns the row
+  const int er = tid >> 3, eu = tid & 7;         // tile row 0..31, unit 0..7
+  const int em = m0 + er, u = u0 + eu;
+  if (em >= p.S_t || u >= H) return;
+  const int reg = (er & 3) | ((er >> 3) << 2);
+  const int lbase = 32 * ((er >> 2) & 1) + eu;
+  float xr = 0.f, xz = 0.f, xn = 0.f, hr = 0.f, hz = 0.f, hn_ = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    xr += red[w][0][reg][lbase];
+    xz += red[w][0][reg][lbase + 8];
+    xn += red[w][0][reg][lbase + 16];
+    hr += red[w][1][reg][lbase];
+    hz += red[w][1][reg][lbase + 8];
+    hn_ += red[w][1][reg][lbase + 16];
+  }
+  float hp = 0.f;
+  if (p.t > 0)
+    hp = p.hs[(p.off_prev + em) * H + u];
+  else if (p.h0_rows != nullptr)
+    hp = reinterpret_cast<const float*>(p.h0_rows[em])[u];
+  const float rg = sigmoidf_(xr + hr + p.b_ih[u] + p.b_hh[u]);
+  const float zg = sigmoidf_(xz + hz + p.b_ih[H + u] + p.b_hh[H + u]);
+  const float ng = tanhf(xn + p.b_ih[2 * H + u] + rg * (hn_ + p.b_hh[2 * H + u]));
+  const float hn = (1.0f - zg) * ng + zg * hp;
+  p.hs[(p.off_cur + em) * H + u] = hn;
+  if (p.pool_mode == CMHSE_POOL_MAX) {
+    float* o = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
+    *o = (p.t == 0) ? hn : fmaxf(*o, hn);
+  } else if (p.pool_mode == CMHSE_POOL_LAST) {
+    if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
 // ---------------------------------------------------------------------------------------------
 struct AttnEnergyParams {
@@ -172,6 +303,7 @@ struct AttnEnergyParams {
 constexpr int kAttBM = 128;
 constexpr int kAttBN = 256;
 
+template <bool VEC>
 __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyParams p) {
   constexpr int BM = kAttBM, BN = kAttBN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -183,18 +315,20 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
   const int srow = tid >> 2;
   const int H = p.H;
 
-  const float* ar[BM / 64];
-  const float* br[BN / 64];
-  const bool vec = (H % 4 == 0) && aligned16(p.hs) && aligned16(p.w_lin);
+  rowaddr_t ar[BM / 64];
+  rowaddr_t br[BN / 64];
+  bool av[BM / 64], bv[BN / 64];
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i) {
     const int64_t m = m0 + srow + 64 * i;
-    ar[i] = (m < p.rows) ? p.hs + m * H : nullptr;
+    av[i] = m < p.rows;
+    ar[i] = row_addr(p.hs + (av[i] ? m : (p.rows - 1)) * H);
   }
 #pragma unroll
   for (int i = 0; i < BN / 64; ++i) {
     const int n = n0 + srow + 64 * i;
-    br[i] = (n < H) ? p.w_lin + static_cast<int64_t>(n) * H : nullptr;
+    bv[i] = n < H;
+    br[i] = row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
   }
   f32x16 acc[2][4];
 #pragma unroll
@@ -202,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
   const int b_row0[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-  nt_phase<BM, BN, 2, 4, 4, 3>(smem, ar, br, H, vec, vec, wm * 64, b_row0, acc);
+  nt_phase<BM, BN, 2, 4, 4, 3, VEC>(smem, ar, av, br, bv, H, wm * 64, b_row0, acc);
 
   // epilogue: per-row partial dot over this wave's 128 columns, then the two N-waves via LDS
   float wa[4], bl[4];
@@ -351,6 +485,15 @@ struct Timer {
   hipEvent_t start, stop;
 };
 
+// Tuning override (benchmarks / tests): CMHSE_TINY_MAX_SEQS=<n> moves the tiny/tiled crossover.
+static int tiny_max_seqs() {
+  static const int v = [] {
+    const char* e = getenv("CMHSE_TINY_MAX_SEQS");
+    return e ? atoi(e) : kTinyMaxSeqs;
+  }();
+  return v;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace cmhse
@@ -415,9 +558,12 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   p.pool_mode = pool_mode;
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
   const size_t smem = TileSmem<kGruBM, 3 * kGruBU>::kBytes;
+  // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
+  const bool vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
+  const int tiny_limit = tiny_max_seqs();
   Timer* timer = static_cast<Timer*>(b->step_timer);
-  if (timer) hipEventRecord(timer->start, stream);
+  if (timer) (void)hipEventRecord(timer->start, stream);
   int64_t off = 0;
   for (int t = 0; t < b->Tmax; ++t) {
     const int S_t = b->step_count_host[t];
@@ -425,11 +571,23 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     p.S_t = S_t;
     p.off_prev = off - (t > 0 ? b->step_count_host[t - 1] : 0);
     p.off_cur = off;
-    const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + kGruBM - 1) / kGruBM);
-    hipLaunchKernelGGL(gru_step_kernel, dim3(grid), dim3(kThreads), smem, stream, p);
+    if (S_t <= tiny_limit) {
+      const unsigned grid = static_cast<unsigned>((b->H + kTinyBU - 1) / kTinyBU) *
+                            ((S_t + kTinyBM - 1) / kTinyBM);
+      if (vec)
+        hipLaunchKernelGGL(gru_step_tiny_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, p);
+      else
+        hipLaunchKernelGGL(gru_step_tiny_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, p);
+    } else {
+      const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + kGruBM - 1) / kGruBM);
+      if (vec)
+        hipLaunchKernelGGL(gru_step_kernel<true>, dim3(grid), dim3(kThreads), smem, stream, p);
+      else
+        hipLaunchKernelGGL(gru_step_kernel<false>, dim3(grid), dim3(kThreads), smem, stream, p);
+    }
     off += S_t;
   }
-  if (timer) hipEventRecord(timer->stop, stream);
+  if (timer) (void)hipEventRecord(timer->stop, stream);
   if (pool_mode == CMHSE_POOL_ATTN) {
     const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
     float* e_part = reinterpret_cast<float*>(
@@ -446,8 +604,12 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     const int64_t m_tiles = (sum_T + kAttBM - 1) / kAttBM;
     if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
     const size_t att_smem = TileSmem<kAttBM, kAttBN>::kBytes;
-    hipLaunchKernelGGL(attn_energy_kernel, dim3(static_cast<unsigned>(m_tiles * att_tiles)),
-                       dim3(kThreads), att_smem, stream, ep);
+    if (vec)
+      hipLaunchKernelGGL(attn_energy_kernel<true>, dim3(static_cast<unsigned>(m_tiles * att_tiles)),
+                         dim3(kThreads), att_smem, stream, ep);
+    else
+      hipLaunchKernelGGL(attn_energy_kernel<false>, dim3(static_cast<unsigned>(m_tiles * att_tiles)),
+                         dim3(kThreads), att_smem, stream, ep);
     AttnPoolParams pp;
     pp.hs = hs;
     pp.e_part = e_part;
@@ -491,7 +653,7 @@ extern "C" void* cmhse_timer_create(void) {
     return nullptr;
   }
   if (hipEventCreate(&t->stop) != hipSuccess) {
-    hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->start);
     delete t;
     return nullptr;
   }
@@ -501,8 +663,8 @@ extern "C" void* cmhse_timer_create(void) {
 extern "C" void cmhse_timer_destroy(void* timer) {
   Timer* t = static_cast<Timer*>(timer);
   if (!t) return;
-  hipEventDestroy(t->start);
-  hipEventDestroy(t->stop);
+  (void)hipEventDestroy(t->start);
+  (void)hipEventDestroy(t->stop);
   delete t;
 }
 

@@ -31,16 +31,57 @@ constexpr int kThreads = 256; // 4 waves
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// Guarded 4-float load of row `p` at k..k+3 (< klim).  `vec` = row base 16-byte aligned & K%4==0.
-__device__ __forceinline__ float4 load_row4(const float* __restrict__ p, int k, int klim,
-                                            bool vec) {
-  if (p == nullptr || k >= klim) return zero4();
-  if (vec) return *reinterpret_cast<const float4*>(p + k);
+// Branch-free guarded 4-float load of row `p` (never null) at k..k+3 (< klim), split in two:
+//   issue_row4    always issues the load (address clamped into the row) — global address space,
+//                 so it is a global_load (vmcnt only), never a flat_load;
+//   finish_row4   zeroes what lies outside the row / the tile once the data is needed.
+// Keeping the two apart (with a scheduling barrier after the issue) holds the prefetch of chunk
+// c+1 in flight across all MFMAs of chunk c; hipcc otherwise sinks the loads next to their use
+// and waits for them there (cdna_hip_programming.md §5 item 4c, Guideline 15).
+typedef const __attribute__((address_space(1))) float* gptr_f32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
+
+// Row bases travel as 64-bit integer addresses: an integer -> address_space(1) pointer cast gives
+// global_load, a generic-pointer cast would still be emitted as flat_load (which also counts on
+// lgkmcnt and would be waited for together with the LDS fragment reads).
+typedef uint64_t rowaddr_t;
+__device__ __forceinline__ rowaddr_t row_addr(const float* p) {
+  return reinterpret_cast<rowaddr_t>(p);
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 issue_row4(rowaddr_t p, int k, int klim) {
   float4 v;
-  v.x = p[k];
-  v.y = (k + 1 < klim) ? p[k + 1] : 0.f;
-  v.z = (k + 2 < klim) ? p[k + 2] : 0.f;
-  v.w = (k + 3 < klim) ? p[k + 3] : 0.f;
+  if (VEC) {
+    const int kk = (k < klim) ? k : (klim - 4);
+    const f32x4 g = *(gptr_f32x4)(p + static_cast<rowaddr_t>(kk) * 4u);
+    v = make_float4(g.x, g.y, g.z, g.w);
+  } else {
+    const int last = klim - 1;
+    gptr_f32 g = (gptr_f32)p;
+    v.x = g[(k < last) ? k : last];
+    v.y = g[(k + 1 < last) ? k + 1 : last];
+    v.z = g[(k + 2 < last) ? k + 2 : last];
+    v.w = g[(k + 3 < last) ? k + 3 : last];
+  }
+  return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 finish_row4(float4 v, bool valid, int k, int klim) {
+  if (VEC) {
+    const bool ok = valid && (k < klim);
+    v.x = ok ? v.x : 0.f;
+    v.y = ok ? v.y : 0.f;
+    v.z = ok ? v.z : 0.f;
+    v.w = ok ? v.w : 0.f;
+  } else {
+    v.x = (valid && k < klim) ? v.x : 0.f;
+    v.y = (valid && k + 1 < klim) ? v.y : 0.f;
+    v.z = (valid && k + 2 < klim) ? v.z : 0.f;
+    v.w = (valid && k + 3 < klim) ? v.w : 0.f;
+  }
   return v;
 }
 
@@ -62,13 +103,16 @@ struct TileSmem {
 //   NACC         accumulators per M sub-tile the caller owns; sub-tile ns of this phase adds into
 //                accumulator (ns == NSUB-1 ? LAST : ns) — lets the GRU share r/z accumulators
 //                between its x phase and its h phase while keeping the two n-gate terms apart.
-//   arow[i]/brow[i]  per-thread row base pointers (nullptr = zero row) for the rows this thread
-//                stages: row = (tid >> 2) + 64*i, 16-byte slot = tid & 3.
-template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST>
-__device__ __forceinline__ void nt_phase(float* smem, const float* const (&arow)[BM / 64],
-                                         const float* const (&brow)[BNR / 64], int K, bool avec,
-                                         bool bvec, int a_row0, const int (&b_row0)[NSUB],
-                                         f32x16 (&acc)[MSUB][NACC]) {
+//   arow[i]/brow[i]  per-thread row base pointers (always dereferenceable; aval/bval = false
+//                makes the row read as zeros) for the rows this thread stages:
+//                row = (tid >> 2) + 64*i, 16-byte slot = tid & 3.
+//   VEC          K % 4 == 0: dwordx4 global loads.
+template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST, bool VEC>
+__device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM / 64],
+                                         const bool (&aval)[BM / 64],
+                                         const rowaddr_t (&brow)[BNR / 64],
+                                         const bool (&bval)[BNR / 64], int K, int a_row0,
+                                         const int (&b_row0)[NSUB], f32x16 (&acc)[MSUB][NACC]) {
   using SM = TileSmem<BM, BNR>;
   constexpr int AP = BM / 64, BP = BNR / 64;
   const int tid = threadIdx.x;
@@ -80,9 +124,11 @@ __device__ __forceinline__ void nt_phase(float* smem, const float* const (&arow)
 
   float4 ra[AP], rb[BP];
 #pragma unroll
-  for (int i = 0; i < AP; ++i) ra[i] = load_row4(arow[i], sk, K, avec);
+  for (int i = 0; i < AP; ++i)
+    ra[i] = finish_row4<VEC>(issue_row4<VEC>(arow[i], sk, K), aval[i], sk, K);
 #pragma unroll
-  for (int i = 0; i < BP; ++i) rb[i] = load_row4(brow[i], sk, K, bvec);
+  for (int i = 0; i < BP; ++i)
+    rb[i] = finish_row4<VEC>(issue_row4<VEC>(brow[i], sk, K), bval[i], sk, K);
   __syncthreads();  // previous phase / kernel section finished reading LDS
 #pragma unroll
   for (int i = 0; i < AP; ++i)
@@ -96,14 +142,14 @@ __device__ __forceinline__ void nt_phase(float* smem, const float* const (&arow)
   const int fk = (lane >> 5) * 4;
   for (int c = 0; c < nchunks; ++c) {
     const int cur = c & 1;
-    const bool more = (c + 1 < nchunks);
-    if (more) {
-      const int k = (c + 1) * kBK + sk;
+    // prefetch chunk c+1 (past the end: clamped address, later zeroed) — unconditional, issued
+    // before the MFMAs and pinned there
+    const int kn = (c + 1) * kBK + sk;
 #pragma unroll
-      for (int i = 0; i < AP; ++i) ra[i] = load_row4(arow[i], k, K, avec);
+    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC>(arow[i], kn, K);
 #pragma unroll
-      for (int i = 0; i < BP; ++i) rb[i] = load_row4(brow[i], k, K, bvec);
-    }
+    for (int i = 0; i < BP; ++i) rb[i] = issue_row4<VEC>(brow[i], kn, K);
+    __builtin_amdgcn_sched_barrier(0);
     const float* As = SM::a(smem, cur);
     const float* Bs = SM::b(smem, cur);
 #pragma unroll
@@ -134,14 +180,17 @@ __device__ __forceinline__ void nt_phase(float* smem, const float* const (&arow)
         }
       }
     }
-    if (more) {
+    __builtin_amdgcn_sched_barrier(0);
+    {
       const int nxt = cur ^ 1;
 #pragma unroll
       for (int i = 0; i < AP; ++i)
-        *reinterpret_cast<float4*>(SM::a(smem, nxt) + (srow + 64 * i) * kLdsLd + sk) = ra[i];
+        *reinterpret_cast<float4*>(SM::a(smem, nxt) + (srow + 64 * i) * kLdsLd + sk) =
+            finish_row4<VEC>(ra[i], aval[i], kn, K);
 #pragma unroll
       for (int i = 0; i < BP; ++i)
-        *reinterpret_cast<float4*>(SM::b(smem, nxt) + (srow + 64 * i) * kLdsLd + sk) = rb[i];
+        *reinterpret_cast<float4*>(SM::b(smem, nxt) + (srow + 64 * i) * kLdsLd + sk) =
+            finish_row4<VEC>(rb[i], bval[i], kn, K);
     }
     __syncthreads();
   }

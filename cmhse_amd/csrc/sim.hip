@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int MODE>
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p) {
   constexpr int BM = kSimBM, BN = kSimBN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -61,18 +61,20 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p) {
     j0 = (blockIdx.x % p.n_tiles) * BN;
     i0 = (blockIdx.x / p.n_tiles) * BM;
   }
-  const float* ar[BM / 64];
-  const float* br[BN / 64];
-  const bool vec = (p.D % 4 == 0) && aligned16s(p.A) && aligned16s(p.B);
+  rowaddr_t ar[BM / 64];
+  rowaddr_t br[BN / 64];
+  bool av[BM / 64], bv[BN / 64];
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i) {
     const int li = i0 + srow + 64 * i;
-    ar[i] = (li < p.nrows) ? p.A + static_cast<int64_t>(p.row0 + li) * p.D : nullptr;
+    av[i] = li < p.nrows;
+    ar[i] = row_addr(p.A + static_cast<int64_t>(p.row0 + (av[i] ? li : 0)) * p.D);
   }
 #pragma unroll
   for (int i = 0; i < BN / 64; ++i) {
     const int j = j0 + srow + 64 * i;
-    br[i] = (j < p.M) ? p.B + static_cast<int64_t>(j) * p.D : nullptr;
+    bv[i] = j < p.M;
+    br[i] = row_addr(p.B + static_cast<int64_t>(bv[i] ? j : 0) * p.D);
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p) {
 #pragma unroll
     for (int ns = 0; ns < 2; ++ns) acc[ms][ns] = zero16();
   const int b_row0[2] = {wn * 64, wn * 64 + 32};
-  nt_phase<BM, BN, 2, 2, 2, 1>(smem, ar, br, p.D, vec, vec, wm * 64, b_row0, acc);
+  nt_phase<BM, BN, 2, 2, 2, 1, VEC>(smem, ar, av, br, bv, p.D, wm * 64, b_row0, acc);
 
 #pragma unroll
   for (int ms = 0; ms < 2; ++ms) {
@@ -248,8 +250,12 @@ static int launch_sim_store(const float* A, const float* B, int n, int m, int D,
   const int64_t blocks = static_cast<int64_t>(p.n_tiles) * ((n + kSimBM - 1) / kSimBM);
   if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
   const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
-  hipLaunchKernelGGL(sim_kernel<kSimStore>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
-                     smem, stream, p);
+  if (D % 4 == 0)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, true>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), smem, stream, p);
+  else
+    hipLaunchKernelGGL((sim_kernel<kSimStore, false>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), smem, stream, p);
   return CMHSE_OK;
 }
 
@@ -295,9 +301,15 @@ extern "C" int cmhse_sim_rank(const float* A, const float* B, int32_t N, int32_t
   if (hipMemsetAsync(p.top1key, 0, sizeof(unsigned long long) * nrows, stream) != hipSuccess)
     return CMHSE_ERR_LAUNCH;
   const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
-  hipLaunchKernelGGL(sim_kernel<kSimDiag>, dim3(m_tiles), dim3(kThreads), smem, stream, p);
-  hipLaunchKernelGGL(sim_kernel<kSimRank>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads),
-                     smem, stream, p);
+  if (D % 4 == 0) {
+    hipLaunchKernelGGL((sim_kernel<kSimDiag, true>), dim3(m_tiles), dim3(kThreads), smem, stream, p);
+    hipLaunchKernelGGL((sim_kernel<kSimRank, true>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), smem, stream, p);
+  } else {
+    hipLaunchKernelGGL((sim_kernel<kSimDiag, false>), dim3(m_tiles), dim3(kThreads), smem, stream, p);
+    hipLaunchKernelGGL((sim_kernel<kSimRank, false>), dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), smem, stream, p);
+  }
   hipLaunchKernelGGL(top1_finalize_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream,
                      p.top1key, top1, nrows);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
