@@ -46,6 +46,10 @@ SIGNATURES = {
     'cmhse_contrastive_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_float,
                                              c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                              c_size_t, c_void_p]),
+    'cmhse_contrastive_blocks_workspace': (c_size_t, [c_int32, c_int32]),
+    'cmhse_contrastive_blocks_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                    c_int32, c_float, c_int32, c_int32, c_void_p,
+                                                    c_void_p, c_size_t, c_void_p]),
     'cmhse_timer_create': (c_void_p, []),
     'cmhse_timer_destroy': (None, [c_void_p]),
     'cmhse_timer_elapsed_ms': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float)]),

@@ -34,6 +34,10 @@ struct SimParams {
   int32_t* rank;                // [nrows]
   unsigned long long* top1key;  // [nrows]
   float* scores;                // [nrows, M] (kSimStore)
+  // batched square blocks (blockIdx.y = block): rows/cols [blk_off[b], blk_off[b+1]) of A and B,
+  // scores of block b at scores + b * blk_stride, leading dimension = the block's size
+  const int32_t* blk_off;
+  int64_t blk_stride;
 };
 
 __device__ __forceinline__ bool aligned16s(const void* p) {
@@ -47,8 +51,19 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
 }
 
 template <int MODE, bool VEC>
-__global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p) {
+__global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
   constexpr int BM = kSimBM, BN = kSimBN;
+  SimParams p = p_;
+  if (p.blk_off != nullptr) {
+    const int off = p.blk_off[blockIdx.y];
+    const int n = p.blk_off[blockIdx.y + 1] - off;
+    p.A += static_cast<int64_t>(off) * p.D;
+    p.B += static_cast<int64_t>(off) * p.D;
+    p.N = p.M = p.nrows = n;
+    p.scores += static_cast<int64_t>(blockIdx.y) * p.blk_stride;
+    const int jt = blockIdx.x % p.n_tiles, it = blockIdx.x / p.n_tiles;
+    if (jt * BN >= n || it * BM >= n) return;  // tile outside this (smaller) block
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -152,9 +167,23 @@ struct LossParams {
   int32_t max_violation, norm;
   double* partial;  // [2 * nrb]
   float* loss;
+  const int32_t* blk_off;  // batched blocks (blockIdx.y): see SimParams
+  int64_t blk_stride;
 };
 
-__global__ __launch_bounds__(kThreads) void contrastive_partial_kernel(const LossParams p) {
+__device__ __forceinline__ LossParams loss_block(const LossParams& q) {
+  LossParams p = q;
+  if (p.blk_off != nullptr) {
+    p.n = p.blk_off[blockIdx.y + 1] - p.blk_off[blockIdx.y];
+    p.scores += static_cast<int64_t>(blockIdx.y) * p.blk_stride;
+    p.partial += static_cast<int64_t>(blockIdx.y) * 2 * p.nrb;
+    p.loss += blockIdx.y;
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(kThreads) void contrastive_partial_kernel(const LossParams p_) {
+  const LossParams p = loss_block(p_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = p.n;
   const float* S = p.scores;
@@ -218,7 +247,8 @@ __global__ __launch_bounds__(kThreads) void contrastive_partial_kernel(const Los
   }
 }
 
-__global__ void contrastive_final_kernel(const LossParams p) {
+__global__ void contrastive_final_kernel(const LossParams p_) {
+  const LossParams p = loss_block(p_);
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double cs = 0.0, ci = 0.0;
     for (int b = 0; b < p.nrb; ++b) cs += p.partial[b];
@@ -247,6 +277,8 @@ static int launch_sim_store(const float* A, const float* B, int n, int m, int D,
   p.rank = nullptr;
   p.top1key = nullptr;
   p.scores = scores;
+  p.blk_off = nullptr;
+  p.blk_stride = 0;
   const int64_t blocks = static_cast<int64_t>(p.n_tiles) * ((n + kSimBM - 1) / kSimBM);
   if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
   const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
@@ -294,6 +326,8 @@ extern "C" int cmhse_sim_rank(const float* A, const float* B, int32_t N, int32_t
       static_cast<char*>(workspace) + align_up_(static_cast<size_t>(nrows) * sizeof(float), 256));
   p.rank = rank;
   p.scores = nullptr;
+  p.blk_off = nullptr;
+  p.blk_stride = 0;
   const int m_tiles = (nrows + kSimBM - 1) / kSimBM;
   const int64_t blocks = static_cast<int64_t>(p.n_tiles) * m_tiles;
   if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
@@ -352,8 +386,70 @@ extern "C" int cmhse_contrastive_fwd(const float* im, const float* s, int32_t n,
   lp.partial = reinterpret_cast<double*>(static_cast<char*>(workspace) +
                                          align_up_(static_cast<size_t>(n) * n * sizeof(float), 256));
   lp.loss = loss;
+  lp.blk_off = nullptr;
+  lp.blk_stride = 0;
   hipLaunchKernelGGL(contrastive_partial_kernel, dim3(2 * lp.nrb), dim3(kThreads), 0, stream, lp);
   hipLaunchKernelGGL(contrastive_final_kernel, dim3(1), dim3(64), 0, stream, lp);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" size_t cmhse_contrastive_blocks_workspace(int32_t n_blocks, int32_t max_n) {
+  if (n_blocks <= 0 || max_n <= 0) return 0;
+  const size_t nrb = (max_n + 63) / 64;
+  return align_up_(static_cast<size_t>(n_blocks) * max_n * max_n * sizeof(float), 256) +
+         align_up_(static_cast<size_t>(n_blocks) * 2 * nrb * sizeof(double), 256);
+}
+
+extern "C" int cmhse_contrastive_blocks_fwd(const float* im, const float* s,
+                                            const int32_t* blk_off, int32_t n_blocks,
+                                            int32_t max_n, int32_t D, float margin,
+                                            int32_t max_violation, int32_t norm, float* losses,
+                                            void* workspace, size_t workspace_bytes,
+                                            void* stream_) {
+  if (!im || !s || !blk_off || !losses || !workspace || n_blocks <= 0 || max_n <= 0 || D <= 0)
+    return CMHSE_ERR_ARG;
+  if (n_blocks > 65535) return CMHSE_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_contrastive_blocks_workspace(n_blocks, max_n))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SimParams p;
+  p.A = im;
+  p.B = s;
+  p.N = p.M = p.nrows = max_n;
+  p.D = D;
+  p.row0 = 0;
+  p.n_tiles = (max_n + kSimBN - 1) / kSimBN;
+  p.diag = nullptr;
+  p.rank = nullptr;
+  p.top1key = nullptr;
+  p.scores = static_cast<float*>(workspace);
+  p.blk_off = blk_off;
+  p.blk_stride = static_cast<int64_t>(max_n) * max_n;
+  const unsigned tiles = static_cast<unsigned>(p.n_tiles) * ((max_n + kSimBM - 1) / kSimBM);
+  const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
+  if (D % 4 == 0)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, true>), dim3(tiles, n_blocks), dim3(kThreads), smem,
+                       stream, p);
+  else
+    hipLaunchKernelGGL((sim_kernel<kSimStore, false>), dim3(tiles, n_blocks), dim3(kThreads), smem,
+                       stream, p);
+  LossParams lp;
+  lp.scores = p.scores;
+  lp.n = max_n;
+  lp.nrb = (max_n + 63) / 64;
+  lp.margin = margin;
+  lp.max_violation = max_violation;
+  lp.norm = norm;
+  lp.partial = reinterpret_cast<double*>(
+      static_cast<char*>(workspace) +
+      align_up_(static_cast<size_t>(n_blocks) * max_n * max_n * sizeof(float), 256));
+  lp.loss = losses;
+  lp.blk_off = blk_off;
+  lp.blk_stride = p.blk_stride;
+  hipLaunchKernelGGL(contrastive_partial_kernel, dim3(2 * lp.nrb, n_blocks), dim3(kThreads), 0,
+                     stream, lp);
+  hipLaunchKernelGGL(contrastive_final_kernel, dim3(1, n_blocks), dim3(64), 0, stream, lp);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 

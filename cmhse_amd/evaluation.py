@@ -180,11 +180,10 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
       for k in outs:
         outs[k].append(enc[k])
       # per-loader-batch 'Letest' loss (evaluation.py:129), all on device, one sync per group
-      losses, pos = [], 0
-      for bs in enc['batch_sizes']:
-        losses.append(model.criterion(enc['vid_emb'][pos:pos + bs], enc['para_emb'][pos:pos + bs]))
-        pos += bs
-      loss_vals = torch.stack(losses).cpu().tolist()
+      crit = model.criterion
+      loss_vals = ops.contrastive_blocks_fwd(enc['vid_emb'], enc['para_emb'], enc['batch_sizes'],
+                                             crit.margin, crit.max_violation,
+                                             crit.norm).cpu().tolist()
       for b, bs, lv in zip(group, enc['batch_sizes'], loss_vals):
         num_clips_total.extend(b[8])
         cur_vid_total.extend(b[11])

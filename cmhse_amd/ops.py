@@ -251,3 +251,27 @@ def contrastive_fwd(im, s, margin, max_violation, norm, want_scores=False):
                                  ws_bytes, _stream())
   _lib.check(rc, 'cmhse_contrastive_fwd')
   return (loss, scores) if want_scores else loss
+
+
+def contrastive_blocks_fwd(im, s, block_sizes, margin, max_violation, norm):
+  """Per-block ContrastiveLoss over consecutive row blocks of im / s (cmhse_contrastive_blocks_fwd):
+  returns a float32 device tensor [len(block_sizes)]."""
+  lib = _lib.load()
+  im = _f32c(im, 'im')
+  s = _f32c(s, 's')
+  sizes = np.asarray(block_sizes, dtype=np.int64)
+  if sizes.sum() != im.shape[0] or im.shape != s.shape:
+    raise ValueError('block sizes must tile the rows of im and s')
+  nb, max_n = len(sizes), int(sizes.max())
+  off = np.zeros(nb + 1, dtype=np.int32)
+  np.cumsum(sizes, out=off[1:])
+  off_d = torch.from_numpy(off).to(im.device)
+  losses = torch.empty(nb, dtype=torch.float32, device=im.device)
+  ws_bytes = lib.cmhse_contrastive_blocks_workspace(nb, max_n)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
+  rc = lib.cmhse_contrastive_blocks_fwd(im.data_ptr(), s.data_ptr(), off_d.data_ptr(), nb, max_n,
+                                        im.shape[1], float(margin), int(bool(max_violation)),
+                                        int(bool(norm)), losses.data_ptr(), ws.data_ptr(),
+                                        ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_contrastive_blocks_fwd')
+  return losses

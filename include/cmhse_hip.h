@@ -135,6 +135,17 @@ int cmhse_contrastive_fwd(const float* im, const float* s, int32_t n, int32_t D,
                           int32_t max_violation, int32_t norm, float* loss, float* scores_out,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Batched form of cmhse_contrastive_fwd for evaluation.encode_data's per-loader-batch 'Letest'
+ * loss (evaluation.py:129 -> model.py:287-292): block b is the square problem on rows
+ * [blk_off[b], blk_off[b+1]) of im and s (blk_off: device int32 [n_blocks+1], block sizes
+ * <= max_n); losses[b] receives its loss.  One launch set for all blocks instead of one per
+ * loader batch. */
+size_t cmhse_contrastive_blocks_workspace(int32_t n_blocks, int32_t max_n);
+int cmhse_contrastive_blocks_fwd(const float* im, const float* s, const int32_t* blk_off,
+                                 int32_t n_blocks, int32_t max_n, int32_t D, float margin,
+                                 int32_t max_violation, int32_t norm, float* losses,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement aid (bench.py's roofline leg): a pair of HIP events owned by the handle.  A timer
  * passed in cmhse_seq_batch.step_timer is recorded before the first and after the last GRU step
  * kernel of that call; cmhse_timer_elapsed_ms waits for the stop event and returns the span. */

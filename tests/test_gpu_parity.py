@@ -290,6 +290,25 @@ def test_contrastive_vs_oracle(dev, oracle, n):
       assert loss_close(got, want), (n, mv, nm, got, want)
 
 
+def test_contrastive_blocks_equal_single_calls(dev):
+  """The batched per-loader-batch loss equals one cmhse_contrastive_fwd call per block, bitwise."""
+  from cmhse_amd import ops
+  rng = np.random.RandomState(7)
+  sizes = [32, 32, 7, 1, 130, 64]
+  n = sum(sizes)
+  a = torch.from_numpy(rng.standard_normal((n, 96)).astype(np.float32)).to(dev)
+  b = torch.from_numpy(rng.standard_normal((n, 96)).astype(np.float32)).to(dev)
+  a, b = ops.l2norm_rows(a), ops.l2norm_rows(b)
+  for mv in (False, True):
+    for nm in (False, True):
+      got = ops.contrastive_blocks_fwd(a, b, sizes, 0.2, mv, nm).cpu().numpy()
+      pos = 0
+      for i, sz in enumerate(sizes):
+        want = ops.contrastive_fwd(a[pos:pos + sz], b[pos:pos + sz], 0.2, mv, nm).item()
+        assert got[i] == np.float32(want), (mv, nm, i)
+        pos += sz
+
+
 def test_superbatch_equals_per_batch(dev):
   """encode_data's fused super-batch gives the same embeddings as per-batch VSE calls."""
   from cmhse_amd import synthetic
