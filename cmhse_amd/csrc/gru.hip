@@ -70,9 +70,9 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 constexpr int kGruBM = 128;  // sequences per workgroup
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
-template <bool VEC>
+template <bool VEC, int MSUB>
 __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams p) {
-  constexpr int BM = kGruBM, BU = kGruBU, BNR = 3 * BU;
+  constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -121,17 +121,17 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
   }
 
   // accumulators per 32-sequence sub-tile: 0 = r, 1 = z, 2 = W_in x, 3 = W_hn h
-  f32x16 acc[2][4];
+  f32x16 acc[MSUB][4];
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms)
+  for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
 
-  const int a_row0 = wm * 64;
+  const int a_row0 = wm * 32 * MSUB;
   const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
-  nt_phase<BM, BNR, 2, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+  nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-  if (have_h) nt_phase<BM, BNR, 2, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
+  if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
 
   // ---- epilogue: gates, state update, pooling ----
   const int u = u0 + wn * 32 + acc_col(lane);
@@ -141,10 +141,10 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
   const float b_in = p.b_ih[2 * H + u];
   const float b_hn = p.b_hh[2 * H + u];
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms) {
+  for (int ms = 0; ms < MSUB; ++ms) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
+      const int m = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
       if (m >= p.S_t) continue;
       float hp = 0.f;
       if (p.t > 0)
@@ -309,12 +309,11 @@ struct AttnEnergyParams {
   int32_t H, n_tiles;
 };
 
-constexpr int kAttBM = 128;
 constexpr int kAttBN = 256;
 
-template <bool VEC>
+template <bool VEC, int MSUB>
 __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyParams p) {
-  constexpr int BM = kAttBM, BN = kAttBN;
+  constexpr int BM = 64 * MSUB, BN = kAttBN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -339,13 +338,13 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
     bv[i] = n < H;
     br[i] = row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
   }
-  f32x16 acc[2][4];
+  f32x16 acc[MSUB][4];
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms)
+  for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
   const int b_row0[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-  nt_phase<BM, BN, 2, 4, 4, 3, VEC>(smem, ar, av, br, bv, H, wm * 64, b_row0, acc);
+  nt_phase<BM, BN, MSUB, 4, 4, 3, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
 
   // epilogue: per-row partial dot over this wave's 128 columns, then the two N-waves via LDS
   float wa[4], bl[4];
@@ -357,15 +356,15 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
   }
   float* red = smem;  // [2 (wn)][BM]; main loop ended with a barrier
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms) {
+  for (int ms = 0; ms < MSUB; ++ms) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float s = 0.f;
 #pragma unroll
-      for (int ns = 0; ns < 4; ++ns) s += wa[ns] * tanhf(acc[ms][ns][r] + bl[ns]);
+      for (int ns = 0; ns < 4; ++ns) s += wa[ns] * tanhf_(acc[ms][ns][r] + bl[ns]);
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-      if ((lane & 31) == 0) red[wn * BM + wm * 64 + ms * 32 + acc_row(r, lane)] = s;
+      if ((lane & 31) == 0) red[wn * BM + wm * 32 * MSUB + ms * 32 + acc_row(r, lane)] = s;
     }
   }
   __syncthreads();
@@ -571,6 +570,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   const bool vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
   const int tiny_limit = tiny_max_seqs();
+  static const int msub = [] { const char* e = getenv("CMHSE_GRU_MSUB"); return (e && atoi(e) == 2) ? 2 : 1; }();
   Timer* timer = static_cast<Timer*>(b->step_timer);
   if (timer) (void)hipEventRecord(timer->start, stream);
   int64_t off = 0;
@@ -588,11 +588,20 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
       else
         hipLaunchKernelGGL(gru_step_tiny_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, p);
     } else {
-      const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + kGruBM - 1) / kGruBM);
-      if (vec)
-        hipLaunchKernelGGL(gru_step_kernel<true>, dim3(grid), dim3(kThreads), smem, stream, p);
-      else
-        hipLaunchKernelGGL(gru_step_kernel<false>, dim3(grid), dim3(kThreads), smem, stream, p);
+      if (msub == 2) {
+        const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 127) / 128);
+        if (vec)
+          hipLaunchKernelGGL((gru_step_kernel<true, 2>), dim3(grid), dim3(kThreads), smem, stream, p);
+        else
+          hipLaunchKernelGGL((gru_step_kernel<false, 2>), dim3(grid), dim3(kThreads), smem, stream, p);
+      } else {
+        const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 63) / 64);
+        const size_t smem1 = TileSmem<64, 3 * kGruBU>::kBytes;
+        if (vec)
+          hipLaunchKernelGGL((gru_step_kernel<true, 1>), dim3(grid), dim3(kThreads), smem1, stream, p);
+        else
+          hipLaunchKernelGGL((gru_step_kernel<false, 1>), dim3(grid), dim3(kThreads), smem1, stream, p);
+      }
     }
     off += S_t;
   }
@@ -610,15 +619,23 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     ep.rows = sum_T;
     ep.H = b->H;
     ep.n_tiles = att_tiles;
-    const int64_t m_tiles = (sum_T + kAttBM - 1) / kAttBM;
+    const int att_bm = 64 * msub;
+    const int64_t m_tiles = (sum_T + att_bm - 1) / att_bm;
     if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
-    const size_t att_smem = TileSmem<kAttBM, kAttBN>::kBytes;
-    if (vec)
-      hipLaunchKernelGGL(attn_energy_kernel<true>, dim3(static_cast<unsigned>(m_tiles * att_tiles)),
-                         dim3(kThreads), att_smem, stream, ep);
-    else
-      hipLaunchKernelGGL(attn_energy_kernel<false>, dim3(static_cast<unsigned>(m_tiles * att_tiles)),
-                         dim3(kThreads), att_smem, stream, ep);
+    const unsigned att_grid = static_cast<unsigned>(m_tiles * att_tiles);
+    if (msub == 2) {
+      const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
+      if (vec)
+        hipLaunchKernelGGL((attn_energy_kernel<true, 2>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+      else
+        hipLaunchKernelGGL((attn_energy_kernel<false, 2>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+    } else {
+      const size_t att_smem = TileSmem<64, kAttBN>::kBytes;
+      if (vec)
+        hipLaunchKernelGGL((attn_energy_kernel<true, 1>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+      else
+        hipLaunchKernelGGL((attn_energy_kernel<false, 1>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+    }
     AttnPoolParams pp;
     pp.hs = hs;
     pp.e_part = e_part;

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace cmhse {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -122,78 +124,105 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   const int nchunks = (K + kBK - 1) / kBK;
   if (nchunks == 0) return;
 
-  float4 ra[AP], rb[BP];
-#pragma unroll
-  for (int i = 0; i < AP; ++i)
-    ra[i] = finish_row4<VEC>(issue_row4<VEC>(arow[i], sk, K), aval[i], sk, K);
-#pragma unroll
-  for (int i = 0; i < BP; ++i)
-    rb[i] = finish_row4<VEC>(issue_row4<VEC>(brow[i], sk, K), bval[i], sk, K);
-  __syncthreads();  // previous phase / kernel section finished reading LDS
-#pragma unroll
-  for (int i = 0; i < AP; ++i)
-    *reinterpret_cast<float4*>(SM::a(smem, 0) + (srow + 64 * i) * kLdsLd + sk) = ra[i];
-#pragma unroll
-  for (int i = 0; i < BP; ++i)
-    *reinterpret_cast<float4*>(SM::b(smem, 0) + (srow + 64 * i) * kLdsLd + sk) = rb[i];
-  __syncthreads();
-
   const int frow = lane & 31;
   const int fk = (lane >> 5) * 4;
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    // prefetch chunk c+1 (past the end: clamped address, later zeroed) — unconditional, issued
-    // before the MFMAs and pinned there
-    const int kn = (c + 1) * kBK + sk;
+  float4 ra[AP], rb[BP];
+  float4 f0a[MSUB], f0b[NSUB], f1a[MSUB], f1b[NSUB];
+
+  // Pieces of the pipeline (all force-inlined lambdas; `buf` is wave-uniform).
+  auto issue_global = [&](int kn) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC>(arow[i], kn, K);
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = issue_row4<VEC>(brow[i], kn, K);
-    __builtin_amdgcn_sched_barrier(0);
-    const float* As = SM::a(smem, cur);
-    const float* Bs = SM::b(smem, cur);
+  };
+  auto write_lds = [&](int buf, int kn) {
 #pragma unroll
-    for (int kb = 0; kb < kBK / 8; ++kb) {
-      float4 af[MSUB], bf[NSUB];
+    for (int i = 0; i < AP; ++i)
+      *reinterpret_cast<float4*>(SM::a(smem, buf) + (srow + 64 * i) * kLdsLd + sk) =
+          finish_row4<VEC>(ra[i], aval[i], kn, K);
 #pragma unroll
-      for (int ms = 0; ms < MSUB; ++ms)
-        af[ms] = *reinterpret_cast<const float4*>(As + (a_row0 + ms * 32 + frow) * kLdsLd +
-                                                  kb * 8 + fk);
+    for (int i = 0; i < BP; ++i)
+      *reinterpret_cast<float4*>(SM::b(smem, buf) + (srow + 64 * i) * kLdsLd + sk) =
+          finish_row4<VEC>(rb[i], bval[i], kn, K);
+  };
+  auto read_frags = [&](int buf, int kb, float4(&fa)[MSUB], float4(&fb)[NSUB]) {
 #pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns)
-        bf[ns] = *reinterpret_cast<const float4*>(Bs + (b_row0[ns] + frow) * kLdsLd + kb * 8 +
-                                                  fk);
+    for (int ms = 0; ms < MSUB; ++ms)
+      fa[ms] = *reinterpret_cast<const float4*>(SM::a(smem, buf) +
+                                                (a_row0 + ms * 32 + frow) * kLdsLd + kb * 8 + fk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+    for (int ns = 0; ns < NSUB; ++ns)
+      fb[ns] = *reinterpret_cast<const float4*>(SM::b(smem, buf) +
+                                                (b_row0[ns] + frow) * kLdsLd + kb * 8 + fk);
+  };
+  // MFMAs of one 8-k block for k sub-steps j in [J0, J1)
+  auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB], auto j0c, auto j1c) {
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
 #pragma unroll
-        for (int ms = 0; ms < MSUB; ++ms) {
-          const float av = (j == 0) ? af[ms].x : (j == 1) ? af[ms].y : (j == 2) ? af[ms].z
-                                                                                : af[ms].w;
+    for (int j = J0; j < J1; ++j) {
 #pragma unroll
-          for (int ns = 0; ns < NSUB; ++ns) {
-            const float bv = (j == 0) ? bf[ns].x : (j == 1) ? bf[ns].y : (j == 2) ? bf[ns].z
-                                                                                  : bf[ns].w;
-            constexpr int kLast = LAST;
-            const int ai = (ns == NSUB - 1) ? kLast : ns;
-            acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ms][ai], 0, 0, 0);
-          }
+      for (int ms = 0; ms < MSUB; ++ms) {
+        const float av = (j == 0) ? fa[ms].x : (j == 1) ? fa[ms].y : (j == 2) ? fa[ms].z
+                                                                              : fa[ms].w;
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          const float bv = (j == 0) ? fb[ns].x : (j == 1) ? fb[ns].y : (j == 2) ? fb[ns].z
+                                                                                : fb[ns].w;
+          constexpr int kLast = LAST;
+          const int ai = (ns == NSUB - 1) ? kLast : ns;
+          acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ms][ai], 0, 0, 0);
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int nxt = cur ^ 1;
-#pragma unroll
-      for (int i = 0; i < AP; ++i)
-        *reinterpret_cast<float4*>(SM::a(smem, nxt) + (srow + 64 * i) * kLdsLd + sk) =
-            finish_row4<VEC>(ra[i], aval[i], kn, K);
-#pragma unroll
-      for (int i = 0; i < BP; ++i)
-        *reinterpret_cast<float4*>(SM::b(smem, nxt) + (srow + 64 * i) * kLdsLd + sk) =
-            finish_row4<VEC>(rb[i], bval[i], kn, K);
-    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+
+  // Rotated software pipeline.  An MFMA runs for 64 cycles after issue, so a wave's own memory
+  // instructions hide under its MFMAs when they are issued just ahead of a block of them:
+  //   barrier                      chunk c complete in LDS, every wave holds its (c-1, kb1) frags
+  //   LDS reads  F0 <- (c, kb0);  global prefetch R <- chunk c+1
+  //   MFMAs (c-1, kb1) from F1     <- covers the LDS-read and global latency
+  //   LDS reads  F1 <- (c, kb1)
+  //   MFMAs (c, kb0) from F0, k sub-steps 0..2
+  //   tail-mask R, LDS writes chunk c+1 -> other buffer (all waves are past reading it)
+  //   MFMAs (c, kb0) sub-step 3    <- covers the LDS-write latency before the next barrier
+  // Only the barrier itself is exposed.
+  issue_global(sk);
+  __syncthreads();  // previous phase / kernel section finished with the LDS buffers
+  write_lds(0, sk);
+  __syncthreads();
+  read_frags(0, 0, f0a, f0b);
+  issue_global(kBK + sk);
+  read_frags(0, 1, f1a, f1b);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_block(f0a, f0b, I0{}, I3{});
+  __builtin_amdgcn_sched_barrier(0);
+  write_lds(1, kBK + sk);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_block(f0a, f0b, I3{}, I4{});
+  for (int c = 1; c < nchunks; ++c) {
+    const int cur = c & 1;
+    const int kn = (c + 1) * kBK + sk;  // past the end: clamped address, zeroed by finish_row4
     __syncthreads();
+    read_frags(cur, 0, f0a, f0b);
+    issue_global(kn);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f1a, f1b, I0{}, I4{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(cur, 1, f1a, f1b);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f0a, f0b, I0{}, I3{});
+    __builtin_amdgcn_sched_barrier(0);
+    write_lds(cur ^ 1, kn);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f0a, f0b, I3{}, I4{});
   }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_block(f1a, f1b, I0{}, I4{});
+  __syncthreads();  // all waves done with LDS before the caller reuses it
 }
 
 // Row / column owned by accumulator register r of lane `lane` inside a 32x32 sub-tile.
