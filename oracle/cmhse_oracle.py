@@ -322,3 +322,215 @@ def train_losses(rnn_type, params, batch, margin=0.2, max_violation=False, norm=
               fl(n(cap_emb), n(cap_emb), '_cap_inloss')) / 2
     loss = loss + loss_2 + loss_6
   return log, float(loss)
+
+
+# --------------------------------------------------------------------------------------------
+# Backward pass.  The reference gets its gradients from torch.autograd
+# (`loss.backward()`, /root/reference/model.py:367); these are the same derivatives written out,
+# pinned against gradients of the reference itself (tests/golden: `grad.*`, `bwd.*`).
+# --------------------------------------------------------------------------------------------
+def gru_forward_cache(x, lens, p, h0=None, dtype=np.float64):
+  """gru_forward that also keeps what BPTT needs."""
+  x = np.asarray(x, dtype=dtype)
+  lens = np.asarray(lens).astype(np.int64)
+  w_ih = np.asarray(p['rnn.rnn.weight_ih_l0'], dtype=dtype)
+  w_hh = np.asarray(p['rnn.rnn.weight_hh_l0'], dtype=dtype)
+  b_ih = np.asarray(p['rnn.rnn.bias_ih_l0'], dtype=dtype)
+  b_hh = np.asarray(p['rnn.rnn.bias_hh_l0'], dtype=dtype)
+  S, T, I = x.shape
+  H = w_hh.shape[1]
+  Tmax = int(lens.max())
+  h = np.zeros((S, H), dtype=dtype) if h0 is None else np.array(h0, dtype=dtype)
+  hs = np.zeros((S, Tmax, H), dtype=dtype)
+  hprev = np.zeros((S, Tmax, H), dtype=dtype)
+  gates = np.zeros((S, Tmax, 4, H), dtype=dtype)      # r, z, n, (W_hn h + b_hn)
+  for t in range(Tmax):
+    act = lens > t
+    gi = x[:, t] @ w_ih.T + b_ih
+    gh = h @ w_hh.T + b_hh
+    r = _sigmoid(gi[:, :H] + gh[:, :H])
+    z = _sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = np.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn = (1.0 - z) * n + z * h
+    hprev[:, t] = h
+    gates[:, t, 0], gates[:, t, 1], gates[:, t, 2], gates[:, t, 3] = r, z, n, gh[:, 2 * H:]
+    h = np.where(act[:, None], hn, h)
+    hs[:, t] = np.where(act[:, None], hn, 0)
+  return dict(x=x, lens=lens, hs=hs, hprev=hprev, gates=gates, w_ih=w_ih, w_hh=w_hh, H=H, I=I,
+              Tmax=Tmax, has_h0=h0 is not None)
+
+
+def gru_backward(c, dhs):
+  """BPTT.  dhs [S,Tmax,H]: gradient arriving at every hidden state from the pooling.
+  Returns (param grads with reference keys, dx [S,Tmax,I], dh0 [S,H])."""
+  S, Tmax, H, I = c['hs'].shape[0], c['Tmax'], c['H'], c['I']
+  dt = c['hs'].dtype
+  dw_ih = np.zeros_like(c['w_ih']); dw_hh = np.zeros_like(c['w_hh'])
+  db_ih = np.zeros(3 * H, dtype=dt); db_hh = np.zeros(3 * H, dtype=dt)
+  dx = np.zeros((S, Tmax, I), dtype=dt)
+  dh = np.zeros((S, H), dtype=dt)
+  for t in range(Tmax - 1, -1, -1):
+    act = (c['lens'] > t)[:, None]
+    dh = np.where(act, dh + dhs[:, t], dh)        # finished sequences carry nothing back
+    r, z, n, ghn = (c['gates'][:, t, k] for k in range(4))
+    hp = c['hprev'][:, t]
+    dn = dh * (1.0 - z)
+    dz = dh * (hp - n)
+    dn_pre = dn * (1.0 - n * n)
+    dr = dn_pre * ghn
+    dr_pre = dr * r * (1.0 - r)
+    dz_pre = dz * z * (1.0 - z)
+    dgx = np.where(act, np.concatenate([dr_pre, dz_pre, dn_pre], 1), 0)
+    dgh = np.where(act, np.concatenate([dr_pre, dz_pre, dn_pre * r], 1), 0)
+    dw_ih += dgx.T @ c['x'][:, t]
+    dw_hh += dgh.T @ hp
+    db_ih += dgx.sum(0)
+    db_hh += dgh.sum(0)
+    dx[:, t] = dgx @ c['w_ih']
+    dh = np.where(act, dh * z + dgh @ c['w_hh'], dh)
+  grads = {'rnn.rnn.weight_ih_l0': dw_ih, 'rnn.rnn.weight_hh_l0': dw_hh,
+           'rnn.rnn.bias_ih_l0': db_ih, 'rnn.rnn.bias_hh_l0': db_hh}
+  return grads, dx, dh
+
+
+def pooled_gru_forward_cache(rnn_type, x, lens, p, h0=None, dtype=np.float64):
+  c = gru_forward_cache(x, lens, p, h0, dtype)
+  c['rnn_type'] = rnn_type
+  hs, lens = c['hs'], c['lens']
+  S, Tmax, H = hs.shape
+  mask = np.arange(Tmax)[None, :] < lens[:, None]
+  if rnn_type == 'seq2seq':
+    out = hs[np.arange(S), lens - 1]
+  elif rnn_type == 'maxout':
+    masked = np.where(mask[:, :, None], hs, -np.inf)
+    c['argmax'] = masked.argmax(axis=1)          # first maximum on ties
+    out = masked.max(axis=1)
+  elif rnn_type == 'attention':
+    w_lin = np.asarray(p['rnn.lin.weight'], dtype=dtype)
+    b_lin = np.asarray(p['rnn.lin.bias'], dtype=dtype)
+    w_att = np.asarray(p['rnn.att_w.weight'], dtype=dtype).reshape(-1)
+    v = np.tanh(hs @ w_lin.T + b_lin)
+    e = v @ w_att
+    ex = np.exp(e) * mask
+    att = ex / (ex.sum(axis=1, keepdims=True) + 1e-4)
+    c.update(v=v, att=att, w_lin=w_lin, w_att=w_att, mask=mask)
+    out = (att[:, :, None] * hs).sum(axis=1)
+  else:
+    raise ValueError('Unsupported RNN type')
+  return out.astype(dtype), c
+
+
+def pooled_gru_backward(c, dout):
+  """Gradient of pooled_gru_forward wrt parameters, inputs and h0 given d(out) [S,H]."""
+  hs, lens = c['hs'], c['lens']
+  S, Tmax, H = hs.shape
+  dhs = np.zeros_like(hs)
+  extra = {}
+  if c['rnn_type'] == 'seq2seq':
+    dhs[np.arange(S), lens - 1] = dout
+  elif c['rnn_type'] == 'maxout':
+    s_idx, u_idx = np.meshgrid(np.arange(S), np.arange(H), indexing='ij')
+    dhs[s_idx, c['argmax'], u_idx] = dout
+  else:
+    att, v, mask = c['att'], c['v'], c['mask']
+    da = (hs * dout[:, None, :]).sum(axis=2)                 # [S,T]
+    de = att * (da - (att * da).sum(axis=1, keepdims=True))  # softmax-with-eps Jacobian
+    de = de * mask
+    dv = de[:, :, None] * c['w_att'][None, None, :]
+    du = dv * (1.0 - v * v)
+    extra['rnn.att_w.weight'] = (de[:, :, None] * v).sum(axis=(0, 1)).reshape(1, H)
+    extra['rnn.lin.weight'] = du.reshape(S * Tmax, H).T @ hs.reshape(S * Tmax, H)
+    extra['rnn.lin.bias'] = du.sum(axis=(0, 1))
+    dhs = att[:, :, None] * dout[:, None, :] + du @ c['w_lin']
+    dhs = dhs * mask[:, :, None]
+  grads, dx, dh0 = gru_backward(c, dhs)
+  grads.update(extra)
+  return grads, dx, dh0
+
+
+def l2_normalize_backward(x, g, dtype=np.float64):
+  x = np.asarray(x, dtype=dtype); g = np.asarray(g, dtype=dtype)
+  nrm = np.maximum(np.sqrt((x * x).sum(axis=1, keepdims=True)), 1e-12)
+  y = x / nrm
+  return (g - y * (y * g).sum(axis=1, keepdims=True)) / nrm
+
+
+def contrastive_loss_backward(im, s, margin=0.0, max_violation=False, norm=True, dtype=np.float64):
+  """d loss / d im, d loss / d s of contrastive_loss (upstream gradient 1)."""
+  im = np.asarray(im, dtype=dtype); s = np.asarray(s, dtype=dtype)
+  scores = im @ s.T
+  n = scores.shape[0]
+  diag = np.diag(scores).reshape(n, 1)
+  eye = np.eye(n, dtype=bool)
+  cost_s = np.where(eye, 0, np.maximum(margin + scores - diag, 0))
+  cost_im = np.where(eye, 0, np.maximum(margin + scores - diag.T, 0))
+  if max_violation:
+    g_s = np.zeros_like(scores); g_im = np.zeros_like(scores)
+    js = cost_s.argmax(axis=1)
+    g_s[np.arange(n), js] = (cost_s[np.arange(n), js] > 0)
+    is_ = cost_im.argmax(axis=0)
+    g_im[is_, np.arange(n)] = (cost_im[is_, np.arange(n)] > 0)
+  else:
+    g_s = (cost_s > 0).astype(dtype); g_im = (cost_im > 0).astype(dtype)
+  G = g_s + g_im
+  G[np.arange(n), np.arange(n)] -= g_s.sum(axis=1) + g_im.sum(axis=0)
+  if norm:
+    G = G / (n * n)
+  return G @ s, G.T @ im
+
+
+def train_step_grads(rnn_type, params, batch, margin=0.2, max_violation=False, norm=False,
+                     low_level_loss=False, dtype=np.float64):
+  """Parameter gradients of the total loss of VSE.train_emb (model.py:319-344, no reconstruction):
+  a list of four dicts keyed like the reference's state-dicts."""
+  (clips, captions, videos, paragraphs, lengths_clip, lengths_cap, lengths_video,
+   lengths_paragraph, num_clips, num_caps) = batch[:10]
+  table = np.asarray(params[1]['embed.weight'], dtype=dtype)
+  fw = lambda p, x, l, h0=None: pooled_gru_forward_cache(rnn_type, x, l, p, h0, dtype)
+  clip_emb, c_clip = fw(params[0], clips, lengths_clip)
+  cap_emb, c_cap = fw(params[1], table[np.asarray(captions)], lengths_cap)
+  vid_ctx, c_vid = fw(params[0], videos, lengths_video)
+  para_ctx, c_par = fw(params[1], table[np.asarray(paragraphs)], lengths_paragraph)
+  x_v = scatter_rows(clip_emb, num_clips, dtype)
+  x_p = scatter_rows(cap_emb, num_caps, dtype)
+  vid_emb, c_v2 = fw(params[2], x_v, num_clips, vid_ctx)
+  para_emb, c_p2 = fw(params[3], x_p, num_caps, para_ctx)
+
+  d = {k: 0.0 for k in ['vid', 'para', 'vctx', 'pctx', 'clip', 'cap']}
+  raw = dict(vid=vid_emb, para=para_emb, vctx=vid_ctx, pctx=para_ctx, clip=clip_emb, cap=cap_emb)
+
+  def add_loss(a, b, scale):
+    na, nb = l2_normalize(raw[a], dtype), l2_normalize(raw[b], dtype)
+    ga, gb = contrastive_loss_backward(na, nb, margin, max_violation, norm, dtype)
+    d[a] = d[a] + scale * l2_normalize_backward(raw[a], ga, dtype)
+    d[b] = d[b] + scale * l2_normalize_backward(raw[b], gb, dtype)
+
+  add_loss('vid', 'para', 1.0)
+  add_loss('vctx', 'pctx', 1.0)
+  add_loss('vid', 'vid', 0.5)
+  add_loss('para', 'para', 0.5)
+  if low_level_loss:
+    add_loss('clip', 'cap', 1.0)
+    add_loss('clip', 'clip', 0.5)
+    add_loss('cap', 'cap', 0.5)
+
+  def gather_rows_grad(dxp, counts):
+    return np.concatenate([dxp[i, :c] for i, c in enumerate(counts)], 0)
+
+  g_v2, dx_v2, dh0_v2 = pooled_gru_backward(c_v2, d['vid'])
+  g_p2, dx_p2, dh0_p2 = pooled_gru_backward(c_p2, d['para'])
+  d_clip = d['clip'] + gather_rows_grad(dx_v2, num_clips)
+  d_cap = d['cap'] + gather_rows_grad(dx_p2, num_caps)
+  g_clip, _, _ = pooled_gru_backward(c_clip, d_clip)
+  g_vid, _, _ = pooled_gru_backward(c_vid, d['vctx'] + dh0_v2)
+  g_cap, dx_cap, _ = pooled_gru_backward(c_cap, d_cap)
+  g_par, dx_par, _ = pooled_gru_backward(c_par, d['pctx'] + dh0_p2)
+  g0 = {k: g_clip[k] + g_vid[k] for k in g_clip}
+  g1 = {k: g_cap[k] + g_par[k] for k in g_cap}
+  dtable = np.zeros_like(table)
+  for toks, lens, dxx in [(captions, lengths_cap, dx_cap), (paragraphs, lengths_paragraph, dx_par)]:
+    toks = np.asarray(toks)
+    for i, l in enumerate(np.asarray(lens)):
+      np.add.at(dtable, toks[i, :l], dxx[i, :l])
+  g1['embed.weight'] = dtable
+  return [g0, g1, g_v2, g_p2]

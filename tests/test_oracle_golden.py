@@ -103,3 +103,60 @@ def test_train_loss_meters(oracle, rnn_type):
       assert [l[0] for l in log] == [str(s) for s in g[tag + '.names']]
       np.testing.assert_allclose([l[1] for l in log], g[tag + '.values'], rtol=1e-5, atol=2e-6)
       assert [l[2] for l in log] == list(g[tag + '.n'])
+
+
+# ------------------------------------------------------------------------------------------
+# backward: the oracle's written-out derivatives against the reference's autograd gradients
+# ------------------------------------------------------------------------------------------
+GTOL = dict(rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('cls,rnn_type', [('Attention', 'attention'), ('Maxout', 'maxout'),
+                                          ('Seq2Seq', 'seq2seq')])
+@pytest.mark.parametrize('tag', ['ragged', 'equal', 'one'])
+def test_layer_backward(oracle, cls, rnn_type, tag):
+  g = load_golden('layers.npz')
+  p = {k[len(cls) + 4:]: g[k] for k in g.files if k.startswith(cls + '.sd.')}
+  key = '%s.%s' % (cls, tag)
+  x, lens, h0, w = g[key + '.x'], g[key + '.lens'], g[key + '.h0'], g[key + '.bwd.w']
+  out, c = oracle.pooled_gru_forward_cache(rnn_type, x, lens, p, h0)
+  np.testing.assert_allclose(out, g[key + '.out_h0'], atol=TOL, rtol=0)
+  grads, dx, dh0 = oracle.pooled_gru_backward(c, w.astype(np.float64))
+  np.testing.assert_allclose(dx, g[key + '.bwd.dx'][:, :dx.shape[1]], **GTOL)
+  np.testing.assert_allclose(dh0, g[key + '.bwd.dh0'], **GTOL)
+  for k in g.files:
+    if k.startswith(key + '.bwd.grad.'):
+      name = k[len(key + '.bwd.grad.'):]
+      np.testing.assert_allclose(grads[name], g[k], err_msg=name, **GTOL)
+
+
+@pytest.mark.parametrize('n', [5, 16, 37])
+def test_loss_backward(oracle, n):
+  g = load_golden('loss.npz')
+  a, b = g['n%d.a' % n].astype(np.float64), g['n%d.b' % n].astype(np.float64)
+  an, bn = oracle.l2_normalize(a, np.float64), oracle.l2_normalize(b, np.float64)
+  for mv in (0, 1):
+    for nm in (0, 1):
+      tag = 'n%d.mv%d.norm%d' % (n, mv, nm)
+      ga, gb = oracle.contrastive_loss_backward(an, bn, 0.2, bool(mv), bool(nm))
+      np.testing.assert_allclose(oracle.l2_normalize_backward(a, ga), g[tag + '.da'], **GTOL)
+      np.testing.assert_allclose(oracle.l2_normalize_backward(b, gb), g[tag + '.db'], **GTOL)
+      g1, g2 = oracle.contrastive_loss_backward(an, an, 0.2, bool(mv), bool(nm))
+      np.testing.assert_allclose(oracle.l2_normalize_backward(a, g1 + g2), g[tag + '.da_self'],
+                                 **GTOL)
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_train_step_gradients(oracle, rnn_type):
+  g = load_golden('model_%s.npz' % rnn_type)
+  sds = golden_state_dicts(g)
+  batch = golden_batches(g)[1]
+  for mv in (0, 1):
+    for nm in (0, 1):
+      tag = 'train.mv%d.norm%d' % (mv, nm)
+      grads = oracle.train_step_grads(rnn_type, sds, batch, margin=0.2, max_violation=bool(mv),
+                                      norm=bool(nm), low_level_loss=True)
+      for i in range(4):
+        for k, v in grads[i].items():
+          np.testing.assert_allclose(v, g['%s.grad%d.%s' % (tag, i, k)], rtol=5e-4, atol=5e-6,
+                                     err_msg='%s enc%d %s' % (tag, i, k))

@@ -122,6 +122,17 @@ def golden_layers(ref_layers, out):
       cases[key + '.h0'] = h0.numpy()
       cases[key + '.out'] = y.numpy()
       cases[key + '.out_h0'] = y_h0.numpy()
+      # gradients of sum(out * w) wrt parameters, input and h0 (reference autograd)
+      w = torch.randn(S, H, generator=gen)
+      xg = x.clone().requires_grad_(True)
+      hg = h0.clone().requires_grad_(True)
+      layer.zero_grad()
+      (layer(xg, torch.tensor(lens), hg) * w).sum().backward()
+      cases[key + '.bwd.w'] = w.numpy()
+      cases[key + '.bwd.dx'] = xg.grad.numpy()
+      cases[key + '.bwd.dh0'] = hg.grad.numpy()
+      for pn, pp in layer.named_parameters():
+        cases[key + '.bwd.grad.rnn.' + pn] = pp.grad.detach().numpy().copy()
     for k, v in sd.items():
       cases['%s.sd.%s' % (cls_name, k)] = v
   np.savez_compressed(os.path.join(out, 'layers.npz'), **cases)
@@ -146,6 +157,16 @@ def golden_loss(ref_loss, out):
         cases[tag + '.ab'] = np.float32(crit(an, bn).item())
         cases[tag + '.aa'] = np.float32(crit(an, an).item())
     cases['n%d.scores' % n] = ref_loss.cosine_sim(an, bn).numpy()
+    for mv in [False, True]:
+      for nm in [False, True]:
+        crit = ref_loss.ContrastiveLoss(margin=0.2, measure='cosine', max_violation=mv, norm=nm)
+        ag = a.clone().requires_grad_(True); bg = b.clone().requires_grad_(True)
+        crit(F.normalize(ag), F.normalize(bg)).backward()
+        tag = 'n%d.mv%d.norm%d' % (n, int(mv), int(nm))
+        cases[tag + '.da'] = ag.grad.numpy(); cases[tag + '.db'] = bg.grad.numpy()
+        ag2 = a.clone().requires_grad_(True)
+        crit(F.normalize(ag2), F.normalize(ag2)).backward()
+        cases[tag + '.da_self'] = ag2.grad.numpy()
   from decoder.loss import EuclideanLoss
   a = torch.randn(13, 24, generator=gen); b = torch.randn(13, 24, generator=gen)
   cases['euclid.a'] = a.numpy(); cases['euclid.b'] = b.numpy()
@@ -272,6 +293,10 @@ def golden_model(ref_model, ref_eval, out):
         model.train_emb(topt, *batches[1])
         tag = 'train.mv%d.norm%d' % (int(mv), int(nm_))
         calls = [c for c in model.logger.calls if c[0].startswith('Le')]
+        for i, enc in enumerate([model.clip_enc, model.txt_enc, model.vid_seq_enc,
+                                 model.txt_seq_enc]):
+          for pn, pp in enc.named_parameters():
+            cases['%s.grad%d.%s' % (tag, i, pn)] = pp.grad.detach().numpy().copy()
         cases[tag + '.names'] = np.array([c[0] for c in calls])
         cases[tag + '.values'] = np.array([c[1] for c in calls], dtype=np.float64)
         cases[tag + '.n'] = np.array([c[2] for c in calls], dtype=np.int64)
