@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcmhse_hip.so')
 
 POOL_LAST, POOL_ATTN, POOL_MAX = 0, 1, 2
+SAVE_FOR_BACKWARD = 0x100
 POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}
 
 c_void_p, c_int32, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
@@ -19,6 +20,11 @@ c_void_p, c_int32, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int32
 class GruWeights(ctypes.Structure):
   _fields_ = [('w_ih', c_void_p), ('w_hh', c_void_p), ('b_ih', c_void_p), ('b_hh', c_void_p),
               ('w_lin', c_void_p), ('b_lin', c_void_p), ('w_att', c_void_p)]
+
+
+class GruGrads(ctypes.Structure):
+  _fields_ = [('dw_ih', c_void_p), ('dw_hh', c_void_p), ('db_ih', c_void_p), ('db_hh', c_void_p),
+              ('dw_lin', c_void_p), ('db_lin', c_void_p), ('dw_att', c_void_p)]
 
 
 class SeqBatch(ctypes.Structure):
@@ -50,6 +56,18 @@ SIGNATURES = {
     'cmhse_contrastive_blocks_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_float, c_int32, c_int32, c_void_p,
                                                     c_void_p, c_size_t, c_void_p]),
+    'cmhse_gru_pool_bwd_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32,
+                                                c_int32]),
+    'cmhse_gru_pool_bwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),
+                                          c_int32, c_void_p, c_void_p, ctypes.POINTER(GruGrads),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]),
+    'cmhse_l2norm_rows_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                             c_void_p]),
+    'cmhse_contrastive_bwd_workspace': (c_size_t, [c_int32]),
+    'cmhse_contrastive_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                             c_float, c_int32, c_int32, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_size_t, c_void_p]),
     'cmhse_timer_create': (c_void_p, []),
     'cmhse_timer_destroy': (None, [c_void_p]),
     'cmhse_timer_elapsed_ms': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float)]),

@@ -1,0 +1,767 @@
+// bwd.hip — backward pass of the hot path: what `loss.backward()`
+// (/root/reference/model.py:367) computes through layers.{Seq2Seq,Attention,Maxout}.forward,
+// F.normalize and ContrastiveLoss.forward, as hand-written gfx950 kernels.
+//
+//   cmhse_gru_pool_bwd      pooling backward -> dpool[sumT,H]; BPTT over the packed steps in reverse
+//                           (one launch per step: dh_{t} = dgates_{t+1} . W_hh + carry, gate
+//                           derivatives in the epilogue); weight gradients as TN GEMMs over all
+//                           packed rows; optional d(input) / d(h0) / d(embedding table).
+//   cmhse_l2norm_rows_bwd   F.normalize backward.
+//   cmhse_contrastive_bwd   d loss / d im, d loss / d s from the stored score matrix.
+//
+// Determinism: every reduction runs in a fixed order except the embedding-table scatter
+// (float atomics, like torch's CUDA embedding backward).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/cmhse_hip.h"
+#include "gru_ws.hpp"
+#include "nt_core.hpp"
+#include "tn_core.hpp"
+
+namespace cmhse {
+
+// ---------------------------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, int R,
+                                                             int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = in[static_cast<int64_t>(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) out[static_cast<int64_t>(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+// Column sums over the packed rows: out[c] = sum_p w[p] * in[p][c] (w == NULL -> 1).
+// 64 columns per workgroup (one per lane), the 4 waves split the rows, fixed-order LDS combine.
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const float* __restrict__ in,
+                                                          const float* __restrict__ w,
+                                                          float* __restrict__ out, int64_t rows,
+                                                          int cols, int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t p = wave; p < rows; p += 4) s += (w ? w[p] : 1.0f) * in[p * ld + c];
+  __shared__ float part[4][64];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < cols) out[c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+// Per packed row p = (t, s): addresses of x_{t,s} and of h_{t-1,s} (a zero row when there is none).
+struct RowAddrParams {
+  const uint64_t* x_rows;
+  const uint64_t* tok_rows;
+  const float* emb;
+  const uint64_t* h0_rows;
+  const int32_t* step_off;
+  const float* hs;
+  const float* zero_row;
+  uint64_t* xaddr;
+  uint64_t* hpaddr;
+  int32_t* p_t;
+  int32_t Tmax, I, H, vocab;
+  int64_t sum_T;
+};
+
+__global__ void row_addr_kernel(const RowAddrParams q) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= q.sum_T) return;
+  int lo = 0, hi = q.Tmax;  // largest t with step_off[t] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (q.step_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  const int t = lo, s = static_cast<int>(p - q.step_off[t]);
+  q.p_t[p] = t;
+  if (q.tok_rows != nullptr) {
+    long long tok = reinterpret_cast<const long long*>(q.tok_rows[s])[t];
+    tok = tok < 0 ? 0 : (tok >= q.vocab ? q.vocab - 1 : tok);
+    q.xaddr[p] = reinterpret_cast<uint64_t>(q.emb + tok * q.I);
+  } else {
+    q.xaddr[p] = q.x_rows[s] + static_cast<uint64_t>(t) * q.I * 4u;
+  }
+  if (t > 0)
+    q.hpaddr[p] = reinterpret_cast<uint64_t>(q.hs + (static_cast<int64_t>(q.step_off[t - 1]) + s) * q.H);
+  else if (q.h0_rows != nullptr)
+    q.hpaddr[p] = q.h0_rows[s];
+  else
+    q.hpaddr[p] = reinterpret_cast<uint64_t>(q.zero_row);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooling backward: fills dpool[p][u] = d loss / d h_p[u] coming from the pooling
+// ---------------------------------------------------------------------------------------------
+struct PoolBwdParams {
+  const float* dout;  // [S, H] indexed by out_row
+  const int32_t* lens;
+  const int32_t* out_row;
+  const int32_t* step_off;
+  const int32_t* argmax;
+  float* dpool;
+  int32_t S, H, mode;
+};
+
+__global__ __launch_bounds__(kThreads) void pool_scatter_bwd_kernel(const PoolBwdParams q) {
+  const int s = blockIdx.x;
+  const float* g = q.dout + static_cast<int64_t>(q.out_row[s]) * q.H;
+  for (int u = threadIdx.x; u < q.H; u += kThreads) {
+    const int t = (q.mode == CMHSE_POOL_MAX) ? q.argmax[static_cast<int64_t>(s) * q.H + u]
+                                             : (q.lens[s] - 1);
+    q.dpool[(static_cast<int64_t>(q.step_off[t]) + s) * q.H + u] = g[u];
+  }
+}
+
+// attention: a_t = exp(e_t)/(sum exp + 1e-4); da_t = g . h_t; de_t = a_t (da_t - sum a da);
+// dpool[p] = a_t g.  One workgroup per sequence.
+struct AttnBwdParams {
+  const float* dout;
+  const float* hs;
+  const float* e_part;
+  const int32_t* lens;
+  const int32_t* out_row;
+  const int32_t* step_off;
+  float* dpool;
+  float* de;  // [sumT]
+  int64_t rows;
+  int32_t H, n_tiles;
+};
+
+__global__ __launch_bounds__(kThreads) void attn_pool_bwd_kernel(const AttnBwdParams q) {
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = q.lens[s], H = q.H;
+  const float* g = q.dout + static_cast<int64_t>(q.out_row[s]) * H;
+  __shared__ float red[kThreads];
+  __shared__ float s_den, s_c;
+  __shared__ float wpart[4];
+  auto energy = [&](int t) {
+    const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
+    float e = 0.f;
+    for (int k = 0; k < q.n_tiles; ++k) e += q.e_part[k * q.rows + row];
+    return e;
+  };
+  float part = 0.f;
+  for (int t = tid; t < len; t += kThreads) part += expf(energy(t));
+  red[tid] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float d = 0.f;
+    for (int i = 0; i < kThreads; ++i) d += red[i];
+    s_den = d + 0.0001f;
+  }
+  __syncthreads();
+  const float den = s_den;
+  // pass 1: da_t (block dot product) -> de scratch holds da_t; c = sum_t a_t da_t
+  float c_acc = 0.f;
+  for (int t = 0; t < len; ++t) {
+    const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
+    float d = 0.f;
+    for (int u = tid; u < H; u += kThreads) d += g[u] * q.hs[row * H + u];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane == 0) wpart[wave] = d;
+    __syncthreads();
+    if (tid == 0) {
+      const float da = wpart[0] + wpart[1] + wpart[2] + wpart[3];
+      const float a = expf(energy(t)) / den;
+      q.de[row] = da;  // temporarily da_t
+      c_acc += a * da;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) s_c = c_acc;
+  __syncthreads();
+  const float c = s_c;
+  // pass 2: de_t and dpool rows
+  for (int t = 0; t < len; ++t) {
+    const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
+    const float a = expf(energy(t)) / den;
+    for (int u = tid; u < H; u += kThreads) q.dpool[row * H + u] = a * g[u];
+    __syncthreads();
+    if (tid == 0) q.de[row] = a * (q.de[row] - c);
+  }
+}
+
+// du[p][n] = de[p] * w_att[n] * (1 - v[p][n]^2)
+__global__ __launch_bounds__(kThreads) void attn_du_kernel(const float* __restrict__ de,
+                                                           const float* __restrict__ v,
+                                                           const float* __restrict__ w_att,
+                                                           float* __restrict__ du, int64_t rows,
+                                                           int H) {
+  const int64_t p = blockIdx.x;
+  const float d = de[p];
+  for (int n = threadIdx.x; n < H; n += kThreads) {
+    const float tv = v[p * H + n];
+    du[p * H + n] = d * w_att[n] * (1.0f - tv * tv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic GEMM kernels
+// ---------------------------------------------------------------------------------------------
+struct TnParams {
+  const float* a;  // [K, lda], columns m
+  int64_t lda;
+  const float* b;  // [K, ldb] or rows through b_addr
+  int64_t ldb;
+  const uint64_t* b_addr;
+  float* c;  // [M, ldc]
+  int64_t ldc;
+  int32_t M, N, n_tiles;
+  int64_t K;
+  const float* scale;  // optional device scalar multiplied into C
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const TnParams q) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = (blockIdx.x % q.n_tiles) * BN, m0 = (blockIdx.x / q.n_tiles) * BM;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  tn_mainloop<BM, BN, VEC>(smem, q.a, q.lda, q.M, q.b, q.ldb, q.b_addr, q.N, q.K, m0, n0, acc);
+  const float sc = q.scale ? *q.scale : 1.0f;
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
+        const int n = n0 + wn * 64 + ns * 32 + acc_col(lane);
+        if (m < q.M && n < q.N) q.c[static_cast<int64_t>(m) * q.ldc + n] = sc * acc[ms][ns][r];
+      }
+}
+
+// C[m][n] = sum_k A[m][k] B[n][k]; output row m goes to c_addr[m] (or c + m*ldc);
+// mode 0 store, 1 accumulate (+=), 2 atomic add (rows may repeat: embedding-table scatter).
+struct NtOutParams {
+  const float* a;  // [M, lda]
+  int64_t lda;
+  const float* b;  // [N, ldb]
+  int64_t ldb;
+  float* c;
+  int64_t ldc;
+  const uint64_t* c_addr;
+  int32_t M, N, K, n_tiles, mode;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void gemm_nt_out_kernel(const NtOutParams q) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, srow = tid >> 2;
+  const int n0 = (blockIdx.x % q.n_tiles) * BN, m0 = (blockIdx.x / q.n_tiles) * BM;
+  rowaddr_t ar[2], br[2];
+  bool av[2], bv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + srow + 64 * i, n = n0 + srow + 64 * i;
+    av[i] = m < q.M;
+    bv[i] = n < q.N;
+    ar[i] = row_addr(q.a + static_cast<int64_t>(av[i] ? m : 0) * q.lda);
+    br[i] = row_addr(q.b + static_cast<int64_t>(bv[i] ? n : 0) * q.ldb);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  const int b_row0[2] = {wn * 64, wn * 64 + 32};
+  nt_phase<BM, BN, 2, 2, 2, 1, VEC>(smem, ar, av, br, bv, q.K, wm * 64, b_row0, acc);
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
+      if (m >= q.M) continue;
+      float* crow = q.c_addr ? reinterpret_cast<float*>(q.c_addr[m])
+                             : q.c + static_cast<int64_t>(m) * q.ldc;
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns) {
+        const int n = n0 + b_row0[ns] + acc_col(lane);
+        if (n >= q.N) continue;
+        const float v = acc[ms][ns][r];
+        if (q.mode == 0) crow[n] = v;
+        else if (q.mode == 1) crow[n] += v;
+        else atomicAdd(crow + n, v);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BPTT step (latency-shaped like gru_step_tiny_kernel): 32 sequences x 32 hidden units per
+// workgroup, the 4 waves split K = 3H of  rec = dGh_{t+1} . W_hh  (W_hh^T rows are K-contiguous),
+// fixed-order LDS combine, then the gate derivatives of step t in the epilogue.
+// ---------------------------------------------------------------------------------------------
+struct BwdStepParams {
+  const float* dgh_next;  // rows of step t+1: [S_next, 3H]
+  const float* whh_t;     // [H, 3H]
+  const float* dpool;     // [sumT, H]
+  const float* gates;     // [sumT, 4H]
+  const float* hs;        // [sumT, H]
+  const uint64_t* h0_rows;
+  const int32_t* out_row;
+  float* carry;  // [S, H]  dh_{t+1} * z_{t+1}
+  float* dgx;    // [sumT, 3H]
+  float* dgh;    // [sumT, 3H]
+  float* dh0;    // [S, H] by out_row (final launch only)
+  int32_t H, t, S_t, S_next;
+  int64_t off_cur, off_prev;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void gru_bwd_step_kernel(const BwdStepParams q) {
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = q.H, K = 3 * H;
+  const int u_tiles = (H + 31) / 32;
+  const int u0 = (blockIdx.x % u_tiles) * 32, m0 = (blockIdx.x / u_tiles) * 32;
+  const int row = lane & 31, hi = lane >> 5;
+  f32x16 acc = zero16();
+  if (q.S_next > 0) {
+    const int m = m0 + row;
+    const int mc = (m < q.S_next) ? m : (q.S_next - 1);
+    const int u = u0 + row;
+    const int uc = (u < H) ? u : (H - 1);
+    tiny_phase<VEC>(row_addr(q.dgh_next + static_cast<int64_t>(mc) * K),
+                    row_addr(q.whh_t + static_cast<int64_t>(uc) * K), u < H, K, wave, hi, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // 4 elements per thread: tile row er, columns ec..ec+3
+  const int er = tid >> 3, ec = (tid & 7) * 4;
+  const int m = m0 + er;
+  if (m >= q.S_t) return;
+  const int reg = (er & 3) | ((er >> 3) << 2);
+  const int lb = 32 * ((er >> 2) & 1) + ec;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int u = u0 + ec + j;
+    if (u >= H) continue;
+    float rec = 0.f;
+    if (m < q.S_next)
+      rec = red[0][reg][lb + j] + red[1][reg][lb + j] + red[2][reg][lb + j] + red[3][reg][lb + j] +
+            q.carry[static_cast<int64_t>(m) * H + u];
+    if (q.t < 0) {  // final launch: d loss / d h0
+      q.dh0[static_cast<int64_t>(q.out_row[m]) * H + u] = rec;
+      continue;
+    }
+    const int64_t p = q.off_cur + m;
+    const float dh = rec + q.dpool[p * H + u];
+    const float* gp = q.gates + p * 4 * H + u;
+    const float rg = gp[0], zg = gp[H], ng = gp[2 * H], ghn = gp[3 * H];
+    float hp = 0.f;
+    if (q.t > 0)
+      hp = q.hs[(q.off_prev + m) * H + u];
+    else if (q.h0_rows != nullptr)
+      hp = reinterpret_cast<const float*>(q.h0_rows[m])[u];
+    const float dn_pre = dh * (1.0f - zg) * (1.0f - ng * ng);
+    const float dz_pre = dh * (hp - ng) * zg * (1.0f - zg);
+    const float dr_pre = dn_pre * ghn * rg * (1.0f - rg);
+    float* gx = q.dgx + p * K + u;
+    float* gh = q.dgh + p * K + u;
+    gx[0] = dr_pre;
+    gx[H] = dz_pre;
+    gx[2 * H] = dn_pre;
+    gh[0] = dr_pre;
+    gh[H] = dz_pre;
+    gh[2 * H] = dn_pre * rg;
+    q.carry[static_cast<int64_t>(m) * H + u] = dh * zg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize backward: dx = (g - y (y.g)) / max(||x||, eps), y = x / max(||x||, eps)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ g,
+                                                              float* __restrict__ dx, int cols) {
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * cols;
+  const float* gr = g + row * cols;
+  float ss = 0.f, sg = 0.f;
+  for (int c = threadIdx.x; c < cols; c += kThreads) {
+    ss += xr[c] * xr[c];
+    sg += xr[c] * gr[c];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    sg += __shfl_xor(sg, o, 64);
+  }
+  __shared__ float p1[4], p2[4];
+  __shared__ float s_inv, s_dot;
+  if ((threadIdx.x & 63) == 0) {
+    p1[threadIdx.x >> 6] = ss;
+    p2[threadIdx.x >> 6] = sg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float n2 = p1[0] + p1[1] + p1[2] + p1[3];
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    s_inv = inv;
+    s_dot = (p2[0] + p2[1] + p2[2] + p2[3]) * inv * inv;  // (y.g)/||x||
+  }
+  __syncthreads();
+  const float inv = s_inv, d = s_dot;
+  for (int c = threadIdx.x; c < cols; c += kThreads) dx[row * cols + c] = (gr[c] - xr[c] * d) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ContrastiveLoss backward: G = d loss / d scores (loss.py:94-117 differentiated), then
+// d im = G . s and d s = G^T . im as TN GEMMs on G^T and G.
+// ---------------------------------------------------------------------------------------------
+struct LossBwdParams {
+  const float* scores;  // [n, n]
+  const float* gout;    // device scalar: upstream gradient
+  int32_t n, max_violation, norm;
+  float margin;
+  int32_t* row_arg;  // [n] max_violation: argmax_j cost_s(i,j) (or -1 when the max is 0)
+  int32_t* col_arg;  // [n] max_violation: argmax_i cost_im(i,j)
+  float* row_cnt;    // [n] sum_j g_s(i,j)
+  float* col_cnt;    // [n] sum_i g_im(i,j)
+  float* G;          // [n, n]
+  float* GT;         // [n, n]
+};
+
+// one wave per row (rows pass) or per column (columns pass): counts / argmax of violating entries
+__global__ __launch_bounds__(kThreads) void loss_bwd_stats_kernel(const LossBwdParams q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = q.n;
+  const int idx = blockIdx.x * 4 + wave;  // [0, 2n): rows then columns
+  if (idx >= 2 * n) return;
+  const bool is_row = idx < n;
+  const int i = is_row ? idx : idx - n;
+  const float dii = q.scores[static_cast<int64_t>(i) * n + i];
+  float cnt = 0.f, best = 0.f;
+  int arg = 0x7fffffff;
+  for (int j = lane; j < n; j += 64) {
+    if (j == i) continue;
+    const float sv = is_row ? q.scores[static_cast<int64_t>(i) * n + j]
+                            : q.scores[static_cast<int64_t>(j) * n + i];
+    const float c = fmaxf(q.margin + sv - dii, 0.f);
+    cnt += (c > 0.f) ? 1.f : 0.f;
+    if (c > best) {  // first maximum along the reduced index
+      best = c;
+      arg = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    const float ob = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) {
+      best = ob;
+      arg = oa;
+    }
+  }
+  if (lane == 0) {
+    const int a = (best > 0.f) ? arg : -1;
+    const float c = q.max_violation ? ((best > 0.f) ? 1.f : 0.f) : cnt;
+    if (is_row) {
+      q.row_arg[i] = a;
+      q.row_cnt[i] = c;
+    } else {
+      q.col_arg[i] = a;
+      q.col_cnt[i] = c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void loss_bwd_build_kernel(const LossBwdParams q) {
+  const int n = q.n;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= static_cast<int64_t>(n) * n) return;
+  const int i = static_cast<int>(e / n), j = static_cast<int>(e % n);
+  float scale = *q.gout;
+  if (q.norm) scale /= static_cast<float>(static_cast<int64_t>(n) * n);
+  float g;
+  if (i == j) {
+    g = -(q.row_cnt[i] + q.col_cnt[i]);
+  } else if (q.max_violation) {
+    g = ((q.row_arg[i] == j) ? 1.f : 0.f) + ((q.col_arg[j] == i) ? 1.f : 0.f);
+  } else {
+    const float sv = q.scores[e];
+    const float cs = q.margin + sv - q.scores[static_cast<int64_t>(i) * n + i];
+    const float ci = q.margin + sv - q.scores[static_cast<int64_t>(j) * n + j];
+    g = ((cs > 0.f) ? 1.f : 0.f) + ((ci > 0.f) ? 1.f : 0.f);
+  }
+  g *= scale;
+  q.G[e] = g;
+  q.GT[static_cast<int64_t>(j) * n + i] = g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------------------------
+static void launch_transpose(const float* in, float* out, int R, int C, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(kThreads), 0, st,
+                     in, out, R, C);
+}
+
+static void launch_colsum(const float* in, const float* w, float* out, int64_t rows, int cols,
+                          int64_t ld, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(kThreads), 0, st, in, w, out,
+                     rows, cols, ld);
+}
+
+static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
+                      const uint64_t* b_addr, float* c, int64_t ldc, int M, int N, int64_t K,
+                      const float* scale, bool vec, hipStream_t st) {
+  TnParams q;
+  q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.b_addr = b_addr; q.c = c; q.ldc = ldc;
+  q.M = M; q.N = N; q.K = K; q.n_tiles = (N + 127) / 128; q.scale = scale;
+  const unsigned grid = static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
+  const size_t smem = TnSmem<128, 128>::kBytes;
+  if (vec)
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(grid), dim3(kThreads), smem, st, q);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid), dim3(kThreads), smem, st, q);
+}
+
+static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
+                          int64_t ldc, const uint64_t* c_addr, int M, int N, int K, int mode,
+                          hipStream_t st) {
+  NtOutParams q;
+  q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.c = c; q.ldc = ldc; q.c_addr = c_addr;
+  q.M = M; q.N = N; q.K = K; q.mode = mode; q.n_tiles = (N + 127) / 128;
+  const unsigned grid = static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
+  const size_t smem = TileSmem<128, 128>::kBytes;
+  const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
+  if (vec)
+    hipLaunchKernelGGL(gemm_nt_out_kernel<true>, dim3(grid), dim3(kThreads), smem, st, q);
+  else
+    hipLaunchKernelGGL(gemm_nt_out_kernel<false>, dim3(grid), dim3(kThreads), smem, st, q);
+}
+
+struct BwdWs {
+  size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, p_t, zero_row, total;
+};
+
+static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
+  BwdWs L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += ws_align(bytes); return o; };
+  L.dgx = take(static_cast<size_t>(sum_T) * 3 * H * 4);
+  L.dgh = take(static_cast<size_t>(sum_T) * 3 * H * 4);
+  L.dpool = take(static_cast<size_t>(sum_T) * H * 4);
+  L.carry = take(static_cast<size_t>(S) * H * 4);
+  L.whh_t = take(static_cast<size_t>(3) * H * H * 4);
+  L.wih_t = take(static_cast<size_t>(3) * H * I * 4);
+  L.wlin_t = take(mode == CMHSE_POOL_ATTN ? static_cast<size_t>(H) * H * 4 : 0);
+  L.du = take(mode == CMHSE_POOL_ATTN ? static_cast<size_t>(sum_T) * H * 4 : 0);
+  L.de = take(mode == CMHSE_POOL_ATTN ? static_cast<size_t>(sum_T) * 4 : 0);
+  L.xaddr = take(static_cast<size_t>(sum_T) * 8);
+  L.hpaddr = take(static_cast<size_t>(sum_T) * 8);
+  L.p_t = take(static_cast<size_t>(sum_T) * 4);
+  L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
+  L.total = off;
+  return L;
+}
+
+}  // namespace cmhse
+
+using namespace cmhse;
+
+extern "C" size_t cmhse_gru_pool_bwd_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I,
+                                               int32_t H, int32_t pool_mode) {
+  (void)Tmax;
+  if (S <= 0 || sum_T <= 0 || I <= 0 || H <= 0) return 0;
+  return bwd_ws_layout(S, sum_T, I, H, pool_mode & ~CMHSE_SAVE_FOR_BACKWARD).total;
+}
+
+extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
+                                  int32_t pool_mode, const float* dout, const void* fwd_workspace,
+                                  const cmhse_gru_grads* g, const uint64_t* dx_rows,
+                                  float* d_emb_table, float* dh0, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+  if (!b || !w || !dout || !fwd_workspace || !g || !workspace) return CMHSE_ERR_ARG;
+  pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
+  if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX)
+    return CMHSE_ERR_ARG;
+  if (b->S <= 0 || b->Tmax <= 0 || b->I <= 0 || b->H <= 0 || !b->step_count_host) return CMHSE_ERR_ARG;
+  if (!g->dw_ih || !g->dw_hh || !g->db_ih || !g->db_hh) return CMHSE_ERR_ARG;
+  if (pool_mode == CMHSE_POOL_ATTN && (!g->dw_lin || !g->db_lin || !g->dw_att || !w->w_lin || !w->w_att))
+    return CMHSE_ERR_ARG;
+  if (dx_rows && d_emb_table) return CMHSE_ERR_ARG;
+  if (d_emb_table && !b->tok_rows) return CMHSE_ERR_ARG;
+  if (dh0 && !b->h0_rows) return CMHSE_ERR_ARG;
+  const int S = b->S, Tmax = b->Tmax, I = b->I, H = b->H;
+  int64_t sum_T = 0;
+  for (int t = 0; t < Tmax; ++t) sum_T += b->step_count_host[t];
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_gru_pool_bwd_workspace(S, Tmax, sum_T, I, H, pool_mode))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const GruWs F = gru_ws_layout(S, sum_T, H, pool_mode | CMHSE_SAVE_FOR_BACKWARD);
+  const char* fws = static_cast<const char*>(fwd_workspace);
+  const float* hs = reinterpret_cast<const float*>(fws + F.hs);
+  const float* gates = reinterpret_cast<const float*>(fws + F.gates);
+  const BwdWs L = bwd_ws_layout(S, sum_T, I, H, pool_mode);
+  char* ws = static_cast<char*>(workspace);
+  float* dgx = reinterpret_cast<float*>(ws + L.dgx);
+  float* dgh = reinterpret_cast<float*>(ws + L.dgh);
+  float* dpool = reinterpret_cast<float*>(ws + L.dpool);
+  float* carry = reinterpret_cast<float*>(ws + L.carry);
+  float* whh_t = reinterpret_cast<float*>(ws + L.whh_t);
+  float* wih_t = reinterpret_cast<float*>(ws + L.wih_t);
+  uint64_t* xaddr = reinterpret_cast<uint64_t*>(ws + L.xaddr);
+  uint64_t* hpaddr = reinterpret_cast<uint64_t*>(ws + L.hpaddr);
+  int32_t* p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
+  float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
+  const bool vec = (I % 4 == 0) && (H % 4 == 0);
+
+  (void)hipMemsetAsync(zero_row, 0, static_cast<size_t>(H > I ? H : I) * 4, st);
+  (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
+
+  // ---- 1. pooling backward -> dpool ----
+  if (pool_mode == CMHSE_POOL_ATTN) {
+    float* du = reinterpret_cast<float*>(ws + L.du);
+    float* de = reinterpret_cast<float*>(ws + L.de);
+    float* wlin_t = reinterpret_cast<float*>(ws + L.wlin_t);
+    const float* v = reinterpret_cast<const float*>(fws + F.v);
+    AttnBwdParams ap;
+    ap.dout = dout; ap.hs = hs; ap.e_part = reinterpret_cast<const float*>(fws + F.e_part);
+    ap.lens = b->lens; ap.out_row = b->out_row; ap.step_off = b->step_off;
+    ap.dpool = dpool; ap.de = de; ap.rows = sum_T; ap.H = H; ap.n_tiles = (H + kAttBN - 1) / kAttBN;
+    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(S), dim3(kThreads), 0, st, ap);
+    hipLaunchKernelGGL(attn_du_kernel, dim3(static_cast<unsigned>(sum_T)), dim3(kThreads), 0, st,
+                       de, v, w->w_att, du, sum_T, H);
+    launch_colsum(v, de, g->dw_att, sum_T, H, H, st);      // d att_w = sum_p de_p v_p
+    launch_colsum(du, nullptr, g->db_lin, sum_T, H, H, st);
+    // d W_lin[n][k] = sum_p du[p][n] hs[p][k]
+    launch_tn(du, H, hs, H, nullptr, g->dw_lin, H, H, H, sum_T, nullptr, vec, st);
+    // dpool += du . W_lin  (NT on W_lin^T)
+    launch_transpose(w->w_lin, wlin_t, H, H, st);
+    launch_nt_out(du, H, wlin_t, H, dpool, H, nullptr, static_cast<int>(sum_T), H, H, 1, st);
+  } else {
+    (void)hipMemsetAsync(dpool, 0, static_cast<size_t>(sum_T) * H * 4, st);
+    PoolBwdParams pp;
+    pp.dout = dout; pp.lens = b->lens; pp.out_row = b->out_row; pp.step_off = b->step_off;
+    pp.argmax = reinterpret_cast<const int32_t*>(fws + F.argmax);
+    pp.dpool = dpool; pp.S = S; pp.H = H; pp.mode = pool_mode;
+    hipLaunchKernelGGL(pool_scatter_bwd_kernel, dim3(S), dim3(kThreads), 0, st, pp);
+  }
+
+  // ---- 2. BPTT over the packed steps, last to first ----
+  launch_transpose(w->w_hh, whh_t, 3 * H, H, st);
+  BwdStepParams sp;
+  sp.whh_t = whh_t; sp.dpool = dpool; sp.gates = gates; sp.hs = hs; sp.h0_rows = b->h0_rows;
+  sp.out_row = b->out_row; sp.carry = carry; sp.dgx = dgx; sp.dgh = dgh; sp.dh0 = dh0; sp.H = H;
+  const int u_tiles = (H + 31) / 32;
+  int64_t off = sum_T;
+  for (int t = Tmax - 1; t >= -1; --t) {
+    if (t < 0 && !dh0) break;
+    const int S_t = (t >= 0) ? b->step_count_host[t] : S;
+    const int S_next = (t + 1 < Tmax) ? b->step_count_host[t + 1] : 0;
+    const int64_t off_next = off;           // step_off[t+1]
+    if (t >= 0) off -= S_t;                  // step_off[t]
+    sp.t = t; sp.S_t = S_t; sp.S_next = S_next;
+    sp.dgh_next = dgh + off_next * 3 * H;
+    sp.off_cur = off;
+    sp.off_prev = (t > 0) ? off - b->step_count_host[t - 1] : 0;
+    const unsigned grid = static_cast<unsigned>(u_tiles) * ((S_t + 31) / 32);
+    if (H % 4 == 0)
+      hipLaunchKernelGGL(gru_bwd_step_kernel<true>, dim3(grid), dim3(kThreads), 0, st, sp);
+    else
+      hipLaunchKernelGGL(gru_bwd_step_kernel<false>, dim3(grid), dim3(kThreads), 0, st, sp);
+  }
+
+  // ---- 3. weight gradients over all packed rows ----
+  RowAddrParams rp;
+  rp.x_rows = b->x_rows; rp.tok_rows = b->tok_rows; rp.emb = b->emb_table; rp.h0_rows = b->h0_rows;
+  rp.step_off = b->step_off; rp.hs = hs; rp.zero_row = zero_row; rp.xaddr = xaddr;
+  rp.hpaddr = hpaddr; rp.p_t = p_t; rp.Tmax = Tmax; rp.I = I; rp.H = H; rp.vocab = b->vocab;
+  rp.sum_T = sum_T;
+  hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)), dim3(256),
+                     0, st, rp);
+  launch_tn(dgx, 3 * H, nullptr, 0, xaddr, g->dw_ih, I, 3 * H, I, sum_T, nullptr, vec, st);
+  launch_tn(dgh, 3 * H, nullptr, 0, hpaddr, g->dw_hh, H, 3 * H, H, sum_T, nullptr, vec, st);
+  launch_colsum(dgx, nullptr, g->db_ih, sum_T, 3 * H, 3 * H, st);
+  launch_colsum(dgh, nullptr, g->db_hh, sum_T, 3 * H, 3 * H, st);
+
+  // ---- 4. d(input): dx_p = dgx_p . W_ih, scattered to the caller's rows / the embedding table ----
+  if (dx_rows || d_emb_table) {
+    launch_transpose(w->w_ih, wih_t, 3 * H, I, st);
+    if (dx_rows) {
+      // reuse xaddr as the output row table: d x_{t,s} lives at dx_rows[s] + t*I floats
+      RowAddrParams rq = rp;
+      rq.x_rows = dx_rows; rq.tok_rows = nullptr;
+      hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)),
+                         dim3(256), 0, st, rq);
+      launch_nt_out(dgx, 3 * H, wih_t, 3 * H, nullptr, 0, xaddr, static_cast<int>(sum_T), I, 3 * H,
+                    0, st);
+    } else {
+      // xaddr[p] = table row of token (t,s); same row offset inside d_emb_table
+      RowAddrParams rq = rp;
+      rq.emb = d_emb_table;
+      hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)),
+                         dim3(256), 0, st, rq);
+      launch_nt_out(dgx, 3 * H, wih_t, 3 * H, nullptr, 0, xaddr, static_cast<int>(sum_T), I, 3 * H,
+                    2, st);
+    }
+  }
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_l2norm_rows_bwd(const float* x, const float* g, float* dx, int32_t rows,
+                                     int32_t cols, void* stream_) {
+  if (!x || !g || !dx || rows < 0 || cols <= 0) return CMHSE_ERR_ARG;
+  if (rows == 0) return CMHSE_OK;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream_), x, g, dx, cols);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" size_t cmhse_contrastive_bwd_workspace(int32_t n) {
+  if (n <= 0) return 0;
+  return 2 * ws_align(static_cast<size_t>(n) * n * 4) + 4 * ws_align(static_cast<size_t>(n) * 4);
+}
+
+extern "C" int cmhse_contrastive_bwd(const float* im, const float* s, const float* scores,
+                                     int32_t n, int32_t D, float margin, int32_t max_violation,
+                                     int32_t norm, const float* grad_out, float* d_im, float* d_s,
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!im || !s || !scores || !grad_out || !d_im || !d_s || !workspace || n <= 0 || D <= 0)
+    return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_contrastive_bwd_workspace(n))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  char* ws = static_cast<char*>(workspace);
+  const size_t mat = ws_align(static_cast<size_t>(n) * n * 4), vecb = ws_align(static_cast<size_t>(n) * 4);
+  LossBwdParams q;
+  q.scores = scores; q.gout = grad_out; q.n = n; q.max_violation = max_violation; q.norm = norm;
+  q.margin = margin;
+  q.G = reinterpret_cast<float*>(ws);
+  q.GT = reinterpret_cast<float*>(ws + mat);
+  q.row_arg = reinterpret_cast<int32_t*>(ws + 2 * mat);
+  q.col_arg = reinterpret_cast<int32_t*>(ws + 2 * mat + vecb);
+  q.row_cnt = reinterpret_cast<float*>(ws + 2 * mat + 2 * vecb);
+  q.col_cnt = reinterpret_cast<float*>(ws + 2 * mat + 3 * vecb);
+  hipLaunchKernelGGL(loss_bwd_stats_kernel, dim3((2 * n + 3) / 4), dim3(kThreads), 0, st, q);
+  const int64_t elems = static_cast<int64_t>(n) * n;
+  hipLaunchKernelGGL(loss_bwd_build_kernel, dim3(static_cast<unsigned>((elems + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, st, q);
+  const bool vec = (n % 4 == 0) && (D % 4 == 0);
+  // d im[i][d] = sum_j G[i][j] s[j][d]  = TN(A = G^T, B = s);  d s[j][d] = sum_i G[i][j] im[i][d]
+  launch_tn(q.GT, n, s, D, nullptr, d_im, D, n, D, n, nullptr, vec, st);
+  launch_tn(q.G, n, im, D, nullptr, d_s, D, n, D, n, nullptr, vec, st);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}

@@ -31,6 +31,7 @@
 #include <new>
 
 #include "../../include/cmhse_hip.h"
+#include "gru_ws.hpp"
 #include "nt_core.hpp"
 
 namespace cmhse {
@@ -48,6 +49,8 @@ struct GruStepParams {
   const float* b_hh;
   float* hs;
   float* out;
+  float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
+  int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
   int32_t I, H, t, S_t, vocab, pool_mode, n_tiles;
   int64_t off_prev, off_cur;
 };
@@ -153,12 +156,23 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
         hp = reinterpret_cast<const float*>(p.h0_rows[m])[u];
       const float rg = sigmoidf_(acc[ms][0][r] + b_r);
       const float zg = sigmoidf_(acc[ms][1][r] + b_z);
-      const float ng = tanhf_(acc[ms][2][r] + b_in + rg * (acc[ms][3][r] + b_hn));
+      const float ghn = acc[ms][3][r] + b_hn;
+      const float ng = tanhf_(acc[ms][2][r] + b_in + rg * ghn);
       const float hn = (1.0f - zg) * ng + zg * hp;
       p.hs[(p.off_cur + m) * H + u] = hn;
+      if (p.gates != nullptr) {
+        float* gp = p.gates + (p.off_cur + m) * 4 * H + u;
+        gp[0] = rg;
+        gp[H] = zg;
+        gp[2 * H] = ng;
+        gp[3 * H] = ghn;
+      }
       if (p.pool_mode == CMHSE_POOL_MAX) {
         float* o = p.out + static_cast<int64_t>(p.out_row[m]) * H + u;
-        *o = (p.t == 0) ? hn : fmaxf(*o, hn);
+        if (p.t == 0 || hn > *o) {  // strict '>': the first maximum wins, like max_pool1d
+          *o = hn;
+          if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(m) * H + u] = p.t;
+        }
       } else if (p.pool_mode == CMHSE_POOL_LAST) {
         if (p.t == p.lens[m] - 1) p.out[static_cast<int64_t>(p.out_row[m]) * H + u] = hn;
       }
@@ -181,38 +195,7 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTinyBM = 32;
 constexpr int kTinyBU = 8;
-constexpr int kTinyRing = 4;
 constexpr int kTinyMaxSeqs = 2048;  // above this the 128 x 64 LDS-tiled kernel is faster
-
-template <bool VEC>
-__device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool bvalid, int K,
-                                           int wave, int hi, f32x16& acc) {
-  const int nkb = (K + 7) / 8;                     // k-blocks of 8 in this phase
-  const int nmine = (nkb - wave + 3) / 4;          // blocks kb = wave, wave+4, ...
-  if (nmine <= 0) return;
-  float4 ra[kTinyRing], rb[kTinyRing];
-#pragma unroll
-  for (int d = 0; d < kTinyRing; ++d) {
-    const int k = (wave + 4 * d) * 8 + 4 * hi;
-    ra[d] = issue_row4<VEC>(arow, k, K);
-    rb[d] = issue_row4<VEC>(brow, k, K);
-  }
-  for (int it = 0; it < nmine; it += kTinyRing) {
-#pragma unroll
-    for (int d = 0; d < kTinyRing; ++d) {
-      const int k = (wave + 4 * (it + d)) * 8 + 4 * hi;
-      const float4 a = finish_row4<VEC>(ra[d], true, k, K);
-      const float4 b = finish_row4<VEC>(rb[d], bvalid, k, K);
-      const int kn = k + 4 * kTinyRing * 8;
-      ra[d] = issue_row4<VEC>(arow, kn, K);
-      rb[d] = issue_row4<VEC>(brow, kn, K);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-    }
-  }
-}
 
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepParams p) {
@@ -285,12 +268,23 @@ __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepPa
     hp = reinterpret_cast<const float*>(p.h0_rows[em])[u];
   const float rg = sigmoidf_(xr + hr + p.b_ih[u] + p.b_hh[u]);
   const float zg = sigmoidf_(xz + hz + p.b_ih[H + u] + p.b_hh[H + u]);
-  const float ng = tanhf_(xn + p.b_ih[2 * H + u] + rg * (hn_ + p.b_hh[2 * H + u]));
+  const float ghn = hn_ + p.b_hh[2 * H + u];
+  const float ng = tanhf_(xn + p.b_ih[2 * H + u] + rg * ghn);
   const float hn = (1.0f - zg) * ng + zg * hp;
   p.hs[(p.off_cur + em) * H + u] = hn;
+  if (p.gates != nullptr) {
+    float* gp = p.gates + (p.off_cur + em) * 4 * H + u;
+    gp[0] = rg;
+    gp[H] = zg;
+    gp[2 * H] = ng;
+    gp[3 * H] = ghn;
+  }
   if (p.pool_mode == CMHSE_POOL_MAX) {
     float* o = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
-    *o = (p.t == 0) ? hn : fmaxf(*o, hn);
+    if (p.t == 0 || hn > *o) {
+      *o = hn;
+      if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(em) * H + u] = p.t;
+    }
   } else if (p.pool_mode == CMHSE_POOL_LAST) {
     if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
   }
@@ -305,11 +299,11 @@ struct AttnEnergyParams {
   const float* b_lin;
   const float* w_att;
   float* e_part;  // [n_tiles, rows]
+  float* v;       // [rows, H] tanh(W_lin h + b) kept for the backward pass, or NULL
   int64_t rows;
   int32_t H, n_tiles;
 };
 
-constexpr int kAttBN = 256;
 
 template <bool VEC, int MSUB>
 __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyParams p) {
@@ -360,8 +354,14 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float s = 0.f;
+      const int64_t vm = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
 #pragma unroll
-      for (int ns = 0; ns < 4; ++ns) s += wa[ns] * tanhf_(acc[ms][ns][r] + bl[ns]);
+      for (int ns = 0; ns < 4; ++ns) {
+        const float tv = tanhf_(acc[ms][ns][r] + bl[ns]);
+        s += wa[ns] * tv;
+        const int n = n0 + b_row0[ns] + acc_col(lane);
+        if (p.v != nullptr && vm < p.rows && n < H) p.v[vm * H + n] = tv;
+      }
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
       if ((lane & 31) == 0) red[wn * BM + wm * 32 * MSUB + ms * 32 + acc_row(r, lane)] = s;
@@ -510,15 +510,9 @@ using namespace cmhse;
 
 extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t H,
                                            int32_t pool_mode) {
-  (void)S;
   (void)Tmax;
-  if (sum_T <= 0 || H <= 0) return 0;
-  size_t bytes = align_up(static_cast<size_t>(sum_T) * H * sizeof(float), 256);
-  if (pool_mode == CMHSE_POOL_ATTN) {
-    const size_t n_tiles = (H + kAttBN - 1) / kAttBN;
-    bytes += align_up(n_tiles * static_cast<size_t>(sum_T) * sizeof(float), 256);
-  }
-  return bytes;
+  if (sum_T <= 0 || H <= 0 || S <= 0) return 0;
+  return gru_ws_layout(S, sum_T, H, pool_mode).total;
 }
 
 extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
@@ -530,6 +524,9 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if (b->tok_rows && (!b->emb_table || b->vocab <= 0)) return CMHSE_ERR_ARG;
   if (!b->lens || !b->out_row || !b->step_off || !b->step_count_host) return CMHSE_ERR_ARG;
   if (!w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh) return CMHSE_ERR_ARG;
+  const int32_t mode_flags = pool_mode;
+  const bool save = (pool_mode & CMHSE_SAVE_FOR_BACKWARD) != 0;
+  pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
   if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX)
     return CMHSE_ERR_ARG;
   if (pool_mode == CMHSE_POOL_ATTN && (!w->w_lin || !w->b_lin || !w->w_att)) return CMHSE_ERR_ARG;
@@ -542,11 +539,13 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if (b->step_count_host[0] != b->S) return CMHSE_ERR_ARG;
   if (sum_T * b->H >= (int64_t(1) << 40)) return CMHSE_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
-      workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->H, pool_mode))
+      workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->H, mode_flags))
     return CMHSE_ERR_WORKSPACE;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const GruWs L = gru_ws_layout(b->S, sum_T, b->H, mode_flags);
+  char* wsb = static_cast<char*>(workspace);
 
-  float* hs = static_cast<float*>(workspace);
+  float* hs = reinterpret_cast<float*>(wsb + L.hs);
   GruStepParams p;
   p.x_rows = b->x_rows;
   p.tok_rows = b->tok_rows;
@@ -560,6 +559,8 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   p.b_hh = w->b_hh;
   p.hs = hs;
   p.out = out;
+  p.gates = save ? reinterpret_cast<float*>(wsb + L.gates) : nullptr;
+  p.argmax = (save && pool_mode == CMHSE_POOL_MAX) ? reinterpret_cast<int32_t*>(wsb + L.argmax) : nullptr;
   p.I = b->I;
   p.H = b->H;
   p.vocab = b->vocab;
@@ -608,14 +609,14 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if (timer) (void)hipEventRecord(timer->stop, stream);
   if (pool_mode == CMHSE_POOL_ATTN) {
     const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
-    float* e_part = reinterpret_cast<float*>(
-        static_cast<char*>(workspace) + align_up(static_cast<size_t>(sum_T) * b->H * sizeof(float), 256));
+    float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
     AttnEnergyParams ep;
     ep.hs = hs;
     ep.w_lin = w->w_lin;
     ep.b_lin = w->b_lin;
     ep.w_att = w->w_att;
     ep.e_part = e_part;
+    ep.v = save ? reinterpret_cast<float*>(wsb + L.v) : nullptr;
     ep.rows = sum_T;
     ep.H = b->H;
     ep.n_tiles = att_tiles;

@@ -1,0 +1,45 @@
+// gru_ws.hpp — layout of cmhse_gru_pool_fwd's workspace, shared by the forward and backward
+// launchers.  Regions (each 256-byte aligned):
+//   hs      [sumT, H]     hidden states, time-major packed (always)
+//   e_part  [ceil(H/256), sumT]  attention energy partials (CMHSE_POOL_ATTN)
+// and, with CMHSE_SAVE_FOR_BACKWARD:
+//   gates   [sumT, 4H]    r, z, n, (W_hn h + b_hn) per packed row
+//   argmax  [S, H] int32  step of the maximum (CMHSE_POOL_MAX)
+//   v       [sumT, H]     tanh(W_lin h + b_lin) (CMHSE_POOL_ATTN)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/cmhse_hip.h"
+
+namespace cmhse {
+
+constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
+
+struct GruWs {
+  size_t hs, e_part, gates, argmax, v, total;
+};
+
+static inline size_t ws_align(size_t v) { return (v + 255) / 256 * 256; }
+
+static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t mode_flags) {
+  const bool save = (mode_flags & CMHSE_SAVE_FOR_BACKWARD) != 0;
+  const int mode = mode_flags & ~CMHSE_SAVE_FOR_BACKWARD;
+  GruWs L;
+  size_t off = 0;
+  L.hs = off;
+  off += ws_align(static_cast<size_t>(sum_T) * H * sizeof(float));
+  L.e_part = off;
+  if (mode == CMHSE_POOL_ATTN)
+    off += ws_align(static_cast<size_t>((H + kAttBN - 1) / kAttBN) * sum_T * sizeof(float));
+  L.gates = off;
+  if (save) off += ws_align(static_cast<size_t>(sum_T) * 4 * H * sizeof(float));
+  L.argmax = off;
+  if (save && mode == CMHSE_POOL_MAX) off += ws_align(static_cast<size_t>(S) * H * sizeof(int32_t));
+  L.v = off;
+  if (save && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(sum_T) * H * sizeof(float));
+  L.total = off;
+  return L;
+}
+
+}  // namespace cmhse

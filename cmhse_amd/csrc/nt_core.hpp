@@ -225,6 +225,42 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   __syncthreads();  // all waves done with LDS before the caller reuses it
 }
 
+// Split-K building block of the latency-shaped kernels (gru_step_tiny_kernel, gru_bwd_step_kernel):
+// one 32x32 accumulator; this wave takes the 8-k blocks wave, wave+4, ... of K; the A and B
+// fragments (row = lane&31, k = 8*kb + 4*(lane>>5) .. +3) go global -> registers directly in MFMA
+// layout through a 4-deep register ring, no LDS and no barrier.
+constexpr int kTinyRing = 4;
+
+template <bool VEC>
+__device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool bvalid, int K,
+                                           int wave, int hi, f32x16& acc) {
+  const int nkb = (K + 7) / 8;                     // k-blocks of 8 in this phase
+  const int nmine = (nkb - wave + 3) / 4;          // blocks kb = wave, wave+4, ...
+  if (nmine <= 0) return;
+  float4 ra[kTinyRing], rb[kTinyRing];
+#pragma unroll
+  for (int d = 0; d < kTinyRing; ++d) {
+    const int k = (wave + 4 * d) * 8 + 4 * hi;
+    ra[d] = issue_row4<VEC>(arow, k, K);
+    rb[d] = issue_row4<VEC>(brow, k, K);
+  }
+  for (int it = 0; it < nmine; it += kTinyRing) {
+#pragma unroll
+    for (int d = 0; d < kTinyRing; ++d) {
+      const int k = (wave + 4 * (it + d)) * 8 + 4 * hi;
+      const float4 a = finish_row4<VEC>(ra[d], true, k, K);
+      const float4 b = finish_row4<VEC>(rb[d], bvalid, k, K);
+      const int kn = k + 4 * kTinyRing * 8;
+      ra[d] = issue_row4<VEC>(arow, kn, K);
+      rb[d] = issue_row4<VEC>(brow, kn, K);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+}
+
 // Row / column owned by accumulator register r of lane `lane` inside a 32x32 sub-tile.
 __device__ __forceinline__ int acc_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

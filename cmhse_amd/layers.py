@@ -17,37 +17,94 @@ import torch.nn.init as init
 from . import ops
 
 
+class SeqInput(object):
+  """Non-tensor description of how one packed batch is addressed (see cmhse_seq_batch):
+    kind 'padded'  x is [S,T,I] features (layers.*.forward);
+    kind 'tokens'  token ids [S,L] int64 + the embedding table (model.EncoderText.forward);
+    kind 'rows'    x is [R,I] level-1 embeddings, sequence s = `counts[s]` consecutive rows
+                   (VSE.structure_emb, model.py:238-255)."""
+
+  def __init__(self, kind, lens, pool, tokens=None, counts=None):
+    self.kind, self.lens, self.pool, self.tokens, self.counts = kind, lens, pool, tokens, counts
+
+
 class _PackedGRUPoolFn(torch.autograd.Function):
-  """Forward = HIP packed GRU + pooling.  Backward (BPTT) is SURVEY.md §8(f) row 1."""
+  """Forward = cmhse_gru_pool_fwd, backward = cmhse_gru_pool_bwd (BPTT on the HIP path)."""
 
   @staticmethod
-  def forward(ctx, pool_mode, q_emb, lens_np, hidden, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin,
-              w_att):
-    ops._require_cuda(q_emb, 'q_emb')
-    x = q_emb.detach()
-    if x.dtype != torch.float32:
-      x = x.float()
-    x = x.contiguous()
-    S, T, I = x.shape
+  def forward(ctx, spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w_att):
+    pool = spec.pool
+    weights = dict(w_ih=w_ih.detach(), w_hh=w_hh.detach(), b_ih=b_ih.detach(),
+                   b_hh=b_hh.detach())
+    if pool == ops.POOL_ATTN:
+      weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
     H = w_hh.shape[1]
+    keep, x_ptrs, tok_ptrs, emb = [], None, None, None
+    if spec.kind == 'tokens':
+      tok = spec.tokens
+      ops._require_cuda(tok, 'tokens')
+      tok = tok.detach().contiguous()
+      if tok.dtype != torch.int64:
+        tok = tok.long()
+      emb = table.detach().float().contiguous()
+      I = emb.shape[1]
+      tok_ptrs = ops.padded_row_ptrs(tok)
+      device = tok.device
+      keep += [tok, emb]
+    else:
+      ops._require_cuda(x, 'x')
+      xc = x.detach().float().contiguous()
+      device = xc.device
+      keep.append(xc)
+      if spec.kind == 'padded':
+        I = xc.shape[2]
+        x_ptrs = ops.padded_row_ptrs(xc)
+      else:
+        I = xc.shape[1]
+        counts = np.asarray(spec.counts, dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+        x_ptrs = np.uint64(xc.data_ptr()) + starts * np.uint64(I * 4)
+        ctx.row_starts = starts
     h0_ptrs = None
     if hidden is not None:
       ops._require_cuda(hidden, 'hidden')
       h0 = hidden.detach().float().contiguous()
+      keep.append(h0)
       h0_ptrs = ops.padded_row_ptrs(h0)
-    weights = dict(w_ih=w_ih.detach(), w_hh=w_hh.detach(), b_ih=b_ih.detach(),
-                   b_hh=b_hh.detach())
-    if pool_mode == ops.POOL_ATTN:
-      weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
-    out, fctx = ops.gru_pool_fwd(weights, pool_mode, lens_np, I, H, x.device,
-                                 x_ptrs=ops.padded_row_ptrs(x), h0_ptrs=h0_ptrs)
-    ctx.fctx = fctx
+    need_grad = any(ctx.needs_input_grad)   # (grad mode itself is off inside Function.forward)
+    out, fctx = ops.gru_pool_fwd(weights, pool, spec.lens, I, H, device, x_ptrs=x_ptrs,
+                                 tok_ptrs=tok_ptrs, emb_table=emb, h0_ptrs=h0_ptrs,
+                                 save_for_backward=need_grad)
+    ctx.fctx, ctx.spec, ctx.keep = fctx, spec, keep
+    ctx.x_shape = None if x is None else tuple(x.shape)
+    ctx.table_shape = None if table is None else tuple(table.shape)
+    ctx.has_hidden = hidden is not None
+    ctx.saved_for_bwd = need_grad
     return out
 
   @staticmethod
   def backward(ctx, grad_out):
-    raise NotImplementedError(
-        'cmhse_amd: BPTT backward of the packed GRU is not built yet (SURVEY.md §8(f) row 1)')
+    if not ctx.saved_for_bwd:
+      raise RuntimeError('cmhse_amd: forward ran without saving state for backward')
+    spec, fctx = ctx.spec, ctx.fctx
+    need = ctx.needs_input_grad
+    device = fctx['device']
+    dx = dtable = None
+    dx_ptrs = None
+    if spec.kind != 'tokens' and need[1]:
+      dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=device)
+      if spec.kind == 'padded':
+        dx_ptrs = ops.padded_row_ptrs(dx)
+      else:
+        dx_ptrs = np.uint64(dx.data_ptr()) + ctx.row_starts * np.uint64(ctx.x_shape[1] * 4)
+    if spec.kind == 'tokens' and need[3]:
+      dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=device)
+    grads, dh0 = ops.gru_pool_bwd(fctx, grad_out, dx_ptrs=dx_ptrs, d_emb_table=dtable,
+                                  want_dh0=ctx.has_hidden and need[2])
+    w_att_g = grads.get('w_att')
+    return (None, dx, dh0, dtable, grads['w_ih'], grads['w_hh'], grads['b_ih'], grads['b_hh'],
+            grads.get('w_lin'), grads.get('b_lin'),
+            None if w_att_g is None else w_att_g.reshape(1, -1))
 
 
 def _lens_numpy(q_len):
@@ -85,11 +142,20 @@ class _GRUPoolBase(nn.Module):
   def _extra_weights(self):
     return None, None, None
 
-  def forward(self, q_emb, q_len, hidden=None):
+  def _run(self, spec, x, hidden, table):
     w_lin, b_lin, w_att = self._extra_weights()
-    return _PackedGRUPoolFn.apply(self.POOL, q_emb, _lens_numpy(q_len), hidden,
-                                  self.rnn.weight_ih_l0, self.rnn.weight_hh_l0,
-                                  self.rnn.bias_ih_l0, self.rnn.bias_hh_l0, w_lin, b_lin, w_att)
+    return _PackedGRUPoolFn.apply(spec, x, hidden, table, self.rnn.weight_ih_l0,
+                                  self.rnn.weight_hh_l0, self.rnn.bias_ih_l0,
+                                  self.rnn.bias_hh_l0, w_lin, b_lin, w_att)
+
+  def forward(self, q_emb, q_len, hidden=None):
+    return self._run(SeqInput('padded', _lens_numpy(q_len), self.POOL), q_emb, hidden, None)
+
+  def forward_rows(self, rows, counts, hidden=None):
+    """Level-2 form (VSE.structure_emb): sequence s is `counts[s]` consecutive rows of `rows`;
+    differentiable wrt `rows` and `hidden`."""
+    counts = np.asarray(counts, dtype=np.int64)
+    return self._run(SeqInput('rows', counts, self.POOL, counts=counts), rows, hidden, None)
 
   def _weights(self):
     w_lin, b_lin, w_att = self._extra_weights()
@@ -112,12 +178,8 @@ class _GRUPoolBase(nn.Module):
   def forward_tokens(self, tokens, q_len, table):
     """Fused embedding-lookup + encoder (model.EncoderText.forward, model.py:92-99): the word
     vectors are gathered inside the GRU operand load and never materialised."""
-    ops._require_cuda(tokens, 'tokens')
-    tok = tokens.detach().contiguous()
-    if tok.dtype != torch.int64:
-      tok = tok.long()
-    return self.forward_ptrs(_lens_numpy(q_len), table.shape[1], tok.device,
-                             tok_ptrs=ops.padded_row_ptrs(tok), table=table.detach())
+    return self._run(SeqInput('tokens', _lens_numpy(q_len), self.POOL, tokens=tokens), None,
+                       None, table)
 
 
 class Seq2Seq(_GRUPoolBase):

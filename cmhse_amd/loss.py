@@ -18,16 +18,45 @@ def cosine_sim(im, s):
 
 
 class _ContrastiveFn(torch.autograd.Function):
-  """Forward = HIP similarity + hinge reduction.  Backward is SURVEY.md §8(f) row 1."""
+  """Forward = cmhse_contrastive_fwd (keeps the score matrix), backward = cmhse_contrastive_bwd."""
 
   @staticmethod
   def forward(ctx, im, s, margin, max_violation, norm):
-    return ops.contrastive_fwd(im.detach(), s.detach(), margin, max_violation, norm)
+    imd, sd = im.detach(), s.detach()
+    need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+    if not need:
+      return ops.contrastive_fwd(imd, sd, margin, max_violation, norm)
+    loss, scores = ops.contrastive_fwd(imd, sd, margin, max_violation, norm, want_scores=True)
+    ctx.save_for_backward(imd, sd, scores)
+    ctx.cfg = (margin, max_violation, norm)
+    return loss
 
   @staticmethod
   def backward(ctx, grad):
-    raise NotImplementedError(
-        'cmhse_amd: ContrastiveLoss backward is not built yet (SURVEY.md §8(f) row 1)')
+    im, s, scores = ctx.saved_tensors
+    margin, max_violation, norm = ctx.cfg
+    d_im, d_s = ops.contrastive_bwd(im, s, scores, margin, max_violation, norm, grad)
+    return d_im, d_s, None, None, None
+
+
+class _L2NormFn(torch.autograd.Function):
+  """F.normalize (model.py:333-343) with its backward on the HIP path."""
+
+  @staticmethod
+  def forward(ctx, x):
+    xd = x.detach()
+    ctx.save_for_backward(xd)
+    return ops.l2norm_rows(xd)
+
+  @staticmethod
+  def backward(ctx, g):
+    (x,) = ctx.saved_tensors
+    return ops.l2norm_rows_bwd(x, g)
+
+
+def normalize(x):
+  """torch.nn.functional.normalize(x) for [rows, cols] on the HIP path, differentiable."""
+  return _L2NormFn.apply(x)
 
 
 class ContrastiveLoss(nn.Module):

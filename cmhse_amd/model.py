@@ -3,8 +3,8 @@
 Class names, constructor arguments, attributes and method signatures follow
 /root/reference/model.py:21-99 (encoders) and :102-369 (VSE) so a train.py-style driver
 (train.py:124-172,193; evaluation.py:97-129) runs unchanged; every arithmetic step is a HIP
-kernel behind include/cmhse_hip.h.  Out of scope here: the reconstruction
-decoders and the weak (group-wise) loss.
+kernel behind include/cmhse_hip.h (forward AND backward).  Out of scope here: the
+reconstruction decoders and the weak (group-wise) loss.
 """
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import ops
 from .layers import Attention, Maxout, Seq2Seq
-from .loss import ContrastiveLoss
+from .loss import ContrastiveLoss, normalize
 
 
 def _make_rnn(rnn_type, in_dim, embed_size, bidirectional):
@@ -157,19 +157,7 @@ class VSE(object):
 
   @staticmethod
   def _level2(enc, rows, counts, context):
-    rnn = enc.rnn
-    ops._require_cuda(rows, 'level-1 embeddings')
-    rows_c = rows.detach().float().contiguous()
-    counts = np.asarray(counts, dtype=np.int64)
-    H_in = rows_c.shape[1]
-    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
-    x_ptrs = np.uint64(rows_c.data_ptr()) + starts * np.uint64(H_in * 4)
-    h0_ptrs = None
-    if context is not None:
-      ctx_c = context.detach().float().contiguous()
-      h0_ptrs = ops.padded_row_ptrs(ctx_c)
-    out = rnn.forward_ptrs(counts, H_in, rows_c.device, x_ptrs=x_ptrs, h0_ptrs=h0_ptrs)
-    return out
+    return enc.rnn.forward_rows(rows, counts, context)
 
   def forward_loss(self, clip_emb, cap_emb, name, **kwargs):
     """model.py:287-292."""
@@ -187,7 +175,7 @@ class VSE(object):
                                                  lengths_paragraph)
     vid_emb, para_emb = self.structure_emb(clip_emb, cap_emb, num_clips, num_caps, vid_context,
                                            para_context)
-    n = ops.l2norm_rows
+    n = normalize
     nv, npar = n(vid_emb), n(para_emb)
     loss_1 = self.forward_loss(nv, npar, '_vid')
     loss_3 = self.forward_loss(n(vid_context), n(para_context), '_ctx_low_lvel')
@@ -204,12 +192,15 @@ class VSE(object):
 
   def train_emb(self, opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
                 lengths_video, lengths_paragraph, num_clips, num_caps, ind, cur_vid, *args):
-    """model.py:309-369.  The forward/loss half runs on the HIP path; the optimisation step needs
-    the backward kernels, which are not built yet."""
+    """model.py:309-369: one optimisation step.  Forward, losses and backward run on the HIP
+    path; the parameter update is torch.optim.Adam as upstream (model.py:160,369)."""
     self.Eiters += 1
     self.logger.update('Eit', self.Eiters)
     self.logger.update('lr', self.optimizer.param_groups[0]['lr'])
-    self.train_losses(opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
-                      lengths_video, lengths_paragraph, num_clips, num_caps, ind, cur_vid)
-    raise NotImplementedError('cmhse_amd: backward + optimizer step need the BPTT kernels '
-                              '(SURVEY.md §8(f) row 1, not built yet)')
+    self.optimizer.zero_grad()
+    loss = self.train_losses(opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
+                             lengths_video, lengths_paragraph, num_clips, num_caps, ind, cur_vid)
+    loss.backward()
+    if self.grad_clip > 0:
+      torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+    self.optimizer.step()

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF  # noqa: F401
+from ._lib import POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF, SAVE_FOR_BACKWARD  # noqa: F401
 
 
 def _stream():
@@ -118,15 +118,17 @@ class StepTimers(object):
 
 
 def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
-                 emb_table=None, h0_ptrs=None, out=None):
+                 emb_table=None, h0_ptrs=None, out=None, save_for_backward=False):
   """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
-  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and schedule."""
+  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and schedule;
+  with `save_for_backward` the workspace also keeps what gru_pool_bwd needs."""
   lib = _lib.load()
   sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs)
   S = sched.S
   if out is None:
     out = torch.empty(S, H, dtype=torch.float32, device=device)
-  ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, H, pool_mode)
+  mode_flags = pool_mode | (SAVE_FOR_BACKWARD if save_for_backward else 0)
+  ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, H, mode_flags)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
 
   w = _lib.GruWeights()
@@ -158,10 +160,12 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     b.step_timer = handle
     StepTimers.active.items.append((handle, (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None,
                                              S)))
-  rc = lib.cmhse_gru_pool_fwd(ctypes.byref(b), ctypes.byref(w), pool_mode, out.data_ptr(),
+  rc = lib.cmhse_gru_pool_fwd(ctypes.byref(b), ctypes.byref(w), mode_flags, out.data_ptr(),
                               ws.data_ptr(), ws_bytes, _stream())
   _lib.check(rc, 'cmhse_gru_pool_fwd')
-  ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I)
+  b.step_timer = None
+  ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
+             device=device)
   return out, ctx
 
 
@@ -275,3 +279,69 @@ def contrastive_blocks_fwd(im, s, block_sizes, margin, max_violation, norm):
                                         ws_bytes, _stream())
   _lib.check(rc, 'cmhse_contrastive_blocks_fwd')
   return losses
+
+
+def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
+  """cmhse_gru_pool_bwd for a forward run with save_for_backward=True.
+  dx_ptrs: numpy uint64 [S] (input order) addresses receiving d x of step 0 of each sequence.
+  Returns (grads dict of fresh tensors, dh0 [S,H] or None)."""
+  lib = _lib.load()
+  sched, b, w = fctx['sched'], fctx['batch'], fctx['weights']
+  H, I, device, pool_mode = fctx['H'], fctx['I'], fctx['device'], fctx['pool_mode']
+  S = sched.S
+  dout = _f32c(dout, 'dout')
+  g = _lib.GruGrads()
+  grads = dict(w_ih=torch.empty(3 * H, I, dtype=torch.float32, device=device),
+               w_hh=torch.empty(3 * H, H, dtype=torch.float32, device=device),
+               b_ih=torch.empty(3 * H, dtype=torch.float32, device=device),
+               b_hh=torch.empty(3 * H, dtype=torch.float32, device=device))
+  if pool_mode == POOL_ATTN:
+    grads.update(w_lin=torch.empty(H, H, dtype=torch.float32, device=device),
+                 b_lin=torch.empty(H, dtype=torch.float32, device=device),
+                 w_att=torch.empty(H, dtype=torch.float32, device=device))
+  for k, t in grads.items():
+    setattr(g, 'd' + k, t.data_ptr())
+  dx_dev = None
+  if dx_ptrs is not None:
+    dx_dev = torch.from_numpy(np.asarray(dx_ptrs, dtype=np.uint64)[sched.order].view(np.int64)
+                              .copy()).to(device)
+  dh0 = torch.empty(S, H, dtype=torch.float32, device=device) if want_dh0 else None
+  ws_bytes = lib.cmhse_gru_pool_bwd_workspace(S, sched.Tmax, sched.sum_T, I, H, pool_mode)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+  rc = lib.cmhse_gru_pool_bwd(ctypes.byref(b), ctypes.byref(w), pool_mode, dout.data_ptr(),
+                              fctx['ws'].data_ptr(), ctypes.byref(g),
+                              dx_dev.data_ptr() if dx_dev is not None else None,
+                              d_emb_table.data_ptr() if d_emb_table is not None else None,
+                              dh0.data_ptr() if dh0 is not None else None, ws.data_ptr(),
+                              ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_gru_pool_bwd')
+  return grads, dh0
+
+
+def l2norm_rows_bwd(x, g):
+  lib = _lib.load()
+  x = _f32c(x, 'x')
+  g = _f32c(g, 'g')
+  dx = torch.empty_like(x)
+  rc = lib.cmhse_l2norm_rows_bwd(x.data_ptr(), g.data_ptr(), dx.data_ptr(), x.shape[0],
+                                 x.shape[1], _stream())
+  _lib.check(rc, 'cmhse_l2norm_rows_bwd')
+  return dx
+
+
+def contrastive_bwd(im, s, scores, margin, max_violation, norm, grad_out):
+  lib = _lib.load()
+  im = _f32c(im, 'im')
+  s = _f32c(s, 's')
+  n, D = im.shape
+  grad_out = _f32c(grad_out, 'grad_out').reshape(1)
+  d_im = torch.empty_like(im)
+  d_s = torch.empty_like(s)
+  ws_bytes = lib.cmhse_contrastive_bwd_workspace(n)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
+  rc = lib.cmhse_contrastive_bwd(im.data_ptr(), s.data_ptr(), scores.data_ptr(), n, D,
+                                 float(margin), int(bool(max_violation)), int(bool(norm)),
+                                 grad_out.data_ptr(), d_im.data_ptr(), d_s.data_ptr(),
+                                 ws.data_ptr(), ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_contrastive_bwd')
+  return d_im, d_s

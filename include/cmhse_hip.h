@@ -40,7 +40,10 @@ enum {
 enum {
   CMHSE_POOL_LAST = 0, /* layers.Seq2Seq.forward   layers.py:47-66   h at t = len-1            */
   CMHSE_POOL_ATTN = 1, /* layers.Attention.forward layers.py:93-119  masked exp-softmax pooling */
-  CMHSE_POOL_MAX = 2   /* layers.Maxout.forward    layers.py:185-204 max over valid steps       */
+  CMHSE_POOL_MAX = 2,  /* layers.Maxout.forward    layers.py:185-204 max over valid steps       */
+  /* OR-ed into pool_mode for training: the forward also keeps gate activations (and the arg-max
+   * step / tanh(lin(h))) in its workspace, which cmhse_gru_pool_bwd consumes. */
+  CMHSE_SAVE_FOR_BACKWARD = 0x100
 };
 
 /* Weights of one encoder layer, laid out exactly as the reference's state-dict tensors
@@ -145,6 +148,48 @@ int cmhse_contrastive_blocks_fwd(const float* im, const float* s, const int32_t*
                                  int32_t n_blocks, int32_t max_n, int32_t D, float margin,
                                  int32_t max_violation, int32_t norm, float* losses,
                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- backward pass (what loss.backward(), model.py:367, computes through the operators above) ---- */
+
+/* Parameter gradients of one encoder layer, same shapes as cmhse_gru_weights; overwritten. */
+typedef struct cmhse_gru_grads {
+  float* dw_ih;  /* [3H, I] */
+  float* dw_hh;  /* [3H, H] */
+  float* db_ih;  /* [3H] */
+  float* db_hh;  /* [3H] */
+  float* dw_lin; /* [H, H]  (CMHSE_POOL_ATTN) */
+  float* db_lin; /* [H] */
+  float* dw_att; /* [H] */
+} cmhse_gru_grads;
+
+/* Backward of cmhse_gru_pool_fwd for the same `seqs` / `w` / pooling, given dout = d loss / d out
+ * ([S,H], same row indexing as `out`) and the forward's workspace (run with
+ * pool_mode | CMHSE_SAVE_FOR_BACKWARD).  Writes the parameter gradients to `grads` and, optionally,
+ *   dx_rows      [S] device addresses: d loss / d x of step 0 of (sorted) sequence s goes there, rows
+ *                of stride I floats (used for the level-2 encoders, whose inputs are level-1
+ *                embeddings, model.py:252-253);
+ *   d_emb_table  [vocab, I]: gradient of embed.weight, ACCUMULATED with float atomics (zero it
+ *                first); token batches only (model.py:94);
+ *   dh0          [S, H] (row indexing of `out`): d loss / d hidden (layers.py:98-100).
+ * Any of the three may be NULL; dx_rows and d_emb_table are mutually exclusive. */
+size_t cmhse_gru_pool_bwd_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I, int32_t H,
+                                    int32_t pool_mode);
+int cmhse_gru_pool_bwd(const cmhse_seq_batch* seqs, const cmhse_gru_weights* w, int32_t pool_mode,
+                       const float* dout, const void* fwd_workspace, const cmhse_gru_grads* grads,
+                       const uint64_t* dx_rows, float* d_emb_table, float* dh0, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Backward of F.normalize (model.py:333-343): dx from x [rows, cols] (contiguous) and g = d/dy. */
+int cmhse_l2norm_rows_bwd(const float* x, const float* g, float* dx, int32_t rows, int32_t cols,
+                          void* stream);
+
+/* Backward of ContrastiveLoss.forward (loss.py:86-117) from the score matrix the forward stored
+ * (`scores_out`) and the upstream gradient *grad_out (device scalar): d_im, d_s [n, D]. */
+size_t cmhse_contrastive_bwd_workspace(int32_t n);
+int cmhse_contrastive_bwd(const float* im, const float* s, const float* scores, int32_t n, int32_t D,
+                          float margin, int32_t max_violation, int32_t norm, const float* grad_out,
+                          float* d_im, float* d_s, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* Measurement aid (bench.py's roofline leg): a pair of HIP events owned by the handle.  A timer
  * passed in cmhse_seq_batch.step_timer is recorded before the first and after the last GRU step

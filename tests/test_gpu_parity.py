@@ -365,3 +365,112 @@ def test_full_size_rank_properties(dev, oracle):
   want = (d64 > diag).sum(axis=1)
   np.testing.assert_array_equal(rank.cpu().numpy()[sample][ok], want[ok])
   assert ok.mean() > 0.98
+
+
+# ------------------------------------------------------------------------------------------
+# backward: HIP gradients vs the reference's autograd gradients (golden)
+# ------------------------------------------------------------------------------------------
+def grad_close(got, want, name=''):
+  got = np.asarray(got, dtype=np.float64)
+  want = np.asarray(want, dtype=np.float64)
+  assert got.shape == want.shape, (name, got.shape, want.shape)
+  tol = 2e-4 * max(1e-30, np.abs(want).max()) + 2e-6
+  err = np.abs(got - want).max()
+  assert err <= tol, '%s: max |diff| %.3e > tol %.3e' % (name, err, tol)
+
+
+@pytest.mark.parametrize('cls', ['Attention', 'Maxout', 'Seq2Seq'])
+@pytest.mark.parametrize('tag', ['ragged', 'equal', 'one'])
+def test_layer_backward_vs_golden(dev, cls, tag):
+  g = load_golden('layers.npz')
+  sd = {k[len(cls) + 4:]: g[k] for k in g.files if k.startswith(cls + '.sd.')}
+  layer = make_layer(cls, 24, 32, sd, dev)
+  key = '%s.%s' % (cls, tag)
+  x = torch.from_numpy(g[key + '.x']).to(dev).requires_grad_(True)
+  lens = torch.from_numpy(g[key + '.lens'])
+  h0 = torch.from_numpy(g[key + '.h0']).to(dev).requires_grad_(True)
+  w = torch.from_numpy(g[key + '.bwd.w']).to(dev)
+  out = layer(x, lens, h0)
+  np.testing.assert_allclose(out.detach().cpu().numpy(), g[key + '.out_h0'], atol=EMB_TOL, rtol=0)
+  (out * w).sum().backward()
+  grad_close(x.grad.cpu().numpy(), g[key + '.bwd.dx'], 'dx')
+  grad_close(h0.grad.cpu().numpy(), g[key + '.bwd.dh0'], 'dh0')
+  for pn, pp in layer.named_parameters():
+    grad_close(pp.grad.cpu().numpy(), g[key + '.bwd.grad.rnn.' + pn], pn)
+
+
+@pytest.mark.parametrize('n', [5, 16, 37])
+def test_loss_backward_vs_golden(dev, n):
+  from cmhse_amd.loss import ContrastiveLoss, normalize
+  g = load_golden('loss.npz')
+  for mv in (0, 1):
+    for nm in (0, 1):
+      crit = ContrastiveLoss(margin=0.2, measure='cosine', max_violation=bool(mv), norm=bool(nm))
+      tag = 'n%d.mv%d.norm%d' % (n, mv, nm)
+      a = torch.from_numpy(g['n%d.a' % n]).to(dev).requires_grad_(True)
+      b = torch.from_numpy(g['n%d.b' % n]).to(dev).requires_grad_(True)
+      crit(normalize(a), normalize(b)).backward()
+      grad_close(a.grad.cpu().numpy(), g[tag + '.da'], tag + '.da')
+      grad_close(b.grad.cpu().numpy(), g[tag + '.db'], tag + '.db')
+      a2 = torch.from_numpy(g['n%d.a' % n]).to(dev).requires_grad_(True)
+      na = normalize(a2)
+      crit(na, na).backward()
+      grad_close(a2.grad.cpu().numpy(), g[tag + '.da_self'], tag + '.da_self')
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_train_emb_gradients_vs_golden(dev, rnn_type):
+  """One full VSE.train_emb step (forward, 7 losses, backward, Adam): the parameter gradients
+  left in .grad equal the reference's for every encoder, and the parameters moved."""
+  g = load_golden('model_%s.npz' % rnn_type)
+  batch = torch_batches(golden_batches(g))[1]
+  for mv in (0, 1):
+    for nm in (0, 1):
+      opt, model = golden_model(rnn_type, g, max_violation=bool(mv), norm=bool(nm),
+                                low_level_loss=True)
+      model.logger = MeterLog()
+      before = [p.detach().clone() for p in model.params]
+      model.train_start(opt)
+      model.train_emb(opt, *batch)
+      tag = 'train.mv%d.norm%d' % (mv, nm)
+      for c, want in zip([c for c in model.logger.calls if c[0].startswith('Le')],
+                         g[tag + '.values']):
+        assert loss_close(c[1], want), (tag, c)
+      for i, enc in enumerate([model.clip_enc, model.txt_enc, model.vid_seq_enc,
+                               model.txt_seq_enc]):
+        for pn, pp in enc.named_parameters():
+          grad_close(pp.grad.cpu().numpy(), g['%s.grad%d.%s' % (tag, i, pn)],
+                     '%s enc%d %s' % (tag, i, pn))
+      assert any(not torch.equal(a, b) for a, b in zip(before, model.params))
+      assert model.Eiters == 1
+
+
+def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
+  """Sizes that cross tile boundaries in the backward GEMMs (H, I not tile multiples, > 32 seqs)."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(5)
+  S, T, I, H = 45, 6, 20, 40
+  for pool, cls in [('attention', 'Attention'), ('maxout', 'Maxout'), ('seq2seq', 'Seq2Seq')]:
+    torch.manual_seed(4)
+    layer = getattr(layers, cls)(I, H)
+    with torch.no_grad():
+      layer.rnn.bias_ih_l0.normal_(0, 0.1)
+      layer.rnn.bias_hh_l0.normal_(0, 0.1)
+    sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    layer = layer.to(dev)
+    lens = rng.randint(1, T + 1, size=S)
+    lens[0] = T
+    x = np.zeros((S, T, I), dtype=np.float32)
+    for i, l in enumerate(lens):
+      x[i, :l] = rng.standard_normal((l, I))
+    h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+    w = rng.standard_normal((S, H)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
+    _, c = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+    grads, dx, dh0 = oracle.pooled_gru_backward(c, w.astype(np.float64))
+    grad_close(xt.grad.cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
+    grad_close(ht.grad.cpu().numpy(), dh0, pool + ' dh0')
+    for pn, pp in layer.named_parameters():
+      grad_close(pp.grad.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
