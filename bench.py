@@ -138,23 +138,80 @@ def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full):
                                    feat=wl['feat'])
   np_batches = [tuple(x.numpy() if hasattr(x, 'numpy') else x for x in b) for b in batches]
   sds = [{k: v.detach().cpu().numpy() for k, v in sd.items()} for sd in model.state_dict(opt)]
-  t0 = time.time()
-  res = oracle.encode_data(opt.rnn_type, sds, np_batches, margin=opt.margin)
-  t_enc = time.time() - t0
-  t0 = time.time()
-  oracle.i2t(res[0], res[1])
-  oracle.t2i(res[0], res[1])
-  t_score = time.time() - t0
+  # BLAS thread count: the per-step GEMMs are small, so all host cores oversubscribe; calibrate on
+  # one loader batch and keep the fastest setting (that count is what `cores` reports)
+  from threadpoolctl import threadpool_limits
+  ncpu = os.cpu_count() or 1
+  best_n, best_t = ncpu, None
+  for n_thr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+    with threadpool_limits(limits=n_thr):
+      t0 = time.time()
+      oracle.encode_data(opt.rnn_type, sds, np_batches[:1], margin=opt.margin)
+      dt = time.time() - t0
+    if best_t is None or dt < best_t:
+      best_n, best_t = n_thr, dt
+  with threadpool_limits(limits=best_n):
+    t0 = time.time()
+    res = oracle.encode_data(opt.rnn_type, sds, np_batches, margin=opt.margin)
+    t_enc = time.time() - t0
+    t0 = time.time()
+    oracle.i2t(res[0], res[1])
+    oracle.t2i(res[0], res[1])
+    t_score = time.time() - t0
   scale = n_full / float(nv)
   t_full = t_enc * scale + t_score * scale * scale
   return {
-      'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': os.cpu_count(),
+      'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': best_n,
       'kind': 'port',
-      'sample': ('NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS threads = host cores) on the '
-                 'first %d videos (%d loader batches) of the same split: encode %.2f s, i2t+t2i '
-                 '%.3f s; extrapolated to N=%d with encode ~ N and scoring ~ N^2'
-                 % (nv, len(batches), t_enc, t_score, n_full)),
+      'sample': ('NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS limited to %d threads = fastest of '
+                 'a calibration over {8,16,32,64,%d} on this %d-core host) on the first %d videos '
+                 '(%d loader batches) of the same split: encode %.2f s, i2t+t2i %.3f s; '
+                 'extrapolated to N=%d with encode ~ N and scoring ~ N^2'
+                 % (best_n, ncpu, ncpu, nv, len(batches), t_enc, t_score, n_full)),
   }
+
+
+def train_bench(wl, opt, model, batches, n_steps):
+  """Supplementary: BASELINE configs[1] as a TRAINING step (VSE.train_emb, model.py:309-369:
+  6 encoder passes, 7 contrastive losses with --low_level_loss --norm, backward, Adam) on loader
+  batches of the same split — forward and backward on the HIP path, torch.optim.Adam update."""
+  import copy
+  from cmhse_amd.evaluation import LogCollector
+  topt = copy.copy(opt)
+  topt.low_level_loss, topt.norm = True, True
+  model.criterion.norm = True
+  model.logger = LogCollector()
+  model.train_start(topt)
+  use = [batches[i % len(batches)] for i in range(n_steps + 2)]
+  for b in use[:2]:
+    model.train_emb(topt, *b)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for b in use[2:]:
+    model.train_emb(topt, *b)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / n_steps
+  model.criterion.norm = opt.norm
+  return {'config': 'train_emb, batch %d, img_dim %d, %s pooling, --low_level_loss --norm'
+                    % (wl['batch'], wl['img_dim'], opt.rnn_type),
+          'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt}
+
+
+def measured_traffic():
+  """HBM bytes per GRU-step launch from the committed rocprofv3 PMC passes of this same command
+  (profiles/r01_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
+  FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM).  None if absent."""
+  path = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')
+  if not os.path.exists(path):
+    return None
+  d = json.load(open(path))
+  tot, n = 0.0, 0
+  for k, v in d.items():
+    if 'gru_step' in k:
+      tot += v['launches'] * (v['hbm_read_bytes_per_launch_corrected'] +
+                              v['hbm_write_bytes_per_launch'])
+      n += v['launches']
+  return tot / n if n else None
 
 
 def main():
@@ -166,6 +223,8 @@ def main():
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
+  ap.add_argument('--train_steps', type=int, default=10,
+                  help='also time this many VSE.train_emb steps on loader batches (0 = skip)')
   ap.add_argument('--cpu_batches', type=int, default=8,
                   help='loader batches in the CPU-baseline sample (0 = skip)')
   args = ap.parse_args()
@@ -254,11 +313,14 @@ def main():
         'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
         'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(),
+                     'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)',
                      'launches': launches, 'avg_launch_us': (ms * 1e3 / launches) if launches else None,
                      'flops_per_launch': (flops / launches) if launches else None,
                      'kernel_time_share': (ms * 1e-3) / elapsed if elapsed > 0 else None},
     }
+    if world == 1 and args.train_steps > 0:
+      out['train_step'] = train_bench(wl, opt, model, batches[lo:hi], args.train_steps)
     if world == 1 and args.cpu_batches > 0:
       out['cpu_baseline'] = cpu_baseline(wl, opt, model, spec, args.cpu_batches, N)
     print(json.dumps(out))
