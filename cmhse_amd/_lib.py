@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcmhse_hip.so')
 
-POOL_LAST, POOL_ATTN, POOL_MAX = 0, 1, 2
+POOL_LAST, POOL_ATTN, POOL_MAX, POOL_ALL = 0, 1, 2, 3
 SAVE_FOR_BACKWARD = 0x100
 POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}
 
@@ -29,7 +29,8 @@ class GruGrads(ctypes.Structure):
 
 class SeqBatch(ctypes.Structure):
   _fields_ = [('S', c_int32), ('Tmax', c_int32), ('I', c_int32), ('H', c_int32),
-              ('x_rows', c_void_p), ('tok_rows', c_void_p), ('emb_table', c_void_p),
+              ('x_rows', c_void_p), ('x_step_floats', c_int32), ('tok_rows', c_void_p),
+              ('emb_table', c_void_p),
               ('vocab', c_int32), ('h0_rows', c_void_p), ('lens', c_void_p),
               ('out_row', c_void_p), ('step_off', c_void_p), ('step_count_host', c_void_p),
               ('step_timer', c_void_p)]
@@ -68,6 +69,10 @@ SIGNATURES = {
     'cmhse_contrastive_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                              c_float, c_int32, c_int32, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_euclid_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                        c_void_p, c_void_p, c_void_p]),
+    'cmhse_euclid_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                        c_void_p, c_void_p, c_void_p]),
     'cmhse_timer_create': (c_void_p, []),
     'cmhse_timer_destroy': (None, [c_void_p]),
     'cmhse_timer_elapsed_ms': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float)]),

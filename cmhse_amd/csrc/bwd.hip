@@ -67,7 +67,7 @@ struct RowAddrParams {
   uint64_t* xaddr;
   uint64_t* hpaddr;
   int32_t* p_t;
-  int32_t Tmax, I, H, vocab;
+  int32_t Tmax, I, H, vocab, x_step;
   int64_t sum_T;
 };
 
@@ -86,7 +86,7 @@ __global__ void row_addr_kernel(const RowAddrParams q) {
     tok = tok < 0 ? 0 : (tok >= q.vocab ? q.vocab - 1 : tok);
     q.xaddr[p] = reinterpret_cast<uint64_t>(q.emb + tok * q.I);
   } else {
-    q.xaddr[p] = q.x_rows[s] + static_cast<uint64_t>(t) * q.I * 4u;
+    q.xaddr[p] = q.x_rows[s] + static_cast<uint64_t>(t) * q.x_step * 4u;
   }
   if (t > 0)
     q.hpaddr[p] = reinterpret_cast<uint64_t>(q.hs + (static_cast<int64_t>(q.step_off[t - 1]) + s) * q.H);
@@ -111,6 +111,15 @@ struct PoolBwdParams {
 
 __global__ __launch_bounds__(kThreads) void pool_scatter_bwd_kernel(const PoolBwdParams q) {
   const int s = blockIdx.x;
+  if (q.mode == CMHSE_POOL_ALL) {  // every hidden state is an output row: out_row[s] + t
+    const int len = q.lens[s];
+    for (int t = 0; t < len; ++t) {
+      const float* g = q.dout + (static_cast<int64_t>(q.out_row[s]) + t) * q.H;
+      float* d = q.dpool + (static_cast<int64_t>(q.step_off[t]) + s) * q.H;
+      for (int u = threadIdx.x; u < q.H; u += kThreads) d[u] = g[u];
+    }
+    return;
+  }
   const float* g = q.dout + static_cast<int64_t>(q.out_row[s]) * q.H;
   for (int u = threadIdx.x; u < q.H; u += kThreads) {
     const int t = (q.mode == CMHSE_POOL_MAX) ? q.argmax[static_cast<int64_t>(s) * q.H + u]
@@ -508,6 +517,55 @@ __global__ __launch_bounds__(kThreads) void loss_bwd_build_kernel(const LossBwdP
 }
 
 // ---------------------------------------------------------------------------------------------
+// EuclideanLoss (decoder/loss.py:17-26): per-row distances, fixed-order fp64 total
+// ---------------------------------------------------------------------------------------------
+struct EuclidParams {
+  const float* a;
+  const float* b;
+  const uint64_t* b_rows;
+  float* dist;  // [rows]
+  float* d_a;   // backward
+  const float* gout;
+  float* loss;
+  int32_t rows, cols, norm;
+};
+
+__global__ __launch_bounds__(kThreads) void euclid_rows_kernel(const EuclidParams q, int backward) {
+  const int64_t r = blockIdx.x;
+  const float* ar = q.a + r * q.cols;
+  const float* br = q.b_rows ? reinterpret_cast<const float*>(q.b_rows[r]) : q.b + r * q.cols;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < q.cols; c += kThreads) {
+    const float d = ar[c] - br[c];
+    ss += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  __shared__ float part[4];
+  __shared__ float s_d;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) s_d = sqrtf(part[0] + part[1] + part[2] + part[3]);
+  __syncthreads();
+  const float dist = s_d;
+  if (!backward) {
+    if (threadIdx.x == 0) q.dist[r] = dist;
+    return;
+  }
+  float sc = *q.gout / dist;
+  if (q.norm) sc /= static_cast<float>(q.rows);
+  for (int c = threadIdx.x; c < q.cols; c += kThreads) q.d_a[r * q.cols + c] = (ar[c] - br[c]) * sc;
+}
+
+__global__ void euclid_final_kernel(const EuclidParams q) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t = 0.0;
+  for (int r = 0; r < q.rows; ++r) t += q.dist[r];
+  if (q.norm) t /= q.rows;
+  *q.loss = static_cast<float>(t);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
 static void launch_transpose(const float* in, float* out, int R, int C, hipStream_t st) {
@@ -593,7 +651,8 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
                                   size_t workspace_bytes, void* stream_) {
   if (!b || !w || !dout || !fwd_workspace || !g || !workspace) return CMHSE_ERR_ARG;
   pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
-  if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX)
+  if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX &&
+      pool_mode != CMHSE_POOL_ALL)
     return CMHSE_ERR_ARG;
   if (b->S <= 0 || b->Tmax <= 0 || b->I <= 0 || b->H <= 0 || !b->step_count_host) return CMHSE_ERR_ARG;
   if (!g->dw_ih || !g->dw_hh || !g->db_ih || !g->db_hh) return CMHSE_ERR_ARG;
@@ -651,7 +710,8 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     launch_transpose(w->w_lin, wlin_t, H, H, st);
     launch_nt_out(du, H, wlin_t, H, dpool, H, nullptr, static_cast<int>(sum_T), H, H, 1, st);
   } else {
-    (void)hipMemsetAsync(dpool, 0, static_cast<size_t>(sum_T) * H * 4, st);
+    if (pool_mode != CMHSE_POOL_ALL)
+      (void)hipMemsetAsync(dpool, 0, static_cast<size_t>(sum_T) * H * 4, st);
     PoolBwdParams pp;
     pp.dout = dout; pp.lens = b->lens; pp.out_row = b->out_row; pp.step_off = b->step_off;
     pp.argmax = reinterpret_cast<const int32_t*>(fws + F.argmax);
@@ -688,6 +748,7 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   rp.x_rows = b->x_rows; rp.tok_rows = b->tok_rows; rp.emb = b->emb_table; rp.h0_rows = b->h0_rows;
   rp.step_off = b->step_off; rp.hs = hs; rp.zero_row = zero_row; rp.xaddr = xaddr;
   rp.hpaddr = hpaddr; rp.p_t = p_t; rp.Tmax = Tmax; rp.I = I; rp.H = H; rp.vocab = b->vocab;
+  rp.x_step = b->x_step_floats;
   rp.sum_T = sum_T;
   hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)), dim3(256),
                      0, st, rp);
@@ -705,8 +766,10 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
       rq.x_rows = dx_rows; rq.tok_rows = nullptr;
       hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)),
                          dim3(256), 0, st, rq);
+      // a time-constant input receives the SUM over its steps: rows repeat -> atomic accumulate
+      // into the caller's (zeroed) rows; ordinary inputs are written exactly once
       launch_nt_out(dgx, 3 * H, wih_t, 3 * H, nullptr, 0, xaddr, static_cast<int>(sum_T), I, 3 * H,
-                    0, st);
+                    b->x_step_floats == 0 ? 2 : 0, st);
     } else {
       // xaddr[p] = table row of token (t,s); same row offset inside d_emb_table
       RowAddrParams rq = rp;
@@ -763,5 +826,30 @@ extern "C" int cmhse_contrastive_bwd(const float* im, const float* s, const floa
   // d im[i][d] = sum_j G[i][j] s[j][d]  = TN(A = G^T, B = s);  d s[j][d] = sum_i G[i][j] im[i][d]
   launch_tn(q.GT, n, s, D, nullptr, d_im, D, n, D, n, nullptr, vec, st);
   launch_tn(q.G, n, im, D, nullptr, d_s, D, n, D, n, nullptr, vec, st);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_euclid_fwd(const float* a, const float* b, const uint64_t* b_rows, int32_t rows,
+                                int32_t cols, int32_t norm, float* loss, float* row_dist,
+                                void* stream_) {
+  if (!a || (!b && !b_rows) || !loss || !row_dist || rows <= 0 || cols <= 0) return CMHSE_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  EuclidParams q;
+  q.a = a; q.b = b; q.b_rows = b_rows; q.dist = row_dist; q.d_a = nullptr; q.gout = nullptr;
+  q.loss = loss; q.rows = rows; q.cols = cols; q.norm = norm;
+  hipLaunchKernelGGL(euclid_rows_kernel, dim3(rows), dim3(kThreads), 0, st, q, 0);
+  hipLaunchKernelGGL(euclid_final_kernel, dim3(1), dim3(64), 0, st, q);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_euclid_bwd(const float* a, const float* b, const uint64_t* b_rows, int32_t rows,
+                                int32_t cols, int32_t norm, const float* grad_out, float* d_a,
+                                void* stream_) {
+  if (!a || (!b && !b_rows) || !grad_out || !d_a || rows <= 0 || cols <= 0) return CMHSE_ERR_ARG;
+  EuclidParams q;
+  q.a = a; q.b = b; q.b_rows = b_rows; q.dist = nullptr; q.d_a = d_a; q.gout = grad_out;
+  q.loss = nullptr; q.rows = rows; q.cols = cols; q.norm = norm;
+  hipLaunchKernelGGL(euclid_rows_kernel, dim3(rows), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream_), q, 1);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }

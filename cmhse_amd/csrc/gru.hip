@@ -51,7 +51,7 @@ struct GruStepParams {
   float* out;
   float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
   int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
-  int32_t I, H, t, S_t, vocab, pool_mode, n_tiles;
+  int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
   int64_t off_prev, off_cur;
 };
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
       tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
       ax[i] = row_addr(p.emb + tok * I);
     } else {
-      ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * I * 4u;
+      ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * p.x_step * 4u;
     }
     if (p.t > 0)
       ah[i] = row_addr(p.hs + (p.off_prev + mc) * H);
@@ -175,6 +175,8 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
         }
       } else if (p.pool_mode == CMHSE_POOL_LAST) {
         if (p.t == p.lens[m] - 1) p.out[static_cast<int64_t>(p.out_row[m]) * H + u] = hn;
+      } else if (p.pool_mode == CMHSE_POOL_ALL) {
+        p.out[(static_cast<int64_t>(p.out_row[m]) + p.t) * H + u] = hn;
       }
     }
   }
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepPa
     tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
     ax = row_addr(p.emb + tok * I);
   } else {
-    ax = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * I * 4u;
+    ax = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * p.x_step * 4u;
   }
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
   if (p.t > 0)
@@ -287,6 +289,8 @@ __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepPa
     }
   } else if (p.pool_mode == CMHSE_POOL_LAST) {
     if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
+  } else if (p.pool_mode == CMHSE_POOL_ALL) {
+    p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
   }
 }
 
@@ -527,9 +531,11 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   const int32_t mode_flags = pool_mode;
   const bool save = (pool_mode & CMHSE_SAVE_FOR_BACKWARD) != 0;
   pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
-  if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX)
+  if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX &&
+      pool_mode != CMHSE_POOL_ALL)
     return CMHSE_ERR_ARG;
   if (pool_mode == CMHSE_POOL_ATTN && (!w->w_lin || !w->b_lin || !w->w_att)) return CMHSE_ERR_ARG;
+  if (b->x_rows && b->x_step_floats != 0 && b->x_step_floats < b->I) return CMHSE_ERR_ARG;
   int64_t sum_T = 0;
   for (int t = 0; t < b->Tmax; ++t) {
     const int c = b->step_count_host[t];
@@ -565,6 +571,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   p.H = b->H;
   p.vocab = b->vocab;
   p.pool_mode = pool_mode;
+  p.x_step = b->x_step_floats;
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
   const size_t smem = TileSmem<kGruBM, 3 * kGruBU>::kBytes;
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)

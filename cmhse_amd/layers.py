@@ -22,7 +22,9 @@ class SeqInput(object):
     kind 'padded'  x is [S,T,I] features (layers.*.forward);
     kind 'tokens'  token ids [S,L] int64 + the embedding table (model.EncoderText.forward);
     kind 'rows'    x is [R,I] level-1 embeddings, sequence s = `counts[s]` consecutive rows
-                   (VSE.structure_emb, model.py:238-255)."""
+                   (VSE.structure_emb, model.py:238-255);
+    kind 'repeat'  x is [S,I]; sequence s is x[s] repeated lens[s] times (the decoders' input,
+                   VSE.reconstruct_emb, model.py:257-270) — never materialised."""
 
   def __init__(self, kind, lens, pool, tokens=None, counts=None):
     self.kind, self.lens, self.pool, self.tokens, self.counts = kind, lens, pool, tokens, counts
@@ -59,6 +61,9 @@ class _PackedGRUPoolFn(torch.autograd.Function):
       if spec.kind == 'padded':
         I = xc.shape[2]
         x_ptrs = ops.padded_row_ptrs(xc)
+      elif spec.kind == 'repeat':
+        I = xc.shape[1]
+        x_ptrs = ops.padded_row_ptrs(xc)
       else:
         I = xc.shape[1]
         counts = np.asarray(spec.counts, dtype=np.int64)
@@ -74,7 +79,8 @@ class _PackedGRUPoolFn(torch.autograd.Function):
     need_grad = any(ctx.needs_input_grad)   # (grad mode itself is off inside Function.forward)
     out, fctx = ops.gru_pool_fwd(weights, pool, spec.lens, I, H, device, x_ptrs=x_ptrs,
                                  tok_ptrs=tok_ptrs, emb_table=emb, h0_ptrs=h0_ptrs,
-                                 save_for_backward=need_grad)
+                                 save_for_backward=need_grad,
+                                 constant_input=(spec.kind == 'repeat'))
     ctx.fctx, ctx.spec, ctx.keep = fctx, spec, keep
     ctx.x_shape = None if x is None else tuple(x.shape)
     ctx.table_shape = None if table is None else tuple(table.shape)
@@ -93,8 +99,8 @@ class _PackedGRUPoolFn(torch.autograd.Function):
     dx_ptrs = None
     if spec.kind != 'tokens' and need[1]:
       dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=device)
-      if spec.kind == 'padded':
-        dx_ptrs = ops.padded_row_ptrs(dx)
+      if spec.kind in ('padded', 'repeat'):
+        dx_ptrs = ops.padded_row_ptrs(dx)      # 'repeat': the kernel accumulates over the steps
       else:
         dx_ptrs = np.uint64(dx.data_ptr()) + ctx.row_starts * np.uint64(ctx.x_shape[1] * 4)
     if spec.kind == 'tokens' and need[3]:

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .decoder import DecoderSequence, EuclideanLoss
 from .layers import Attention, Maxout, Seq2Seq
 from .loss import ContrastiveLoss, normalize
 
@@ -89,8 +90,10 @@ class VSE(object):
   """/root/reference/model.py:102-369."""
 
   def __init__(self, opt):
-    if getattr(opt, 'reconstruct_loss', False) or getattr(opt, 'lowest_reconstruct_loss', False):
-      raise NotImplementedError('reconstruction decoders: SURVEY.md §8(f) row 2 (not built yet)')
+    self.reconstruct_loss = bool(getattr(opt, 'reconstruct_loss', False))
+    self.lowest_reconstruct_loss = bool(getattr(opt, 'lowest_reconstruct_loss', False))
+    if self.lowest_reconstruct_loss and not self.reconstruct_loss:
+      raise ValueError('--lowest_reconstruct_loss needs --reconstruct_loss (model.py:324-326)')
     if getattr(opt, 'weak_low_level_loss', False):
       raise NotImplementedError('GroupWiseContrastiveLoss: SURVEY.md §8(f) row 4 (not built yet)')
     if not torch.cuda.is_available():
@@ -111,29 +114,50 @@ class VSE(object):
     params += list(self.clip_enc.parameters())
     params += list(self.vid_seq_enc.parameters())
     params += list(self.txt_seq_enc.parameters())
+    decode_rnn_type = getattr(opt, 'decode_rnn_type', 'seq2seq')
+    if self.reconstruct_loss:       # model.py:138-149
+      self.vid_seq_dec = DecoderSequence(opt.embed_size, opt.img_first_size,
+                                         rnn_type=decode_rnn_type).cuda()
+      self.txt_seq_dec = DecoderSequence(opt.embed_size, opt.cap_first_size,
+                                         rnn_type=decode_rnn_type).cuda()
+      self.criterion_Euclid_Distance = EuclideanLoss(norm=self.norm)
+      params += list(self.vid_seq_dec.parameters())
+      params += list(self.txt_seq_dec.parameters())
+    if self.lowest_reconstruct_loss:   # model.py:151-158
+      self.clip_seq_dec = DecoderSequence(opt.embed_size, opt.img_dim,
+                                          rnn_type=decode_rnn_type).cuda()
+      self.sent_seq_dec = DecoderSequence(opt.embed_size, opt.word_dim,
+                                          rnn_type=decode_rnn_type).cuda()
+      params += list(self.clip_seq_dec.parameters())
+      params += list(self.sent_seq_dec.parameters())
     self.params = params
     self.optimizer = torch.optim.Adam(params, lr=opt.learning_rate)
     self.Eiters = 0
     self.logger = None
 
-  # -- checkpoint contract: a LIST of state-dicts (model.py:166-191) --------------------------
+  # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
+  def _modules(self):
+    mods = [self.clip_enc, self.txt_enc, self.vid_seq_enc, self.txt_seq_enc]
+    if self.reconstruct_loss:
+      mods += [self.vid_seq_dec, self.txt_seq_dec]
+    if self.lowest_reconstruct_loss:
+      mods += [self.clip_seq_dec, self.sent_seq_dec]
+    return mods
+
   def state_dict(self, opt=None):
-    return [self.clip_enc.state_dict(), self.txt_enc.state_dict(),
-            self.vid_seq_enc.state_dict(), self.txt_seq_enc.state_dict()]
+    return [m.state_dict() for m in self._modules()]
 
   def load_state_dict(self, state_dict, opt=None):
-    self.clip_enc.load_state_dict(state_dict[0])
-    self.txt_enc.load_state_dict(state_dict[1])
-    self.vid_seq_enc.load_state_dict(state_dict[2])
-    self.txt_seq_enc.load_state_dict(state_dict[3])
+    for m, sd in zip(self._modules(), state_dict):
+      m.load_state_dict(sd)
 
   def train_start(self, opt=None):
-    for enc in (self.clip_enc, self.txt_enc, self.vid_seq_enc, self.txt_seq_enc):
-      enc.train()
+    for m in self._modules():
+      m.train()
 
   def val_start(self, opt=None):
-    for enc in (self.clip_enc, self.txt_enc, self.vid_seq_enc, self.txt_seq_enc):
-      enc.eval()
+    for m in self._modules():
+      m.eval()
 
   # -- forward --------------------------------------------------------------------------------
   def forward_emb(self, clips, captions, lengths_clip, lengths_cap, return_word=False):
@@ -159,6 +183,26 @@ class VSE(object):
   def _level2(enc, rows, counts, context):
     return enc.rnn.forward_rows(rows, counts, context)
 
+  def reconstruct_emb(self, vid_emb, para_emb, num_clips, num_caps):
+    """model.py:257-270: decode every video / paragraph embedding back into its clips /
+    sentences.  The repeated-embedding input tensor of the reference is never built."""
+    clip_emb = self.vid_seq_dec.forward_repeat(vid_emb, num_clips)
+    sent_emb = self.txt_seq_dec.forward_repeat(para_emb, num_caps)
+    return clip_emb, sent_emb
+
+  def lowest_reconstruct_emb(self, vid_emb, para_emb, num_clips, num_caps):
+    """model.py:272-285 (called with the reconstructed clip / sentence embeddings and the
+    frame / word counts)."""
+    frame_emb = self.clip_seq_dec.forward_repeat(vid_emb, num_clips)
+    word_emb = self.sent_seq_dec.forward_repeat(para_emb, num_caps)
+    return frame_emb, word_emb
+
+  def forward_reconstruct_loss(self, clip_recon, clip_emb, name, **kwargs):
+    """model.py:301-306."""
+    loss = self.criterion_Euclid_Distance(clip_recon, clip_emb)
+    self.logger.update('Le' + name, loss.item(), clip_emb.size(0))
+    return loss
+
   def forward_loss(self, clip_emb, cap_emb, name, **kwargs):
     """model.py:287-292."""
     loss = self.criterion(clip_emb, cap_emb)
@@ -170,11 +214,23 @@ class VSE(object):
                    *args):
     """Forward half of train_emb (model.py:319-344): embeddings and the 4-7 contrastive losses,
     logged exactly like the reference.  Returns the total loss tensor."""
-    clip_emb, cap_emb = self.forward_emb(clips, captions, lengths_clip, lengths_cap)
+    clips = clips.cuda(non_blocking=True)
+    if self.lowest_reconstruct_loss:
+      clip_emb, cap_emb, word = self.forward_emb(clips, captions, lengths_clip, lengths_cap,
+                                                 return_word=True)
+    else:
+      clip_emb, cap_emb = self.forward_emb(clips, captions, lengths_clip, lengths_cap)
+      word = None
     vid_context, para_context = self.forward_emb(videos, paragraphs, lengths_video,
                                                  lengths_paragraph)
     vid_emb, para_emb = self.structure_emb(clip_emb, cap_emb, num_clips, num_caps, vid_context,
                                            para_context)
+    if self.reconstruct_loss:
+      clip_recon, cap_recon = self.reconstruct_emb(vid_emb, para_emb, num_clips, num_caps)
+    if self.lowest_reconstruct_loss:
+      lc = np.asarray(lengths_clip, dtype=np.int64)
+      lw = np.asarray(lengths_cap, dtype=np.int64)
+      frame_recon, sent_recon = self.lowest_reconstruct_emb(clip_recon, cap_recon, lc, lw)
     n = normalize
     nv, npar = n(vid_emb), n(para_emb)
     loss_1 = self.forward_loss(nv, npar, '_vid')
@@ -188,6 +244,24 @@ class VSE(object):
       loss_6 = (self.forward_loss(nc, nc, '_clip_inloss') +
                 self.forward_loss(ns, ns, '_cap_inloss')) / 2
       loss = loss + loss_2 + loss_6
+    if self.reconstruct_loss:        # model.py:346-348
+      loss_recon = (self.forward_reconstruct_loss(clip_recon, clip_emb.detach(), '_clip_recon') +
+                    self.forward_reconstruct_loss(cap_recon, cap_emb.detach(), '_cap_recon'))
+      loss = loss + loss_recon * opts.weight_recon
+    if self.lowest_reconstruct_loss:   # model.py:350-364: targets = valid frames / word vectors
+      def valid_rows(t, lens):
+        S, T = t.shape[0], t.shape[1]
+        row_bytes = t.shape[2] * 4
+        idx = np.concatenate([i * T + np.arange(l) for i, l in enumerate(lens)])
+        return np.uint64(t.data_ptr()) + idx.astype(np.uint64) * np.uint64(row_bytes)
+      clips_c = clips.detach().float().contiguous()
+      word_c = word.detach().contiguous()
+      crit = self.criterion_Euclid_Distance
+      l_fr = crit.forward_rows(frame_recon, valid_rows(clips_c, lc), clips_c)
+      self.logger.update('Le_reconstruct_frame_hier', l_fr.item(), int(lc.sum()))
+      l_wd = crit.forward_rows(sent_recon, valid_rows(word_c, lw), word_c)
+      self.logger.update('Le_reconstruct_word_hier', l_wd.item(), int(lw.sum()))
+      loss = loss + (l_fr + l_wd) * opts.lowest_weight_recon
     return loss
 
   def train_emb(self, opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF, SAVE_FOR_BACKWARD  # noqa: F401
+from ._lib import (POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
+                   SAVE_FOR_BACKWARD)
 
 
 def _stream():
@@ -39,7 +40,8 @@ class SeqSchedule(object):
   All small per-sequence arrays go to the device in ONE copy.
   """
 
-  def __init__(self, lens, device, x_ptrs=None, tok_ptrs=None, h0_ptrs=None):
+  def __init__(self, lens, device, x_ptrs=None, tok_ptrs=None, h0_ptrs=None,
+               out_rows_are_starts=False):
     lens = np.asarray(lens, dtype=np.int64).reshape(-1)
     if lens.size == 0 or lens.min() < 1:
       raise ValueError('all sequence lengths must be >= 1 (pack_padded_sequence contract)')
@@ -70,7 +72,12 @@ class SeqSchedule(object):
     if h0_ptrs is not None:
       v64[S:2 * S] = np.asarray(h0_ptrs, dtype=np.uint64)[order]
     v32[:S] = ls
-    v32[S:2 * S] = order
+    if out_rows_are_starts:
+      # CMHSE_POOL_ALL: sequence i (input order) owns output rows [start_i, start_i + len_i)
+      starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+      v32[S:2 * S] = starts[order]
+    else:
+      v32[S:2 * S] = order
     v32[2 * S:] = step_off
     self.meta = torch.from_numpy(buf).to(device)
     base = self.meta.data_ptr()
@@ -118,15 +125,18 @@ class StepTimers(object):
 
 
 def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
-                 emb_table=None, h0_ptrs=None, out=None, save_for_backward=False):
+                 emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
+                 constant_input=False):
   """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
   Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and schedule;
   with `save_for_backward` the workspace also keeps what gru_pool_bwd needs."""
   lib = _lib.load()
-  sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs)
+  sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs,
+                      out_rows_are_starts=(pool_mode == POOL_ALL))
   S = sched.S
   if out is None:
-    out = torch.empty(S, H, dtype=torch.float32, device=device)
+    n_out = sched.sum_T if pool_mode == POOL_ALL else S
+    out = torch.empty(n_out, H, dtype=torch.float32, device=device)
   mode_flags = pool_mode | (SAVE_FOR_BACKWARD if save_for_backward else 0)
   ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, H, mode_flags)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -152,6 +162,7 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     b.vocab = emb_table.shape[0]
   else:
     b.x_rows = sched.p_rows
+    b.x_step_floats = 0 if constant_input else I
   b.h0_rows = sched.p_h0
   b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
   b.step_count_host = sched.step_count_host.ctypes.data
@@ -345,3 +356,36 @@ def contrastive_bwd(im, s, scores, margin, max_violation, norm, grad_out):
                                  ws.data_ptr(), ws_bytes, _stream())
   _lib.check(rc, 'cmhse_contrastive_bwd')
   return d_im, d_s
+
+
+def euclid_fwd(a, b=None, b_rows=None, norm=True):
+  """decoder.loss.EuclideanLoss forward (cmhse_euclid_fwd).  `b_rows`: numpy uint64 addresses of
+  the target rows when they are not one contiguous [rows, cols] tensor."""
+  lib = _lib.load()
+  a = _f32c(a, 'a')
+  rows, cols = a.shape
+  loss = torch.empty((), dtype=torch.float32, device=a.device)
+  scratch = torch.empty(rows, dtype=torch.float32, device=a.device)
+  bd = None
+  if b_rows is not None:
+    bd = torch.from_numpy(np.asarray(b_rows, dtype=np.uint64).view(np.int64).copy()).to(a.device)
+  else:
+    b = _f32c(b, 'b')
+  rc = lib.cmhse_euclid_fwd(a.data_ptr(), b.data_ptr() if b is not None else None,
+                            bd.data_ptr() if bd is not None else None, rows, cols,
+                            int(bool(norm)), loss.data_ptr(), scratch.data_ptr(), _stream())
+  _lib.check(rc, 'cmhse_euclid_fwd')
+  return loss, bd
+
+
+def euclid_bwd(a, b, bd, norm, grad_out):
+  lib = _lib.load()
+  a = _f32c(a, 'a')
+  rows, cols = a.shape
+  d_a = torch.empty_like(a)
+  g = _f32c(grad_out, 'grad_out').reshape(1)
+  rc = lib.cmhse_euclid_bwd(a.data_ptr(), b.data_ptr() if b is not None else None,
+                            bd.data_ptr() if bd is not None else None, rows, cols,
+                            int(bool(norm)), g.data_ptr(), d_a.data_ptr(), _stream())
+  _lib.check(rc, 'cmhse_euclid_bwd')
+  return d_a

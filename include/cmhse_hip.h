@@ -41,6 +41,9 @@ enum {
   CMHSE_POOL_LAST = 0, /* layers.Seq2Seq.forward   layers.py:47-66   h at t = len-1            */
   CMHSE_POOL_ATTN = 1, /* layers.Attention.forward layers.py:93-119  masked exp-softmax pooling */
   CMHSE_POOL_MAX = 2,  /* layers.Maxout.forward    layers.py:185-204 max over valid steps       */
+  CMHSE_POOL_ALL = 3,  /* decoder Seq2Seq_Decode + DecoderSequence.forward (decoder/layers.py:34-52,
+                          decoder/model.py:36-45): every hidden state, sequence after sequence:
+                          out[out_row[s] + t, :] = h_{s,t} */
   /* OR-ed into pool_mode for training: the forward also keeps gate activations (and the arg-max
    * step / tanh(lin(h))) in its workspace, which cmhse_gru_pool_bwd consumes. */
   CMHSE_SAVE_FOR_BACKWARD = 0x100
@@ -71,6 +74,9 @@ typedef struct cmhse_seq_batch {
   int32_t H;    /* hidden size (embed_size) */
   const uint64_t* x_rows;   /* [S] address of step 0 of sequence s: fp32 rows, stride I floats;
                                NULL when tok_rows is used */
+  int32_t x_step_floats;    /* floats between consecutive steps of a sequence in x_rows storage: I for
+                               ordinary [T, I] rows, 0 for a time-constant input (the repeated
+                               embedding a decoder is fed, model.py:261-265) */
   const uint64_t* tok_rows; /* [S] address of token 0 of sequence s (int64 ids, contiguous);
                                the embedding lookup of model.EncoderText.forward (model.py:94) is
                                fused into the operand load.  NULL when x_rows is used */
@@ -190,6 +196,15 @@ int cmhse_contrastive_bwd(const float* im, const float* s, const float* scores, 
                           float margin, int32_t max_violation, int32_t norm, const float* grad_out,
                           float* d_im, float* d_s, void* workspace, size_t workspace_bytes,
                           void* stream);
+
+/* decoder/loss.py:17-26 EuclideanLoss: loss = mean_r (or sum_r) sqrt(sum_c (a[r,c] - b_r[c])^2).
+ * a is [rows, cols] contiguous; row r of b is at b_rows[r] (device addresses) when b_rows != NULL,
+ * else b + r*cols.  The backward gives d loss / d a (b is detached upstream, model.py:347,363). */
+int cmhse_euclid_fwd(const float* a, const float* b, const uint64_t* b_rows, int32_t rows,
+                     int32_t cols, int32_t norm, float* loss, float* row_dist /* [rows] scratch */,
+                     void* stream);
+int cmhse_euclid_bwd(const float* a, const float* b, const uint64_t* b_rows, int32_t rows,
+                     int32_t cols, int32_t norm, const float* grad_out, float* d_a, void* stream);
 
 /* Measurement aid (bench.py's roofline leg): a pair of HIP events owned by the handle.  A timer
  * passed in cmhse_seq_batch.step_timer is recorded before the first and after the last GRU step

@@ -534,3 +534,136 @@ def train_step_grads(rnn_type, params, batch, margin=0.2, max_violation=False, n
       np.add.at(dtable, toks[i, :l], dxx[i, :l])
   g1['embed.weight'] = dtable
   return [g0, g1, g_v2, g_p2]
+
+
+# --------------------------------------------------------------------------------------------
+# Reconstruction path: decoder/model.py:16-47 DecoderSequence,
+# decoder/layers.py:34-52 Seq2Seq_Decode, decoder/loss.py:17-26 EuclideanLoss,
+# model.py:257-285 reconstruct_emb / lowest_reconstruct_emb, model.py:346-364 loss composition.
+# --------------------------------------------------------------------------------------------
+def decoder_forward_cache(rows, counts, p, dtype=np.float64):
+  """DecoderSequence.forward on `rows[i]` repeated counts[i] times (model.py:261-268): a GRU with a
+  time-constant input, no h0; returns all hidden states concatenated sequence by sequence
+  [sum(counts), H_dec] (decoder/model.py:39-45) and the BPTT cache."""
+  rows = np.asarray(rows, dtype=dtype)
+  counts = np.asarray(counts).astype(np.int64)
+  B, T = len(counts), int(counts.max())
+  x = np.zeros((B, T, rows.shape[1]), dtype=dtype)
+  for i, c in enumerate(counts):
+    x[i, :c] = rows[i]
+  c = gru_forward_cache(x, counts, p, None, dtype)
+  out = np.concatenate([c['hs'][i, :n] for i, n in enumerate(counts)], 0)
+  c['counts'] = counts
+  return out, c
+
+
+def decoder_backward(c, dout):
+  counts = c['counts']
+  dhs = np.zeros_like(c['hs'])
+  pos = 0
+  for i, n in enumerate(counts):
+    dhs[i, :n] = dout[pos:pos + n]
+    pos += n
+  grads, dx, _ = gru_backward(c, dhs)
+  drows = np.stack([dx[i, :n].sum(0) for i, n in enumerate(counts)], 0)
+  return grads, drows
+
+
+def euclidean_loss_backward(a, b, norm=True, dtype=np.float64):
+  """d EuclideanLoss(a, b) / d a  (b is detached upstream, model.py:347,363)."""
+  d = np.asarray(a, dtype=dtype) - np.asarray(b, dtype=dtype)
+  sub = np.sqrt((d * d).sum(axis=1, keepdims=True))
+  g = d / sub
+  return g / d.shape[0] if norm else g
+
+
+def train_step_recon(rnn_type, params, batch, margin=0.2, max_violation=False, norm=False,
+                     low_level_loss=False, lowest=False, weight_recon=0.0005,
+                     lowest_weight_recon=0.0001, dtype=np.float64):
+  """VSE.train_emb with --reconstruct_loss (and optionally --lowest_reconstruct_loss),
+  model.py:319-364.  `params`: the 6 (or 8) state-dicts.  Returns (logger triples, total loss,
+  list of per-module gradient dicts)."""
+  (clips, captions, videos, paragraphs, lengths_clip, lengths_cap, lengths_video,
+   lengths_paragraph, num_clips, num_caps) = batch[:10]
+  table = np.asarray(params[1]['embed.weight'], dtype=dtype)
+  fw = lambda p, x, l, h0=None: pooled_gru_forward_cache(rnn_type, x, l, p, h0, dtype)
+  clip_emb, c_clip = fw(params[0], clips, lengths_clip)
+  word = table[np.asarray(captions)]
+  cap_emb, c_cap = fw(params[1], word, lengths_cap)
+  vid_ctx, c_vid = fw(params[0], videos, lengths_video)
+  para_ctx, c_par = fw(params[1], table[np.asarray(paragraphs)], lengths_paragraph)
+  vid_emb, c_v2 = fw(params[2], scatter_rows(clip_emb, num_clips, dtype), num_clips, vid_ctx)
+  para_emb, c_p2 = fw(params[3], scatter_rows(cap_emb, num_caps, dtype), num_caps, para_ctx)
+  clip_recon, d_vdec = decoder_forward_cache(vid_emb, num_clips, params[4], dtype)
+  cap_recon, d_tdec = decoder_forward_cache(para_emb, num_caps, params[5], dtype)
+  if lowest:
+    frame_recon, d_cdec = decoder_forward_cache(clip_recon, lengths_clip, params[6], dtype)
+    sent_recon, d_sdec = decoder_forward_cache(cap_recon, lengths_cap, params[7], dtype)
+
+  log = []
+  d = {k: 0.0 for k in ['vid', 'para', 'vctx', 'pctx', 'clip', 'cap']}
+  raw = dict(vid=vid_emb, para=para_emb, vctx=vid_ctx, pctx=para_ctx, clip=clip_emb, cap=cap_emb)
+  total = 0.0
+
+  def add_loss(a, b, scale, name):
+    nonlocal total
+    na, nb = l2_normalize(raw[a], dtype), l2_normalize(raw[b], dtype)
+    v = float(contrastive_loss(na, nb, margin, max_violation, norm, dtype))
+    log.append(('Le' + name, v, na.shape[0]))
+    total += scale * v
+    ga, gb = contrastive_loss_backward(na, nb, margin, max_violation, norm, dtype)
+    d[a] = d[a] + scale * l2_normalize_backward(raw[a], ga, dtype)
+    d[b] = d[b] + scale * l2_normalize_backward(raw[b], gb, dtype)
+
+  add_loss('vid', 'para', 1.0, '_vid')
+  add_loss('vctx', 'pctx', 1.0, '_ctx_low_lvel')
+  add_loss('vid', 'vid', 0.5, '_vid_inloss')
+  add_loss('para', 'para', 0.5, '_para_inloss')
+  if low_level_loss:
+    add_loss('clip', 'cap', 1.0, '_low_lvel')
+    add_loss('clip', 'clip', 0.5, '_clip_inloss')
+    add_loss('cap', 'cap', 0.5, '_cap_inloss')
+
+  def euclid(a, b, name):
+    v = float(euclidean_loss(a, b, norm, dtype))
+    log.append(('Le' + name, v, b.shape[0]))
+    return v, euclidean_loss_backward(a, b, norm, dtype)
+
+  v1, g_clip_recon = euclid(clip_recon, clip_emb, '_clip_recon')
+  v2, g_cap_recon = euclid(cap_recon, cap_emb, '_cap_recon')
+  total += (v1 + v2) * weight_recon
+  g_clip_recon = g_clip_recon * weight_recon
+  g_cap_recon = g_cap_recon * weight_recon
+  grads = [None] * (8 if lowest else 6)
+  if lowest:
+    frames = np.concatenate([np.asarray(clips, dtype=dtype)[i, :l]
+                             for i, l in enumerate(np.asarray(lengths_clip))], 0)
+    words = np.concatenate([word[i, :l] for i, l in enumerate(np.asarray(lengths_cap))], 0)
+    v3, g_fr = euclid(frame_recon, frames, '_reconstruct_frame_hier')
+    v4, g_wd = euclid(sent_recon, words, '_reconstruct_word_hier')
+    total += (v3 + v4) * lowest_weight_recon
+    grads[6], d_cr = decoder_backward(d_cdec, g_fr * lowest_weight_recon)
+    grads[7], d_pr = decoder_backward(d_sdec, g_wd * lowest_weight_recon)
+    g_clip_recon = g_clip_recon + d_cr
+    g_cap_recon = g_cap_recon + d_pr
+  grads[4], d_vid_dec = decoder_backward(d_vdec, g_clip_recon)
+  grads[5], d_para_dec = decoder_backward(d_tdec, g_cap_recon)
+  d['vid'] = d['vid'] + d_vid_dec
+  d['para'] = d['para'] + d_para_dec
+
+  gather = lambda dxp, counts: np.concatenate([dxp[i, :c] for i, c in enumerate(counts)], 0)
+  grads[2], dx_v2, dh0_v2 = pooled_gru_backward(c_v2, d['vid'])
+  grads[3], dx_p2, dh0_p2 = pooled_gru_backward(c_p2, d['para'])
+  g_clip, _, _ = pooled_gru_backward(c_clip, d['clip'] + gather(dx_v2, num_clips))
+  g_vid, _, _ = pooled_gru_backward(c_vid, d['vctx'] + dh0_v2)
+  g_cap, dx_cap, _ = pooled_gru_backward(c_cap, d['cap'] + gather(dx_p2, num_caps))
+  g_par, dx_par, _ = pooled_gru_backward(c_par, d['pctx'] + dh0_p2)
+  grads[0] = {k: g_clip[k] + g_vid[k] for k in g_clip}
+  grads[1] = {k: g_cap[k] + g_par[k] for k in g_cap}
+  dtable = np.zeros_like(table)
+  for toks, lens, dxx in [(captions, lengths_cap, dx_cap), (paragraphs, lengths_paragraph, dx_par)]:
+    toks = np.asarray(toks)
+    for i, l in enumerate(np.asarray(lens)):
+      np.add.at(dtable, toks[i, :l], dxx[i, :l])
+  grads[1]['embed.weight'] = dtable
+  return log, total, grads

@@ -474,3 +474,63 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
     grad_close(ht.grad.cpu().numpy(), dh0, pool + ' dh0')
     for pn, pp in layer.named_parameters():
       grad_close(pp.grad.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
+# ------------------------------------------------------------------------------------------
+# reconstruction path: BASELINE configs 3/4 use --reconstruct_loss
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('lowest', [0, 1])
+def test_reconstruction_train_step_vs_golden(dev, lowest):
+  from cmhse_amd.model import VSE
+  g = load_golden('model_recon.npz')
+  tag = 'lowest%d' % lowest
+  n_sd = 8 if lowest else 6
+  sds = [dict() for _ in range(n_sd)]
+  for k in g.files:
+    if k.startswith(tag + '.sd'):
+      i, key = k[len(tag) + 3:].split('.', 1)
+      sds[int(i)][key] = torch.from_numpy(g[k])
+  p = tag + '.batch0.'
+  nc = tuple(int(c) for c in g[p + 'num_clips'])
+  batch = tuple(torch.from_numpy(g[p + nm]) for nm in
+                ['clips', 'captions', 'videos', 'paragraphs', 'lengths_clip', 'lengths_cap',
+                 'lengths_video', 'lengths_paragraph']) + (
+                     nc, tuple(int(c) for c in g[p + 'num_caps']), tuple(range(len(nc))),
+                     tuple('v%d' % j for j in range(len(nc))))
+  opt = golden_opt('maxout', reconstruct_loss=True, lowest_reconstruct_loss=bool(lowest),
+                   low_level_loss=True, norm=True, word_dim=300 if lowest else 12,
+                   weight_recon=0.0005, lowest_weight_recon=0.0001, decode_rnn_type='seq2seq')
+  model = VSE(opt)
+  assert len(model.state_dict(opt)) == n_sd
+  model.load_state_dict(sds, opt)
+  model.logger = MeterLog()
+  model.train_start(opt)
+  model.train_emb(opt, *batch)
+  calls = [c for c in model.logger.calls if c[0].startswith('Le')]
+  assert [c[0] for c in calls] == [str(s) for s in g[tag + '.names']]
+  for c, want in zip(calls, g[tag + '.values']):
+    assert loss_close(c[1], want), (tag, c, want)
+  assert [c[2] for c in calls] == list(g[tag + '.n'])
+  for i, m in enumerate(model._modules()):
+    for pn, pp in m.named_parameters():
+      grad_close(pp.grad.cpu().numpy(), g['%s.grad%d.%s' % (tag, i, pn)],
+                 '%s mod%d %s' % (tag, i, pn))
+
+
+def test_decoder_forward_matches_oracle(dev, oracle):
+  """DecoderSequence on a padded, NON-constant input (the reference's generic entry)."""
+  from cmhse_amd.decoder import DecoderSequence
+  rng = np.random.RandomState(3)
+  torch.manual_seed(2)
+  dec = DecoderSequence(20, 36)
+  sd = {k: v.detach().numpy() for k, v in dec.state_dict().items()}
+  dec = dec.to(dev)
+  lens = np.array([3, 1, 5, 2])
+  x = np.zeros((4, 5, 20), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, 20))
+  with torch.no_grad():
+    y = dec(torch.from_numpy(x).to(dev), torch.from_numpy(lens)).cpu().numpy()
+  c = oracle.gru_forward_cache(x, lens, sd, None, np.float64)
+  want = np.concatenate([c['hs'][i, :l] for i, l in enumerate(lens)], 0)
+  np.testing.assert_allclose(y, want, atol=EMB_TOL, rtol=0)

@@ -160,3 +160,37 @@ def test_train_step_gradients(oracle, rnn_type):
         for k, v in grads[i].items():
           np.testing.assert_allclose(v, g['%s.grad%d.%s' % (tag, i, k)], rtol=5e-4, atol=5e-6,
                                      err_msg='%s enc%d %s' % (tag, i, k))
+
+
+def recon_golden(lowest):
+  g = load_golden('model_recon.npz')
+  tag = 'lowest%d' % lowest
+  n_sd = 8 if lowest else 6
+  sds = [dict() for _ in range(n_sd)]
+  for k in g.files:
+    if k.startswith(tag + '.sd'):
+      i, key = k[len(tag) + 3:].split('.', 1)
+      sds[int(i)][key] = g[k]
+  p = tag + '.batch0.'
+  nc = tuple(int(c) for c in g[p + 'num_clips'])
+  batch = (g[p + 'clips'], g[p + 'captions'], g[p + 'videos'], g[p + 'paragraphs'],
+           g[p + 'lengths_clip'], g[p + 'lengths_cap'], g[p + 'lengths_video'],
+           g[p + 'lengths_paragraph'], nc, tuple(int(c) for c in g[p + 'num_caps']),
+           tuple(range(len(nc))), tuple('v%d' % j for j in range(len(nc))))
+  return g, tag, sds, batch
+
+
+@pytest.mark.parametrize('lowest', [0, 1])
+def test_reconstruction_train_step(oracle, lowest):
+  """--reconstruct_loss (+ --lowest_reconstruct_loss): logger triples and every gradient."""
+  g, tag, sds, batch = recon_golden(lowest)
+  log, total, grads = oracle.train_step_recon('maxout', sds, batch, margin=0.2, norm=True,
+                                              low_level_loss=True, lowest=bool(lowest))
+  assert [l[0] for l in log] == [str(s) for s in g[tag + '.names']]
+  np.testing.assert_allclose([l[1] for l in log], g[tag + '.values'], rtol=2e-5, atol=2e-6)
+  assert [l[2] for l in log] == list(g[tag + '.n'])
+  for i, gd in enumerate(grads):
+    for k, v in gd.items():
+      want = g['%s.grad%d.%s' % (tag, i, k)]
+      tol = 5e-4 * np.abs(want).max() + 1e-9
+      assert np.abs(v - want).max() <= tol, (tag, i, k, np.abs(v - want).max(), tol)

@@ -303,6 +303,49 @@ def golden_model(ref_model, ref_eval, out):
     np.savez_compressed(os.path.join(out, 'model_%s.npz' % rnn_type), **cases)
 
 
+def golden_recon(ref_model, out):
+  """VSE.train_emb with --reconstruct_loss (+ --lowest_reconstruct_loss): decoders'
+  state-dicts, logger triples, total-loss pieces and every parameter gradient."""
+  gen = torch.Generator().manual_seed(15)
+  spec = synthetic.ragged_spec(6, seed=4)
+  cases = {}
+  for lowest in [False, True]:
+    # model.py:357 hard-codes a word width of 300 for --lowest_reconstruct_loss
+    wd = 300 if lowest else 12
+    opt = make_opt(rnn_type='maxout', reconstruct_loss=True, lowest_reconstruct_loss=lowest,
+                   low_level_loss=True, norm=True, word_dim=wd)
+    rng = np.random.RandomState(77)
+    np.savez(os.path.join(os.getcwd(), 'vocab', 'anet_precomp_w2v_total.npz'),
+             (0.1 * rng.standard_normal((opt.vocab_size, wd))).astype(np.float32))
+    torch.manual_seed(31)
+    model = ref_model.VSE(opt)
+    mods = [model.clip_enc, model.txt_enc, model.vid_seq_enc, model.txt_seq_enc,
+            model.vid_seq_dec, model.txt_seq_dec]
+    if lowest:
+      mods += [model.clip_seq_dec, model.sent_seq_dec]
+    for m in mods:
+      randomize_biases(m, gen)
+    batches = synthetic.make_batches(spec, 6, opt.img_dim, opt.vocab_size, seed=3)
+    tag = 'lowest%d' % int(lowest)
+    for k, v in batches_np(batches).items():
+      cases[tag + '.' + k] = v
+    for i, sd in enumerate(model.state_dict(opt)):
+      for k, v in sd.items():
+        cases['%s.sd%d.%s' % (tag, i, k)] = v.detach().numpy().copy()
+    model.optimizer = torch.optim.Adam(model.params, lr=0.0)
+    model.logger = MeterLog()
+    model.train_start(opt)
+    model.train_emb(opt, *batches[0])
+    calls = [c for c in model.logger.calls if c[0].startswith('Le')]
+    cases[tag + '.names'] = np.array([c[0] for c in calls])
+    cases[tag + '.values'] = np.array([c[1] for c in calls], dtype=np.float64)
+    cases[tag + '.n'] = np.array([c[2] for c in calls], dtype=np.int64)
+    for i, m in enumerate(mods):
+      for pn, pp in m.named_parameters():
+        cases['%s.grad%d.%s' % (tag, i, pn)] = pp.grad.detach().numpy().copy()
+  np.savez_compressed(os.path.join(out, 'model_recon.npz'), **cases)
+
+
 def main():
   out = os.path.join(REPO, 'tests', 'golden')
   os.makedirs(out, exist_ok=True)
@@ -312,6 +355,7 @@ def main():
   golden_loss(ref_loss, out)
   golden_rank(ref_eval, out)
   golden_model(ref_model, ref_eval, out)
+  golden_recon(ref_model, out)
   for f in sorted(os.listdir(out)):
     print(f, os.path.getsize(os.path.join(out, f)))
 
