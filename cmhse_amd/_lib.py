@@ -69,6 +69,15 @@ SIGNATURES = {
     'cmhse_contrastive_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                              c_float, c_int32, c_int32, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_groupwise_workspace': (c_size_t, [c_int32, c_int32]),
+    'cmhse_groupwise_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_int32, c_float, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_groupwise_bwd_workspace': (c_size_t, [c_int32, c_int32]),
+    'cmhse_groupwise_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_int32, c_float, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
     'cmhse_euclid_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                         c_void_p, c_void_p, c_void_p]),
     'cmhse_euclid_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,

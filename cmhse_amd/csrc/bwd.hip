@@ -516,6 +516,32 @@ __global__ __launch_bounds__(kThreads) void loss_bwd_build_kernel(const LossBwdP
   q.GT[static_cast<int64_t>(j) * n + i] = g;
 }
 
+// GroupWiseContrastiveLoss backward: spread G_red[i][j] over block (i, j) of d scores (uniformly
+// for the block mean, onto the arg-max for the block max); writes dS and dS^T.
+struct ExpandParams {
+  const float* g_red;  // [B, B]
+  const int32_t* arg;  // [B, B]
+  const int32_t* row_off;
+  const int32_t* col_off;
+  float* dS;
+  float* dST;
+  int32_t n, B, use_max;
+};
+
+__global__ __launch_bounds__(kThreads) void groupwise_expand_kernel(const ExpandParams q) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int r0 = q.row_off[bi], r1 = q.row_off[bi + 1], c0 = q.col_off[bj], c1 = q.col_off[bj + 1];
+  const int w = c1 - c0, cnt = (r1 - r0) * w;
+  const float g = q.g_red[bi * q.B + bj];
+  const int a = q.arg[bi * q.B + bj];
+  for (int e = threadIdx.x; e < cnt; e += kThreads) {
+    const int r = r0 + e / w, c = c0 + e % w;
+    const float v = q.use_max ? ((r * q.n + c == a) ? g : 0.f) : g / static_cast<float>(cnt);
+    q.dS[static_cast<int64_t>(r) * q.n + c] = v;
+    q.dST[static_cast<int64_t>(c) * q.n + r] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // EuclideanLoss (decoder/loss.py:17-26): per-row distances, fixed-order fp64 total
 // ---------------------------------------------------------------------------------------------
@@ -851,5 +877,52 @@ extern "C" int cmhse_euclid_bwd(const float* a, const float* b, const uint64_t* 
   q.loss = nullptr; q.rows = rows; q.cols = cols; q.norm = norm;
   hipLaunchKernelGGL(euclid_rows_kernel, dim3(rows), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream_), q, 1);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" size_t cmhse_groupwise_bwd_workspace(int32_t n, int32_t B) {
+  if (n <= 0 || B <= 0) return 0;
+  return 2 * ws_align(static_cast<size_t>(n) * n * 4) + cmhse_contrastive_bwd_workspace(B);
+}
+
+extern "C" int cmhse_groupwise_bwd(const float* im, const float* s, int32_t n, int32_t D,
+                                   const int32_t* row_off, const int32_t* col_off, int32_t B,
+                                   float margin, int32_t max_violation, int32_t norm,
+                                   const float* reduced, const int32_t* arg, const float* grad_out,
+                                   float* d_im, float* d_s, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+  if (!im || !s || !row_off || !col_off || !reduced || !arg || !grad_out || !d_im || !d_s ||
+      !workspace || n <= 0 || D <= 0 || B <= 0 || B > 65535)
+    return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_groupwise_bwd_workspace(n, B))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  char* ws = static_cast<char*>(workspace);
+  const size_t big = ws_align(static_cast<size_t>(n) * n * 4);
+  float* dS = reinterpret_cast<float*>(ws);
+  float* dST = reinterpret_cast<float*>(ws + big);
+  char* lws = ws + 2 * big;
+  const size_t mat = ws_align(static_cast<size_t>(B) * B * 4), vecb = ws_align(static_cast<size_t>(B) * 4);
+  LossBwdParams q;
+  q.scores = reduced; q.gout = grad_out; q.n = B; q.max_violation = max_violation; q.norm = norm;
+  q.margin = margin;
+  q.G = reinterpret_cast<float*>(lws);
+  q.GT = reinterpret_cast<float*>(lws + mat);
+  q.row_arg = reinterpret_cast<int32_t*>(lws + 2 * mat);
+  q.col_arg = reinterpret_cast<int32_t*>(lws + 2 * mat + vecb);
+  q.row_cnt = reinterpret_cast<float*>(lws + 2 * mat + 2 * vecb);
+  q.col_cnt = reinterpret_cast<float*>(lws + 2 * mat + 3 * vecb);
+  hipLaunchKernelGGL(loss_bwd_stats_kernel, dim3((2 * B + 3) / 4), dim3(kThreads), 0, st, q);
+  const int64_t elems = static_cast<int64_t>(B) * B;
+  hipLaunchKernelGGL(loss_bwd_build_kernel, dim3(static_cast<unsigned>((elems + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, st, q);
+  ExpandParams ep;
+  ep.g_red = q.G; ep.arg = arg; ep.row_off = row_off; ep.col_off = col_off; ep.dS = dS;
+  ep.dST = dST; ep.n = n; ep.B = B; ep.use_max = max_violation;
+  hipLaunchKernelGGL(groupwise_expand_kernel, dim3(B, B), dim3(kThreads), 0, st, ep);
+  const bool vec = (n % 4 == 0) && (D % 4 == 0);
+  launch_tn(dST, n, s, D, nullptr, d_im, D, n, D, n, nullptr, vec, st);
+  launch_tn(dS, n, im, D, nullptr, d_s, D, n, D, n, nullptr, vec, st);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }

@@ -453,6 +453,101 @@ extern "C" int cmhse_contrastive_blocks_fwd(const float* im, const float* s,
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
+// GroupWiseContrastiveLoss (loss.py:26-38): block (video i's clips x video j's captions) max or
+// mean of the clip x caption score matrix.  One workgroup per block; the arg-max (row-major first
+// maximum) is kept for the backward pass.
+struct BlockReduceParams {
+  const float* scores;  // [n, n]
+  const int32_t* row_off;
+  const int32_t* col_off;
+  float* reduced;   // [B, B]
+  int32_t* arg;     // [B, B] flat index r*n + c of the block maximum
+  int32_t n, B, use_max;
+};
+
+__global__ __launch_bounds__(kThreads) void block_reduce_kernel(const BlockReduceParams q) {
+  const int bi = blockIdx.y, bj = blockIdx.x, tid = threadIdx.x;
+  const int r0 = q.row_off[bi], r1 = q.row_off[bi + 1], c0 = q.col_off[bj], c1 = q.col_off[bj + 1];
+  const int w = c1 - c0, cnt = (r1 - r0) * w;
+  double sum = 0.0;
+  float best = -INFINITY;
+  int arg = 0x7fffffff;
+  for (int e = tid; e < cnt; e += kThreads) {
+    const int r = r0 + e / w, c = c0 + e % w;
+    const float v = q.scores[static_cast<int64_t>(r) * q.n + c];
+    sum += v;
+    const int flat = r * q.n + c;
+    if (v > best || (v == best && flat < arg)) {
+      best = v;
+      arg = flat;
+    }
+  }
+  __shared__ double s_sum[kThreads];
+  __shared__ float s_best[kThreads];
+  __shared__ int s_arg[kThreads];
+  s_sum[tid] = sum;
+  s_best[tid] = best;
+  s_arg[tid] = arg;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    float b = -INFINITY;
+    int a = 0x7fffffff;
+    for (int i = 0; i < kThreads; ++i) {
+      t += s_sum[i];
+      if (s_best[i] > b || (s_best[i] == b && s_arg[i] < a)) {
+        b = s_best[i];
+        a = s_arg[i];
+      }
+    }
+    q.reduced[bi * q.B + bj] = q.use_max ? b : static_cast<float>(t / cnt);
+    q.arg[bi * q.B + bj] = a;
+  }
+}
+
+extern "C" size_t cmhse_groupwise_workspace(int32_t n, int32_t B) {
+  if (n <= 0 || B <= 0) return 0;
+  const size_t nrb = (B + 63) / 64;
+  return align_up_(static_cast<size_t>(n) * n * sizeof(float), 256) +
+         align_up_(2 * nrb * sizeof(double), 256);
+}
+
+extern "C" int cmhse_groupwise_fwd(const float* im, const float* s, int32_t n, int32_t D,
+                                   const int32_t* row_off, const int32_t* col_off, int32_t B,
+                                   float margin, int32_t max_violation, int32_t norm, float* loss,
+                                   float* reduced, int32_t* arg, float* scores_out,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!im || !s || !row_off || !col_off || !loss || !reduced || !arg || !workspace || n <= 0 ||
+      D <= 0 || B <= 0 || B > 65535)
+    return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_groupwise_workspace(n, B))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* scores = scores_out ? scores_out : static_cast<float*>(workspace);
+  const int rc = launch_sim_store(im, s, n, n, D, scores, stream);
+  if (rc != CMHSE_OK) return rc;
+  BlockReduceParams bp;
+  bp.scores = scores; bp.row_off = row_off; bp.col_off = col_off; bp.reduced = reduced;
+  bp.arg = arg; bp.n = n; bp.B = B; bp.use_max = max_violation;
+  hipLaunchKernelGGL(block_reduce_kernel, dim3(B, B), dim3(kThreads), 0, stream, bp);
+  LossParams lp;
+  lp.scores = reduced;
+  lp.n = B;
+  lp.nrb = (B + 63) / 64;
+  lp.margin = margin;
+  lp.max_violation = max_violation;
+  lp.norm = norm;
+  lp.partial = reinterpret_cast<double*>(static_cast<char*>(workspace) +
+                                         align_up_(static_cast<size_t>(n) * n * sizeof(float), 256));
+  lp.loss = loss;
+  lp.blk_off = nullptr;
+  lp.blk_stride = 0;
+  hipLaunchKernelGGL(contrastive_partial_kernel, dim3(2 * lp.nrb), dim3(kThreads), 0, stream, lp);
+  hipLaunchKernelGGL(contrastive_final_kernel, dim3(1), dim3(64), 0, stream, lp);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
 extern "C" const char* cmhse_strerror(int code) {
   switch (code) {
     case CMHSE_OK: return "ok";

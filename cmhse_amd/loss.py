@@ -74,3 +74,39 @@ class ContrastiveLoss(nn.Module):
 
   def forward(self, im, s):
     return _ContrastiveFn.apply(im, s, self.margin, self.max_violation, self.norm)
+
+
+class _GroupWiseFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, im, s, num_clips, num_caps, margin, max_violation, norm):
+    imd = im.detach().float().contiguous()
+    sd = s.detach().float().contiguous()
+    loss, st = ops.groupwise_fwd(imd, sd, num_clips, num_caps, margin, max_violation, norm)
+    ctx.save_for_backward(imd, sd)
+    ctx.st, ctx.cfg = st, (margin, max_violation, norm)
+    return loss
+
+  @staticmethod
+  def backward(ctx, grad):
+    im, s = ctx.saved_tensors
+    margin, max_violation, norm = ctx.cfg
+    d_im, d_s = ops.groupwise_bwd(im, s, ctx.st, margin, max_violation, norm, grad)
+    return d_im, d_s, None, None, None, None, None
+
+
+class GroupWiseContrastiveLoss(nn.Module):
+  """/root/reference/loss.py:15-72 (--weak_low_level_loss): clip x caption scores reduced per
+  video pair by max (max_violation) or mean, then the contrastive hinge on the [B,B] matrix."""
+
+  def __init__(self, margin=0, measure=False, max_violation=False, norm=True):
+    super(GroupWiseContrastiveLoss, self).__init__()
+    self.margin = margin
+    if measure == 'order':
+      raise NotImplementedError("measure='order' is undefined in the reference (loss.py:18-21)")
+    self.sim = cosine_sim
+    self.norm = norm
+    self.max_violation = max_violation
+
+  def forward(self, im, s, num_clips, num_caps):
+    return _GroupWiseFn.apply(im, s, [int(c) for c in num_clips], [int(c) for c in num_caps],
+                              self.margin, self.max_violation, self.norm)

@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import ops
 from .decoder import DecoderSequence, EuclideanLoss
 from .layers import Attention, Maxout, Seq2Seq
-from .loss import ContrastiveLoss, normalize
+from .loss import ContrastiveLoss, GroupWiseContrastiveLoss, normalize
 
 
 def _make_rnn(rnn_type, in_dim, embed_size, bidirectional):
@@ -94,8 +94,6 @@ class VSE(object):
     self.lowest_reconstruct_loss = bool(getattr(opt, 'lowest_reconstruct_loss', False))
     if self.lowest_reconstruct_loss and not self.reconstruct_loss:
       raise ValueError('--lowest_reconstruct_loss needs --reconstruct_loss (model.py:324-326)')
-    if getattr(opt, 'weak_low_level_loss', False):
-      raise NotImplementedError('GroupWiseContrastiveLoss: SURVEY.md §8(f) row 4 (not built yet)')
     if not torch.cuda.is_available():
       raise RuntimeError('cmhse_amd.VSE needs an MI355X (no CPU fallback for the hot path)')
     self.norm = opt.norm
@@ -110,6 +108,9 @@ class VSE(object):
 
     self.criterion = ContrastiveLoss(margin=opt.margin, measure=opt.measure,
                                      max_violation=opt.max_violation, norm=self.norm)
+    self.weak_criterion = GroupWiseContrastiveLoss(margin=opt.margin, measure=opt.measure,
+                                                   max_violation=opt.max_violation,
+                                                   norm=self.norm)      # model.py:127-129
     params = list(self.txt_enc.parameters())
     params += list(self.clip_enc.parameters())
     params += list(self.vid_seq_enc.parameters())
@@ -197,6 +198,12 @@ class VSE(object):
     word_emb = self.sent_seq_dec.forward_repeat(para_emb, num_caps)
     return frame_emb, word_emb
 
+  def forward_weak_loss(self, clip_emb, cap_emb, num_clips, num_caps, name, **kwargs):
+    """model.py:294-299."""
+    loss = self.weak_criterion(clip_emb, cap_emb, num_clips, num_caps)
+    self.logger.update('Le' + name, loss.item(), clip_emb.size(0))
+    return loss
+
   def forward_reconstruct_loss(self, clip_recon, clip_emb, name, **kwargs):
     """model.py:301-306."""
     loss = self.criterion_Euclid_Distance(clip_recon, clip_emb)
@@ -240,7 +247,10 @@ class VSE(object):
     loss = loss_1 + loss_3 + loss_5
     if opts.low_level_loss:
       nc, ns = n(clip_emb), n(cap_emb)
-      loss_2 = self.forward_loss(nc, ns, '_low_lvel')
+      if getattr(opts, 'weak_low_level_loss', False):      # model.py:338-340
+        loss_2 = self.forward_weak_loss(nc, ns, num_clips, num_caps, '_wlow_lvel')
+      else:
+        loss_2 = self.forward_loss(nc, ns, '_low_lvel')
       loss_6 = (self.forward_loss(nc, nc, '_clip_inloss') +
                 self.forward_loss(ns, ns, '_cap_inloss')) / 2
       loss = loss + loss_2 + loss_6

@@ -389,3 +389,48 @@ def euclid_bwd(a, b, bd, norm, grad_out):
                             int(bool(norm)), g.data_ptr(), d_a.data_ptr(), _stream())
   _lib.check(rc, 'cmhse_euclid_bwd')
   return d_a
+
+
+def groupwise_fwd(im, s, num_clips, num_caps, margin, max_violation, norm):
+  """loss.GroupWiseContrastiveLoss forward (cmhse_groupwise_fwd).  Returns (loss, saved state)."""
+  lib = _lib.load()
+  im = _f32c(im, 'im')
+  s = _f32c(s, 's')
+  n, D = im.shape
+  B = len(num_clips)
+  if len(num_caps) != B or sum(num_clips) != n or sum(num_caps) != s.shape[0] or s.shape[0] != n:
+    raise ValueError('GroupWiseContrastiveLoss: block sizes must tile the rows (loss.py:33)')
+  off = np.zeros(2 * (B + 1), dtype=np.int32)
+  np.cumsum(np.asarray(num_clips), out=off[1:B + 1])
+  np.cumsum(np.asarray(num_caps), out=off[B + 2:])
+  off_d = torch.from_numpy(off).to(im.device)
+  loss = torch.empty((), dtype=torch.float32, device=im.device)
+  reduced = torch.empty(B, B, dtype=torch.float32, device=im.device)
+  arg = torch.empty(B, B, dtype=torch.int32, device=im.device)
+  ws_bytes = lib.cmhse_groupwise_workspace(n, B)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
+  rc = lib.cmhse_groupwise_fwd(im.data_ptr(), s.data_ptr(), n, D, off_d.data_ptr(),
+                               off_d.data_ptr() + 4 * (B + 1), B, float(margin),
+                               int(bool(max_violation)), int(bool(norm)), loss.data_ptr(),
+                               reduced.data_ptr(), arg.data_ptr(), None, ws.data_ptr(), ws_bytes,
+                               _stream())
+  _lib.check(rc, 'cmhse_groupwise_fwd')
+  return loss, dict(off=off_d, reduced=reduced, arg=arg, B=B)
+
+
+def groupwise_bwd(im, s, st, margin, max_violation, norm, grad_out):
+  lib = _lib.load()
+  n, D = im.shape
+  B = st['B']
+  g = _f32c(grad_out, 'grad_out').reshape(1)
+  d_im = torch.empty_like(im)
+  d_s = torch.empty_like(s)
+  ws_bytes = lib.cmhse_groupwise_bwd_workspace(n, B)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
+  rc = lib.cmhse_groupwise_bwd(im.data_ptr(), s.data_ptr(), n, D, st['off'].data_ptr(),
+                               st['off'].data_ptr() + 4 * (B + 1), B, float(margin),
+                               int(bool(max_violation)), int(bool(norm)),
+                               st['reduced'].data_ptr(), st['arg'].data_ptr(), g.data_ptr(),
+                               d_im.data_ptr(), d_s.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_groupwise_bwd')
+  return d_im, d_s

@@ -197,6 +197,24 @@ int cmhse_contrastive_bwd(const float* im, const float* s, const float* scores, 
                           float* d_im, float* d_s, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* loss.GroupWiseContrastiveLoss.forward (loss.py:26-71, --weak_low_level_loss): clip x caption
+ * scores [n, n], reduced per (video i, video j) block to their max (max_violation) or mean, then
+ * the same hinge loss on the reduced [B, B] matrix (norm divides by B*B).  row_off / col_off:
+ * device int32 [B+1] prefix sums of num_clips / num_caps.  `reduced` [B,B] and `arg` [B,B] are
+ * kept by the caller for cmhse_groupwise_bwd. */
+size_t cmhse_groupwise_workspace(int32_t n, int32_t B);
+int cmhse_groupwise_fwd(const float* im, const float* s, int32_t n, int32_t D,
+                        const int32_t* row_off, const int32_t* col_off, int32_t B, float margin,
+                        int32_t max_violation, int32_t norm, float* loss, float* reduced,
+                        int32_t* arg, float* scores_out, void* workspace, size_t workspace_bytes,
+                        void* stream);
+size_t cmhse_groupwise_bwd_workspace(int32_t n, int32_t B);
+int cmhse_groupwise_bwd(const float* im, const float* s, int32_t n, int32_t D,
+                        const int32_t* row_off, const int32_t* col_off, int32_t B, float margin,
+                        int32_t max_violation, int32_t norm, const float* reduced,
+                        const int32_t* arg, const float* grad_out, float* d_im, float* d_s,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* decoder/loss.py:17-26 EuclideanLoss: loss = mean_r (or sum_r) sqrt(sum_c (a[r,c] - b_r[c])^2).
  * a is [rows, cols] contiguous; row r of b is at b_rows[r] (device addresses) when b_rows != NULL,
  * else b + r*cols.  The backward gives d loss / d a (b is detached upstream, model.py:347,363). */

@@ -667,3 +667,75 @@ def train_step_recon(rnn_type, params, batch, margin=0.2, max_violation=False, n
       np.add.at(dtable, toks[i, :l], dxx[i, :l])
   grads[1]['embed.weight'] = dtable
   return log, total, grads
+
+
+# --------------------------------------------------------------------------------------------
+# GroupWiseContrastiveLoss, /root/reference/loss.py:15-72
+# --------------------------------------------------------------------------------------------
+def _block_bounds(counts):
+  off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+  return off
+
+
+def groupwise_reduce(scores, num_clips, num_caps, max_violation):
+  """loss.py:27-38: block max (max_violation) or mean of the clip x caption score matrix.
+  Returns the reduced [B,B] matrix and, for max, the flat arg-max inside each block."""
+  ro, co = _block_bounds(num_clips), _block_bounds(num_caps)
+  B = len(num_clips)
+  red = np.zeros((B, B), dtype=scores.dtype)
+  arg = np.zeros((B, B, 2), dtype=np.int64)
+  for i in range(B):
+    for j in range(B):
+      blk = scores[ro[i]:ro[i + 1], co[j]:co[j + 1]]
+      if max_violation:
+        k = np.unravel_index(np.argmax(blk), blk.shape)
+        red[i, j] = blk[k]
+        arg[i, j] = (ro[i] + k[0], co[j] + k[1])
+      else:
+        red[i, j] = blk.mean()
+  return red, arg
+
+
+def _hinge_from_scores(scores, margin, max_violation, norm, dtype):
+  n = scores.shape[0]
+  diag = np.diag(scores).reshape(n, 1)
+  eye = np.eye(n, dtype=bool)
+  cost_s = np.where(eye, 0, np.maximum(margin + scores - diag, 0))
+  cost_im = np.where(eye, 0, np.maximum(margin + scores - diag.T, 0))
+  if max_violation:
+    g_s = np.zeros_like(scores); g_im = np.zeros_like(scores)
+    js = cost_s.argmax(axis=1)
+    g_s[np.arange(n), js] = (cost_s[np.arange(n), js] > 0)
+    is_ = cost_im.argmax(axis=0)
+    g_im[is_, np.arange(n)] = (cost_im[is_, np.arange(n)] > 0)
+    loss = cost_s.max(axis=1).sum() + cost_im.max(axis=0).sum()
+  else:
+    g_s = (cost_s > 0).astype(dtype); g_im = (cost_im > 0).astype(dtype)
+    loss = cost_s.sum() + cost_im.sum()
+  G = g_s + g_im
+  G[np.arange(n), np.arange(n)] -= g_s.sum(axis=1) + g_im.sum(axis=0)
+  if norm:
+    loss = loss / (n * n)
+    G = G / (n * n)
+  return loss, G
+
+
+def groupwise_contrastive_loss(im, s, num_clips, num_caps, margin=0.0, max_violation=False,
+                               norm=True, dtype=np.float64, want_grad=False):
+  """GroupWiseContrastiveLoss.forward (loss.py:26-71) and, optionally, (d im, d s)."""
+  im = np.asarray(im, dtype=dtype); s = np.asarray(s, dtype=dtype)
+  scores = im @ s.T
+  red, arg = groupwise_reduce(scores, num_clips, num_caps, max_violation)
+  loss, G = _hinge_from_scores(red, margin, max_violation, norm, dtype)
+  if not want_grad:
+    return dtype(loss)
+  ro, co = _block_bounds(num_clips), _block_bounds(num_caps)
+  dS = np.zeros_like(scores)
+  B = len(num_clips)
+  for i in range(B):
+    for j in range(B):
+      if max_violation:
+        dS[arg[i, j, 0], arg[i, j, 1]] += G[i, j]
+      else:
+        dS[ro[i]:ro[i + 1], co[j]:co[j + 1]] += G[i, j] / (num_clips[i] * num_caps[j])
+  return dtype(loss), dS @ s, dS.T @ im

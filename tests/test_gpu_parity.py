@@ -534,3 +534,67 @@ def test_decoder_forward_matches_oracle(dev, oracle):
   c = oracle.gru_forward_cache(x, lens, sd, None, np.float64)
   want = np.concatenate([c['hs'][i, :l] for i, l in enumerate(lens)], 0)
   np.testing.assert_allclose(y, want, atol=EMB_TOL, rtol=0)
+
+
+@pytest.mark.parametrize('n', [11, 9])
+def test_groupwise_loss_vs_golden(dev, n):
+  """GroupWiseContrastiveLoss (--weak_low_level_loss): value and gradients vs the reference."""
+  from cmhse_amd.loss import GroupWiseContrastiveLoss, normalize
+  g = load_golden('loss.npz')
+  nc, ncap = list(g['gw%d.num_clips' % n]), list(g['gw%d.num_caps' % n])
+  for mv in (0, 1):
+    for nm in (0, 1):
+      tag = 'gw%d.mv%d.norm%d' % (n, mv, nm)
+      crit = GroupWiseContrastiveLoss(margin=0.2, measure='cosine', max_violation=bool(mv),
+                                      norm=bool(nm))
+      a = torch.from_numpy(g['gw%d.a' % n]).to(dev).requires_grad_(True)
+      b = torch.from_numpy(g['gw%d.b' % n]).to(dev).requires_grad_(True)
+      loss = crit(normalize(a), normalize(b), nc, ncap)
+      assert loss_close(loss.item(), g[tag + '.loss']), tag
+      loss.backward()
+      grad_close(a.grad.cpu().numpy(), g[tag + '.da'], tag + '.da')
+      grad_close(b.grad.cpu().numpy(), g[tag + '.db'], tag + '.db')
+
+
+def test_weak_low_level_loss_train_step(dev, oracle):
+  """train_emb with --weak_low_level_loss runs end to end and logs '_wlow_lvel' with the oracle's
+  value."""
+  g = load_golden('model_maxout.npz')
+  batch = torch_batches(golden_batches(g))[1]
+  opt, model = golden_model('maxout', g, low_level_loss=True, weak_low_level_loss=True, norm=True)
+  model.logger = MeterLog()
+  model.train_start(opt)
+  model.train_emb(opt, *batch)
+  names = [c[0] for c in model.logger.calls if c[0].startswith('Le')]
+  assert names == ['Le_vid', 'Le_ctx_low_lvel', 'Le_vid_inloss', 'Le_para_inloss', 'Le_wlow_lvel',
+                   'Le_clip_inloss', 'Le_cap_inloss']
+  sds = golden_state_dicts(g)
+  nb = golden_batches(g)[1]
+  clip_emb, cap_emb, _ = oracle.forward_emb('maxout', sds, nb[0], nb[1], nb[4], nb[5], np.float64)
+  want = oracle.groupwise_contrastive_loss(oracle.l2_normalize(clip_emb, np.float64),
+                                           oracle.l2_normalize(cap_emb, np.float64), nb[8], nb[9],
+                                           0.2, False, True)
+  got = [c[1] for c in model.logger.calls if c[0] == 'Le_wlow_lvel'][0]
+  assert loss_close(got, want)
+
+
+def test_checkpoint_round_trip_in_reference_format(dev, tmp_path):
+  """train.save_checkpoint's payload (train.py:166-172: {'epoch','model': [state_dicts],...})
+  round-trips through torch.save / load_state_dict and reproduces the embeddings."""
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import encode_data
+  g = load_golden('model_attention.npz')
+  opt, model = golden_model('attention', g)
+  path = str(tmp_path / 'ckpt.pth.tar')
+  torch.save({'epoch': 3, 'model': model.state_dict(opt), 'best_rsum': 1.0, 'opt': opt,
+              'Eiters': 7}, path)
+  ck = torch.load(path, weights_only=False)
+  from cmhse_amd.model import VSE
+  torch.manual_seed(99)
+  model2 = VSE(opt)
+  model2.load_state_dict(ck['model'], opt)
+  batches = torch_batches(golden_batches(g))
+  r1 = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  r2 = encode_data(opt, model2, synthetic.ListLoader(batches), logging=lambda *a: None)
+  np.testing.assert_array_equal(r1[0], r2[0])
+  np.testing.assert_allclose(r2[0], g['enc.vid_embs'], atol=EMB_TOL, rtol=0)

@@ -194,3 +194,19 @@ def test_reconstruction_train_step(oracle, lowest):
       want = g['%s.grad%d.%s' % (tag, i, k)]
       tol = 5e-4 * np.abs(want).max() + 1e-9
       assert np.abs(v - want).max() <= tol, (tag, i, k, np.abs(v - want).max(), tol)
+
+
+@pytest.mark.parametrize('n', [11, 9])
+def test_groupwise_loss(oracle, n):
+  g = load_golden('loss.npz')
+  a, b = g['gw%d.a' % n].astype(np.float64), g['gw%d.b' % n].astype(np.float64)
+  nc, ncap = list(g['gw%d.num_clips' % n]), list(g['gw%d.num_caps' % n])
+  an, bn = oracle.l2_normalize(a, np.float64), oracle.l2_normalize(b, np.float64)
+  for mv in (0, 1):
+    for nm in (0, 1):
+      tag = 'gw%d.mv%d.norm%d' % (n, mv, nm)
+      loss, ga, gb = oracle.groupwise_contrastive_loss(an, bn, nc, ncap, 0.2, bool(mv), bool(nm),
+                                                       want_grad=True)
+      np.testing.assert_allclose(loss, g[tag + '.loss'], rtol=2e-6, atol=1e-6)
+      np.testing.assert_allclose(oracle.l2_normalize_backward(a, ga), g[tag + '.da'], **GTOL)
+      np.testing.assert_allclose(oracle.l2_normalize_backward(b, gb), g[tag + '.db'], **GTOL)

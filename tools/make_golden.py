@@ -167,6 +167,25 @@ def golden_loss(ref_loss, out):
         ag2 = a.clone().requires_grad_(True)
         crit(F.normalize(ag2), F.normalize(ag2)).backward()
         cases[tag + '.da_self'] = ag2.grad.numpy()
+  # GroupWiseContrastiveLoss (loss.py:15-72): block max / mean of clip x caption scores
+  for n, counts in [(11, [3, 1, 4, 3]), (9, [2, 2, 5])]:
+    a = torch.randn(n, 32, generator=gen)
+    b = a + 0.8 * torch.randn(n, 32, generator=gen)
+    caps = counts[::-1] if n == 9 else counts      # also a case with num_clips != num_caps blocks
+    if sum(caps) != n:
+      caps = counts
+    cases['gw%d.a' % n] = a.numpy(); cases['gw%d.b' % n] = b.numpy()
+    cases['gw%d.num_clips' % n] = np.array(counts); cases['gw%d.num_caps' % n] = np.array(caps)
+    for mv in [False, True]:
+      for nm in [False, True]:
+        crit = ref_loss.GroupWiseContrastiveLoss(margin=0.2, measure='cosine', max_violation=mv,
+                                                 norm=nm)
+        ag = a.clone().requires_grad_(True); bg = b.clone().requires_grad_(True)
+        val = crit(F.normalize(ag), F.normalize(bg), counts, caps)
+        val.backward()
+        tag = 'gw%d.mv%d.norm%d' % (n, int(mv), int(nm))
+        cases[tag + '.loss'] = np.float32(val.item())
+        cases[tag + '.da'] = ag.grad.numpy(); cases[tag + '.db'] = bg.grad.numpy()
   from decoder.loss import EuclideanLoss
   a = torch.randn(13, 24, generator=gen); b = torch.randn(13, 24, generator=gen)
   cases['euclid.a'] = a.numpy(); cases['euclid.b'] = b.numpy()
