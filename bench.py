@@ -171,6 +171,41 @@ def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full):
   }
 
 
+def fast_mode_bench(opt, model, batches, N, n_steps):
+  """Supplementary: the same validation pass with CMHSE_MATH_BF16X3 (3-term bf16 hi/lo split on
+  the bf16 matrix pipe, fp32 accumulate, for the large encoder GEMMs; ranking stays exact fp32),
+  with its measured deviation from the exact-fp32 embeddings.  Never the headline `value`."""
+  quiet = lambda *a, **k: None
+
+  def one_pass():
+    cat, _, _ = encode_data_device(opt, model, batches, logging=quiet)
+    r_i, _ = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
+    r_t, _ = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
+    return cat, r_i, r_t
+
+  ref_cat, ref_ri, _ = one_pass()          # exact fp32
+  try:
+    ops.set_math_mode('bf16x3')
+    one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+      cat, r_i, _ = one_pass()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+  finally:
+    ops.set_math_mode('fp32')
+  diff = max(float((cat[k] - ref_cat[k]).abs().max()) for k in ['vid_emb', 'para_emb', 'clip_emb',
+                                                                 'cap_emb', 'vid_ctx', 'para_ctx'])
+  same = float((r_i == ref_ri).float().mean())
+  return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
+                  'accumulate (encoder GEMMs of steps with > 2048 active sequences and the '
+                  'attention projection); ranking kernel exact fp32',
+          'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
+          'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
+          'i2t_ranks_identical_fraction': same}
+
+
 def train_bench(wl, opt, model, batches, n_steps):
   """Supplementary: BASELINE configs[1] as a TRAINING step (VSE.train_emb, model.py:309-369:
   6 encoder passes, 7 contrastive losses with --low_level_loss --norm, backward, Adam) on loader
@@ -223,6 +258,8 @@ def main():
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
+  ap.add_argument('--fast_steps', type=int, default=2,
+                  help='also time this many passes in the bf16x3 math mode (0 = skip)')
   ap.add_argument('--train_steps', type=int, default=10,
                   help='also time this many VSE.train_emb steps on loader batches (0 = skip)')
   ap.add_argument('--cpu_batches', type=int, default=8,
@@ -319,6 +356,8 @@ def main():
                      'flops_per_launch': (flops / launches) if launches else None,
                      'kernel_time_share': (ms * 1e-3) / elapsed if elapsed > 0 else None},
     }
+    if world == 1 and args.fast_steps > 0:
+      out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)
     if world == 1 and args.train_steps > 0:
       out['train_step'] = train_bench(wl, opt, model, batches[lo:hi], args.train_steps)
     if world == 1 and args.cpu_batches > 0:

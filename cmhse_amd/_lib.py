@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libcmhse_hip.so')
 
 POOL_LAST, POOL_ATTN, POOL_MAX, POOL_ALL = 0, 1, 2, 3
 SAVE_FOR_BACKWARD = 0x100
+MATH_BF16X3 = 0x200
 POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}
 
 c_void_p, c_int32, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
@@ -38,7 +39,7 @@ class SeqBatch(ctypes.Structure):
 
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
 SIGNATURES = {
-    'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32]),
+    'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
     'cmhse_gru_pool_fwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),
                                           c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),

@@ -49,6 +49,8 @@ struct GruStepParams {
   const float* b_hh;
   float* hs;
   float* out;
+  const float* w_ih_s;  // bf16x3 pre-split weights (rows of split_ld(K) float units) or NULL
+  const float* w_hh_s;
   float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
   int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
   int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
@@ -73,7 +75,7 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 constexpr int kGruBM = 128;  // sequences per workgroup
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
-template <bool VEC, int MSUB>
+template <bool VEC, int MSUB, bool BF3>
 __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams p) {
   constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -119,8 +121,13 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
     const int g = br / BU, u = u0 + (br % BU);
     bv[i] = u < H;
     const int uc = bv[i] ? u : (H - 1);
-    bx[i] = row_addr(p.w_ih + (static_cast<int64_t>(g) * H + uc) * I);
-    bh[i] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
+    if (BF3) {
+      bx[i] = row_addr(p.w_ih_s + (static_cast<int64_t>(g) * H + uc) * split_ld(I));
+      bh[i] = row_addr(p.w_hh_s + (static_cast<int64_t>(g) * H + uc) * split_ld(H));
+    } else {
+      bx[i] = row_addr(p.w_ih + (static_cast<int64_t>(g) * H + uc) * I);
+      bh[i] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
+    }
   }
 
   // accumulators per 32-sequence sub-tile: 0 = r, 1 = z, 2 = W_in x, 3 = W_hn h
@@ -132,9 +139,14 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
 
   const int a_row0 = wm * 32 * MSUB;
   const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
-  nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-  if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
+  if (BF3) {
+    nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
+  } else {
+    nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
+  }
 
   // ---- epilogue: gates, state update, pooling ----
   const int u = u0 + wn * 32 + acc_col(lane);
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepPa
 struct AttnEnergyParams {
   const float* hs;     // [rows, H]
   const float* w_lin;  // [H, H]
+  const float* w_lin_s;  // bf16x3 pre-split copy or NULL
   const float* b_lin;
   const float* w_att;
   float* e_part;  // [n_tiles, rows]
@@ -309,7 +322,7 @@ struct AttnEnergyParams {
 };
 
 
-template <bool VEC, int MSUB>
+template <bool VEC, int MSUB, bool BF3>
 __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyParams p) {
   constexpr int BM = 64 * MSUB, BN = kAttBN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -334,7 +347,8 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
   for (int i = 0; i < BN / 64; ++i) {
     const int n = n0 + srow + 64 * i;
     bv[i] = n < H;
-    br[i] = row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
+    br[i] = BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
+                : row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
   }
   f32x16 acc[MSUB][4];
 #pragma unroll
@@ -342,7 +356,10 @@ __global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyP
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
   const int b_row0[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-  nt_phase<BM, BN, MSUB, 4, 4, 3, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+  if (BF3)
+    nt_phase_bf3<BM, BN, MSUB, 4, 4, 3>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+  else
+    nt_phase<BM, BN, MSUB, 4, 4, 3, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
 
   // epilogue: per-row partial dot over this wave's 128 columns, then the two N-waves via LDS
   float wa[4], bl[4];
@@ -497,6 +514,35 @@ struct Timer {
   hipEvent_t start, stop;
 };
 
+// bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
+// split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
+// (k beyond K zero-filled), see nt_phase_bf3.
+__global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __restrict__ W,
+                                                                uint32_t* __restrict__ out, int R,
+                                                                int K) {
+  const int64_t ld = split_ld(K);
+  const int64_t pairs = ld / 2;  // one thread per (row, k pair)
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (idx >= static_cast<int64_t>(R) * pairs) return;
+  const int r = static_cast<int>(idx / pairs);
+  const int pp = static_cast<int>(idx % pairs);
+  const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
+  const float x0 = (k < K) ? W[static_cast<int64_t>(r) * K + k] : 0.f;
+  const float x1 = (k + 1 < K) ? W[static_cast<int64_t>(r) * K + k + 1] : 0.f;
+  const uint32_t hi = pack_bf16(x0, x1);
+  const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
+  const uint32_t lo = pack_bf16(x0 - f0, x1 - f1);
+  uint32_t* o = out + static_cast<int64_t>(r) * ld + c * 16;
+  o[q] = hi;
+  o[8 + q] = lo;
+}
+
+static void launch_split(const float* W, float* out, int R, int K, hipStream_t st) {
+  const int64_t n = static_cast<int64_t>(R) * (split_ld(K) / 2);
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, st, W, reinterpret_cast<uint32_t*>(out), R, K);
+}
+
 // Tuning override (benchmarks / tests): CMHSE_TINY_MAX_SEQS=<n> moves the tiny/tiled crossover.
 static int tiny_max_seqs() {
   static const int v = [] {
@@ -512,11 +558,11 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 using namespace cmhse;
 
-extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t H,
-                                           int32_t pool_mode) {
+extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I,
+                                           int32_t H, int32_t pool_mode) {
   (void)Tmax;
-  if (sum_T <= 0 || H <= 0 || S <= 0) return 0;
-  return gru_ws_layout(S, sum_T, H, pool_mode).total;
+  if (sum_T <= 0 || H <= 0 || S <= 0 || I <= 0) return 0;
+  return gru_ws_layout(S, sum_T, H, pool_mode, I).total;
 }
 
 extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
@@ -530,7 +576,8 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if (!w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh) return CMHSE_ERR_ARG;
   const int32_t mode_flags = pool_mode;
   const bool save = (pool_mode & CMHSE_SAVE_FOR_BACKWARD) != 0;
-  pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
+  bool bf3 = (pool_mode & CMHSE_MATH_BF16X3) != 0;
+  pool_mode &= kModeMask;
   if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX &&
       pool_mode != CMHSE_POOL_ALL)
     return CMHSE_ERR_ARG;
@@ -545,10 +592,10 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if (b->step_count_host[0] != b->S) return CMHSE_ERR_ARG;
   if (sum_T * b->H >= (int64_t(1) << 40)) return CMHSE_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
-      workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->H, mode_flags))
+      workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->I, b->H, mode_flags))
     return CMHSE_ERR_WORKSPACE;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const GruWs L = gru_ws_layout(b->S, sum_T, b->H, mode_flags);
+  const GruWs L = gru_ws_layout(b->S, sum_T, b->H, mode_flags, b->I);
   char* wsb = static_cast<char*>(workspace);
 
   float* hs = reinterpret_cast<float*>(wsb + L.hs);
@@ -576,8 +623,20 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   const size_t smem = TileSmem<kGruBM, 3 * kGruBU>::kBytes;
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
   const bool vec = (b->I % 4 == 0) && (b->H % 4 == 0);
-  const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
   const int tiny_limit = tiny_max_seqs();
+  // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
+  bf3 = bf3 && vec && (b->S > tiny_limit || pool_mode == CMHSE_POOL_ATTN);
+  p.w_ih_s = nullptr;
+  p.w_hh_s = nullptr;
+  if (bf3) {
+    float* wih_s = reinterpret_cast<float*>(wsb + L.wih_s);
+    float* whh_s = reinterpret_cast<float*>(wsb + L.whh_s);
+    launch_split(w->w_ih, wih_s, 3 * b->H, b->I, stream);
+    launch_split(w->w_hh, whh_s, 3 * b->H, b->H, stream);
+    p.w_ih_s = wih_s;
+    p.w_hh_s = whh_s;
+  }
+  const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
   static const int msub = [] { const char* e = getenv("CMHSE_GRU_MSUB"); return (e && atoi(e) == 2) ? 2 : 1; }();
   Timer* timer = static_cast<Timer*>(b->step_timer);
   if (timer) (void)hipEventRecord(timer->start, stream);
@@ -596,19 +655,23 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
       else
         hipLaunchKernelGGL(gru_step_tiny_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, p);
     } else {
-      if (msub == 2) {
+      if (bf3) {
+        // staging-bound loop: the 128-row tile halves the weight bytes per MFMA
+        const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 127) / 128);
+        hipLaunchKernelGGL((gru_step_kernel<true, 2, true>), dim3(grid), dim3(kThreads), smem, stream, p);
+      } else if (msub == 2) {
         const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 127) / 128);
         if (vec)
-          hipLaunchKernelGGL((gru_step_kernel<true, 2>), dim3(grid), dim3(kThreads), smem, stream, p);
+          hipLaunchKernelGGL((gru_step_kernel<true, 2, false>), dim3(grid), dim3(kThreads), smem, stream, p);
         else
-          hipLaunchKernelGGL((gru_step_kernel<false, 2>), dim3(grid), dim3(kThreads), smem, stream, p);
+          hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads), smem, stream, p);
       } else {
         const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 63) / 64);
         const size_t smem1 = TileSmem<64, 3 * kGruBU>::kBytes;
         if (vec)
-          hipLaunchKernelGGL((gru_step_kernel<true, 1>), dim3(grid), dim3(kThreads), smem1, stream, p);
+          hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads), smem1, stream, p);
         else
-          hipLaunchKernelGGL((gru_step_kernel<false, 1>), dim3(grid), dim3(kThreads), smem1, stream, p);
+          hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads), smem1, stream, p);
       }
     }
     off += S_t;
@@ -627,22 +690,30 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     ep.rows = sum_T;
     ep.H = b->H;
     ep.n_tiles = att_tiles;
-    const int att_bm = 64 * msub;
+    const bool att_bf3 = bf3 && sum_T > tiny_limit;
+    const int att_bm = att_bf3 ? 128 : 64 * msub;
     const int64_t m_tiles = (sum_T + att_bm - 1) / att_bm;
     if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
     const unsigned att_grid = static_cast<unsigned>(m_tiles * att_tiles);
-    if (msub == 2) {
+    ep.w_lin_s = nullptr;
+    if (att_bf3) {
+      float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
+      launch_split(w->w_lin, wlin_s, b->H, b->H, stream);
+      ep.w_lin_s = wlin_s;
+      const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
+      hipLaunchKernelGGL((attn_energy_kernel<true, 2, true>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+    } else if (msub == 2) {
       const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
       if (vec)
-        hipLaunchKernelGGL((attn_energy_kernel<true, 2>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+        hipLaunchKernelGGL((attn_energy_kernel<true, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
       else
-        hipLaunchKernelGGL((attn_energy_kernel<false, 2>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+        hipLaunchKernelGGL((attn_energy_kernel<false, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
     } else {
       const size_t att_smem = TileSmem<64, kAttBN>::kBytes;
       if (vec)
-        hipLaunchKernelGGL((attn_energy_kernel<true, 1>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+        hipLaunchKernelGGL((attn_energy_kernel<true, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
       else
-        hipLaunchKernelGGL((attn_energy_kernel<false, 1>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+        hipLaunchKernelGGL((attn_energy_kernel<false, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
     }
     AttnPoolParams pp;
     pp.hs = hs;

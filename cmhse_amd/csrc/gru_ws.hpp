@@ -6,7 +6,9 @@
 //   gates   [sumT, 4H]    r, z, n, (W_hn h + b_hn) per packed row
 //   argmax  [S, H] int32  step of the maximum (CMHSE_POOL_MAX)
 //   v       [sumT, H]     tanh(W_lin h + b_lin) (CMHSE_POOL_ATTN)
+// and, with CMHSE_MATH_BF16X3: the hi/lo pre-split copies of W_ih, W_hh (and W_lin).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -17,14 +19,21 @@ namespace cmhse {
 constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
 
 struct GruWs {
-  size_t hs, e_part, gates, argmax, v, total;
+  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, total;
 };
+
+constexpr int32_t kModeMask = ~(CMHSE_SAVE_FOR_BACKWARD | CMHSE_MATH_BF16X3);
+
+// row length (in float units) of a bf16x3 pre-split weight row: K rounded up to whole 16-k chunks
+__host__ __device__ static inline int64_t split_ld(int K) { return (static_cast<int64_t>(K) + 15) / 16 * 16; }
 
 static inline size_t ws_align(size_t v) { return (v + 255) / 256 * 256; }
 
-static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t mode_flags) {
+static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t mode_flags,
+                                  int32_t I = 0) {
   const bool save = (mode_flags & CMHSE_SAVE_FOR_BACKWARD) != 0;
-  const int mode = mode_flags & ~CMHSE_SAVE_FOR_BACKWARD;
+  const bool bf3 = (mode_flags & CMHSE_MATH_BF16X3) != 0;
+  const int mode = mode_flags & kModeMask;
   GruWs L;
   size_t off = 0;
   L.hs = off;
@@ -38,6 +47,12 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   if (save && mode == CMHSE_POOL_MAX) off += ws_align(static_cast<size_t>(S) * H * sizeof(int32_t));
   L.v = off;
   if (save && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(sum_T) * H * sizeof(float));
+  L.wih_s = off;
+  if (bf3) off += ws_align(static_cast<size_t>(3) * H * split_ld(I) * sizeof(float));
+  L.whh_s = off;
+  if (bf3) off += ws_align(static_cast<size_t>(3) * H * split_ld(H) * sizeof(float));
+  L.wlin_s = off;
+  if (bf3 && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(H) * split_ld(H) * sizeof(float));
   L.total = off;
   return L;
 }

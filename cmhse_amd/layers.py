@@ -28,6 +28,7 @@ class SeqInput(object):
 
   def __init__(self, kind, lens, pool, tokens=None, counts=None):
     self.kind, self.lens, self.pool, self.tokens, self.counts = kind, lens, pool, tokens, counts
+    self.need_grad = False
 
 
 class _PackedGRUPoolFn(torch.autograd.Function):
@@ -76,7 +77,7 @@ class _PackedGRUPoolFn(torch.autograd.Function):
       h0 = hidden.detach().float().contiguous()
       keep.append(h0)
       h0_ptrs = ops.padded_row_ptrs(h0)
-    need_grad = any(ctx.needs_input_grad)   # (grad mode itself is off inside Function.forward)
+    need_grad = spec.need_grad   # decided by the caller: grad mode is off inside Function.forward
     out, fctx = ops.gru_pool_fwd(weights, pool, spec.lens, I, H, device, x_ptrs=x_ptrs,
                                  tok_ptrs=tok_ptrs, emb_table=emb, h0_ptrs=h0_ptrs,
                                  save_for_backward=need_grad,
@@ -150,6 +151,10 @@ class _GRUPoolBase(nn.Module):
 
   def _run(self, spec, x, hidden, table):
     w_lin, b_lin, w_att = self._extra_weights()
+    spec.need_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad
+        for t in (x, hidden, table, self.rnn.weight_ih_l0, self.rnn.weight_hh_l0,
+                  self.rnn.bias_ih_l0, self.rnn.bias_hh_l0, w_lin, b_lin, w_att))
     return _PackedGRUPoolFn.apply(spec, x, hidden, table, self.rnn.weight_ih_l0,
                                   self.rnn.weight_hh_l0, self.rnn.bias_ih_l0,
                                   self.rnn.bias_hh_l0, w_lin, b_lin, w_att)

@@ -21,9 +21,8 @@ class _ContrastiveFn(torch.autograd.Function):
   """Forward = cmhse_contrastive_fwd (keeps the score matrix), backward = cmhse_contrastive_bwd."""
 
   @staticmethod
-  def forward(ctx, im, s, margin, max_violation, norm):
+  def forward(ctx, im, s, margin, max_violation, norm, need):
     imd, sd = im.detach(), s.detach()
-    need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
     if not need:
       return ops.contrastive_fwd(imd, sd, margin, max_violation, norm)
     loss, scores = ops.contrastive_fwd(imd, sd, margin, max_violation, norm, want_scores=True)
@@ -36,7 +35,7 @@ class _ContrastiveFn(torch.autograd.Function):
     im, s, scores = ctx.saved_tensors
     margin, max_violation, norm = ctx.cfg
     d_im, d_s = ops.contrastive_bwd(im, s, scores, margin, max_violation, norm, grad)
-    return d_im, d_s, None, None, None
+    return d_im, d_s, None, None, None, None
 
 
 class _L2NormFn(torch.autograd.Function):
@@ -73,7 +72,8 @@ class ContrastiveLoss(nn.Module):
     self.max_violation = max_violation
 
   def forward(self, im, s):
-    return _ContrastiveFn.apply(im, s, self.margin, self.max_violation, self.norm)
+    need = torch.is_grad_enabled() and (im.requires_grad or s.requires_grad)
+    return _ContrastiveFn.apply(im, s, self.margin, self.max_violation, self.norm, need)
 
 
 class _GroupWiseFn(torch.autograd.Function):

@@ -5,12 +5,13 @@ fallback — tensors must live on the MI355X.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
+from ._lib import (MATH_BF16X3, POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
                    SAVE_FOR_BACKWARD)
 
 
@@ -29,6 +30,21 @@ def _f32c(t, name):
   if t.dtype != torch.float32:
     t = t.float()
   return t.contiguous()
+
+
+_MATH_MODE = [os.environ.get('CMHSE_MATH', 'fp32')]
+
+
+def math_mode():
+  """'fp32' (exact, default) or 'bf16x3' (3-term bf16 split on the matrix pipe for the large
+  inference GEMMs; ~1e-6 on the embeddings).  Set with set_math_mode() or CMHSE_MATH."""
+  return _MATH_MODE[0]
+
+
+def set_math_mode(mode):
+  if mode not in ('fp32', 'bf16x3'):
+    raise ValueError("math mode must be 'fp32' or 'bf16x3'")
+  _MATH_MODE[0] = mode
 
 
 class SeqSchedule(object):
@@ -138,7 +154,9 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     n_out = sched.sum_T if pool_mode == POOL_ALL else S
     out = torch.empty(n_out, H, dtype=torch.float32, device=device)
   mode_flags = pool_mode | (SAVE_FOR_BACKWARD if save_for_backward else 0)
-  ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, H, mode_flags)
+  if math_mode() == 'bf16x3' and not save_for_backward:
+    mode_flags |= MATH_BF16X3
+  ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, I, H, mode_flags)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
 
   w = _lib.GruWeights()

@@ -46,7 +46,12 @@ enum {
                           out[out_row[s] + t, :] = h_{s,t} */
   /* OR-ed into pool_mode for training: the forward also keeps gate activations (and the arg-max
    * step / tanh(lin(h))) in its workspace, which cmhse_gru_pool_bwd consumes. */
-  CMHSE_SAVE_FOR_BACKWARD = 0x100
+  CMHSE_SAVE_FOR_BACKWARD = 0x100,
+  /* OR-ed into pool_mode: run the large GEMMs of the call on the bf16 matrix pipe with a 3-term
+   * hi/lo split (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate): ~2^-17 relative error per
+   * product, ~1e-6 on the embeddings (parity bar 1e-4), ~5x the matrix rate of exact fp32.
+   * Default (flag clear) is exact fp32. */
+  CMHSE_MATH_BF16X3 = 0x200
 };
 
 /* Weights of one encoder layer, laid out exactly as the reference's state-dict tensors
@@ -97,7 +102,7 @@ typedef struct cmhse_seq_batch {
 /* Bytes of workspace cmhse_gru_pool_fwd needs for this batch: the time-major packed hidden states
  * hs[sumT, H] (kept for the attention pooling and for a later backward pass) plus the attention
  * energy partials. */
-size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t H,
+size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I, int32_t H,
                                 int32_t pool_mode);
 
 /* Replaces the body of layers.{Seq2Seq,Attention,Maxout}.forward (layers.py:47-66, 93-119,

@@ -598,3 +598,42 @@ def test_checkpoint_round_trip_in_reference_format(dev, tmp_path):
   r2 = encode_data(opt, model2, synthetic.ListLoader(batches), logging=lambda *a: None)
   np.testing.assert_array_equal(r1[0], r2[0])
   np.testing.assert_allclose(r2[0], g['enc.vid_embs'], atol=EMB_TOL, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------
+# bf16x3 math mode (CMHSE_MATH_BF16X3): fp32-grade split products on the bf16 matrix pipe
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('pool', ['attention', 'maxout', 'seq2seq'])
+@pytest.mark.parametrize('S,T,I,H', [(2300, 5, 36, 72), (2200, 3, 500, 128)])
+def test_bf16x3_mode_vs_oracle(dev, oracle, pool, S, T, I, H):
+  """Same parity bar (1e-4) as the exact path; also reports how close the split really is."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(S + I)
+  cls = {'attention': 'Attention', 'maxout': 'Maxout', 'seq2seq': 'Seq2Seq'}[pool]
+  torch.manual_seed(3)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy() for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[0] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  want = oracle.pooled_gru_forward(pool, x, lens, sd, h0, np.float64)
+  xt, ht = torch.from_numpy(x).to(dev), torch.from_numpy(h0).to(dev)
+  try:
+    ops.set_math_mode('bf16x3')
+    with torch.no_grad():
+      y3 = layer(xt, torch.from_numpy(lens), ht).cpu().numpy()
+  finally:
+    ops.set_math_mode('fp32')
+  with torch.no_grad():
+    y = layer(xt, torch.from_numpy(lens), ht).cpu().numpy()
+  err3, err = np.abs(y3 - want).max(), np.abs(y - want).max()
+  assert err <= EMB_TOL and err3 <= EMB_TOL, (err, err3)
+  assert err3 <= 2e-5, 'bf16x3 should be ~1e-6, got %g' % err3
+  assert not np.array_equal(y3, y), 'bf16x3 mode did not engage'

@@ -24,8 +24,9 @@ def test_library_exports_every_declared_symbol():
   assert lib.cmhse_version().decode().endswith('gfx950')
   assert lib.cmhse_strerror(-2).decode().startswith('workspace')
   # size queries are pure host functions
-  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 32, 0) >= 10 * 32 * 4
-  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 32, 1) > lib.cmhse_gru_pool_workspace(4, 3, 10, 32, 0)
+  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 24, 32, 0) >= 10 * 32 * 4
+  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 24, 32, 1) > lib.cmhse_gru_pool_workspace(4, 3, 10, 24, 32, 0)
+  assert lib.cmhse_gru_pool_workspace(4, 3, 10, 24, 32, 0x200) > lib.cmhse_gru_pool_workspace(4, 3, 10, 24, 32, 0)
   assert lib.cmhse_sim_rank_workspace(100) >= 100 * 12
   assert lib.cmhse_contrastive_workspace(10) >= 400
 
