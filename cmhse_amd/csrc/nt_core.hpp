@@ -159,6 +159,7 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   // MFMAs of one 8-k block for k sub-steps j in [J0, J1)
   auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB], auto j0c, auto j1c) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
 #pragma unroll
@@ -175,6 +176,7 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I3 = std::integral_constant<int, 3>;

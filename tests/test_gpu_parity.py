@@ -637,3 +637,39 @@ def test_bf16x3_mode_vs_oracle(dev, oracle, pool, S, T, I, H):
   assert err <= EMB_TOL and err3 <= EMB_TOL, (err, err3)
   assert err3 <= 2e-5, 'bf16x3 should be ~1e-6, got %g' % err3
   assert not np.array_equal(y3, y), 'bf16x3 mode did not engage'
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE full sizes (H = 1024, C3D 500-d / words 300-d, T <= 80): size-independent properties
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('pool', ['attention', 'maxout'])
+def test_full_size_encoder_properties(dev, oracle, pool):
+  """S = 3000 ragged sequences at embed 1024, img_dim 500, T <= 80 (both step kernels in play):
+  (1) a 12-sequence sample equals the fp64 oracle within 1e-4 after L2 normalisation;
+  (2) the embedding of a sequence does not depend on the batch it is in or on its position:
+      permuting the batch permutes the outputs bit for bit;
+  (3) the same 12 sequences encoded alone (tiny kernel only) agree with their in-batch values."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(17)
+  S, T, I, H = 3000, 80, 500, 1024
+  cls = {'attention': 'Attention', 'maxout': 'Maxout'}[pool]
+  torch.manual_seed(8)
+  layer = getattr(layers, cls)(I, H)
+  sd = {'rnn.' + k: v.detach().numpy() for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = np.where(rng.uniform(size=S) < 0.5, T, rng.randint(1, T, size=S))
+  x = torch.randn(S, T, I, generator=torch.Generator().manual_seed(3))
+  x = x * (torch.arange(T)[None, :] < torch.from_numpy(lens)[:, None])[:, :, None]
+  xd = x.to(dev)
+  with torch.no_grad():
+    y = layer(xd, torch.from_numpy(lens))
+    perm = torch.from_numpy(rng.permutation(S))
+    yp = layer(xd[perm.to(dev)], torch.from_numpy(lens)[perm])
+    assert torch.equal(yp, y[perm.to(dev)])
+    sample = np.sort(rng.choice(S, 12, replace=False))
+    ys = layer(xd[torch.from_numpy(sample).to(dev)], torch.from_numpy(lens[sample]))
+  yn = ops.l2norm_rows(y).cpu().numpy()
+  want = oracle.pooled_gru_forward(pool, x[sample].numpy(), lens[sample], sd, None, np.float64)
+  want = want / np.linalg.norm(want, axis=1, keepdims=True)
+  np.testing.assert_allclose(yn[sample], want, atol=EMB_TOL, rtol=0)
+  np.testing.assert_allclose(ops.l2norm_rows(ys).cpu().numpy(), yn[sample], atol=2e-6, rtol=0)
