@@ -38,21 +38,39 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __rest
     if (c0 + i < C && r0 + tx < R) out[static_cast<int64_t>(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
-// Column sums over the packed rows: out[c] = sum_p w[p] * in[p][c] (w == NULL -> 1).
-// 64 columns per workgroup (one per lane), the 4 waves split the rows, fixed-order LDS combine.
-__global__ __launch_bounds__(kThreads) void colsum_kernel(const float* __restrict__ in,
-                                                          const float* __restrict__ w,
-                                                          float* __restrict__ out, int64_t rows,
-                                                          int cols, int64_t ld) {
+// Column sums over the packed rows: out[c] = sum_p w[p] * in[p][c] (w == NULL -> 1), two stages,
+// both in a fixed order (bitwise reproducible): stage 1 sums kColsumRows-row slabs (64 columns per
+// workgroup, one per lane, the 4 waves interleave the slab's rows), stage 2 adds the slabs.
+constexpr int kColsumRows = 512;
+
+__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* __restrict__ in,
+                                                                  const float* __restrict__ w,
+                                                                  float* __restrict__ part,
+                                                                  int64_t rows, int cols,
+                                                                  int64_t ld) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * kColsumRows;
+  const int64_t r1 = (r0 + kColsumRows < rows) ? r0 + kColsumRows : rows;
   float s = 0.f;
   if (c < cols)
-    for (int64_t p = wave; p < rows; p += 4) s += (w ? w[p] : 1.0f) * in[p * ld + c];
-  __shared__ float part[4][64];
-  part[wave][lane] = s;
+    for (int64_t p = r0 + wave; p < r1; p += 4) s += (w ? w[p] : 1.0f) * in[p * ld + c];
+  __shared__ float red[4][64];
+  red[wave][lane] = s;
   __syncthreads();
-  if (wave == 0 && c < cols) out[c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (wave == 0 && c < cols)
+    part[static_cast<int64_t>(blockIdx.y) * cols + c] =
+        red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ __launch_bounds__(kThreads) void colsum_final_kernel(const float* __restrict__ part,
+                                                                float* __restrict__ out,
+                                                                int slabs, int cols) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < slabs; ++i) s += part[static_cast<int64_t>(i) * cols + c];
+  out[c] = s;
 }
 
 // Per packed row p = (t, s): addresses of x_{t,s} and of h_{t-1,s} (a zero row when there is none).
@@ -599,10 +617,13 @@ static void launch_transpose(const float* in, float* out, int R, int C, hipStrea
                      in, out, R, C);
 }
 
-static void launch_colsum(const float* in, const float* w, float* out, int64_t rows, int cols,
-                          int64_t ld, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(kThreads), 0, st, in, w, out,
-                     rows, cols, ld);
+static void launch_colsum(const float* in, const float* w, float* out, float* scratch,
+                          int64_t rows, int cols, int64_t ld, hipStream_t st) {
+  const int slabs = static_cast<int>((rows + kColsumRows - 1) / kColsumRows);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, slabs), dim3(kThreads), 0, st,
+                     in, w, scratch, rows, cols, ld);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads),
+                     0, st, scratch, out, slabs, cols);
 }
 
 static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
@@ -635,7 +656,8 @@ static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t l
 }
 
 struct BwdWs {
-  size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, p_t, zero_row, total;
+  size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, p_t, zero_row,
+      colsum, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -655,6 +677,7 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.hpaddr = take(static_cast<size_t>(sum_T) * 8);
   L.p_t = take(static_cast<size_t>(sum_T) * 4);
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
+  L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
   L.total = off;
   return L;
 }
@@ -710,6 +733,7 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   uint64_t* hpaddr = reinterpret_cast<uint64_t*>(ws + L.hpaddr);
   int32_t* p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
   float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
+  float* cs_scratch = reinterpret_cast<float*>(ws + L.colsum);
   const bool vec = (I % 4 == 0) && (H % 4 == 0);
 
   (void)hipMemsetAsync(zero_row, 0, static_cast<size_t>(H > I ? H : I) * 4, st);
@@ -728,8 +752,8 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(S), dim3(kThreads), 0, st, ap);
     hipLaunchKernelGGL(attn_du_kernel, dim3(static_cast<unsigned>(sum_T)), dim3(kThreads), 0, st,
                        de, v, w->w_att, du, sum_T, H);
-    launch_colsum(v, de, g->dw_att, sum_T, H, H, st);      // d att_w = sum_p de_p v_p
-    launch_colsum(du, nullptr, g->db_lin, sum_T, H, H, st);
+    launch_colsum(v, de, g->dw_att, cs_scratch, sum_T, H, H, st);      // d att_w = sum_p de_p v_p
+    launch_colsum(du, nullptr, g->db_lin, cs_scratch, sum_T, H, H, st);
     // d W_lin[n][k] = sum_p du[p][n] hs[p][k]
     launch_tn(du, H, hs, H, nullptr, g->dw_lin, H, H, H, sum_T, nullptr, vec, st);
     // dpool += du . W_lin  (NT on W_lin^T)
@@ -780,8 +804,8 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
                      0, st, rp);
   launch_tn(dgx, 3 * H, nullptr, 0, xaddr, g->dw_ih, I, 3 * H, I, sum_T, nullptr, vec, st);
   launch_tn(dgh, 3 * H, nullptr, 0, hpaddr, g->dw_hh, H, 3 * H, H, sum_T, nullptr, vec, st);
-  launch_colsum(dgx, nullptr, g->db_ih, sum_T, 3 * H, 3 * H, st);
-  launch_colsum(dgh, nullptr, g->db_hh, sum_T, 3 * H, 3 * H, st);
+  launch_colsum(dgx, nullptr, g->db_ih, cs_scratch, sum_T, 3 * H, 3 * H, st);
+  launch_colsum(dgh, nullptr, g->db_hh, cs_scratch, sum_T, 3 * H, 3 * H, st);
 
   // ---- 4. d(input): dx_p = dgx_p . W_ih, scattered to the caller's rows / the embedding table ----
   if (dx_rows || d_emb_table) {

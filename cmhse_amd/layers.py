@@ -24,10 +24,15 @@ class SeqInput(object):
     kind 'rows'    x is [R,I] level-1 embeddings, sequence s = `counts[s]` consecutive rows
                    (VSE.structure_emb, model.py:238-255);
     kind 'repeat'  x is [S,I]; sequence s is x[s] repeated lens[s] times (the decoders' input,
-                   VSE.reconstruct_emb, model.py:257-270) — never materialised."""
+                   VSE.reconstruct_emb, model.py:257-270) — never materialised;
+    kind 'multi'   several padded feature tensors (`tensors`, not differentiated) or several token
+                   tensors (`tokens` is a list) packed into ONE launch sequence: clips + whole
+                   videos share clip_enc, sentences + paragraphs share txt_enc (model.py:319-320),
+                   so one pass over max(T) steps serves both instead of two passes."""
 
-  def __init__(self, kind, lens, pool, tokens=None, counts=None):
+  def __init__(self, kind, lens, pool, tokens=None, counts=None, tensors=None):
     self.kind, self.lens, self.pool, self.tokens, self.counts = kind, lens, pool, tokens, counts
+    self.tensors = tensors
     self.need_grad = False
 
 
@@ -43,17 +48,31 @@ class _PackedGRUPoolFn(torch.autograd.Function):
       weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
     H = w_hh.shape[1]
     keep, x_ptrs, tok_ptrs, emb = [], None, None, None
-    if spec.kind == 'tokens':
-      tok = spec.tokens
-      ops._require_cuda(tok, 'tokens')
-      tok = tok.detach().contiguous()
-      if tok.dtype != torch.int64:
-        tok = tok.long()
+    if spec.kind == 'tokens' or (spec.kind == 'multi' and spec.tokens is not None):
+      toks = spec.tokens if spec.kind == 'multi' else [spec.tokens]
+      ptr_list = []
+      for tok in toks:
+        ops._require_cuda(tok, 'tokens')
+        tok = tok.detach().contiguous()
+        if tok.dtype != torch.int64:
+          tok = tok.long()
+        keep.append(tok)
+        ptr_list.append(ops.padded_row_ptrs(tok))
       emb = table.detach().float().contiguous()
       I = emb.shape[1]
-      tok_ptrs = ops.padded_row_ptrs(tok)
-      device = tok.device
-      keep += [tok, emb]
+      tok_ptrs = np.concatenate(ptr_list)
+      device = keep[0].device
+      keep.append(emb)
+    elif spec.kind == 'multi':
+      ptr_list = []
+      for t in spec.tensors:
+        ops._require_cuda(t, 'x')
+        tc = t.detach().float().contiguous()
+        keep.append(tc)
+        ptr_list.append(ops.padded_row_ptrs(tc))
+      I = keep[0].shape[2]
+      x_ptrs = np.concatenate(ptr_list)
+      device = keep[0].device
     else:
       ops._require_cuda(x, 'x')
       xc = x.detach().float().contiguous()
@@ -98,13 +117,13 @@ class _PackedGRUPoolFn(torch.autograd.Function):
     device = fctx['device']
     dx = dtable = None
     dx_ptrs = None
-    if spec.kind != 'tokens' and need[1]:
+    if spec.kind not in ('tokens', 'multi') and need[1]:
       dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=device)
       if spec.kind in ('padded', 'repeat'):
         dx_ptrs = ops.padded_row_ptrs(dx)      # 'repeat': the kernel accumulates over the steps
       else:
         dx_ptrs = np.uint64(dx.data_ptr()) + ctx.row_starts * np.uint64(ctx.x_shape[1] * 4)
-    if spec.kind == 'tokens' and need[3]:
+    if ctx.table_shape is not None and need[3]:
       dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=device)
     grads, dh0 = ops.gru_pool_bwd(fctx, grad_out, dx_ptrs=dx_ptrs, d_emb_table=dtable,
                                   want_dh0=ctx.has_hidden and need[2])
@@ -175,6 +194,19 @@ class _GRUPoolBase(nn.Module):
     if self.POOL == ops.POOL_ATTN:
       weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
     return weights
+
+  def forward_multi(self, tensors, lens_list):
+    """Several padded feature batches [S_i, T_i, I] through this encoder in one packed pass;
+    returns the [sum S_i, H] outputs in order (differentiable wrt the weights)."""
+    lens = np.concatenate([_lens_numpy(l) for l in lens_list])
+    return self._run(SeqInput('multi', lens, self.POOL, tensors=list(tensors)), None, None, None)
+
+  def forward_tokens_multi(self, token_tensors, lens_list, table):
+    """Several token batches through this encoder in one packed pass (differentiable wrt the
+    weights and the embedding table)."""
+    lens = np.concatenate([_lens_numpy(l) for l in lens_list])
+    return self._run(SeqInput('multi', lens, self.POOL, tokens=list(token_tensors)), None, None,
+                     table)
 
   def forward_ptrs(self, lens, in_dim, device, x_ptrs=None, tok_ptrs=None, table=None,
                    h0_ptrs=None, out=None):

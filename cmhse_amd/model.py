@@ -221,15 +221,22 @@ class VSE(object):
                    *args):
     """Forward half of train_emb (model.py:319-344): embeddings and the 4-7 contrastive losses,
     logged exactly like the reference.  Returns the total loss tensor."""
+    # model.py:319-320 run clip_enc on the clips and again on the whole-video streams (same for
+    # txt_enc on sentences / paragraphs).  The sequences are independent, so both batches go
+    # through each encoder in ONE packed pass: max(T) steps instead of T_clip + T_video.
     clips = clips.cuda(non_blocking=True)
-    if self.lowest_reconstruct_loss:
-      clip_emb, cap_emb, word = self.forward_emb(clips, captions, lengths_clip, lengths_cap,
-                                                 return_word=True)
-    else:
-      clip_emb, cap_emb = self.forward_emb(clips, captions, lengths_clip, lengths_cap)
-      word = None
-    vid_context, para_context = self.forward_emb(videos, paragraphs, lengths_video,
-                                                 lengths_paragraph)
+    videos = videos.cuda(non_blocking=True)
+    captions = captions.cuda(non_blocking=True)
+    paragraphs = paragraphs.cuda(non_blocking=True)
+    n_clip, n_cap = clips.shape[0], captions.shape[0]
+    vis = self.clip_enc.rnn.forward_multi([clips, videos], [lengths_clip, lengths_video])
+    clip_emb, vid_context = vis[:n_clip], vis[n_clip:]
+    txt = self.txt_enc.rnn.forward_tokens_multi([captions, paragraphs],
+                                                [lengths_cap, lengths_paragraph],
+                                                self.txt_enc.embed.weight)
+    cap_emb, para_context = txt[:n_cap], txt[n_cap:]
+    word = (ops.gather_rows(self.txt_enc.embed.weight.detach(), captions)
+            if self.lowest_reconstruct_loss else None)
     vid_emb, para_emb = self.structure_emb(clip_emb, cap_emb, num_clips, num_caps, vid_context,
                                            para_context)
     if self.reconstruct_loss:

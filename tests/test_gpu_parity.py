@@ -673,3 +673,36 @@ def test_full_size_encoder_properties(dev, oracle, pool):
   want = want / np.linalg.norm(want, axis=1, keepdims=True)
   np.testing.assert_allclose(yn[sample], want, atol=EMB_TOL, rtol=0)
   np.testing.assert_allclose(ops.l2norm_rows(ys).cpu().numpy(), yn[sample], atol=2e-6, rtol=0)
+
+
+def test_sharded_validation_on_device_world1(dev):
+  """parallel_eval.validate_sharded through RCCL (backend 'nccl') with a 1-rank group: the real
+  device code path (encode shard, all-gather, stripe ranking, merge) equals encode_data + i2t/t2i."""
+  import os
+  import socket
+  import torch.distributed as dist
+  from cmhse_amd import parallel_eval, synthetic
+  from cmhse_amd.evaluation import encode_data, i2t, t2i
+  g = load_golden('model_maxout.npz')
+  opt, model = golden_model('maxout', g)
+  spec = synthetic.ragged_spec(19, seed=6)
+  batches = synthetic.make_batches(spec, 5, opt.img_dim, opt.vocab_size, seed=2)
+  res = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  rep_i, top1_i, ranks_i = i2t(res[0], res[1])
+  rep_t, top1_t, ranks_t = t2i(res[0], res[1])
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+  try:
+    out = parallel_eval.validate_sharded(opt, model, batches, device=dev, dim=opt.embed_size)
+  finally:
+    dist.destroy_process_group()
+  assert out[0] == rep_i and out[1] == rep_t
+  np.testing.assert_array_equal(out[2], ranks_i)
+  np.testing.assert_array_equal(out[3], ranks_t)
+  np.testing.assert_array_equal(out[4], top1_i)
+  np.testing.assert_array_equal(out[5], top1_t)
