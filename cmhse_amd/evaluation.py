@@ -14,6 +14,7 @@ MI355X-first differences in HOW (not WHAT) things are computed:
 """
 from __future__ import annotations
 
+import os
 import time
 from collections import OrderedDict
 
@@ -86,6 +87,17 @@ def _to_dev(t, device):
   return t if t.is_cuda else t.to(device, non_blocking=True)
 
 
+TWO_STREAMS = [os.environ.get('CMHSE_TWO_STREAMS', '0') == '1']
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+  key = (device.type, device.index)
+  if key not in _SIDE_STREAMS:
+    _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+  return _SIDE_STREAMS[key]
+
+
 def encode_group(model, group, contextual_model=True, device=None):
   """Encode a list of loader batches (12-tuples) as ONE super-batch.  Returns a dict of device
   tensors: the six un-normalised embedding matrices plus their L2-normalised versions, rows in
@@ -118,18 +130,6 @@ def encode_group(model, group, contextual_model=True, device=None):
   img_dim = clips_l[0].shape[2]
   table = model.txt_enc.embed.weight.detach()
 
-  # level 1, visual: clips of all batches, then whole-video streams of all batches (same weights)
-  ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
-  lens = np.concatenate(len_clip + len_vid)
-  vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs)
-  clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
-  # level 1, text: sentences, then paragraphs
-  ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
-  lens = np.concatenate(len_cap + len_par)
-  txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
-  cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
-
-  # level 2: each video's clips are consecutive rows of clip_emb -> addressed in place
   def level2(enc, rows, counts, ctx_rows, Hin):
     counts = np.asarray(counts, dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
@@ -137,11 +137,48 @@ def encode_group(model, group, contextual_model=True, device=None):
     h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
     return enc.rnn.forward_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
 
-  vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v)
-  para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)
   n = ops.l2norm_rows
-  return dict(vid_emb=n(vid_emb), para_emb=n(para_emb), clip_emb=n(clip_emb), cap_emb=n(cap_emb),
-              vid_ctx=n(vid_ctx), para_ctx=n(para_ctx), n_vid=n_vid,
+
+  def visual_tower():
+    # level 1: clips of all batches, then whole-video streams of all batches (same weights)
+    ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
+    lens = np.concatenate(len_clip + len_vid)
+    vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs)
+    clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
+    # level 2: each video's clips are consecutive rows of clip_emb -> addressed in place
+    vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v)
+    return n(vid_emb), n(clip_emb), n(vid_ctx)
+
+  def text_tower():
+    # level 1: sentences, then paragraphs (embedding lookup fused into the operand load)
+    ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
+    lens = np.concatenate(len_cap + len_par)
+    txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
+    cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
+    para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)
+    return n(para_emb), n(cap_emb), n(para_ctx)
+
+  if TWO_STREAMS[0]:
+    # The two towers are independent until the loss.  On two HIP streams the dispatcher can fill
+    # the partial last round of one tower's step grid, and the CUs idle during the other's short
+    # ragged-tail launches, with the other tower's workgroups.
+    main = torch.cuda.current_stream(device)
+    s_vis, s_txt = _side_streams(device)
+    s_vis.wait_stream(main)
+    s_txt.wait_stream(main)
+    with torch.cuda.stream(s_txt):
+      out_txt = text_tower()
+    with torch.cuda.stream(s_vis):
+      out_vis = visual_tower()
+    main.wait_stream(s_vis)
+    main.wait_stream(s_txt)
+    for t in out_vis + out_txt:
+      t.record_stream(main)      # allocated on a side stream, consumed on the caller's stream
+  else:
+    out_vis = visual_tower()
+    out_txt = text_tower()
+  return dict(vid_emb=out_vis[0], para_emb=out_txt[0], clip_emb=out_vis[1], cap_emb=out_txt[1],
+              vid_ctx=out_vis[2], para_ctx=out_txt[2], n_vid=n_vid,
               batch_sizes=[len(b[8]) for b in group])
 
 

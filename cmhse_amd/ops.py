@@ -19,6 +19,16 @@ def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def upload(arr, device):
+  """Small host array -> device without blocking the host: pinned staging + async copy (a pageable
+  copy would make the host wait for everything already queued on the stream).  The pinned block
+  is recycled by torch only after the copy has completed."""
+  t = torch.from_numpy(arr)
+  if torch.device(device).type != 'cuda':
+    return t.to(device)
+  return t.pin_memory().to(device, non_blocking=True)
+
+
 def _require_cuda(t, name):
   if not isinstance(t, torch.Tensor) or not t.is_cuda:
     raise RuntimeError('cmhse_amd: `%s` must be a tensor on the GPU (no CPU fallback; the HIP '
@@ -95,7 +105,7 @@ class SeqSchedule(object):
     else:
       v32[S:2 * S] = order
     v32[2 * S:] = step_off
-    self.meta = torch.from_numpy(buf).to(device)
+    self.meta = upload(buf, device)
     base = self.meta.data_ptr()
     self.p_rows = base
     self.p_h0 = base + S * 8 if h0_ptrs is not None else None
@@ -298,7 +308,7 @@ def contrastive_blocks_fwd(im, s, block_sizes, margin, max_violation, norm):
   nb, max_n = len(sizes), int(sizes.max())
   off = np.zeros(nb + 1, dtype=np.int32)
   np.cumsum(sizes, out=off[1:])
-  off_d = torch.from_numpy(off).to(im.device)
+  off_d = upload(off, im.device)
   losses = torch.empty(nb, dtype=torch.float32, device=im.device)
   ws_bytes = lib.cmhse_contrastive_blocks_workspace(nb, max_n)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
@@ -332,8 +342,8 @@ def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
     setattr(g, 'd' + k, t.data_ptr())
   dx_dev = None
   if dx_ptrs is not None:
-    dx_dev = torch.from_numpy(np.asarray(dx_ptrs, dtype=np.uint64)[sched.order].view(np.int64)
-                              .copy()).to(device)
+    dx_dev = upload(np.asarray(dx_ptrs, dtype=np.uint64)[sched.order].view(np.int64).copy(),
+                    device)
   dh0 = torch.empty(S, H, dtype=torch.float32, device=device) if want_dh0 else None
   ws_bytes = lib.cmhse_gru_pool_bwd_workspace(S, sched.Tmax, sched.sum_T, I, H, pool_mode)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -386,7 +396,7 @@ def euclid_fwd(a, b=None, b_rows=None, norm=True):
   scratch = torch.empty(rows, dtype=torch.float32, device=a.device)
   bd = None
   if b_rows is not None:
-    bd = torch.from_numpy(np.asarray(b_rows, dtype=np.uint64).view(np.int64).copy()).to(a.device)
+    bd = upload(np.asarray(b_rows, dtype=np.uint64).view(np.int64).copy(), a.device)
   else:
     b = _f32c(b, 'b')
   rc = lib.cmhse_euclid_fwd(a.data_ptr(), b.data_ptr() if b is not None else None,
@@ -421,7 +431,7 @@ def groupwise_fwd(im, s, num_clips, num_caps, margin, max_violation, norm):
   off = np.zeros(2 * (B + 1), dtype=np.int32)
   np.cumsum(np.asarray(num_clips), out=off[1:B + 1])
   np.cumsum(np.asarray(num_caps), out=off[B + 2:])
-  off_d = torch.from_numpy(off).to(im.device)
+  off_d = upload(off, im.device)
   loss = torch.empty((), dtype=torch.float32, device=im.device)
   reduced = torch.empty(B, B, dtype=torch.float32, device=im.device)
   arg = torch.empty(B, B, dtype=torch.int32, device=im.device)
