@@ -38,6 +38,32 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __rest
     if (c0 + i < C && r0 + tx < R) out[static_cast<int64_t>(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
+// Gather + transpose: out[c][p] = row(p)[c] for p < R (rows through `addr` when given, else
+// in + p*ld), c < C; out rows have ldo floats and are zero-filled for R <= p < ldo.  Turns the
+// "sum over packed rows" weight-gradient products into K-contiguous NT GEMMs (nt_core.hpp).
+__global__ __launch_bounds__(kThreads) void gather_transpose_kernel(const float* __restrict__ in,
+                                                                    int64_t ld,
+                                                                    const uint64_t* __restrict__ addr,
+                                                                    float* __restrict__ out,
+                                                                    int64_t R, int C, int64_t ldo) {
+  __shared__ float tile[32][33];
+  const int64_t p0 = static_cast<int64_t>(blockIdx.x) * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int64_t p = p0 + i;
+    float v = 0.f;
+    if (p < R && c0 + tx < C) {
+      const float* row = addr ? reinterpret_cast<const float*>(addr[p]) : in + p * ld;
+      v = row[c0 + tx];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && p0 + tx < ldo) out[static_cast<int64_t>(c0 + i) * ldo + p0 + tx] = tile[tx][i];
+}
+
 // Column sums over the packed rows: out[c] = sum_p w[p] * in[p][c] (w == NULL -> 1), two stages,
 // both in a fixed order (bitwise reproducible): stage 1 sums kColsumRows-row slabs (64 columns per
 // workgroup, one per lane, the 4 waves interleave the slab's rows), stage 2 adds the slabs.
@@ -626,6 +652,12 @@ static void launch_colsum(const float* in, const float* w, float* out, float* sc
                      0, st, scratch, out, slabs, cols);
 }
 
+static void launch_gather_t(const float* in, int64_t ld, const uint64_t* addr, float* out, int64_t R,
+                            int C, int64_t ldo, hipStream_t st) {
+  hipLaunchKernelGGL(gather_transpose_kernel, dim3(static_cast<unsigned>((ldo + 31) / 32), (C + 31) / 32),
+                     dim3(kThreads), 0, st, in, ld, addr, out, R, C, ldo);
+}
+
 static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
                       const uint64_t* b_addr, float* c, int64_t ldc, int M, int N, int64_t K,
                       const float* scale, bool vec, hipStream_t st) {
@@ -657,7 +689,7 @@ static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t l
 
 struct BwdWs {
   size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, p_t, zero_row,
-      colsum, total;
+      colsum, t_a, t_b, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -678,6 +710,9 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.p_t = take(static_cast<size_t>(sum_T) * 4);
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
+  const size_t kp = static_cast<size_t>((sum_T + 3) / 4 * 4);
+  L.t_a = take(static_cast<size_t>(3) * H * kp * 4);
+  L.t_b = take(static_cast<size_t>(H > I ? H : I) * kp * 4);
   L.total = off;
   return L;
 }
@@ -734,6 +769,9 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   int32_t* p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
   float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
   float* cs_scratch = reinterpret_cast<float*>(ws + L.colsum);
+  float* t_a = reinterpret_cast<float*>(ws + L.t_a);
+  float* t_b = reinterpret_cast<float*>(ws + L.t_b);
+  const int64_t kp = (sum_T + 3) / 4 * 4;  // packed-row count padded for dwordx4 rows
   const bool vec = (I % 4 == 0) && (H % 4 == 0);
 
   (void)hipMemsetAsync(zero_row, 0, static_cast<size_t>(H > I ? H : I) * 4, st);
@@ -755,7 +793,9 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     launch_colsum(v, de, g->dw_att, cs_scratch, sum_T, H, H, st);      // d att_w = sum_p de_p v_p
     launch_colsum(du, nullptr, g->db_lin, cs_scratch, sum_T, H, H, st);
     // d W_lin[n][k] = sum_p du[p][n] hs[p][k]
-    launch_tn(du, H, hs, H, nullptr, g->dw_lin, H, H, H, sum_T, nullptr, vec, st);
+    launch_gather_t(du, H, nullptr, t_a, sum_T, H, kp, st);
+    launch_gather_t(hs, H, nullptr, t_b, sum_T, H, kp, st);
+    launch_nt_out(t_a, kp, t_b, kp, g->dw_lin, H, nullptr, H, H, static_cast<int>(kp), 0, st);
     // dpool += du . W_lin  (NT on W_lin^T)
     launch_transpose(w->w_lin, wlin_t, H, H, st);
     launch_nt_out(du, H, wlin_t, H, dpool, H, nullptr, static_cast<int>(sum_T), H, H, 1, st);
@@ -802,8 +842,14 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   rp.sum_T = sum_T;
   hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)), dim3(256),
                      0, st, rp);
-  launch_tn(dgx, 3 * H, nullptr, 0, xaddr, g->dw_ih, I, 3 * H, I, sum_T, nullptr, vec, st);
-  launch_tn(dgh, 3 * H, nullptr, 0, hpaddr, g->dw_hh, H, 3 * H, H, sum_T, nullptr, vec, st);
+  // dW_ih[g][i] = sum_p dGx[p][g] x_p[i]: transpose both operands so the packed-row index is
+  // K-contiguous, then the NT tile loop (twice the rate of the [k][m]-staged TN loop)
+  launch_gather_t(dgx, 3 * H, nullptr, t_a, sum_T, 3 * H, kp, st);
+  launch_gather_t(nullptr, 0, xaddr, t_b, sum_T, I, kp, st);
+  launch_nt_out(t_a, kp, t_b, kp, g->dw_ih, I, nullptr, 3 * H, I, static_cast<int>(kp), 0, st);
+  launch_gather_t(dgh, 3 * H, nullptr, t_a, sum_T, 3 * H, kp, st);
+  launch_gather_t(nullptr, 0, hpaddr, t_b, sum_T, H, kp, st);
+  launch_nt_out(t_a, kp, t_b, kp, g->dw_hh, H, nullptr, 3 * H, H, static_cast<int>(kp), 0, st);
   launch_colsum(dgx, nullptr, g->db_ih, cs_scratch, sum_T, 3 * H, 3 * H, st);
   launch_colsum(dgh, nullptr, g->db_hh, cs_scratch, sum_T, 3 * H, 3 * H, st);
 
