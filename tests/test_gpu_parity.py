@@ -706,3 +706,42 @@ def test_sharded_validation_on_device_world1(dev):
   np.testing.assert_array_equal(out[3], ranks_t)
   np.testing.assert_array_equal(out[4], top1_i)
   np.testing.assert_array_equal(out[5], top1_t)
+
+
+def test_abi_error_codes_on_device(dev):
+  """Error behaviour of the C ABI with real device buffers: too-small / misaligned workspace,
+  bad stripe, bad pooling mode -> negative codes, nothing launched, no exception across the ABI."""
+  import ctypes
+  from cmhse_amd import _lib
+  lib = _lib.load()
+  a = torch.randn(8, 16, device=dev)
+  rank = torch.empty(8, dtype=torch.int32, device=dev)
+  top1 = torch.empty(8, dtype=torch.int32, device=dev)
+  ws = torch.empty(4096, dtype=torch.uint8, device=dev)
+  args = (a.data_ptr(), a.data_ptr(), 8, 8, 16)
+  assert lib.cmhse_sim_rank(*args, 0, 8, rank.data_ptr(), top1.data_ptr(), ws.data_ptr(), 8,
+                            None) == -2                       # workspace too small
+  assert lib.cmhse_sim_rank(*args, 0, 8, rank.data_ptr(), top1.data_ptr(), ws.data_ptr() + 4,
+                            4000, None) == -2                 # misaligned
+  assert lib.cmhse_sim_rank(*args, 4, 8, rank.data_ptr(), top1.data_ptr(), ws.data_ptr(), 4096,
+                            None) == -1                       # stripe beyond N
+  loss = torch.empty((), device=dev)
+  assert lib.cmhse_contrastive_fwd(a.data_ptr(), a.data_ptr(), 8, 16, 0.2, 0, 0, loss.data_ptr(),
+                                   None, ws.data_ptr(), 16, None) == -2
+  sb, gw = _lib.SeqBatch(), _lib.GruWeights()
+  assert lib.cmhse_gru_pool_fwd(ctypes.byref(sb), ctypes.byref(gw), 7, a.data_ptr(),
+                                ws.data_ptr(), 4096, None) == -1
+
+
+def test_python_wrappers_validate_shapes(dev):
+  from cmhse_amd import ops
+  from cmhse_amd.loss import ContrastiveLoss, GroupWiseContrastiveLoss
+  a, b = torch.randn(4, 8, device=dev), torch.randn(5, 8, device=dev)
+  with pytest.raises(ValueError):
+    ContrastiveLoss(margin=0.2)(a, b)                 # im / s must pair up (diag view)
+  with pytest.raises(ValueError):
+    ops.sim_rank(a, torch.randn(4, 9, device=dev))
+  with pytest.raises(ValueError):
+    GroupWiseContrastiveLoss(margin=0.2)(a, a, [2, 1], [2, 2])
+  with pytest.raises(NotImplementedError):
+    ContrastiveLoss(margin=0.2, measure='order')

@@ -137,3 +137,34 @@ def test_product_never_imports_the_oracle():
       if f.endswith(('.py', '.hip', '.hpp', '.h')):
         text = open(os.path.join(root, f)).read()
         assert 'cmhse_oracle' not in text and 'import oracle' not in text, f
+
+
+def test_schedule_and_wrappers_reject_bad_input():
+  """Host-side validation happens before any device work."""
+  from cmhse_amd.ops import SeqSchedule
+  with pytest.raises(ValueError):
+    SeqSchedule(np.array([], dtype=np.int64), 'cpu', x_ptrs=np.array([], dtype=np.uint64))
+  with pytest.raises(ValueError):
+    SeqSchedule(np.array([3, -1]), 'cpu', x_ptrs=np.zeros(2, dtype=np.uint64))
+  from cmhse_amd import ops
+  with pytest.raises(ValueError):
+    ops.set_math_mode('fp16')
+  assert ops.math_mode() in ('fp32', 'bf16x3')
+
+
+def test_pool_all_schedule_rows_are_sequence_starts():
+  """CMHSE_POOL_ALL: out_row[s] is the first output row of (sorted) sequence s."""
+  from cmhse_amd.ops import SeqSchedule
+  lens = np.array([2, 5, 1, 3])
+  s = SeqSchedule(lens, 'cpu', x_ptrs=np.zeros(4, dtype=np.uint64), out_rows_are_starts=True)
+  S = len(lens)
+  v32 = s.meta.numpy()[2 * S * 8:].view(np.int32)
+  starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+  assert v32[S:2 * S].tolist() == starts[s.order].tolist()
+
+
+def test_error_strings_cover_all_codes():
+  from cmhse_amd import _lib
+  lib = _lib.load()
+  seen = {lib.cmhse_strerror(c).decode() for c in (0, -1, -2, -3, -4, -99)}
+  assert len(seen) == 6
