@@ -199,7 +199,7 @@ def fast_mode_bench(opt, model, batches, N, n_steps):
                                                                  'cap_emb', 'vid_ctx', 'para_ctx'])
   same = float((r_i == ref_ri).float().mean())
   return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
-                  'accumulate (encoder GEMMs of steps with > 2048 active sequences and the '
+                  'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
                   'attention projection); ranking kernel exact fp32',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
           'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,

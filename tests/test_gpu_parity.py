@@ -193,7 +193,7 @@ def test_train_loss_meters_vs_golden(dev, rnn_type):
 @pytest.mark.parametrize('S,T,I,H', [(3, 5, 10, 33),       # odd widths: scalar-load path
                                      (150, 9, 500, 96),    # > one M tile, H not a tile multiple
                                      (70, 17, 300, 256),
-                                     (2300, 4, 36, 72),    # > 2048 active: LDS-tiled kernel,
+                                     (2300, 4, 36, 72),    # > 1024 active: LDS-tiled kernel,
                                      (2100, 3, 10, 33)])   #   then the tiny kernel on the tail
 def test_gru_pool_vs_oracle(dev, oracle, pool, S, T, I, H):
   from cmhse_amd import layers
