@@ -678,6 +678,15 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   }
   if (timer) (void)hipEventRecord(timer->stop, stream);
   if (pool_mode == CMHSE_POOL_ATTN) {
+    if (b->pool_stream != nullptr && b->pool_stream != stream_) {
+      // hand the pooling over to the caller's second stream, ordered after the GRU steps
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return CMHSE_ERR_LAUNCH;
+      (void)hipEventRecord(ev, stream);
+      stream = static_cast<hipStream_t>(b->pool_stream);
+      (void)hipStreamWaitEvent(stream, ev, 0);
+      (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
+    }
     const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
     float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
     AttnEnergyParams ep;

@@ -209,13 +209,14 @@ class _GRUPoolBase(nn.Module):
                      table)
 
   def forward_ptrs(self, lens, in_dim, device, x_ptrs=None, tok_ptrs=None, table=None,
-                   h0_ptrs=None, out=None):
+                   h0_ptrs=None, out=None, pool_stream=None):
     """Inference-only entry used by the fused paths (EncoderText, structure_emb, encode_data):
     sequences are given by base address (numpy uint64, input order), so padded batches, several
     loader batches at once and consecutive-row level-2 inputs are consumed in place."""
     out, _ = ops.gru_pool_fwd(self._weights(), self.POOL, lens, in_dim,
                               self.rnn.weight_hh_l0.shape[1], device, x_ptrs=x_ptrs,
-                              tok_ptrs=tok_ptrs, emb_table=table, h0_ptrs=h0_ptrs, out=out)
+                              tok_ptrs=tok_ptrs, emb_table=table, h0_ptrs=h0_ptrs, out=out,
+                              pool_stream=pool_stream)
     return out
 
   def forward_tokens(self, tokens, q_len, table):

@@ -152,7 +152,7 @@ class StepTimers(object):
 
 def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
-                 constant_input=False):
+                 constant_input=False, pool_stream=None):
   """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
   Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and schedule;
   with `save_for_backward` the workspace also keeps what gru_pool_bwd needs."""
@@ -194,6 +194,13 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
   b.h0_rows = sched.p_h0
   b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
   b.step_count_host = sched.step_count_host.ctypes.data
+  if pool_stream is not None and pool_mode == POOL_ATTN:
+    b.pool_stream = ctypes.c_void_p(pool_stream.cuda_stream)
+    out.record_stream(pool_stream)
+    ws.record_stream(pool_stream)
+    sched.meta.record_stream(pool_stream)
+    for t in keep:
+      t.record_stream(pool_stream)
   if StepTimers.active is not None:
     handle = lib.cmhse_timer_create()
     b.step_timer = handle
