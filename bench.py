@@ -325,7 +325,8 @@ def main():
 
   # roofline of the dominant kernel from the HIP-event spans around the per-step GRU launches
   spans = timers.collect()
-  flops = sum(sum_T * gru_flops_per_step(I, H) for (_, _, sum_T, I, H, _, _) in spans)
+  flops = sum(sum_T * gru_flops_per_step(I, H)
+              for (_, _, metas) in spans for (_, sum_T, I, H, _, _) in metas)
   ms = sum(s[0] for s in spans)
   launches = sum(s[1] for s in spans)
   achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -7,11 +7,13 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcmhse_hip.so')
+# CMHSE_HIP_LIB: another build of the same sources (kernel experiments); same ABI, still HIP-only
+LIB_PATH = os.environ.get('CMHSE_HIP_LIB') or os.path.join(_HERE, 'libcmhse_hip.so')
 
 POOL_LAST, POOL_ATTN, POOL_MAX, POOL_ALL = 0, 1, 2, 3
 SAVE_FOR_BACKWARD = 0x100
 MATH_BF16X3 = 0x200
+MAX_JOBS = 4            # requests per cmhse_gru_pool_fwd_multi call
 POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}
 
 c_void_p, c_int32, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
@@ -37,11 +39,18 @@ class SeqBatch(ctypes.Structure):
               ('pool_stream', c_void_p), ('step_timer', c_void_p)]
 
 
+class GruJob(ctypes.Structure):
+  _fields_ = [('seqs', ctypes.POINTER(SeqBatch)), ('weights', ctypes.POINTER(GruWeights)),
+              ('pool_mode', c_int32), ('out', c_void_p), ('workspace', c_void_p),
+              ('workspace_bytes', c_size_t)]
+
+
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
     'cmhse_gru_pool_fwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),
                                           c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_gru_pool_fwd_multi': (ctypes.c_int, [ctypes.POINTER(GruJob), c_int32, c_void_p]),
     'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     'cmhse_gather_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                          c_void_p]),
@@ -86,6 +95,7 @@ SIGNATURES = {
     'cmhse_timer_create': (c_void_p, []),
     'cmhse_timer_destroy': (None, [c_void_p]),
     'cmhse_timer_elapsed_ms': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float)]),
+    'cmhse_timer_launches': (c_int32, [c_void_p]),
     'cmhse_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'cmhse_version': (ctypes.c_char_p, []),
 }

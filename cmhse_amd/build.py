@@ -37,6 +37,7 @@ def build(force=False, verbose=False):
     return LIB
   cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-o', LIB + '.tmp'] + [os.path.join(CSRC, s) for s in SOURCES]
+  cmd[1:1] = os.environ.get('CMHSE_HIPCC_FLAGS', '').split()   # experiments: extra -D switches
   if verbose:
     cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
   res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

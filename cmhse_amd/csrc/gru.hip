@@ -57,15 +57,45 @@ struct GruStepParams {
   int64_t off_prev, off_cur;
 };
 
+// Up to kMaxJobs independent GRU chains share one launch per time step: workgroups
+// [start[k], start[k+1]) belong to job k.  Halves (or better) the number of dependent launches and
+// of partially filled last waves of workgroups when two encoders run side by side.
+constexpr int kMaxJobs = CMHSE_MAX_JOBS;
+struct GruStepGroup {
+  GruStepParams j[kMaxJobs];
+  uint32_t start[kMaxJobs];
+  int32_t n;
+};
+
+#ifdef CMHSE_TRACE
+// Timing-only debug build (tools/tile_trace.py): per-workgroup phase timestamps of the tiled step.
+__device__ uint64_t* g_trace = nullptr;
+#define TRACE_MARK(i)                                                              \
+  do {                                                                             \
+    if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define TRACE_MARK(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ int group_job(const GruStepGroup& g, unsigned* bx) {
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxJobs; ++k)
+    if (k < g.n && blockIdx.x >= g.start[k]) ji = k;
+  *bx = blockIdx.x - g.start[ji];
+  return ji;
+}
+
 // Gate nonlinearities on the hardware exp/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the
 // epilogue evaluates 3 of them per (sequence, unit) per step, and the libm-accurate forms cost
 // ~6 % of the step kernel.  Absolute error ~1e-7, far inside the 1e-4 parity bar.
 __device__ __forceinline__ float sigmoidf_(float x) {
-  return __frcp_rn(1.0f + __expf(-x));
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float tanhf_(float x) {
   // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates cleanly for |x| large (exp -> inf or 0)
-  return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
 __device__ __forceinline__ bool aligned16(const void* p) {
@@ -76,15 +106,26 @@ constexpr int kGruBM = 128;  // sequences per workgroup
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
 template <bool VEC, int MSUB, bool BF3>
-__global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
+void gru_step_kernel(const GruStepGroup grp) {
   constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
+  unsigned wg;
+  const GruStepParams& p = grp.j[group_job(grp, &wg)];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  TRACE_MARK(0);
+#ifdef CMHSE_TRACE
+  if (threadIdx.x == 0 && g_trace) {
+    g_trace[static_cast<size_t>(blockIdx.x) * 8 + 6] =
+        static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+        (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
+  }
+#endif
   // 1-D grid, N tile fastest: blocks b and b+8 land on the same XCD (round-robin dispatch), so
   // with H/BU a multiple of 8 every XCD's L2 keeps re-serving the same two weight-row slices.
-  const int u0 = (blockIdx.x % p.n_tiles) * BU;
-  const int m0 = (blockIdx.x / p.n_tiles) * BM;
+  const int u0 = (wg % p.n_tiles) * BU;
+  const int m0 = (wg / p.n_tiles) * BM;
   const int srow = tid >> 2;
   const int I = p.I, H = p.H;
 
@@ -140,55 +181,122 @@ __global__ __launch_bounds__(kThreads) void gru_step_kernel(const GruStepParams 
   const int a_row0 = wm * 32 * MSUB;
   const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
+
+  const int S_t = p.S_t, t = p.t, pool_mode = p.pool_mode;
+  const int64_t off_prev = p.off_prev, off_cur = p.off_cur;
+  float* const hs = p.hs;
+  float* const gates = p.gates;
+  float* const out = p.out;
+  int32_t* const argmax = p.argmax;
+  const uint64_t* const h0_rows = p.h0_rows;
+  const int32_t* const out_row = p.out_row;
+  const int32_t* const lens = p.lens;
+  TRACE_MARK(1);
+#ifdef CMHSE_TRACE
+  if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime();
+#endif
   if (BF3) {
     nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   } else {
     nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    TRACE_MARK(2);
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   }
+  TRACE_MARK(3);
+#ifdef CMHSE_TRACE
+  if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue: gates, state update, pooling ----
+  // The operands that do not come from the MFMA chain — the previous state of this lane's 16
+  // (sequence, unit) elements and the four bias terms — are requested all at once, branch-free
+  // (clamped indices): ONE memory round trip per sub-tile instead of one per element.  The gate
+  // math is then straight-line with predicated stores.  (Requesting them before the K loops would
+  // hide that trip too, but the 20 extra live registers cost the third wave per SIMD.)
   const int u = u0 + wn * 32 + acc_col(lane);
-  if (u >= H) return;
-  const float b_r = p.b_ih[u] + p.b_hh[u];
-  const float b_z = p.b_ih[H + u] + p.b_hh[H + u];
-  const float b_in = p.b_ih[2 * H + u];
-  const float b_hn = p.b_hh[2 * H + u];
+  const bool uv = u < H;
+  const int uc = uv ? u : (H - 1);
+  const float b_r = p.b_ih[uc] + p.b_hh[uc];
+  const float b_z = p.b_ih[H + uc] + p.b_hh[H + uc];
+  const float b_in = p.b_ih[2 * H + uc];
+  const float b_hn = p.b_hh[2 * H + uc];
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms) {
+    const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
+    float hp[16], hn[16];
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + acc_row(r, lane);
+        hp[r] = hs[(off_prev + (m < S_t ? m : (S_t - 1))) * H + uc];
+      }
+    } else if (h0_rows != nullptr) {
+      rowaddr_t hrow[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + acc_row(r, lane);
+        hrow[r] = h0_rows[m < S_t ? m : (S_t - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hp[r] = reinterpret_cast<const float*>(hrow[r])[uc];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hp[r] = 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
-      if (m >= p.S_t) continue;
-      float hp = 0.f;
-      if (p.t > 0)
-        hp = p.hs[(p.off_prev + m) * H + u];
-      else if (p.h0_rows != nullptr)
-        hp = reinterpret_cast<const float*>(p.h0_rows[m])[u];
+      const int m = mrow0 + acc_row(r, lane);
       const float rg = sigmoidf_(acc[ms][0][r] + b_r);
       const float zg = sigmoidf_(acc[ms][1][r] + b_z);
       const float ghn = acc[ms][3][r] + b_hn;
       const float ng = tanhf_(acc[ms][2][r] + b_in + rg * ghn);
-      const float hn = (1.0f - zg) * ng + zg * hp;
-      p.hs[(p.off_cur + m) * H + u] = hn;
-      if (p.gates != nullptr) {
-        float* gp = p.gates + (p.off_cur + m) * 4 * H + u;
-        gp[0] = rg;
-        gp[H] = zg;
-        gp[2 * H] = ng;
-        gp[3 * H] = ghn;
-      }
-      if (p.pool_mode == CMHSE_POOL_MAX) {
-        float* o = p.out + static_cast<int64_t>(p.out_row[m]) * H + u;
-        if (p.t == 0 || hn > *o) {  // strict '>': the first maximum wins, like max_pool1d
-          *o = hn;
-          if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(m) * H + u] = p.t;
+      hn[r] = (1.0f - zg) * ng + zg * hp[r];
+      if (uv && m < S_t) {
+        hs[(off_cur + m) * H + u] = hn[r];
+        if (gates != nullptr) {
+          float* gp = gates + (off_cur + m) * 4 * H + u;
+          gp[0] = rg;
+          gp[H] = zg;
+          gp[2 * H] = ng;
+          gp[3 * H] = ghn;
         }
-      } else if (p.pool_mode == CMHSE_POOL_LAST) {
-        if (p.t == p.lens[m] - 1) p.out[static_cast<int64_t>(p.out_row[m]) * H + u] = hn;
-      } else if (p.pool_mode == CMHSE_POOL_ALL) {
-        p.out[(static_cast<int64_t>(p.out_row[m]) + p.t) * H + u] = hn;
+      }
+    }
+    if (ms == MSUB - 1) TRACE_MARK(4);
+    if (pool_mode == CMHSE_POOL_ATTN) continue;   // pooled by attn_energy / attn_pool from hs
+
+    // pooling fused into the step: index loads four rows at a time, then the dependent accesses
+#pragma unroll
+    for (int r4 = 0; r4 < 16; r4 += 4) {
+      int orow[4], len[4];
+      float cur[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mrow0 + acc_row(r4 + i, lane);
+        const int mc = m < S_t ? m : (S_t - 1);
+        orow[i] = out_row[mc];
+        len[i] = (pool_mode == CMHSE_POOL_LAST) ? lens[mc] : 0;
+      }
+      if (pool_mode == CMHSE_POOL_MAX && t > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = out[static_cast<int64_t>(orow[i]) * H + uc];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mrow0 + acc_row(r4 + i, lane);
+        if (!(uv && m < S_t)) continue;
+        const float v = hn[r4 + i];
+        if (pool_mode == CMHSE_POOL_MAX) {
+          if (t == 0 || v > cur[i]) {  // strict '>': the first maximum wins, like max_pool1d
+            out[static_cast<int64_t>(orow[i]) * H + u] = v;
+            if (argmax != nullptr) argmax[static_cast<int64_t>(m) * H + u] = t;
+          }
+        } else if (pool_mode == CMHSE_POOL_LAST) {
+          if (t == len[i] - 1) out[static_cast<int64_t>(orow[i]) * H + u] = v;
+        } else {  // CMHSE_POOL_ALL
+          out[(static_cast<int64_t>(orow[i]) + t) * H + u] = v;
+        }
       }
     }
   }
@@ -212,13 +320,15 @@ constexpr int kTinyBU = 8;
 constexpr int kTinyMaxSeqs = 1024;  // above this the LDS-tiled kernel is faster (measured sweep)
 
 template <bool VEC>
-__global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepParams p) {
+__global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepGroup grp) {
   constexpr int BM = kTinyBM, BU = kTinyBU;
+  unsigned wg;
+  const GruStepParams& p = grp.j[group_job(grp, &wg)];
   __shared__ float red[4][2][16][64];  // [wave][x|h accumulator][register][lane], 32 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u_tiles = (p.H + BU - 1) / BU;
-  const int u0 = (blockIdx.x % u_tiles) * BU;  // unit tile fastest: b, b+8 share an XCD's L2
-  const int m0 = (blockIdx.x / u_tiles) * BM;
+  const int u0 = (wg % u_tiles) * BU;  // unit tile fastest: b, b+8 share an XCD's L2
+  const int m0 = (wg / u_tiles) * BM;
   const int I = p.I, H = p.H;
   const int row = lane & 31, hi = lane >> 5;
 
@@ -512,6 +622,7 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
 
 struct Timer {
   hipEvent_t start, stop;
+  int32_t launches;  // step kernels launched inside the bracket
 };
 
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
@@ -565,9 +676,28 @@ extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_
   return gru_ws_layout(S, sum_T, H, pool_mode, I).total;
 }
 
-extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
-                                  int32_t pool_mode, float* out, void* workspace,
-                                  size_t workspace_bytes, void* stream_) {
+namespace {
+
+// One validated cmhse_gru_pool_fwd request: step-kernel parameters plus what the pooling tail needs.
+struct FwdJob {
+  GruStepParams p;
+  const cmhse_seq_batch* b;
+  const cmhse_gru_weights* w;
+  float* out;
+  char* wsb;
+  GruWs L;
+  int64_t sum_T, off;
+  int32_t pool_mode;
+  bool vec, bf3, save;
+};
+
+int gru_msub() {
+  static const int msub = [] { const char* e = getenv("CMHSE_GRU_MSUB"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  return msub;
+}
+
+int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode, float* out,
+                void* workspace, size_t workspace_bytes, hipStream_t stream, FwdJob* job) {
   if (!b || !w || !out || !workspace) return CMHSE_ERR_ARG;
   if (b->S <= 0 || b->Tmax <= 0 || b->I <= 0 || b->H <= 0) return CMHSE_ERR_ARG;
   if ((b->x_rows == nullptr) == (b->tok_rows == nullptr)) return CMHSE_ERR_ARG;
@@ -594,12 +724,19 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
       workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->I, b->H, mode_flags))
     return CMHSE_ERR_WORKSPACE;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const GruWs L = gru_ws_layout(b->S, sum_T, b->H, mode_flags, b->I);
-  char* wsb = static_cast<char*>(workspace);
+  job->b = b;
+  job->w = w;
+  job->out = out;
+  job->L = gru_ws_layout(b->S, sum_T, b->H, mode_flags, b->I);
+  job->wsb = static_cast<char*>(workspace);
+  job->sum_T = sum_T;
+  job->off = 0;
+  job->pool_mode = pool_mode;
+  job->save = save;
+  const GruWs& L = job->L;
+  char* wsb = job->wsb;
 
-  float* hs = reinterpret_cast<float*>(wsb + L.hs);
-  GruStepParams p;
+  GruStepParams& p = job->p;
   p.x_rows = b->x_rows;
   p.tok_rows = b->tok_rows;
   p.emb = b->emb_table;
@@ -610,7 +747,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   p.w_hh = w->w_hh;
   p.b_ih = w->b_ih;
   p.b_hh = w->b_hh;
-  p.hs = hs;
+  p.hs = reinterpret_cast<float*>(wsb + L.hs);
   p.out = out;
   p.gates = save ? reinterpret_cast<float*>(wsb + L.gates) : nullptr;
   p.argmax = (save && pool_mode == CMHSE_POOL_MAX) ? reinterpret_cast<int32_t*>(wsb + L.argmax) : nullptr;
@@ -620,15 +757,13 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   p.pool_mode = pool_mode;
   p.x_step = b->x_step_floats;
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
-  const size_t smem = TileSmem<kGruBM, 3 * kGruBU>::kBytes;
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
-  const bool vec = (b->I % 4 == 0) && (b->H % 4 == 0);
-  const int tiny_limit = tiny_max_seqs();
+  job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
-  bf3 = bf3 && vec && (b->S > tiny_limit || pool_mode == CMHSE_POOL_ATTN);
+  job->bf3 = bf3 && job->vec && (b->S > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
   p.w_ih_s = nullptr;
   p.w_hh_s = nullptr;
-  if (bf3) {
+  if (job->bf3) {
     float* wih_s = reinterpret_cast<float*>(wsb + L.wih_s);
     float* whh_s = reinterpret_cast<float*>(wsb + L.whh_s);
     launch_split(w->w_ih, wih_s, 3 * b->H, b->I, stream);
@@ -636,107 +771,203 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     p.w_ih_s = wih_s;
     p.w_hh_s = whh_s;
   }
-  const int n_tiles = (b->H + kGruBU - 1) / kGruBU;
-  static const int msub = [] { const char* e = getenv("CMHSE_GRU_MSUB"); return (e && atoi(e) == 2) ? 2 : 1; }();
-  Timer* timer = static_cast<Timer*>(b->step_timer);
-  if (timer) (void)hipEventRecord(timer->start, stream);
-  int64_t off = 0;
-  for (int t = 0; t < b->Tmax; ++t) {
-    const int S_t = b->step_count_host[t];
-    p.t = t;
-    p.S_t = S_t;
-    p.off_prev = off - (t > 0 ? b->step_count_host[t - 1] : 0);
-    p.off_cur = off;
-    if (S_t <= tiny_limit) {
-      const unsigned grid = static_cast<unsigned>((b->H + kTinyBU - 1) / kTinyBU) *
-                            ((S_t + kTinyBM - 1) / kTinyBM);
+  return CMHSE_OK;
+}
+
+// Which step kernel serves job `j` at its current step: 0 = tiny, 1 = tiled fp32, 2 = tiled bf16x3;
+// bit 2 = scalar-load variant.  Jobs of equal kind share a launch.
+int step_kind(const FwdJob& j, int S_t) {
+  int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
+  return k | (j.vec ? 0 : 4);
+}
+
+void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t stream) {
+  const bool vec = (kind & 4) == 0;
+  const int msub = gru_msub();
+  switch (kind & 3) {
+    case 0:
       if (vec)
-        hipLaunchKernelGGL(gru_step_tiny_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, p);
+        hipLaunchKernelGGL(gru_step_tiny_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, g);
       else
-        hipLaunchKernelGGL(gru_step_tiny_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, p);
-    } else {
-      if (bf3) {
-        // staging-bound loop: the 128-row tile halves the weight bytes per MFMA
-        const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 127) / 128);
-        hipLaunchKernelGGL((gru_step_kernel<true, 2, true>), dim3(grid), dim3(kThreads), smem, stream, p);
-      } else if (msub == 2) {
-        const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 127) / 128);
-        if (vec)
-          hipLaunchKernelGGL((gru_step_kernel<true, 2, false>), dim3(grid), dim3(kThreads), smem, stream, p);
-        else
-          hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads), smem, stream, p);
-      } else {
-        const unsigned grid = static_cast<unsigned>(n_tiles) * ((S_t + 63) / 64);
-        const size_t smem1 = TileSmem<64, 3 * kGruBU>::kBytes;
-        if (vec)
-          hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads), smem1, stream, p);
-        else
-          hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads), smem1, stream, p);
-      }
+        hipLaunchKernelGGL(gru_step_tiny_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, g);
+      break;
+    case 2: {
+      // staging-bound loop: the 128-row tile halves the weight bytes per MFMA
+      const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
+      hipLaunchKernelGGL((gru_step_kernel<true, 2, true>), dim3(grid), dim3(kThreads), smem, stream, g);
+      break;
     }
-    off += S_t;
+    default:
+      if (msub == 2) {
+        const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
+        if (vec)
+          hipLaunchKernelGGL((gru_step_kernel<true, 2, false>), dim3(grid), dim3(kThreads), smem, stream, g);
+        else
+          hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads), smem, stream, g);
+      } else {
+        const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
+        if (vec)
+          hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
+        else
+          hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
+      }
   }
-  if (timer) (void)hipEventRecord(timer->stop, stream);
-  if (pool_mode == CMHSE_POOL_ATTN) {
-    if (b->pool_stream != nullptr && b->pool_stream != stream_) {
+}
+
+unsigned step_grid(const FwdJob& j, int kind, int S_t) {
+  const int H = j.b->H;
+  if ((kind & 3) == 0)
+    return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
+  const int bm = ((kind & 3) == 2 || gru_msub() == 2) ? 128 : 64;
+  return static_cast<unsigned>(j.p.n_tiles) * ((S_t + bm - 1) / bm);
+}
+
+// Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
+int launch_steps(FwdJob* jobs, int n, hipStream_t stream) {
+  int Tmax = 0, launches = 0;
+  for (int k = 0; k < n; ++k) Tmax = jobs[k].b->Tmax > Tmax ? jobs[k].b->Tmax : Tmax;
+  for (int t = 0; t < Tmax; ++t) {
+    int kind[kMaxJobs];
+    bool done[kMaxJobs];
+    for (int k = 0; k < n; ++k) {
+      done[k] = t >= jobs[k].b->Tmax;
+      if (done[k]) continue;
+      FwdJob& j = jobs[k];
+      const int S_t = j.b->step_count_host[t];
+      j.p.t = t;
+      j.p.S_t = S_t;
+      j.p.off_prev = j.off - (t > 0 ? j.b->step_count_host[t - 1] : 0);
+      j.p.off_cur = j.off;
+      j.off += S_t;
+      kind[k] = step_kind(j, S_t);
+    }
+    for (int k = 0; k < n; ++k) {
+      if (done[k]) continue;
+      GruStepGroup g;
+      g.n = 0;
+      unsigned grid = 0;
+      for (int m = k; m < n; ++m) {
+        if (done[m] || kind[m] != kind[k]) continue;
+        g.j[g.n] = jobs[m].p;
+        g.start[g.n] = grid;
+        grid += step_grid(jobs[m], kind[m], jobs[m].p.S_t);
+        ++g.n;
+        done[m] = true;
+      }
+      for (int m = g.n; m < kMaxJobs; ++m) g.start[m] = 0xffffffffu;
+      launch_group(g, kind[k], grid, stream);
+      ++launches;
+    }
+  }
+  return launches;
+}
+
+int launch_attention(const FwdJob& job, hipStream_t stream) {
+  const cmhse_seq_batch* b = job.b;
+  const cmhse_gru_weights* w = job.w;
+  const GruWs& L = job.L;
+  char* wsb = job.wsb;
+  const int64_t sum_T = job.sum_T;
+  const int msub = gru_msub();
+  const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
+  float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
+  AttnEnergyParams ep;
+  ep.hs = job.p.hs;
+  ep.w_lin = w->w_lin;
+  ep.b_lin = w->b_lin;
+  ep.w_att = w->w_att;
+  ep.e_part = e_part;
+  ep.v = job.save ? reinterpret_cast<float*>(wsb + L.v) : nullptr;
+  ep.rows = sum_T;
+  ep.H = b->H;
+  ep.n_tiles = att_tiles;
+  const bool att_bf3 = job.bf3 && sum_T > tiny_max_seqs();
+  const int att_bm = att_bf3 ? 128 : 64 * msub;
+  const int64_t m_tiles = (sum_T + att_bm - 1) / att_bm;
+  if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
+  const unsigned att_grid = static_cast<unsigned>(m_tiles * att_tiles);
+  ep.w_lin_s = nullptr;
+  if (att_bf3) {
+    float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
+    launch_split(w->w_lin, wlin_s, b->H, b->H, stream);
+    ep.w_lin_s = wlin_s;
+    const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
+    hipLaunchKernelGGL((attn_energy_kernel<true, 2, true>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+  } else if (msub == 2) {
+    const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
+    if (job.vec)
+      hipLaunchKernelGGL((attn_energy_kernel<true, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+    else
+      hipLaunchKernelGGL((attn_energy_kernel<false, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+  } else {
+    const size_t att_smem = TileSmem<64, kAttBN>::kBytes;
+    if (job.vec)
+      hipLaunchKernelGGL((attn_energy_kernel<true, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+    else
+      hipLaunchKernelGGL((attn_energy_kernel<false, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+  }
+  AttnPoolParams pp;
+  pp.hs = job.p.hs;
+  pp.e_part = e_part;
+  pp.lens = b->lens;
+  pp.out_row = b->out_row;
+  pp.step_off = b->step_off;
+  pp.out = job.out;
+  pp.rows = sum_T;
+  pp.H = b->H;
+  pp.n_tiles = att_tiles;
+  hipLaunchKernelGGL(attn_pool_kernel, dim3(b->S), dim3(kThreads), 0, stream, pp);
+  return CMHSE_OK;
+}
+
+}  // namespace
+
+extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_jobs, void* stream_) {
+  if (!reqs || n_jobs <= 0 || n_jobs > kMaxJobs) return CMHSE_ERR_ARG;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FwdJob jobs[kMaxJobs];
+  for (int k = 0; k < n_jobs; ++k) {
+    const int rc = prepare_job(reqs[k].seqs, reqs[k].weights, reqs[k].pool_mode, reqs[k].out,
+                               reqs[k].workspace, reqs[k].workspace_bytes, stream, &jobs[k]);
+    if (rc != CMHSE_OK) return rc;
+  }
+  // the first job's step_timer (if any) spans the step launches of the whole group
+  Timer* timer = static_cast<Timer*>(jobs[0].b->step_timer);
+  if (timer) (void)hipEventRecord(timer->start, stream);
+  const int launches = launch_steps(jobs, n_jobs, stream);
+  if (timer) {
+    (void)hipEventRecord(timer->stop, stream);
+    timer->launches = launches;
+  }
+  for (int k = 0; k < n_jobs; ++k) {
+    if (jobs[k].pool_mode != CMHSE_POOL_ATTN) continue;
+    hipStream_t ps = stream;
+    if (jobs[k].b->pool_stream != nullptr && jobs[k].b->pool_stream != stream_) {
       // hand the pooling over to the caller's second stream, ordered after the GRU steps
       hipEvent_t ev;
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return CMHSE_ERR_LAUNCH;
       (void)hipEventRecord(ev, stream);
-      stream = static_cast<hipStream_t>(b->pool_stream);
-      (void)hipStreamWaitEvent(stream, ev, 0);
+      ps = static_cast<hipStream_t>(jobs[k].b->pool_stream);
+      (void)hipStreamWaitEvent(ps, ev, 0);
       (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
     }
-    const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
-    float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
-    AttnEnergyParams ep;
-    ep.hs = hs;
-    ep.w_lin = w->w_lin;
-    ep.b_lin = w->b_lin;
-    ep.w_att = w->w_att;
-    ep.e_part = e_part;
-    ep.v = save ? reinterpret_cast<float*>(wsb + L.v) : nullptr;
-    ep.rows = sum_T;
-    ep.H = b->H;
-    ep.n_tiles = att_tiles;
-    const bool att_bf3 = bf3 && sum_T > tiny_limit;
-    const int att_bm = att_bf3 ? 128 : 64 * msub;
-    const int64_t m_tiles = (sum_T + att_bm - 1) / att_bm;
-    if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
-    const unsigned att_grid = static_cast<unsigned>(m_tiles * att_tiles);
-    ep.w_lin_s = nullptr;
-    if (att_bf3) {
-      float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
-      launch_split(w->w_lin, wlin_s, b->H, b->H, stream);
-      ep.w_lin_s = wlin_s;
-      const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
-      hipLaunchKernelGGL((attn_energy_kernel<true, 2, true>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
-    } else if (msub == 2) {
-      const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
-      if (vec)
-        hipLaunchKernelGGL((attn_energy_kernel<true, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
-      else
-        hipLaunchKernelGGL((attn_energy_kernel<false, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
-    } else {
-      const size_t att_smem = TileSmem<64, kAttBN>::kBytes;
-      if (vec)
-        hipLaunchKernelGGL((attn_energy_kernel<true, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
-      else
-        hipLaunchKernelGGL((attn_energy_kernel<false, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
-    }
-    AttnPoolParams pp;
-    pp.hs = hs;
-    pp.e_part = e_part;
-    pp.lens = b->lens;
-    pp.out_row = b->out_row;
-    pp.step_off = b->step_off;
-    pp.out = out;
-    pp.rows = sum_T;
-    pp.H = b->H;
-    pp.n_tiles = att_tiles;
-    hipLaunchKernelGGL(attn_pool_kernel, dim3(b->S), dim3(kThreads), 0, stream, pp);
+    const int rc = launch_attention(jobs[k], ps);
+    if (rc != CMHSE_OK) return rc;
   }
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
+                                  int32_t pool_mode, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+  cmhse_gru_job req;
+  req.seqs = b;
+  req.weights = w;
+  req.pool_mode = pool_mode;
+  req.out = out;
+  req.workspace = workspace;
+  req.workspace_bytes = workspace_bytes;
+  return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
 }
 
 extern "C" int cmhse_l2norm_rows(const float* x, float* y, int32_t rows, int32_t cols, int64_t ld,
@@ -762,6 +993,7 @@ extern "C" int cmhse_gather_rows(const float* table, const int64_t* ids, int64_t
 extern "C" void* cmhse_timer_create(void) {
   Timer* t = new (std::nothrow) Timer;
   if (!t) return nullptr;
+  t->launches = 0;
   if (hipEventCreate(&t->start) != hipSuccess) {
     delete t;
     return nullptr;
@@ -788,4 +1020,15 @@ extern "C" int cmhse_timer_elapsed_ms(void* timer, float* ms_host) {
   if (hipEventSynchronize(t->stop) != hipSuccess) return CMHSE_ERR_LAUNCH;
   if (hipEventElapsedTime(ms_host, t->start, t->stop) != hipSuccess) return CMHSE_ERR_LAUNCH;
   return CMHSE_OK;
+}
+
+#ifdef CMHSE_TRACE
+extern "C" int cmhse_debug_set_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(cmhse::g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int32_t cmhse_timer_launches(void* timer) {
+  Timer* t = static_cast<Timer*>(timer);
+  return t ? t->launches : 0;
 }

@@ -48,16 +48,21 @@ typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
 // global_load, a generic-pointer cast would still be emitted as flat_load (which also counts on
 // lgkmcnt and would be waited for together with the LDS fragment reads).
 typedef uint64_t rowaddr_t;
+#ifndef CMHSE_STREAM_A
+#define CMHSE_STREAM_A 0
+#endif
+constexpr bool kStreamA = CMHSE_STREAM_A != 0;
 __device__ __forceinline__ rowaddr_t row_addr(const float* p) {
   return reinterpret_cast<rowaddr_t>(p);
 }
 
-template <bool VEC>
+template <bool VEC, bool STREAM = false>
 __device__ __forceinline__ float4 issue_row4(rowaddr_t p, int k, int klim) {
   float4 v;
   if (VEC) {
     const int kk = (k < klim) ? k : (klim - 4);
-    const f32x4 g = *(gptr_f32x4)(p + static_cast<rowaddr_t>(kk) * 4u);
+    gptr_f32x4 src = (gptr_f32x4)(p + static_cast<rowaddr_t>(kk) * 4u);
+    const f32x4 g = STREAM ? __builtin_nontemporal_load(src) : *src;
     v = make_float4(g.x, g.y, g.z, g.w);
   } else {
     const int last = klim - 1;
@@ -132,7 +137,7 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   // Pieces of the pipeline (all force-inlined lambdas; `buf` is wave-uniform).
   auto issue_global = [&](int kn) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC>(arow[i], kn, K);
+    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC, kStreamA>(arow[i], kn, K);
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = issue_row4<VEC>(brow[i], kn, K);
   };

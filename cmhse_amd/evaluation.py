@@ -91,6 +91,7 @@ TWO_STREAMS = [os.environ.get('CMHSE_TWO_STREAMS', '0') == '1']
 # Both side-stream schedules are opt-in: they buy 1.5-3 % wall time, but concurrent kernels stretch
 # each other's durations, which blurs the per-kernel roofline accounting bench.py reports.
 POOL_OVERLAP = [os.environ.get('CMHSE_POOL_OVERLAP', '0') == '1']
+GROUP_TOWERS = [os.environ.get('CMHSE_GROUP_TOWERS', '1') == '1']
 _SIDE_STREAMS = {}
 
 
@@ -194,6 +195,30 @@ def encode_group(model, group, contextual_model=True, device=None):
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
     vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v)
     para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)
+    out_vis = (n(vid_emb), n(clip_emb), n(vid_ctx))
+    out_txt = (n(para_emb), n(cap_emb), n(para_ctx))
+  elif GROUP_TOWERS[0]:
+    # The two towers are independent: step t of both level-1 encoders shares one launch
+    # (cmhse_gru_pool_fwd_multi), then step t of both level-2 encoders.
+    v_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
+    t_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
+    (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
+        clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs),
+        txt_rnn.request_ptrs(np.concatenate(len_cap + len_par), table.shape[1], device,
+                             tok_ptrs=t_ptrs, table=table)])
+    clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
+    cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
+
+    def level2_request(enc, rows, counts, ctx_rows, Hin):
+      counts = np.asarray(counts, dtype=np.int64)
+      starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+      x_ptrs = np.uint64(rows.data_ptr()) + starts * np.uint64(Hin * 4)
+      h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
+      return enc.rnn.request_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
+
+    (vid_emb, _), (para_emb, _) = ops.gru_pool_fwd_multi([
+        level2_request(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v),
+        level2_request(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)])
     out_vis = (n(vid_emb), n(clip_emb), n(vid_ctx))
     out_txt = (n(para_emb), n(cap_emb), n(para_ctx))
   else:

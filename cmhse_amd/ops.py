@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (MATH_BF16X3, POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
+from ._lib import (MATH_BF16X3, MAX_JOBS, POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
                    SAVE_FOR_BACKWARD)
 
 
@@ -125,7 +125,7 @@ def padded_row_ptrs(t):
 class StepTimers(object):
   """Measurement aid for bench.py: while active, every cmhse_gru_pool_fwd call gets a
   cmhse_timer around its per-step GRU kernels; `collect()` returns a list of
-  (elapsed_ms, n_launches, sum_T, I, H, had_h0) and frees the timers."""
+  (elapsed_ms, n_launches, [(Tmax, sum_T, I, H, had_h0, S) per request of the call]) and frees the timers."""
   active = None
 
   def __init__(self):
@@ -144,18 +144,17 @@ class StepTimers(object):
     for handle, meta in self.items:
       ms = ctypes.c_float(0.0)
       _lib.check(lib.cmhse_timer_elapsed_ms(handle, ctypes.byref(ms)), 'cmhse_timer_elapsed_ms')
+      launches = int(lib.cmhse_timer_launches(handle))
       lib.cmhse_timer_destroy(handle)
-      out.append((ms.value,) + meta)
+      out.append((ms.value, launches, meta))
     self.items = []
     return out
 
 
-def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
+def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
                  constant_input=False, pool_stream=None):
-  """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
-  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and schedule;
-  with `save_for_backward` the workspace also keeps what gru_pool_bwd needs."""
+  """Build the ctypes request of one cmhse_gru_pool_fwd call.  Returns (job dict, timer meta)."""
   lib = _lib.load()
   sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs,
                       out_rows_are_starts=(pool_mode == POOL_ALL))
@@ -201,18 +200,53 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     sched.meta.record_stream(pool_stream)
     for t in keep:
       t.record_stream(pool_stream)
-  if StepTimers.active is not None:
-    handle = lib.cmhse_timer_create()
-    b.step_timer = handle
-    StepTimers.active.items.append((handle, (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None,
-                                             S)))
-  rc = lib.cmhse_gru_pool_fwd(ctypes.byref(b), ctypes.byref(w), mode_flags, out.data_ptr(),
-                              ws.data_ptr(), ws_bytes, _stream())
-  _lib.check(rc, 'cmhse_gru_pool_fwd')
-  b.step_timer = None
   ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
              device=device)
-  return out, ctx
+  job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx)
+  meta = (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None, S)
+  return job, meta
+
+
+def gru_pool_fwd(weights, pool_mode, lens, I, H, device, **kw):
+  """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
+  Keywords: x_ptrs | tok_ptrs + emb_table, h0_ptrs, out, save_for_backward, constant_input,
+  pool_stream.  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and
+  schedule; with `save_for_backward` the workspace also keeps what gru_pool_bwd needs."""
+  return gru_pool_fwd_multi([dict(weights=weights, pool_mode=pool_mode, lens=lens, I=I, H=H,
+                                  device=device, **kw)])[0]
+
+
+def gru_pool_fwd_multi(requests):
+  """cmhse_gru_pool_fwd_multi: `requests` is a list of keyword dicts (the arguments of
+  gru_pool_fwd) for INDEPENDENT encoders; their time steps share launches.  Returns a list of
+  (out, ctx), bit-identical to separate gru_pool_fwd calls."""
+  lib = _lib.load()
+  if not 1 <= len(requests) <= MAX_JOBS:
+    raise ValueError('gru_pool_fwd_multi takes 1..%d requests' % MAX_JOBS)
+  prepared = [_prepare_fwd(**r) for r in requests]
+  jobs = (_lib.GruJob * len(prepared))()
+  for k, (job, _) in enumerate(prepared):
+    jobs[k].seqs = ctypes.pointer(job['b'])
+    jobs[k].weights = ctypes.pointer(job['w'])
+    jobs[k].pool_mode = job['mode_flags']
+    jobs[k].out = job['out'].data_ptr()
+    jobs[k].workspace = job['ws'].data_ptr()
+    jobs[k].workspace_bytes = job['ws_bytes']
+  if StepTimers.active is not None:
+    handle = lib.cmhse_timer_create()
+    prepared[0][0]['b'].step_timer = handle
+    StepTimers.active.items.append((handle, [m for _, m in prepared]))
+  if len(prepared) == 1:
+    job = prepared[0][0]
+    rc = lib.cmhse_gru_pool_fwd(ctypes.byref(job['b']), ctypes.byref(job['w']), job['mode_flags'],
+                                job['out'].data_ptr(), job['ws'].data_ptr(), job['ws_bytes'],
+                                _stream())
+    _lib.check(rc, 'cmhse_gru_pool_fwd')
+  else:
+    rc = lib.cmhse_gru_pool_fwd_multi(jobs, len(prepared), _stream())
+    _lib.check(rc, 'cmhse_gru_pool_fwd_multi')
+  prepared[0][0]['b'].step_timer = None
+  return [(job['out'], job['ctx']) for job, _ in prepared]
 
 
 def l2norm_rows(x, out=None):

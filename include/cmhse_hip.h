@@ -118,6 +118,23 @@ size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t 
 int cmhse_gru_pool_fwd(const cmhse_seq_batch* seqs, const cmhse_gru_weights* w, int32_t pool_mode,
                        float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+#define CMHSE_MAX_JOBS 4
+/* Several INDEPENDENT cmhse_gru_pool_fwd requests in one call (at most CMHSE_MAX_JOBS).  Results are bit-identical
+ * to the separate calls; step t of every request shares one launch, so two encoders that do not
+ * depend on each other — the clip and sentence encoders of VSE.forward_emb (model.py:311-331), the
+ * video and paragraph encoders of structure_emb (model.py:345-358) — pay one launch latency and one
+ * partially filled last wave of workgroups per time step instead of two.  The first request's
+ * step_timer (if set) brackets the step launches of the whole group. */
+typedef struct cmhse_gru_job {
+  const cmhse_seq_batch* seqs;
+  const cmhse_gru_weights* weights;
+  int32_t pool_mode;
+  float* out;
+  void* workspace;
+  size_t workspace_bytes;
+} cmhse_gru_job;
+int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
+
 /* torch.nn.functional.normalize(x) (p=2, dim=1, eps=1e-12) — call sites model.py:333-343,
  * evaluation.py:111-116.  y may alias x.  Rows have stride `ld` floats. */
 int cmhse_l2norm_rows(const float* x, float* y, int32_t rows, int32_t cols, int64_t ld,
@@ -240,6 +257,7 @@ int cmhse_euclid_bwd(const float* a, const float* b, const uint64_t* b_rows, int
 void* cmhse_timer_create(void);
 void cmhse_timer_destroy(void* timer);
 int cmhse_timer_elapsed_ms(void* timer, float* ms_host);
+int32_t cmhse_timer_launches(void* timer);   /* step kernels launched inside the bracket */
 
 /* Text for an error code returned by the functions above (static storage). */
 const char* cmhse_strerror(int code);
