@@ -68,7 +68,9 @@ struct GruStepGroup {
 };
 
 #ifdef CMHSE_TRACE
-// Timing-only debug build (tools/tile_trace.py): per-workgroup phase timestamps of the tiled step.
+// Timing-only debug build (tools/tile_trace.py): per-workgroup stamps of the tiled step —
+// [0] first instruction, [1] K loops start, [2] after the kernarg reads, [3] K loops end,
+// [4] state stores drained (s_memrealtime, 10 ns); [5]/[7] s_memtime at [1]/[3]; [6] HW_ID | XCC_ID << 32.
 __device__ uint64_t* g_trace = nullptr;
 #define TRACE_MARK(i)                                                              \
   do {                                                                             \
@@ -109,17 +111,21 @@ template <bool VEC, int MSUB, bool BF3>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_kernel(const GruStepGroup grp) {
   constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
+#ifdef CMHSE_TRACE
+  const uint64_t t_first = wall_clock64();
+#endif
   unsigned wg;
   const GruStepParams& p = grp.j[group_job(grp, &wg)];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  TRACE_MARK(0);
+  TRACE_MARK(2);
 #ifdef CMHSE_TRACE
   if (threadIdx.x == 0 && g_trace) {
     g_trace[static_cast<size_t>(blockIdx.x) * 8 + 6] =
         static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
         (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
+    g_trace[static_cast<size_t>(blockIdx.x) * 8 + 0] = t_first;
   }
 #endif
   // 1-D grid, N tile fastest: blocks b and b+8 land on the same XCD (round-robin dispatch), so
@@ -200,7 +206,6 @@ void gru_step_kernel(const GruStepGroup grp) {
     if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   } else {
     nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
-    TRACE_MARK(2);
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   }
   TRACE_MARK(3);
@@ -263,7 +268,13 @@ void gru_step_kernel(const GruStepGroup grp) {
         }
       }
     }
-    if (ms == MSUB - 1) TRACE_MARK(4);
+#ifdef CMHSE_TRACE
+    if (ms == MSUB - 1) {   // stores of the state drained: what the slot's successor waits for
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      TRACE_MARK(4);
+    }
+#endif
     if (pool_mode == CMHSE_POOL_ATTN) continue;   // pooled by attn_energy / attn_pool from hs
 
     // pooling fused into the step: index loads four rows at a time, then the dependent accesses

@@ -47,7 +47,10 @@ def main():
   g = torch.Generator(device='cpu').manual_seed(0)
   w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.05).to(dev),
            w_hh=torch.randn(3 * H, H, generator=g).mul_(0.05).to(dev),
-           b_ih=torch.zeros(3 * H, device=dev), b_hh=torch.zeros(3 * H, device=dev))
+           b_ih=torch.zeros(3 * H, device=dev), b_hh=torch.zeros(3 * H, device=dev),
+           w_lin=torch.randn(H, H, generator=g).mul_(0.05).to(dev), b_lin=torch.zeros(H, device=dev),
+           w_att=torch.randn(1, H, generator=g).mul_(0.05).to(dev))
+  pool = getattr(ops, os.environ.get('TRACE_POOL', 'POOL_ATTN'))
   n_wg = ((S + 63) // 64) * ((H + 63) // 64)
   trace = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
   ptrs = ops.padded_row_ptrs(x)
@@ -55,7 +58,7 @@ def main():
   for it in range(reps):
     if it == reps - 1:
       assert lib.cmhse_debug_set_trace(trace.data_ptr()) == 0
-    ops.gru_pool_fwd(w, ops.POOL_LAST, lens, I, H, dev, x_ptrs=ptrs)
+    ops.gru_pool_fwd(w, pool, lens, I, H, dev, x_ptrs=ptrs)
     torch.cuda.synchronize()
   lib.cmhse_debug_set_trace(None)
   tr = trace.cpu().numpy().reshape(n_wg, 8)
@@ -68,11 +71,11 @@ def main():
   sh = (hw >> 12) & 0x1
   se = (hw >> 13) & 0x7
   cu_key = xcc * 1000 + se * 100 + sh * 16 + cu
-  names = ['setup (row addresses)', 'x phase', 'h phase', 'epilogue']
+  names = ['first instr -> loop', 'first instr -> mark0', 'loop (x+h)', 'epilogue + drain']
   print('S=%d I=%d H=%d  workgroups=%d  distinct CUs=%d' % (S, I, H, n_wg, len(np.unique(cu_key))))
   span = t[:, 4].max()
   print('launch span %.1f us' % span)
-  dur = np.diff(t, axis=1)
+  dur = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 0], t[:, 3] - t[:, 1], t[:, 4] - t[:, 3]], axis=1)
   for i, nme in enumerate(names):
     print('%-24s mean %8.2f us   p10 %8.2f   p50 %8.2f   p90 %8.2f' %
           (nme, dur[:, i].mean(), *np.percentile(dur[:, i], [10, 50, 90])))
@@ -120,7 +123,7 @@ def main():
   k = keys[len(keys) // 2]
   sel = np.where(cu_key == k)[0]
   sel = sel[np.argsort(t[sel, 0])]
-  print('timeline of CU %d (%d workgroups): start, setup_end, x_end, h_end, end [us]' % (k, len(sel)))
+  print('timeline of CU %d (%d workgroups): first instr, loop start, mark0, loop end, drained [us]' % (k, len(sel)))
   for i in sel[:24]:
     print('   wg %6d  %8.1f %8.1f %8.1f %8.1f %8.1f' % ((i,) + tuple(t[i])))
   per_cu = np.array([np.sum(cu_key == k) for k in keys])
