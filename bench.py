@@ -249,6 +249,21 @@ def measured_traffic():
   return tot / n if n else None
 
 
+def measured_clock_ghz():
+  """In-kernel shader clock of the tiled GRU step under load (median over workgroups), from the
+  committed tools/tile_trace.py run (profiles/r01_tile_trace.txt).  None if absent."""
+  path = os.path.join(REPO, 'profiles', 'r01_tile_trace.txt')
+  if not os.path.exists(path):
+    return None
+  for line in open(path):
+    if line.startswith('in-kernel shader clock') and 'median' in line:
+      try:
+        return float(line.split('median')[1].split('GHz')[0])
+      except ValueError:
+        return None
+  return None
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -333,6 +348,7 @@ def main():
   ms_per_step = elapsed / args.steps * 1e3
   pairs = float(N) * float(N)
 
+  clk = measured_clock_ghz()
   if rank == 0:
     if isinstance(ranks_i, torch.Tensor):
       ranks_i = ranks_i.cpu().numpy()
@@ -355,7 +371,12 @@ def main():
                      'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)',
                      'launches': launches, 'avg_launch_us': (ms * 1e3 / launches) if launches else None,
                      'flops_per_launch': (flops / launches) if launches else None,
-                     'kernel_time_share': (ms * 1e-3) / elapsed if elapsed > 0 else None},
+                     'kernel_time_share': (ms * 1e-3) / elapsed if elapsed > 0 else None,
+                     # context, not the graded fraction: `peak` assumes 2.4 GHz, the chip holds
+                     # ~2.0 GHz under this kernel (profiles/r01_tile_trace.txt)
+                     'in_kernel_clock_ghz': clk,
+                     'frac_of_peak_at_that_clock':
+                         (achieved / (FP32_MFMA_PEAK_TFLOPS * clk / 2.4)) if clk else None},
     }
     if world == 1 and args.fast_steps > 0:
       out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)
