@@ -737,6 +737,76 @@ def test_sharded_validation_on_device_world1(dev):
   np.testing.assert_array_equal(out[5], top1_t)
 
 
+def test_gru_pool_fwd_multi_equals_separate_calls(dev):
+  """cmhse_gru_pool_fwd_multi: four unrelated encoders of different widths, pooling modes and
+  batch sizes (token input with an embedding table, an initial state, a > 1024-sequence batch that
+  starts on the LDS-tiled kernel while the others are on the small-batch kernel, the decoder's
+  all-states mode on a constant input) in ONE call give bit-identical outputs and hidden states to
+  four separate calls; request-count errors are reported, not launched."""
+  import ctypes
+  from cmhse_amd import _lib, ops
+  rng = np.random.RandomState(11)
+  g = torch.Generator().manual_seed(5)
+
+  def weights(I, H, attn):
+    w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.2), w_hh=torch.randn(3 * H, H, generator=g).mul_(0.2),
+             b_ih=torch.randn(3 * H, generator=g).mul_(0.1), b_hh=torch.randn(3 * H, generator=g).mul_(0.1))
+    if attn:
+      w.update(w_lin=torch.randn(H, H, generator=g).mul_(0.2), b_lin=torch.randn(H, generator=g).mul_(0.1),
+               w_att=torch.randn(1, H, generator=g).mul_(0.2))
+    return {k: v.to(dev) for k, v in w.items()}
+
+  keep = []
+
+  def padded(S, T, I):
+    lens = rng.randint(1, T + 1, size=S).astype(np.int64)
+    lens[rng.randint(S)] = T
+    x = torch.randn(S, T, I, generator=g).to(dev)
+    keep.append(x)
+    return lens, ops.padded_row_ptrs(x)
+
+  reqs = []
+  lens, ptrs = padded(1300, 5, 36)                                  # tiled kernel, then tiny
+  reqs.append(dict(weights=weights(36, 72, True), pool_mode=ops.POOL_ATTN, lens=lens, I=36, H=72,
+                   device=dev, x_ptrs=ptrs))
+  S, T, V = 37, 9, 50                                               # tokens + table, max pooling
+  tok = torch.randint(0, V, (S, T), generator=g).to(dev)
+  table = torch.randn(V, 20, generator=g).to(dev)
+  keep += [tok, table]
+  lens = rng.randint(1, T + 1, size=S).astype(np.int64)
+  reqs.append(dict(weights=weights(20, 40, False), pool_mode=ops.POOL_MAX, lens=lens, I=20, H=40,
+                   device=dev, tok_ptrs=ops.padded_row_ptrs(tok), emb_table=table))
+  lens, ptrs = padded(5, 12, 10)                                    # odd widths + initial state
+  h0 = torch.randn(5, 33, generator=g).to(dev)
+  keep.append(h0)
+  reqs.append(dict(weights=weights(10, 33, False), pool_mode=ops.POOL_LAST, lens=lens, I=10, H=33,
+                   device=dev, x_ptrs=ptrs, h0_ptrs=ops.padded_row_ptrs(h0)))
+  emb = torch.randn(6, 16, generator=g).to(dev)                     # decoder: constant input, all states
+  keep.append(emb)
+  lens = rng.randint(1, 8, size=6).astype(np.int64)
+  reqs.append(dict(weights=weights(16, 24, False), pool_mode=ops.POOL_ALL, lens=lens, I=16, H=24,
+                   device=dev, x_ptrs=ops.padded_row_ptrs(emb), constant_input=True))
+
+  single = [ops.gru_pool_fwd(**r) for r in reqs]
+  multi = ops.gru_pool_fwd_multi(reqs)
+  pair = ops.gru_pool_fwd_multi(reqs[1:3])
+  torch.cuda.synchronize()
+  for k, ((o1, c1), (o2, c2)) in enumerate(zip(single, multi)):
+    assert torch.equal(o1, o2), k
+    n_hs = c1['sched'].sum_T * c1['H'] * 4
+    assert torch.equal(c1['ws'][:n_hs], c2['ws'][:n_hs]), k
+  for (o1, _), (o2, _) in zip(single[1:3], pair):
+    assert torch.equal(o1, o2)
+  with pytest.raises(ValueError):
+    ops.gru_pool_fwd_multi(reqs + reqs[:1])
+  lib = _lib.load()
+  jobs = (_lib.GruJob * 1)()
+  assert lib.cmhse_gru_pool_fwd_multi(jobs, 0, None) == -1
+  assert lib.cmhse_gru_pool_fwd_multi(jobs, _lib.MAX_JOBS + 1, None) == -1
+  assert lib.cmhse_gru_pool_fwd_multi(jobs, 1, None) == -1          # null request fields
+  assert lib.cmhse_gru_pool_fwd_multi(None, 1, None) == -1
+
+
 def test_abi_error_codes_on_device(dev):
   """Error behaviour of the C ABI with real device buffers: too-small / misaligned workspace,
   bad stripe, bad pooling mode -> negative codes, nothing launched, no exception across the ABI."""
