@@ -447,10 +447,14 @@ def test_loss_backward_vs_golden(dev, n):
       grad_close(a2.grad.cpu().numpy(), g[tag + '.da_self'], tag + '.da_self')
 
 
+@pytest.mark.parametrize('two_streams', [True, False])
 @pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
-def test_train_emb_gradients_vs_golden(dev, rnn_type):
+def test_train_emb_gradients_vs_golden(dev, rnn_type, two_streams, monkeypatch):  # noqa: C901
   """One full VSE.train_emb step (forward, 7 losses, backward, Adam): the parameter gradients
-  left in .grad equal the reference's for every encoder, and the parameters moved."""
+  left in .grad equal the reference's for every encoder, and the parameters moved — with the two
+  towers on two HIP streams (default) and on one."""
+  from cmhse_amd import model as model_mod
+  monkeypatch.setattr(model_mod, 'TRAIN_TWO_STREAMS', [two_streams])
   g = load_golden('model_%s.npz' % rnn_type)
   batch = torch_batches(golden_batches(g))[1]
   for mv in (0, 1):
