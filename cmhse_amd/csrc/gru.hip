@@ -952,17 +952,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
   }
   for (int k = 0; k < n_jobs; ++k) {
     if (jobs[k].pool_mode != CMHSE_POOL_ATTN) continue;
-    hipStream_t ps = stream;
-    if (jobs[k].b->pool_stream != nullptr && jobs[k].b->pool_stream != stream_) {
-      // hand the pooling over to the caller's second stream, ordered after the GRU steps
-      hipEvent_t ev;
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return CMHSE_ERR_LAUNCH;
-      (void)hipEventRecord(ev, stream);
-      ps = static_cast<hipStream_t>(jobs[k].b->pool_stream);
-      (void)hipStreamWaitEvent(ps, ev, 0);
-      (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
-    }
-    const int rc = launch_attention(jobs[k], ps);
+    const int rc = launch_attention(jobs[k], stream);
     if (rc != CMHSE_OK) return rc;
   }
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;

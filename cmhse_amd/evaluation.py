@@ -88,9 +88,6 @@ def _to_dev(t, device):
 
 
 TWO_STREAMS = [os.environ.get('CMHSE_TWO_STREAMS', '0') == '1']
-# Both side-stream schedules are opt-in: they buy 1.5-3 % wall time, but concurrent kernels stretch
-# each other's durations, which blurs the per-kernel roofline accounting bench.py reports.
-POOL_OVERLAP = [os.environ.get('CMHSE_POOL_OVERLAP', '0') == '1']
 GROUP_TOWERS = [os.environ.get('CMHSE_GROUP_TOWERS', '1') == '1']
 _SIDE_STREAMS = {}
 
@@ -178,25 +175,6 @@ def encode_group(model, group, contextual_model=True, device=None):
     main.wait_stream(s_txt)
     for t in out_vis + out_txt:
       t.record_stream(main)      # allocated on a side stream, consumed on the caller's stream
-  elif POOL_OVERLAP[0] and getattr(clip_rnn, 'POOL', None) == ops.POOL_ATTN:
-    # The visual level-1 attention projection (one big GEMM) does not depend on the text tower;
-    # the text GRU's time steps are a latency chain that leaves MFMA issue slots idle.  Run the
-    # projection + pooling on a side stream while the text steps run on the caller's stream.
-    main = torch.cuda.current_stream(device)
-    side = _side_streams(device)[0]
-    ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
-    lens = np.concatenate(len_clip + len_vid)
-    vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs, pool_stream=side)
-    ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
-    lens = np.concatenate(len_cap + len_par)
-    txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
-    main.wait_stream(side)
-    clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
-    cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
-    vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v)
-    para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)
-    out_vis = (n(vid_emb), n(clip_emb), n(vid_ctx))
-    out_txt = (n(para_emb), n(cap_emb), n(para_ctx))
   elif GROUP_TOWERS[0]:
     # The two towers are independent: step t of both level-1 encoders shares one launch
     # (cmhse_gru_pool_fwd_multi), then step t of both level-2 encoders.

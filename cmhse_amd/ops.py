@@ -153,7 +153,7 @@ class StepTimers(object):
 
 def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
-                 constant_input=False, pool_stream=None):
+                 constant_input=False):
   """Build the ctypes request of one cmhse_gru_pool_fwd call.  Returns (job dict, timer meta)."""
   lib = _lib.load()
   sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs,
@@ -193,13 +193,6 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
   b.h0_rows = sched.p_h0
   b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
   b.step_count_host = sched.step_count_host.ctypes.data
-  if pool_stream is not None and pool_mode == POOL_ATTN:
-    b.pool_stream = ctypes.c_void_p(pool_stream.cuda_stream)
-    out.record_stream(pool_stream)
-    ws.record_stream(pool_stream)
-    sched.meta.record_stream(pool_stream)
-    for t in keep:
-      t.record_stream(pool_stream)
   ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
              device=device)
   job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx)
@@ -209,8 +202,8 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
 
 def gru_pool_fwd(weights, pool_mode, lens, I, H, device, **kw):
   """cmhse_gru_pool_fwd.  `weights`: dict with w_ih, w_hh, b_ih, b_hh (+ w_lin, b_lin, w_att).
-  Keywords: x_ptrs | tok_ptrs + emb_table, h0_ptrs, out, save_for_backward, constant_input,
-  pool_stream.  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and
+  Keywords: x_ptrs | tok_ptrs + emb_table, h0_ptrs, out, save_for_backward, constant_input.
+  Returns (out [S,H], ctx) where ctx keeps the workspace (packed hidden states) and
   schedule; with `save_for_backward` the workspace also keeps what gru_pool_bwd needs."""
   return gru_pool_fwd_multi([dict(weights=weights, pool_mode=pool_mode, lens=lens, I=I, H=H,
                                   device=device, **kw)])[0]

@@ -95,11 +95,6 @@ typedef struct cmhse_seq_batch {
   const int32_t* step_off;  /* [Tmax+1] step_off[t] = sum_{t'<t} #{s : lens[s] > t'}: row offset
                                of step t in the time-major packed hidden-state buffer */
   const int32_t* step_count_host; /* HOST [Tmax] #{s : lens[s] > t} (sizes the per-step grids) */
-  void* pool_stream;        /* optional second hipStream_t (or NULL): with CMHSE_POOL_ATTN the attention
-                               projection + pooling kernels are launched there, ordered after this
-                               call's GRU steps by an event, so the caller can overlap them with
-                               the next encoder's (latency-chained) GRU steps on `stream`.  The
-                               caller orders its consumers after pool_stream itself. */
   void* step_timer;         /* optional cmhse_timer (or NULL): brackets the per-step GRU kernels of
                                this call on `stream` — measurement only, no effect on results */
 } cmhse_seq_batch;
