@@ -213,17 +213,29 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   for (int c = 1; c < nchunks; ++c) {
     const int cur = c & 1;
     const int kn = (c + 1) * kBK + sk;  // past the end: clamped address, zeroed by finish_row4
+    // CMHSE_ABL_*: timing-only ablations for tools/tile_trace.py (wrong results by design): which
+    // part of the loop's data movement costs wall time and shader clock.
+#if !defined(CMHSE_ABL_NOBAR)
     __syncthreads();
+#endif
+#if !defined(CMHSE_ABL_NOLDSR)
     read_frags(cur, 0, f0a, f0b);
+#endif
+#if !defined(CMHSE_ABL_NOGLOBAL)
     issue_global(kn);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f1a, f1b, I0{}, I4{});
     __builtin_amdgcn_sched_barrier(0);
+#if !defined(CMHSE_ABL_NOLDSR)
     read_frags(cur, 1, f1a, f1b);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f0a, f0b, I0{}, I3{});
     __builtin_amdgcn_sched_barrier(0);
+#if !defined(CMHSE_ABL_NOLDSW)
     write_lds(cur ^ 1, kn);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f0a, f0b, I3{}, I4{});
   }

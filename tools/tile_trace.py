@@ -23,9 +23,9 @@ def main():
   I = int(argv[1]) if len(argv) > 1 else 500
   H = int(argv[2]) if len(argv) > 2 else 1024
   csrc = os.path.join(ROOT, 'cmhse_amd', 'csrc')
-  lib_path = os.path.join(ROOT, 'cmhse_amd', 'libcmhse_trace.so')
+  lib_path = os.path.join(ROOT, 'cmhse_amd', os.environ.get('TRACE_LIB', 'libcmhse_trace.so'))
   cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-DCMHSE_TRACE', '-o', lib_path] + [os.path.join(csrc, f) for f in
+         '-DCMHSE_TRACE'] + os.environ.get('TRACE_FLAGS', '').split() + ['-o', lib_path] + [os.path.join(csrc, f) for f in
                                               ('gru.hip', 'sim.hip', 'bwd.hip')]
   if '--build-only' in sys.argv or not os.path.exists(lib_path):
     subprocess.check_call(cmd)
