@@ -164,7 +164,9 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   // MFMAs of one 8-k block for k sub-steps j in [J0, J1)
   auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB], auto j0c, auto j1c) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+#if !defined(CMHSE_ABL_NOPRIO)
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
 #pragma unroll
@@ -181,7 +183,9 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
         }
       }
     }
+#if !defined(CMHSE_ABL_NOPRIO)
     __builtin_amdgcn_s_setprio(0);
+#endif
   };
   using I0 = std::integral_constant<int, 0>;
   using I3 = std::integral_constant<int, 3>;

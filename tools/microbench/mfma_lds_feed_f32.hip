@@ -1,0 +1,144 @@
+// fp32 MFMA loop fed from LDS: how much clock / FLOP rate do the fragment reads cost?
+// Per iteration a wave issues NREAD ds_read_b128 (conflict-free, stride-20-float rows like
+// nt_core.hpp) and 24 v_mfma_f32_32x32x2_f32 (3 accumulators) — the mix of one 16-k chunk of the
+// GRU step kernel is NREAD = 8.  Optional: NWRITE ds_write_b128 per iteration (staging writes).
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_lds_feed_f32 mfma_lds_feed_f32.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kIters = 2048;
+constexpr int kLd = 20;
+
+// NGLOBAL: 0 none; 1 = one A-like dwordx4 (streamed rows, every workgroup its own, never re-read
+// on this XCD -> served from beyond L2) + three B-like dwordx4 (a 2.3 MB slice shared by every
+// workgroup with the same blockIdx %% 16 -> L2-resident) per thread per iteration, written to LDS;
+// 2 = the three B-like loads only; 3 = the A-like load only.
+template <int NREAD, int NWRITE, int NGLOBAL = 0>
+__global__ __launch_bounds__(256) void loop(const float* __restrict__ in, float* out,
+                                            unsigned long long* stamps,
+                                            const float* __restrict__ abuf = nullptr,
+                                            const float* __restrict__ bbuf = nullptr) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 256 * kLd];   // 40 KB like TileSmem<64,192>
+  for (int i = threadIdx.x; i < 2 * 256 * kLd; i += 256) lds[i] = in[i & 4095];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const int srow = threadIdx.x >> 2, sk = (threadIdx.x & 3) * 4;
+  f32x16 acc[3];
+  for (int n = 0; n < 3; ++n)
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  float4 f[8];
+  for (int i = 0; i < 8; ++i) f[i] = make_float4(in[(lane + i) & 4095], in[(lane + 9 * i) & 4095], 0.5f, 0.25f);
+  float4 wv = make_float4(in[lane], in[lane + 1], in[lane + 2], in[lane + 3]);
+  // A rows: 1536 floats each, 64 rows per workgroup, a fresh row block every 96 iterations
+  const float* arow = abuf ? abuf + (size_t(blockIdx.x) * 64 + srow) * 1536 + sk : nullptr;
+  const float* brow = bbuf ? bbuf + (size_t(blockIdx.x % 16) * 192 + srow) * 1536 + sk : nullptr;
+  float4 g[4] = {wv, wv, wv, wv};
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = wall_clock64();
+  for (int it = 0; it < kIters; ++it) {
+    const int buf = (it & 1) * 256 * kLd;
+    const int kc = (it % 96) * 16;
+    if (NGLOBAL == 1 || NGLOBAL == 3) {
+      const size_t blk = (size_t(it / 96) * gridDim.x) * 64 * 1536;
+      g[0] = *reinterpret_cast<const float4*>(arow + blk + kc);
+    }
+    if (NGLOBAL == 1 || NGLOBAL == 2) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g[1 + i] = *reinterpret_cast<const float4*>(brow + size_t(i) * 64 * 1536 + kc);
+    }
+#pragma unroll
+    for (int i = 0; i < NREAD; ++i)
+      f[i] = *reinterpret_cast<const float4*>(lds + buf + (wave * 32 * ((i & 1) + 1) % 224 + frow) * kLd + (i >> 2) * 8 + fk);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 a = f[j & 1], b0 = f[2 + (j & 1)], b1 = f[4 + (j & 1)], b2 = f[6 + (j & 1)];
+      const int c = j >> 1;
+      const float av = c == 0 ? a.x : c == 1 ? a.y : c == 2 ? a.z : a.w;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c == 0 ? b0.x : c == 1 ? b0.y : c == 2 ? b0.z : b0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c == 0 ? b1.x : c == 1 ? b1.y : c == 2 ? b1.z : b1.w, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c == 0 ? b2.x : c == 1 ? b2.y : c == 2 ? b2.z : b2.w, acc[2], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NWRITE; ++i)
+      *reinterpret_cast<float4*>(lds + (buf ^ (256 * kLd)) + (srow + 64 * i) * kLd + sk) = (NGLOBAL ? g[i] : wv);
+    if (NWRITE > 0) __syncthreads();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = wall_clock64();
+  float s = 0.f;
+  for (int n = 0; n < 3; ++n)
+    for (int i = 0; i < 16; ++i) s += acc[n][i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) {
+    stamps[blockIdx.x * 2] = c1 - c0;
+    stamps[blockIdx.x * 2 + 1] = r1 - r0;
+  }
+}
+
+template <typename K>
+static void run(const char* name, K kernel, int blocks, const float* d_in, float* d_out,
+                unsigned long long* d_st, const float* abuf = nullptr, const float* bbuf = nullptr) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_in, d_out, d_st, abuf, bbuf);
+  (void)hipDeviceSynchronize();
+  const int reps = 60;
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_in, d_out, d_st, abuf, bbuf);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> st(blocks * 2);
+  (void)hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
+  double cyc = 0, rt = 0;
+  for (int b = 0; b < blocks; ++b) {
+    cyc += st[b * 2];
+    rt += st[b * 2 + 1];
+  }
+  const double flops = double(blocks) * 4 * kIters * 24.0 * 4096.0 * reps;
+  printf("%-26s %8.2f ms  %7.1f TFLOP/s  in-kernel clock %.3f GHz\n", name, ms,
+         flops / (ms * 1e-3) / 1e12, cyc / (rt * 10.0));
+}
+
+int main() {
+  std::vector<float> h(4096);
+  srand(1);
+  for (auto& v : h) v = (rand() / float(RAND_MAX) - 0.5f) * 2.0f;
+  float *d_in, *d_out;
+  unsigned long long* d_st;
+  (void)hipMalloc(&d_in, 4096 * 4);
+  (void)hipMemcpy(d_in, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+  const int blocks = 256 * 3;   // 3 workgroups per CU = 3 waves per SIMD, like the step kernel
+  (void)hipMalloc(&d_out, blocks * 256 * 4);
+  (void)hipMalloc(&d_st, blocks * 16);
+  // A: ceil(kIters/96) row blocks of gridDim x 64 rows x 1536 floats; B: 16 slices of 192 rows
+  const size_t a_floats = size_t((kIters + 95) / 96) * blocks * 64 * 1536;
+  const size_t b_floats = size_t(16) * 192 * 1536;
+  float *abuf, *bbuf;
+  (void)hipMalloc(&abuf, a_floats * 4);
+  (void)hipMalloc(&bbuf, b_floats * 4);
+  {
+    std::vector<float> hb(b_floats);
+    for (auto& v : hb) v = (rand() / float(RAND_MAX) - 0.5f) * 2.0f;
+    (void)hipMemcpy(bbuf, hb.data(), b_floats * 4, hipMemcpyHostToDevice);
+    for (size_t off = 0; off < a_floats; off += b_floats)
+      (void)hipMemcpy(abuf + off, hb.data(), (a_floats - off < b_floats ? a_floats - off : b_floats) * 4, hipMemcpyHostToDevice);
+  }
+  printf("A buffer %.1f GB, B buffer %.1f MB\n", a_floats * 4 / 1e9, b_floats * 4 / 1e6);
+  for (int rep = 0; rep < 2; ++rep) {
+    run("reads 0  writes 0", loop<0, 0>, blocks, d_in, d_out, d_st);
+    run("reads 4  writes 0", loop<4, 0>, blocks, d_in, d_out, d_st);
+    run("reads 8  writes 0", loop<8, 0>, blocks, d_in, d_out, d_st);
+    run("reads 8  writes 4 + barrier", loop<8, 4>, blocks, d_in, d_out, d_st);
+    run("  + B loads (L2)", loop<8, 4, 2>, blocks, d_in, d_out, d_st, abuf, bbuf);
+    run("  + A loads (streamed)", loop<8, 4, 3>, blocks, d_in, d_out, d_st, abuf, bbuf);
+    run("  + A and B loads", loop<8, 4, 1>, blocks, d_in, d_out, d_st, abuf, bbuf);
+  }
+  return 0;
+}
