@@ -444,7 +444,8 @@ struct AttnEnergyParams {
 
 
 template <bool VEC, int MSUB, bool BF3>
-__global__ __launch_bounds__(kThreads) void attn_energy_kernel(const AttnEnergyParams p) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
+void attn_energy_kernel(const AttnEnergyParams p) {
   constexpr int BM = 64 * MSUB, BN = kAttBN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

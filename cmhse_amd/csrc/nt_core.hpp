@@ -135,11 +135,35 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   float4 f0a[MSUB], f0b[NSUB], f1a[MSUB], f1b[NSUB];
 
   // Pieces of the pipeline (all force-inlined lambdas; `buf` is wave-uniform).
+  // Running row pointers (VEC): pa/pb address k = kp + sk of every staged row, so the caller's row
+  // bases are dead after this point and the steady-state loop needs no address arithmetic.
+  rowaddr_t pa[AP], pb[BP];
+  int kp = 0;
+#pragma unroll
+  for (int i = 0; i < AP; ++i) pa[i] = arow[i] + static_cast<rowaddr_t>(sk) * 4u;
+#pragma unroll
+  for (int i = 0; i < BP; ++i) pb[i] = brow[i] + static_cast<rowaddr_t>(sk) * 4u;
   auto issue_global = [&](int kn) {
+    if (VEC) {
+      // tail clamp of issue_row4, relative to the running pointers
+      const int kk = (kn < K) ? kn : (K - 4);
+      const long long off = static_cast<long long>(kk - (kp + sk)) * 4;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC, kStreamA>(arow[i], kn, K);
+      for (int i = 0; i < AP; ++i) {
+        const f32x4 g = *(gptr_f32x4)(pa[i] + static_cast<rowaddr_t>(off));
+        ra[i] = make_float4(g.x, g.y, g.z, g.w);
+      }
 #pragma unroll
-    for (int i = 0; i < BP; ++i) rb[i] = issue_row4<VEC>(brow[i], kn, K);
+      for (int i = 0; i < BP; ++i) {
+        const f32x4 g = *(gptr_f32x4)(pb[i] + static_cast<rowaddr_t>(off));
+        rb[i] = make_float4(g.x, g.y, g.z, g.w);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC, kStreamA>(arow[i], kn, K);
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = issue_row4<VEC>(brow[i], kn, K);
+    }
   };
   auto write_lds = [&](int buf, int kn) {
 #pragma unroll
@@ -214,7 +238,67 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   write_lds(1, kBK + sk);
   __builtin_amdgcn_sched_barrier(0);
   mfma_block(f0a, f0b, I3{}, I4{});
-  for (int c = 1; c < nchunks; ++c) {
+  int c = 1;
+#if !defined(CMHSE_NO_LEAN_LOOP)
+  if (VEC) {
+    // Lean steady state, two chunks per trip.  Every vector-ALU instruction in this loop costs
+    // matrix-pipe time (tools/microbench/mfma_lds_feed_f32.hip: 32 of them per 24 MFMAs take 19 %
+    // off the loop), so the chunks that lie wholly inside K are staged with no tail clamp, no
+    // masks (rows past the tile edge hold a valid row's data and only feed outputs that are never
+    // stored) and no per-chunk address arithmetic: the running row pointers advance once per trip,
+    // the second chunk's loads use the +64 B immediate, and both LDS buffers are compile-time offsets.
+#pragma unroll
+    for (int i = 0; i < AP; ++i) pa[i] += static_cast<rowaddr_t>(2 * kBK) * 4u;
+#pragma unroll
+    for (int i = 0; i < BP; ++i) pb[i] += static_cast<rowaddr_t>(2 * kBK) * 4u;
+    kp = 2 * kBK;
+    auto lean_chunk = [&](auto curc, auto offc) {
+      constexpr int cur = decltype(curc)::value;
+      constexpr unsigned off = decltype(offc)::value;
+      __syncthreads();
+      read_frags(cur, 0, f0a, f0b);
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const f32x4 g = *(gptr_f32x4)(pa[i] + off);
+        ra[i] = make_float4(g.x, g.y, g.z, g.w);
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const f32x4 g = *(gptr_f32x4)(pb[i] + off);
+        rb[i] = make_float4(g.x, g.y, g.z, g.w);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f1a, f1b, I0{}, I4{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(cur, 1, f1a, f1b);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f0a, f0b, I0{}, I3{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < AP; ++i)
+        *reinterpret_cast<float4*>(SM::a(smem, cur ^ 1) + (srow + 64 * i) * kLdsLd + sk) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BP; ++i)
+        *reinterpret_cast<float4*>(SM::b(smem, cur ^ 1) + (srow + 64 * i) * kLdsLd + sk) = rb[i];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f0a, f0b, I3{}, I4{});
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using U0 = std::integral_constant<unsigned, 0u>;
+    using U64 = std::integral_constant<unsigned, 64u>;
+    // trip (c, c+1), c odd: stages chunks c+1 and c+2, both must end inside K
+    for (; (c + 3) * kBK <= K; c += 2) {
+      lean_chunk(I1{}, U0{});
+      lean_chunk(I0{}, U64{});
+#pragma unroll
+      for (int i = 0; i < AP; ++i) pa[i] += 128u;
+#pragma unroll
+      for (int i = 0; i < BP; ++i) pb[i] += 128u;
+      kp += 2 * kBK;
+    }
+  }
+#endif
+  for (; c < nchunks; ++c) {
     const int cur = c & 1;
     const int kn = (c + 1) * kBK + sk;  // past the end: clamped address, zeroed by finish_row4
     // CMHSE_ABL_*: timing-only ablations for tools/tile_trace.py (wrong results by design): which

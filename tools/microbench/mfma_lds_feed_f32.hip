@@ -16,7 +16,7 @@ constexpr int kLd = 20;
 // on this XCD -> served from beyond L2) + three B-like dwordx4 (a 2.3 MB slice shared by every
 // workgroup with the same blockIdx %% 16 -> L2-resident) per thread per iteration, written to LDS;
 // 2 = the three B-like loads only; 3 = the A-like load only.
-template <int NREAD, int NWRITE, int NGLOBAL = 0>
+template <int NREAD, int NWRITE, int NGLOBAL = 0, int NVALU = 0>
 __global__ __launch_bounds__(256) void loop(const float* __restrict__ in, float* out,
                                             unsigned long long* stamps,
                                             const float* __restrict__ abuf = nullptr,
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ in, float*
   const float* arow = abuf ? abuf + (size_t(blockIdx.x) * 64 + srow) * 1536 + sk : nullptr;
   const float* brow = bbuf ? bbuf + (size_t(blockIdx.x % 16) * 192 + srow) * 1536 + sk : nullptr;
   float4 g[4] = {wv, wv, wv, wv};
+  float dummy[8] = {wv.x, wv.y, wv.z, wv.w, wv.x, wv.y, wv.z, wv.w};
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = wall_clock64();
   for (int it = 0; it < kIters; ++it) {
     const int buf = (it & 1) * 256 * kLd;
@@ -63,6 +64,11 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ in, float*
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, c == 0 ? b2.x : c == 1 ? b2.y : c == 2 ? b2.z : b2.w, acc[2], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // NVALU extra vector ALU instructions per iteration (the step kernel's loop has ~31: tail
+    // masks and address arithmetic)
+#pragma unroll
+    for (int i = 0; i < NVALU; ++i)
+      asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(dummy[i & 7]) : "v"(wv.x));
 #pragma unroll
     for (int i = 0; i < NWRITE; ++i)
       *reinterpret_cast<float4*>(lds + (buf ^ (256 * kLd)) + (srow + 64 * i) * kLd + sk) = (NGLOBAL ? g[i] : wv);
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ in, float*
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = wall_clock64();
   float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += dummy[i];
   for (int n = 0; n < 3; ++n)
     for (int i = 0; i < 16; ++i) s += acc[n][i];
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -139,6 +146,10 @@ int main() {
     run("  + B loads (L2)", loop<8, 4, 2>, blocks, d_in, d_out, d_st, abuf, bbuf);
     run("  + A loads (streamed)", loop<8, 4, 3>, blocks, d_in, d_out, d_st, abuf, bbuf);
     run("  + A and B loads", loop<8, 4, 1>, blocks, d_in, d_out, d_st, abuf, bbuf);
+    run("  + A, B loads, 32 VALU", loop<8, 4, 1, 32>, blocks, d_in, d_out, d_st, abuf, bbuf);
+    run("  + A, B loads, 96 VALU", loop<8, 4, 1, 96>, blocks, d_in, d_out, d_st, abuf, bbuf);
+    run("reads 8 writes 4, 32 VALU", loop<8, 4, 0, 32>, blocks, d_in, d_out, d_st);
+    run("reads 8 writes 4, 96 VALU", loop<8, 4, 0, 96>, blocks, d_in, d_out, d_st);
   }
   return 0;
 }
