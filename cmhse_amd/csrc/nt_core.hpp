@@ -454,6 +454,8 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
   convert_a();
   __builtin_amdgcn_sched_barrier(0);
   write_lds(1, kBK + sk);
+  // (a lean two-chunk steady state like nt_phase's measured 5-8 % SLOWER here: this loop is paced by
+  // the operand conversion, and the extra live pointers cost registers)
   for (int c = 1; c < nchunks; ++c) {
     const int cur = c & 1;
     const int kn = (c + 1) * kBK + sk;
@@ -492,7 +494,35 @@ __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool 
     ra[d] = issue_row4<VEC>(arow, k, K);
     rb[d] = issue_row4<VEC>(brow, k, K);
   }
-  for (int it = 0; it < nmine; it += kTinyRing) {
+  int it = 0;
+#if !defined(CMHSE_NO_LEAN_LOOP)
+  if (VEC) {
+    // Lean steady state (see nt_phase): while every k this trip consumes or prefetches lies inside
+    // K — for all four waves, so the bound is uniform — no tail masks, no clamps, and the loads go
+    // through running pointers with immediate offsets (slot d of the ring is 128 B further).
+    // Columns that are never stored (bvalid == false) need no zeroing either.
+    constexpr unsigned kAhead = 4u * kTinyRing * 8u * 4u;   // prefetch distance in bytes
+    rowaddr_t pa = arow + static_cast<rowaddr_t>(wave * 8 + 4 * hi) * 4u + kAhead;
+    rowaddr_t pb = brow + static_cast<rowaddr_t>(wave * 8 + 4 * hi) * 4u + kAhead;
+    for (; 32 * it + 256 <= K; it += kTinyRing) {
+#pragma unroll
+      for (int d = 0; d < kTinyRing; ++d) {
+        const float4 a = ra[d], b = rb[d];
+        const f32x4 ga = *(gptr_f32x4)(pa + 128u * d);
+        const f32x4 gb = *(gptr_f32x4)(pb + 128u * d);
+        ra[d] = make_float4(ga.x, ga.y, ga.z, ga.w);
+        rb[d] = make_float4(gb.x, gb.y, gb.z, gb.w);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+      pa += 128u * kTinyRing;
+      pb += 128u * kTinyRing;
+    }
+  }
+#endif
+  for (; it < nmine; it += kTinyRing) {
 #pragma unroll
     for (int d = 0; d < kTinyRing; ++d) {
       const int k = (wave + 4 * (it + d)) * 8 + 4 * hi;
