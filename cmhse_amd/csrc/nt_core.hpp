@@ -188,8 +188,8 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   // MFMAs of one 8-k block for k sub-steps j in [J0, J1)
   auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB], auto j0c, auto j1c) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
-#if !defined(CMHSE_ABL_NOPRIO)
-    __builtin_amdgcn_s_setprio(1);
+#if defined(CMHSE_MFMA_SETPRIO)   // raised wave priority around the MFMA blocks: +3 % before the lean
+    __builtin_amdgcn_s_setprio(1);  // loop existed, -0.9 % with it (measured), so off by default
 #endif
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
         }
       }
     }
-#if !defined(CMHSE_ABL_NOPRIO)
+#if defined(CMHSE_MFMA_SETPRIO)
     __builtin_amdgcn_s_setprio(0);
 #endif
   };
