@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -116,7 +117,17 @@ static void run(const char* name, K kernel, int blocks, const float* d_in, float
 int main() {
   std::vector<float> h(4096);
   srand(1);
-  for (auto& v : h) v = (rand() / float(RAND_MAX) - 0.5f) * 2.0f;
+  // MB_DIST=normal: N(0, MB_SCALE^2) operands (Box-Muller) instead of uniform(-1, 1)
+  const char* dist = getenv("MB_DIST");
+  const float scale = getenv("MB_SCALE") ? atof(getenv("MB_SCALE")) : 1.0f;
+  auto draw = [&]() {
+    if (dist && dist[0] == 'n') {
+      const float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / float(RAND_MAX);
+      return scale * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    }
+    return scale * (rand() / float(RAND_MAX) - 0.5f) * 2.0f;
+  };
+  for (auto& v : h) v = draw();
   float *d_in, *d_out;
   unsigned long long* d_st;
   (void)hipMalloc(&d_in, 4096 * 4);
@@ -132,7 +143,7 @@ int main() {
   (void)hipMalloc(&bbuf, b_floats * 4);
   {
     std::vector<float> hb(b_floats);
-    for (auto& v : hb) v = (rand() / float(RAND_MAX) - 0.5f) * 2.0f;
+    for (auto& v : hb) v = draw();
     (void)hipMemcpy(bbuf, hb.data(), b_floats * 4, hipMemcpyHostToDevice);
     for (size_t off = 0; off < a_floats; off += b_floats)
       (void)hipMemcpy(abuf + off, hb.data(), (a_floats - off < b_floats ? a_floats - off : b_floats) * 4, hipMemcpyHostToDevice);

@@ -43,6 +43,8 @@ def main():
   dev = torch.device('cuda', 0)
   T = 2
   x = torch.randn(S, T, I, device=dev)
+  scale = float(os.environ.get('TRACE_DATA_SCALE', '1'))   # 0: all-zero operands (clock ceiling check)
+  x *= scale
   lens = np.full(S, T, dtype=np.int64)
   g = torch.Generator(device='cpu').manual_seed(0)
   w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.05).to(dev),
@@ -51,6 +53,8 @@ def main():
            w_lin=torch.randn(H, H, generator=g).mul_(0.05).to(dev), b_lin=torch.zeros(H, device=dev),
            w_att=torch.randn(1, H, generator=g).mul_(0.05).to(dev))
   pool = getattr(ops, os.environ.get('TRACE_POOL', 'POOL_ATTN'))
+  if scale != 1.0:
+    w = {k: v * scale for k, v in w.items()}
   n_wg = ((S + 63) // 64) * ((H + 63) // 64)
   trace = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
   ptrs = ops.padded_row_ptrs(x)
@@ -62,6 +66,9 @@ def main():
     torch.cuda.synchronize()
   lib.cmhse_debug_set_trace(None)
   tr = trace.cpu().numpy().reshape(n_wg, 8)
+  tr = tr[tr[:, 4] != 0]          # CMHSE_GRU_MSUB=2 launches half as many workgroups
+  n_wg = len(tr)
+  rows_per_tile = 128 if os.environ.get('CMHSE_GRU_MSUB') == '2' else 64
   t = tr[:, :5].astype(np.float64) * 0.01   # us (100 MHz)
   t0 = t[:, 0].min()
   t -= t0
@@ -82,7 +89,7 @@ def main():
   tot = t[:, 4] - t[:, 0]
   print('%-24s mean %8.2f us   p10 %8.2f   p50 %8.2f   p90 %8.2f' %
         ('whole tile', tot.mean(), *np.percentile(tot, [10, 50, 90])))
-  flop_tile = 2.0 * 64 * 192 * (I + H)
+  flop_tile = 2.0 * rows_per_tile * 192 * (I + H)
   print('MFMA-only time of one tile on one CU at peak: %.2f us' % (flop_tile / (157.3e12 / 256) * 1e6))
   # concurrency per CU over time: how many workgroups are inside their K loops
   keys = np.unique(cu_key)
