@@ -104,7 +104,7 @@ __device__ __forceinline__ bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-constexpr int kGruBM = 128;  // sequences per workgroup
+constexpr int kGruBM = 128;  // most sequences a workgroup of the tiled step kernel owns (64 * MSUB)
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
 template <bool VEC, int MSUB, bool BF3>
@@ -315,8 +315,8 @@ void gru_step_kernel(const GruStepGroup grp) {
 
 // ---------------------------------------------------------------------------------------------
 // Latency-shaped GRU step for small active sets (training batches, the long ragged tails of
-// paragraphs): with S_t <= ~2k sequences the 128 x 64 tile above fills only a few CUs and every
-// launch costs one full K loop (~150 us).  Here a workgroup owns 32 sequences x 8 hidden units:
+// paragraphs): with S_t <= ~1k sequences the 64 x 64 tile above fills only part of the chip and every
+// launch costs one full K loop (~100 us).  Here a workgroup owns 32 sequences x 8 hidden units:
 //   * ONE MFMA per k-step computes all three gates of those 8 units: the 32 B columns of
 //     v_mfma_f32_32x32x2_f32 are [r x8 | z x8 | n x8 | 8 unused];
 //   * the x phase and the h phase accumulate into two separate 32x32 accumulators (the n gate
