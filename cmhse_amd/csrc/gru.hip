@@ -104,7 +104,6 @@ __device__ __forceinline__ bool aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-constexpr int kGruBM = 128;  // most sequences a workgroup of the tiled step kernel owns (64 * MSUB)
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
 template <bool VEC, int MSUB, bool BF3>
