@@ -290,6 +290,54 @@ def test_contrastive_vs_oracle(dev, oracle, n):
       assert loss_close(got, want), (n, mv, nm, got, want)
 
 
+@pytest.mark.parametrize('seed', range(8))
+def test_scoring_and_loss_fuzz_vs_oracle(dev, oracle, seed):
+  """Seeded random (n, m, d) — single rows, widths of 1 and of non-multiples of 4, sizes around
+  the 128-row tile: ranks / top-1 exact on tie-free rows, the stored score matrix, the loss value
+  and both loss gradients against the float64 oracle for every (max_violation, norm)."""
+  from cmhse_amd import ops
+  from cmhse_amd.loss import ContrastiveLoss
+  rng = np.random.RandomState(500 + seed)
+  n = int(rng.choice([1, 2, 31, 127, 128, 129, 260]))
+  m = int(rng.choice([n, n + 1, 2 * n + 3]))
+  d = int(rng.choice([1, 3, 8, 30, 64, 257]))
+  a = rng.standard_normal((n, d)).astype(np.float32)
+  b = rng.standard_normal((m, d)).astype(np.float32)
+  b[:n] += 1.5 * a
+  a /= np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+  b /= np.maximum(np.linalg.norm(b, axis=1, keepdims=True), 1e-12)
+  ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+  d64 = a.astype(np.float64) @ b.astype(np.float64).T
+  diag = d64[np.arange(n), np.arange(n)][:, None]
+  gap = np.abs(d64 - diag)
+  gap[np.arange(n), np.arange(n)] = 1.0
+  ok = gap.min(axis=1) > 1e-5
+  rank, top1 = ops.sim_rank(ta, tb)
+  np.testing.assert_array_equal(rank.cpu().numpy()[ok], (d64 > diag).sum(axis=1)[ok])
+  if m > 1:
+    srt = np.sort(d64, axis=1)
+    ok_top = (srt[:, -1] - srt[:, -2]) > 1e-5
+    np.testing.assert_array_equal(top1.cpu().numpy()[ok_top], d64.argmax(axis=1)[ok_top])
+  np.testing.assert_allclose(ops.cosine_sim(ta, tb).cpu().numpy(), d64, atol=2e-6, rtol=0)
+  bs = b[:n]
+  for mv in (False, True):
+    for nm in (False, True):
+      x = ta.clone().requires_grad_(True)
+      y = tb[:n].clone().requires_grad_(True)
+      loss = ContrastiveLoss(margin=0.2, measure='cosine', max_violation=mv, norm=nm)(x, y)
+      want = oracle.contrastive_loss(a, bs, 0.2, mv, nm, np.float64)
+      assert loss_close(loss.item(), want), (n, d, mv, nm, loss.item(), want)
+      # hinge kinks / arg-max ties move the subgradient: only compare where the oracle's own
+      # float32 and float64 evaluations agree on the active set
+      g64 = oracle.contrastive_loss_backward(a, bs, 0.2, mv, nm, np.float64)
+      g32 = oracle.contrastive_loss_backward(a, bs, 0.2, mv, nm, np.float32)
+      if not (np.allclose(g64[0], g32[0], atol=1e-5) and np.allclose(g64[1], g32[1], atol=1e-5)):
+        continue
+      loss.backward()
+      grad_close(x.grad.cpu().numpy(), g64[0], 'fuzz da n%d d%d mv%d nm%d' % (n, d, mv, nm))
+      grad_close(y.grad.cpu().numpy(), g64[1], 'fuzz db n%d d%d mv%d nm%d' % (n, d, mv, nm))
+
+
 def test_contrastive_blocks_equal_single_calls(dev):
   """The batched per-loader-batch loss equals one cmhse_contrastive_fwd call per block, bitwise."""
   from cmhse_amd import ops
@@ -504,6 +552,49 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
     grad_close(ht.grad.cpu().numpy(), dh0, pool + ' dh0')
     for pn, pp in layer.named_parameters():
       grad_close(pp.grad.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_gru_pool_fuzz_forward_backward_vs_oracle(dev, oracle, seed):
+  """Seeded random shapes, deliberately awkward: single sequences and single steps, widths that
+  are not multiples of the 4-float vector path, the 8-unit / 32-sequence / 64-unit tile edges,
+  ragged lengths with many short sequences.  Forward output and every gradient (inputs, initial
+  state, all weights) against the float64 oracle, for the three pooling modes."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(1000 + seed)
+  S = int(rng.choice([1, 2, 7, 31, 33, 65, 130]))
+  T = int(rng.choice([1, 2, 5, 11]))
+  I = int(rng.choice([1, 3, 8, 17, 36, 64]))
+  H = int(rng.choice([1, 5, 8, 9, 31, 64, 66]))
+  use_h0 = bool(rng.randint(2))
+  lens = rng.randint(1, T + 1, size=S)
+  lens[rng.randint(S)] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32) if use_h0 else None
+  w = rng.standard_normal((S, H)).astype(np.float32)
+  for pool, cls in [('attention', 'Attention'), ('maxout', 'Maxout'), ('seq2seq', 'Seq2Seq')]:
+    torch.manual_seed(seed)
+    layer = getattr(layers, cls)(I, H)
+    with torch.no_grad():
+      layer.rnn.bias_ih_l0.normal_(0, 0.1)
+      layer.rnn.bias_hh_l0.normal_(0, 0.1)
+    sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    layer = layer.to(dev)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True) if use_h0 else None
+    y = layer(xt, torch.from_numpy(lens), ht)
+    (y * torch.from_numpy(w).to(dev)).sum().backward()
+    want, c = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+    tag = '%s S%d T%d I%d H%d h0=%d' % (pool, S, T, I, H, use_h0)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, atol=EMB_TOL, rtol=0, err_msg=tag)
+    grads, dx, dh0 = oracle.pooled_gru_backward(c, w.astype(np.float64))
+    grad_close(xt.grad.cpu().numpy()[:, :dx.shape[1]], dx, tag + ' dx')
+    if use_h0:
+      grad_close(ht.grad.cpu().numpy(), dh0, tag + ' dh0')
+    for pn, pp in layer.named_parameters():
+      grad_close(pp.grad.cpu().numpy(), grads['rnn.' + pn], tag + ' ' + pn)
 
 
 # ------------------------------------------------------------------------------------------
