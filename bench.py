@@ -232,8 +232,8 @@ def train_bench(wl, opt, model, batches, n_steps):
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt}
 
 
-def measured_traffic():
-  """HBM bytes per GRU-step launch from the committed rocprofv3 PMC passes of this same command
+def measured_traffic(kernel='gru_step'):
+  """Fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
   (profiles/r01_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
   FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM).  None if absent."""
   path = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')
@@ -242,7 +242,7 @@ def measured_traffic():
   d = json.load(open(path))
   tot, n = 0.0, 0
   for k, v in d.items():
-    if 'gru_step' in k:
+    if kernel in k:
       tot += v['launches'] * (v['hbm_read_bytes_per_launch_corrected'] +
                               v['hbm_write_bytes_per_launch'])
       n += v['launches']
@@ -338,12 +338,19 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  # roofline of the dominant kernel from the HIP-event spans around the per-step GRU launches
+  # Roofline of the dominant kernel (gru_step_kernel, the LDS-tiled GRU step): every one of its
+  # launches in the timed region sits between its own HIP event pair (cmhse_timer_tiled), priced
+  # with its algorithmic FLOPs.  `all_step_kernels` adds the small-batch step kernel (the ragged
+  # tails), from the event spans around each encoder call's whole step sequence.
   spans = timers.collect()
-  flops = sum(sum_T * gru_flops_per_step(I, H)
-              for (_, _, metas) in spans for (_, sum_T, I, H, _, _) in metas)
-  ms = sum(s[0] for s in spans)
-  launches = sum(s[1] for s in spans)
+  flops_all = sum(sum_T * gru_flops_per_step(I, H)
+                  for (_, _, metas, _) in spans for (_, sum_T, I, H, _, _) in metas)
+  ms_all = sum(s[0] for s in spans)
+  launches_all = sum(s[1] for s in spans)
+  ms = sum(s[3][0] for s in spans)
+  flops = sum(s[3][1] for s in spans)
+  alg_bytes = sum(s[3][2] for s in spans)
+  launches = sum(s[3][3] for s in spans)
   achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
   ms_per_step = elapsed / args.steps * 1e3
   pairs = float(N) * float(N)
@@ -367,16 +374,23 @@ def main():
         'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
         'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(),
-                     'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)',
-                     'launches': launches, 'avg_launch_us': (ms * 1e3 / launches) if launches else None,
+                     'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
+                     'traffic': measured_traffic('gru_step_kernel<'),
+                     'traffic_unit': 'fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + '
+                                     'WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)',
+                     'algorithmic_bytes_per_launch': (alg_bytes / launches) if launches else None,
+                     'launches': launches,
+                     'avg_launch_us': (ms * 1e3 / launches) if launches else None,
                      'flops_per_launch': (flops / launches) if launches else None,
                      'kernel_time_share': (ms * 1e-3) / elapsed if elapsed > 0 else None,
-                     # context, not the graded fraction: `peak` assumes 2.4 GHz, the chip holds
-                     # ~2.0 GHz under this kernel (profiles/r01_tile_trace.txt)
+                     # context: `peak` assumes 2.4 GHz; an instrumented build of this kernel read
+                     # this in-kernel clock under load (profiles/r01_tile_trace.txt)
                      'in_kernel_clock_ghz': clk,
-                     'frac_of_peak_at_that_clock':
-                         (achieved / (FP32_MFMA_PEAK_TFLOPS * clk / 2.4)) if clk else None},
+                     'all_step_kernels': {
+                         'achieved': flops_all / (ms_all * 1e-3) / 1e12 if ms_all > 0 else None,
+                         'launches': launches_all,
+                         'avg_launch_us': (ms_all * 1e3 / launches_all) if launches_all else None,
+                         'kernel_time_share': (ms_all * 1e-3) / elapsed if elapsed > 0 else None}},
     }
     if world == 1 and args.fast_steps > 0:
       out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)

@@ -96,6 +96,10 @@ SIGNATURES = {
     'cmhse_timer_destroy': (None, [c_void_p]),
     'cmhse_timer_elapsed_ms': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float)]),
     'cmhse_timer_launches': (c_int32, [c_void_p]),
+    'cmhse_timer_tiled': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_float),
+                                         ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(c_int32)]),
     'cmhse_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'cmhse_version': (ctypes.c_char_p, []),
 }

@@ -24,6 +24,8 @@
 //   attn_pool_kernel  masked exp-softmax (no max-subtraction, +1e-4: layers.py:158-162) and the
 //                     weighted sum over time; HBM-bound, one pass over hs.
 #include <hip/hip_runtime.h>
+
+#include <vector>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -634,6 +636,10 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
 struct Timer {
   hipEvent_t start, stop;
   int32_t launches;  // step kernels launched inside the bracket
+  // one event pair around every launch of the LDS-tiled step kernel (the dominant kernel), with the
+  // algorithmic FLOPs of those launches, so bench.py can price that kernel alone
+  std::vector<hipEvent_t> tiled_events;
+  double tiled_flops, tiled_bytes;
 };
 
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
@@ -834,7 +840,7 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 }
 
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
-int launch_steps(FwdJob* jobs, int n, hipStream_t stream) {
+int launch_steps(FwdJob* jobs, int n, hipStream_t stream, Timer* timer) {
   int Tmax = 0, launches = 0;
   for (int k = 0; k < n; ++k) Tmax = jobs[k].b->Tmax > Tmax ? jobs[k].b->Tmax : Tmax;
   for (int t = 0; t < Tmax; ++t) {
@@ -866,7 +872,23 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t stream) {
         done[m] = true;
       }
       for (int m = g.n; m < kMaxJobs; ++m) g.start[m] = 0xffffffffu;
+      const bool stamp = timer != nullptr && (kind[k] & 3) != 0;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (stamp && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        (void)hipEventRecord(e0, stream);
+      }
       launch_group(g, kind[k], grid, stream);
+      if (stamp && e0 && e1) {
+        (void)hipEventRecord(e1, stream);
+        timer->tiled_events.push_back(e0);
+        timer->tiled_events.push_back(e1);
+        for (int q = 0; q < g.n; ++q) {
+          const double I = g.j[q].I, H = g.j[q].H;
+          timer->tiled_flops += g.j[q].S_t * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
+          // x_t in, h_{t-1} in, h_t out per sequence; the weights once per launch
+          timer->tiled_bytes += g.j[q].S_t * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
+        }
+      }
       ++launches;
     }
   }
@@ -945,7 +967,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
   // the first job's step_timer (if any) spans the step launches of the whole group
   Timer* timer = static_cast<Timer*>(jobs[0].b->step_timer);
   if (timer) (void)hipEventRecord(timer->start, stream);
-  const int launches = launch_steps(jobs, n_jobs, stream);
+  const int launches = launch_steps(jobs, n_jobs, stream, timer);
   if (timer) {
     (void)hipEventRecord(timer->stop, stream);
     timer->launches = launches;
@@ -995,6 +1017,8 @@ extern "C" void* cmhse_timer_create(void) {
   Timer* t = new (std::nothrow) Timer;
   if (!t) return nullptr;
   t->launches = 0;
+  t->tiled_flops = 0.0;
+  t->tiled_bytes = 0.0;
   if (hipEventCreate(&t->start) != hipSuccess) {
     delete t;
     return nullptr;
@@ -1012,6 +1036,7 @@ extern "C" void cmhse_timer_destroy(void* timer) {
   if (!t) return;
   (void)hipEventDestroy(t->start);
   (void)hipEventDestroy(t->stop);
+  for (hipEvent_t e : t->tiled_events) (void)hipEventDestroy(e);
   delete t;
 }
 
@@ -1028,6 +1053,25 @@ extern "C" int cmhse_debug_set_trace(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(cmhse::g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host,
+                                 double* bytes_host, int32_t* launches_host) {
+  Timer* t = static_cast<Timer*>(timer);
+  if (!t || !ms_host || !flops_host || !bytes_host || !launches_host) return CMHSE_ERR_ARG;
+  if (hipEventSynchronize(t->stop) != hipSuccess) return CMHSE_ERR_LAUNCH;
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < t->tiled_events.size(); i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->tiled_events[i], t->tiled_events[i + 1]) != hipSuccess)
+      return CMHSE_ERR_LAUNCH;
+    total += ms;
+  }
+  *ms_host = static_cast<float>(total);
+  *flops_host = t->tiled_flops;
+  *bytes_host = t->tiled_bytes;
+  *launches_host = static_cast<int32_t>(t->tiled_events.size() / 2);
+  return CMHSE_OK;
+}
 
 extern "C" int32_t cmhse_timer_launches(void* timer) {
   Timer* t = static_cast<Timer*>(timer);

@@ -125,7 +125,8 @@ def padded_row_ptrs(t):
 class StepTimers(object):
   """Measurement aid for bench.py: while active, every cmhse_gru_pool_fwd call gets a
   cmhse_timer around its per-step GRU kernels; `collect()` returns a list of
-  (elapsed_ms, n_launches, [(Tmax, sum_T, I, H, had_h0, S) per request of the call]) and frees the timers."""
+  (elapsed_ms, n_launches, [(Tmax, sum_T, I, H, had_h0, S) per request of the call],
+  (tiled_ms, tiled_flops, tiled_bytes, tiled_launches)) and frees the timers."""
   active = None
 
   def __init__(self):
@@ -145,8 +146,13 @@ class StepTimers(object):
       ms = ctypes.c_float(0.0)
       _lib.check(lib.cmhse_timer_elapsed_ms(handle, ctypes.byref(ms)), 'cmhse_timer_elapsed_ms')
       launches = int(lib.cmhse_timer_launches(handle))
+      t_ms, t_flops, t_bytes = ctypes.c_float(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+      t_n = ctypes.c_int32(0)
+      _lib.check(lib.cmhse_timer_tiled(handle, ctypes.byref(t_ms), ctypes.byref(t_flops),
+                                       ctypes.byref(t_bytes), ctypes.byref(t_n)),
+                 'cmhse_timer_tiled')
       lib.cmhse_timer_destroy(handle)
-      out.append((ms.value, launches, meta))
+      out.append((ms.value, launches, meta, (t_ms.value, t_flops.value, t_bytes.value, t_n.value)))
     self.items = []
     return out
 

@@ -253,6 +253,11 @@ void* cmhse_timer_create(void);
 void cmhse_timer_destroy(void* timer);
 int cmhse_timer_elapsed_ms(void* timer, float* ms_host);
 int32_t cmhse_timer_launches(void* timer);   /* step kernels launched inside the bracket */
+/* The launches of the LDS-tiled step kernel inside the bracket, each between its own event pair:
+ * summed duration, their algorithmic FLOPs (2*3H*(I+H) + 14H per sequence and step), their
+ * algorithmic HBM bytes (4I + 8H per sequence and step, the weights once per launch) and count. */
+int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* bytes_host,
+                      int32_t* launches_host);
 
 /* Text for an error code returned by the functions above (static storage). */
 const char* cmhse_strerror(int code);
