@@ -473,21 +473,24 @@ void attn_energy_kernel(const AttnEnergyParams p) {
     br[i] = BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
                 : row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
   }
-  f32x16 acc[MSUB][4];
+  constexpr int NS = BN / 64;   // 32-column sub-tiles per wave
+  f32x16 acc[MSUB][NS];
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
-  const int b_row0[4] = {wn * 128, wn * 128 + 32, wn * 128 + 64, wn * 128 + 96};
-  if (BF3)
-    nt_phase_bf3<BM, BN, MSUB, 4, 4, 3>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-  else
-    nt_phase<BM, BN, MSUB, 4, 4, 3, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-
-  // epilogue: per-row partial dot over this wave's 128 columns, then the two N-waves via LDS
-  float wa[4], bl[4];
+    for (int a = 0; a < NS; ++a) acc[ms][a] = zero16();
+  int b_row0[NS];
 #pragma unroll
-  for (int ns = 0; ns < 4; ++ns) {
+  for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
+  if (BF3)
+    nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+  else
+    nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+
+  // epilogue: per-row partial dot over this wave's BN/2 columns, then the two N-waves via LDS
+  float wa[NS], bl[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
     const int n = n0 + b_row0[ns] + acc_col(lane);
     wa[ns] = (n < H) ? p.w_att[n] : 0.f;
     bl[ns] = (n < H) ? p.b_lin[n] : 0.f;
@@ -500,7 +503,7 @@ void attn_energy_kernel(const AttnEnergyParams p) {
       float s = 0.f;
       const int64_t vm = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
 #pragma unroll
-      for (int ns = 0; ns < 4; ++ns) {
+      for (int ns = 0; ns < NS; ++ns) {
         const float tv = tanhf_(acc[ms][ns][r] + bl[ns]);
         s += wa[ns] * tv;
         const int n = n0 + b_row0[ns] + acc_col(lane);

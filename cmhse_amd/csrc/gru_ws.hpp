@@ -16,7 +16,10 @@
 
 namespace cmhse {
 
-constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
+#ifndef CMHSE_ATT_BN
+#define CMHSE_ATT_BN 256
+#endif
+constexpr int kAttBN = CMHSE_ATT_BN;  // columns of W_lin per attention-energy workgroup (128 or 256)
 
 struct GruWs {
   size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, total;
