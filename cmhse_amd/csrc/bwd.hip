@@ -376,9 +376,9 @@ struct BwdStepParams {
   int64_t off_cur, off_prev;
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(kThreads) void gru_bwd_step_kernel(const BwdStepParams q) {
-  __shared__ float red[4][16][64];
+template <bool VEC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gru_bwd_step_kernel(const BwdStepParams q) {
+  __shared__ float red[NW][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = q.H, K = 3 * H;
   const int u_tiles = (H + 31) / 32;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_step_kernel(const BwdStepPar
     const int mc = (m < q.S_next) ? m : (q.S_next - 1);
     const int u = u0 + row;
     const int uc = (u < H) ? u : (H - 1);
-    tiny_phase<VEC>(row_addr(q.dgh_next + static_cast<int64_t>(mc) * K),
+    tiny_phase<VEC, NW>(row_addr(q.dgh_next + static_cast<int64_t>(mc) * K),
                     row_addr(q.whh_t + static_cast<int64_t>(uc) * K), u < H, K, wave, hi, acc);
   }
 #pragma unroll
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_step_kernel(const BwdStepPar
   // 4 elements per thread: tile row er, columns ec..ec+3
   const int er = tid >> 3, ec = (tid & 7) * 4;
   const int m = m0 + er;
-  if (m >= q.S_t) return;
+  if (tid >= 256 || m >= q.S_t) return;   // (with NW = 8 the upper four waves only split K)
   const int reg = (er & 3) | ((er >> 3) << 2);
   const int lb = 32 * ((er >> 2) & 1) + ec;
 #pragma unroll
@@ -408,8 +408,13 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_step_kernel(const BwdStepPar
     if (u >= H) continue;
     float rec = 0.f;
     if (m < q.S_next)
-      rec = red[0][reg][lb + j] + red[1][reg][lb + j] + red[2][reg][lb + j] + red[3][reg][lb + j] +
-            q.carry[static_cast<int64_t>(m) * H + u];
+    {
+      rec = q.carry[static_cast<int64_t>(m) * H + u];
+      float part = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) part += red[w][reg][lb + j];
+      rec += part;
+    }
     if (q.t < 0) {  // final launch: d loss / d h0
       q.dh0[static_cast<int64_t>(q.out_row[m]) * H + u] = rec;
       continue;
@@ -827,10 +832,18 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     sp.off_cur = off;
     sp.off_prev = (t > 0) ? off - b->step_count_host[t - 1] : 0;
     const unsigned grid = static_cast<unsigned>(u_tiles) * ((S_t + 31) / 32);
-    if (H % 4 == 0)
-      hipLaunchKernelGGL(gru_bwd_step_kernel<true>, dim3(grid), dim3(kThreads), 0, st, sp);
-    else
-      hipLaunchKernelGGL(gru_bwd_step_kernel<false>, dim3(grid), dim3(kThreads), 0, st, sp);
+    // few active sequences: a pure latency chain on an under-filled chip -> 8 waves split K
+    static const int nw8_max = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
+    if (S_t <= nw8_max) {
+      if (H % 4 == 0)
+        hipLaunchKernelGGL((gru_bwd_step_kernel<true, 8>), dim3(grid), dim3(512), 0, st, sp);
+      else
+        hipLaunchKernelGGL((gru_bwd_step_kernel<false, 8>), dim3(grid), dim3(512), 0, st, sp);
+    } else if (H % 4 == 0) {
+      hipLaunchKernelGGL((gru_bwd_step_kernel<true, 4>), dim3(grid), dim3(kThreads), 0, st, sp);
+    } else {
+      hipLaunchKernelGGL((gru_bwd_step_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, st, sp);
+    }
   }
 
   // ---- 3. weight gradients over all packed rows ----

@@ -331,12 +331,14 @@ constexpr int kTinyBM = 32;
 constexpr int kTinyBU = 8;
 constexpr int kTinyMaxSeqs = 1024;  // above this the LDS-tiled kernel is faster (measured sweep)
 
-template <bool VEC>
-__global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepGroup grp) {
+// NW = waves per workgroup splitting K: 4, or 8 when so few sequences are active that the launch
+// is a pure latency chain (half the MFMA chain per wave, twice the waves on an under-filled chip).
+template <bool VEC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGroup grp) {
   constexpr int BM = kTinyBM, BU = kTinyBU;
   unsigned wg;
   const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  __shared__ float red[4][2][16][64];  // [wave][x|h accumulator][register][lane], 32 KB
+  __shared__ float red[NW][2][16][64];  // [wave][x|h accumulator][register][lane], 8 KB per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u_tiles = (p.H + BU - 1) / BU;
   const int u0 = (wg % u_tiles) * BU;  // unit tile fastest: b, b+8 share an XCD's L2
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepGr
   const rowaddr_t bh = row_addr(p.w_hh + (static_cast<int64_t>(gc) * H + uc) * H);
 
   f32x16 acc_x = zero16(), acc_h = zero16();
-  tiny_phase<VEC>(ax, bx, bvalid, I, wave, hi, acc_x);
-  if (have_h) tiny_phase<VEC>(ah, bh, bvalid, H, wave, hi, acc_h);
+  tiny_phase<VEC, NW>(ax, bx, bvalid, I, wave, hi, acc_x);
+  if (have_h) tiny_phase<VEC, NW>(ah, bh, bvalid, H, wave, hi, acc_h);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     red[wave][0][r][lane] = acc_x[r];
@@ -384,12 +386,12 @@ __global__ __launch_bounds__(kThreads) void gru_step_tiny_kernel(const GruStepGr
   // col+16 of the half-wave that owns the row
   const int er = tid >> 3, eu = tid & 7;         // tile row 0..31, unit 0..7
   const int em = m0 + er, u = u0 + eu;
-  if (em >= p.S_t || u >= H) return;
+  if (tid >= 256 || em >= p.S_t || u >= H) return;   // (with NW = 8 the upper four waves only split K)
   const int reg = (er & 3) | ((er >> 3) << 2);
   const int lbase = 32 * ((er >> 2) & 1) + eu;
   float xr = 0.f, xz = 0.f, xn = 0.f, hr = 0.f, hz = 0.f, hn_ = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     xr += red[w][0][reg][lbase];
     xz += red[w][0][reg][lbase + 8];
     xn += red[w][0][reg][lbase + 16];
@@ -796,8 +798,15 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
 
 // Which step kernel serves job `j` at its current step: 0 = tiny, 1 = tiled fp32, 2 = tiled bf16x3;
 // bit 2 = scalar-load variant.  Jobs of equal kind share a launch.
+// active sequences at or below which the small-batch kernels split K over 8 waves instead of 4
+static int tiny_nw8_max() {
+  static const int v = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
+  return v;
+}
+
 int step_kind(const FwdJob& j, int S_t) {
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
+  if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
   return k | (j.vec ? 0 : 4);
 }
 
@@ -806,10 +815,16 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   const int msub = gru_msub();
   switch (kind & 3) {
     case 0:
-      if (vec)
-        hipLaunchKernelGGL(gru_step_tiny_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, g);
-      else
-        hipLaunchKernelGGL(gru_step_tiny_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, g);
+      if ((kind & 16) != 0) {
+        if (vec)
+          hipLaunchKernelGGL((gru_step_tiny_kernel<true, 8>), dim3(grid), dim3(512), 0, stream, g);
+        else
+          hipLaunchKernelGGL((gru_step_tiny_kernel<false, 8>), dim3(grid), dim3(512), 0, stream, g);
+      } else if (vec) {
+        hipLaunchKernelGGL((gru_step_tiny_kernel<true, 4>), dim3(grid), dim3(kThreads), 0, stream, g);
+      } else {
+        hipLaunchKernelGGL((gru_step_tiny_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, stream, g);
+      }
       break;
     case 2: {
       // staging-bound loop: the 128-row tile halves the weight bytes per MFMA

@@ -476,21 +476,22 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
 }
 
 // Split-K building block of the latency-shaped kernels (gru_step_tiny_kernel, gru_bwd_step_kernel):
-// one 32x32 accumulator; this wave takes the 8-k blocks wave, wave+4, ... of K; the A and B
+// one 32x32 accumulator; NW (4 or 8) waves split K, this wave takes the 8-k blocks wave, wave+NW, ...; the A and B
 // fragments (row = lane&31, k = 8*kb + 4*(lane>>5) .. +3) go global -> registers directly in MFMA
 // layout through a 4-deep register ring, no LDS and no barrier.
 constexpr int kTinyRing = 4;
 
-template <bool VEC>
+template <bool VEC, int NW = 4>
 __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool bvalid, int K,
                                            int wave, int hi, f32x16& acc) {
-  const int nkb = (K + 7) / 8;                     // k-blocks of 8 in this phase
-  const int nmine = (nkb - wave + 3) / 4;          // blocks kb = wave, wave+4, ...
+  // NW waves split K: this wave takes the 8-k blocks wave, wave + NW, ...
+  const int nkb = (K + 7) / 8;                          // k-blocks of 8 in this phase
+  const int nmine = (nkb - wave + NW - 1) / NW;
   if (nmine <= 0) return;
   float4 ra[kTinyRing], rb[kTinyRing];
 #pragma unroll
   for (int d = 0; d < kTinyRing; ++d) {
-    const int k = (wave + 4 * d) * 8 + 4 * hi;
+    const int k = (wave + NW * d) * 8 + 4 * hi;
     ra[d] = issue_row4<VEC>(arow, k, K);
     rb[d] = issue_row4<VEC>(brow, k, K);
   }
@@ -498,18 +499,19 @@ __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool 
 #if !defined(CMHSE_NO_LEAN_LOOP)
   if (VEC) {
     // Lean steady state (see nt_phase): while every k this trip consumes or prefetches lies inside
-    // K — for all four waves, so the bound is uniform — no tail masks, no clamps, and the loads go
-    // through running pointers with immediate offsets (slot d of the ring is 128 B further).
+    // K — for all NW waves, so the bound is uniform — no tail masks, no clamps, and the loads go
+    // through running pointers with immediate offsets (slot d of the ring is 32 NW bytes further).
     // Columns that are never stored (bvalid == false) need no zeroing either.
-    constexpr unsigned kAhead = 4u * kTinyRing * 8u * 4u;   // prefetch distance in bytes
+    constexpr unsigned kSlot = NW * 8u * 4u;               // bytes between ring slots
+    constexpr unsigned kAhead = kSlot * kTinyRing;         // prefetch distance in bytes
     rowaddr_t pa = arow + static_cast<rowaddr_t>(wave * 8 + 4 * hi) * 4u + kAhead;
     rowaddr_t pb = brow + static_cast<rowaddr_t>(wave * 8 + 4 * hi) * 4u + kAhead;
-    for (; 32 * it + 256 <= K; it += kTinyRing) {
+    for (; 8 * NW * it + 64 * NW <= K; it += kTinyRing) {
 #pragma unroll
       for (int d = 0; d < kTinyRing; ++d) {
         const float4 a = ra[d], b = rb[d];
-        const f32x4 ga = *(gptr_f32x4)(pa + 128u * d);
-        const f32x4 gb = *(gptr_f32x4)(pb + 128u * d);
+        const f32x4 ga = *(gptr_f32x4)(pa + kSlot * d);
+        const f32x4 gb = *(gptr_f32x4)(pb + kSlot * d);
         ra[d] = make_float4(ga.x, ga.y, ga.z, ga.w);
         rb[d] = make_float4(gb.x, gb.y, gb.z, gb.w);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -517,18 +519,18 @@ __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
       }
-      pa += 128u * kTinyRing;
-      pb += 128u * kTinyRing;
+      pa += kSlot * kTinyRing;
+      pb += kSlot * kTinyRing;
     }
   }
 #endif
   for (; it < nmine; it += kTinyRing) {
 #pragma unroll
     for (int d = 0; d < kTinyRing; ++d) {
-      const int k = (wave + 4 * (it + d)) * 8 + 4 * hi;
+      const int k = (wave + NW * (it + d)) * 8 + 4 * hi;
       const float4 a = finish_row4<VEC>(ra[d], true, k, K);
       const float4 b = finish_row4<VEC>(rb[d], bvalid, k, K);
-      const int kn = k + 4 * kTinyRing * 8;
+      const int kn = k + NW * kTinyRing * 8;
       ra[d] = issue_row4<VEC>(arow, kn, K);
       rb[d] = issue_row4<VEC>(brow, kn, K);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
