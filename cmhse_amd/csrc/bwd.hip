@@ -309,6 +309,7 @@ struct NtOutParams {
   int64_t ldc;
   const uint64_t* c_addr;
   int32_t M, N, K, n_tiles, mode;
+  int32_t k_seg;   // split-K: blockIdx.y takes k in [y*k_seg, min(K, (y+1)*k_seg)); 0 = no split
 };
 
 template <bool VEC>
@@ -328,13 +329,23 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_out_kernel(const NtOutParams
     ar[i] = row_addr(q.a + static_cast<int64_t>(av[i] ? m : 0) * q.lda);
     br[i] = row_addr(q.b + static_cast<int64_t>(bv[i] ? n : 0) * q.ldb);
   }
+  int K = q.K;
+  if (q.k_seg > 0) {
+    const int k0 = static_cast<int>(blockIdx.y) * q.k_seg;
+    K = (q.K - k0 < q.k_seg) ? (q.K - k0) : q.k_seg;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ar[i] += static_cast<rowaddr_t>(k0) * 4u;
+      br[i] += static_cast<rowaddr_t>(k0) * 4u;
+    }
+  }
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
   const int b_row0[2] = {wn * 64, wn * 64 + 32};
-  nt_phase<BM, BN, 2, 2, 2, 1, VEC>(smem, ar, av, br, bv, q.K, wm * 64, b_row0, acc);
+  nt_phase<BM, BN, 2, 2, 2, 1, VEC>(smem, ar, av, br, bv, K, wm * 64, b_row0, acc);
 #pragma unroll
   for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -677,19 +688,35 @@ static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid), dim3(kThreads), smem, st, q);
 }
 
+// `split_ok`: the caller's C is a dense [M, ldc] matrix this call may zero and fill with atomic
+// adds — the weight-gradient GEMMs have few output tiles (24 x 4 for dW_ih at H = 1024, I = 500)
+// and a long K (all packed rows), so K is split until about three workgroups per CU exist.
 static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
                           int64_t ldc, const uint64_t* c_addr, int M, int N, int K, int mode,
-                          hipStream_t st) {
+                          hipStream_t st, bool split_ok = false) {
   NtOutParams q;
   q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.c = c; q.ldc = ldc; q.c_addr = c_addr;
   q.M = M; q.N = N; q.K = K; q.mode = mode; q.n_tiles = (N + 127) / 128;
+  q.k_seg = 0;
   const unsigned grid = static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
+  unsigned splits = 1;
+  if (split_ok && mode == 0 && c_addr == nullptr && ldc == N && grid < 512 && K >= 2048) {
+    splits = (768 + grid - 1) / grid;
+    const unsigned max_splits = static_cast<unsigned>(K / 1024);   // >= 64 chunks per segment
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 1) {
+      q.k_seg = ((K + static_cast<int>(splits) - 1) / static_cast<int>(splits) + 15) / 16 * 16;
+      splits = static_cast<unsigned>((K + q.k_seg - 1) / q.k_seg);
+      q.mode = 2;
+      (void)hipMemsetAsync(c, 0, static_cast<size_t>(M) * N * sizeof(float), st);
+    }
+  }
   const size_t smem = TileSmem<128, 128>::kBytes;
   const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
   if (vec)
-    hipLaunchKernelGGL(gemm_nt_out_kernel<true>, dim3(grid), dim3(kThreads), smem, st, q);
+    hipLaunchKernelGGL(gemm_nt_out_kernel<true>, dim3(grid, splits), dim3(kThreads), smem, st, q);
   else
-    hipLaunchKernelGGL(gemm_nt_out_kernel<false>, dim3(grid), dim3(kThreads), smem, st, q);
+    hipLaunchKernelGGL(gemm_nt_out_kernel<false>, dim3(grid, splits), dim3(kThreads), smem, st, q);
 }
 
 struct BwdWs {
@@ -800,7 +827,7 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     // d W_lin[n][k] = sum_p du[p][n] hs[p][k]
     launch_gather_t(du, H, nullptr, t_a, sum_T, H, kp, st);
     launch_gather_t(hs, H, nullptr, t_b, sum_T, H, kp, st);
-    launch_nt_out(t_a, kp, t_b, kp, g->dw_lin, H, nullptr, H, H, static_cast<int>(kp), 0, st);
+    launch_nt_out(t_a, kp, t_b, kp, g->dw_lin, H, nullptr, H, H, static_cast<int>(kp), 0, st, true);
     // dpool += du . W_lin  (NT on W_lin^T)
     launch_transpose(w->w_lin, wlin_t, H, H, st);
     launch_nt_out(du, H, wlin_t, H, dpool, H, nullptr, static_cast<int>(sum_T), H, H, 1, st);
@@ -859,10 +886,10 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   // K-contiguous, then the NT tile loop (twice the rate of the [k][m]-staged TN loop)
   launch_gather_t(dgx, 3 * H, nullptr, t_a, sum_T, 3 * H, kp, st);
   launch_gather_t(nullptr, 0, xaddr, t_b, sum_T, I, kp, st);
-  launch_nt_out(t_a, kp, t_b, kp, g->dw_ih, I, nullptr, 3 * H, I, static_cast<int>(kp), 0, st);
+  launch_nt_out(t_a, kp, t_b, kp, g->dw_ih, I, nullptr, 3 * H, I, static_cast<int>(kp), 0, st, true);
   launch_gather_t(dgh, 3 * H, nullptr, t_a, sum_T, 3 * H, kp, st);
   launch_gather_t(nullptr, 0, hpaddr, t_b, sum_T, H, kp, st);
-  launch_nt_out(t_a, kp, t_b, kp, g->dw_hh, H, nullptr, 3 * H, H, static_cast<int>(kp), 0, st);
+  launch_nt_out(t_a, kp, t_b, kp, g->dw_hh, H, nullptr, 3 * H, H, static_cast<int>(kp), 0, st, true);
   launch_colsum(dgx, nullptr, g->db_ih, cs_scratch, sum_T, 3 * H, 3 * H, st);
   launch_colsum(dgh, nullptr, g->db_hh, cs_scratch, sum_T, 3 * H, 3 * H, st);
 
