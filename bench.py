@@ -359,6 +359,7 @@ def main():
   pairs = float(N) * float(N)
 
   clk = measured_clock_ghz()
+  traffic = measured_traffic('gru_step_kernel<')
   if rank == 0:
     if isinstance(ranks_i, torch.Tensor):
       ranks_i = ranks_i.cpu().numpy()
@@ -378,10 +379,15 @@ def main():
         'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
-                     'traffic': measured_traffic('gru_step_kernel<'),
+                     'traffic': traffic,
                      'traffic_unit': 'fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + '
                                      'WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)',
                      'algorithmic_bytes_per_launch': (alg_bytes / launches) if launches else None,
+                     # north_star: achieved GB/s of the GRU = PMC traffic / live launch duration
+                     # (against ~8000 GB/s HBM; counts Infinity-Cache hits too — the kernel is
+                     # MFMA-bound, this is context)
+                     'traffic_gbps': (traffic / (ms * 1e-3 / launches) / 1e9)
+                                     if (traffic and launches and ms > 0) else None,
                      'launches': launches,
                      'avg_launch_us': (ms * 1e3 / launches) if launches else None,
                      'flops_per_launch': (flops / launches) if launches else None,
