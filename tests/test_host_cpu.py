@@ -168,3 +168,36 @@ def test_error_strings_cover_all_codes():
   lib = _lib.load()
   seen = {lib.cmhse_strerror(c).decode() for c in (0, -1, -2, -3, -4, -99)}
   assert len(seen) == 6
+
+
+def test_profile_tools_reduce_rocprof_csvs(tmp_path):
+  """tools/pmc_traffic.py and tools/summarize_rocprof.py on hand-made rocprofv3 CSVs: KiB units,
+  the gfx950 doubling of FETCH_SIZE, per-launch averages, and the markdown table."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  head = 'Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n'
+  for name, vals in (('FETCH_SIZE', (1024.0, 3072.0)), ('WRITE_SIZE', (512.0, 512.0))):
+    d = tmp_path / ('pmc_' + name) / 'box'
+    d.mkdir(parents=True)
+    rows = ''.join('%d,"void cmhse::gru_step_kernel<true, 1, false>(cmhse::GruStepGroup)",%s,%f\n'
+                   % (i, name, v) for i, v in enumerate(vals))
+    rows += '9,"void at::native::fill()",%s,7.0\n' % name
+    (d / '1_counter_collection.csv').write_text(head + rows)
+  out = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'pmc_traffic.py'),
+                                 str(tmp_path / 'pmc_FETCH_SIZE'), str(tmp_path / 'pmc_WRITE_SIZE')])
+  res = json.loads(out)
+  assert list(res) == ['void cmhse::gru_step_kernel<true, 1, false>']       # foreign kernels dropped
+  k = res['void cmhse::gru_step_kernel<true, 1, false>']
+  assert k['launches'] == 2
+  assert k['hbm_read_bytes_per_launch_corrected'] == 2.0 * 4096.0 * 1024.0 / 2
+  assert k['hbm_write_bytes_per_launch'] == 1024.0 * 1024.0 / 2
+  stats = tmp_path / 'kernel_stats.csv'
+  stats.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                   '"void cmhse::gru_step_kernel<true, 1, false>(cmhse::GruStepGroup)",4,8000000,'
+                   '2000000.0,80.0,1000000,3000000,1.0\n"k2",1,2000000,2000000.0,20.0,2000000,2000000,0.0\n')
+  md = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'summarize_rocprof.py'),
+                                str(stats), 'title']).decode()
+  assert 'total kernel time 10.000 ms' in md
+  assert '| 4 | 8.000 | 2000.00 | 1000.00 | 3000.00 | 80.00 |' in md
