@@ -711,6 +711,8 @@ struct FwdJob {
   int64_t sum_T, off;
   int32_t pool_mode;
   bool vec, bf3, save;
+  hipStream_t pool_stream;   // optional side stream for an early attention pass (or nullptr)
+  bool pooled;               // attention already launched (early, on pool_stream)
 };
 
 int gru_msub() {
@@ -858,6 +860,8 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 }
 
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
+int launch_attention(const FwdJob& job, hipStream_t stream);
+
 int launch_steps(FwdJob* jobs, int n, hipStream_t stream, Timer* timer) {
   int Tmax = 0, launches = 0;
   for (int k = 0; k < n; ++k) Tmax = jobs[k].b->Tmax > Tmax ? jobs[k].b->Tmax : Tmax;
@@ -908,6 +912,20 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t stream, Timer* timer) {
         }
       }
       ++launches;
+    }
+    // A request whose chain ends here while others go on: its attention pass starts now on its
+    // side stream and overlaps the others' remaining steps (few sequences, latency-bound).
+    for (int k = 0; k < n; ++k) {
+      FwdJob& j = jobs[k];
+      if (j.pooled || j.pool_stream == nullptr || j.pool_stream == stream ||
+          j.pool_mode != CMHSE_POOL_ATTN || t != j.b->Tmax - 1 || t == Tmax - 1)
+        continue;
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
+      (void)hipEventRecord(ev, stream);
+      (void)hipStreamWaitEvent(j.pool_stream, ev, 0);
+      (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
+      if (launch_attention(j, j.pool_stream) == CMHSE_OK) j.pooled = true;
     }
   }
   return launches;
@@ -981,6 +999,8 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     const int rc = prepare_job(reqs[k].seqs, reqs[k].weights, reqs[k].pool_mode, reqs[k].out,
                                reqs[k].workspace, reqs[k].workspace_bytes, stream, &jobs[k]);
     if (rc != CMHSE_OK) return rc;
+    jobs[k].pool_stream = static_cast<hipStream_t>(reqs[k].pool_stream);
+    jobs[k].pooled = false;
   }
   // the first job's step_timer (if any) spans the step launches of the whole group
   Timer* timer = static_cast<Timer*>(jobs[0].b->step_timer);
@@ -991,7 +1011,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     timer->launches = launches;
   }
   for (int k = 0; k < n_jobs; ++k) {
-    if (jobs[k].pool_mode != CMHSE_POOL_ATTN) continue;
+    if (jobs[k].pool_mode != CMHSE_POOL_ATTN || jobs[k].pooled) continue;
     const int rc = launch_attention(jobs[k], stream);
     if (rc != CMHSE_OK) return rc;
   }
@@ -1008,6 +1028,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   req.out = out;
   req.workspace = workspace;
   req.workspace_bytes = workspace_bytes;
+  req.pool_stream = nullptr;
   return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
 }
 

@@ -89,6 +89,7 @@ def _to_dev(t, device):
 
 TWO_STREAMS = [os.environ.get('CMHSE_TWO_STREAMS', '0') == '1']
 GROUP_TOWERS = [os.environ.get('CMHSE_GROUP_TOWERS', '1') == '1']
+EARLY_POOL = [os.environ.get('CMHSE_EARLY_POOL', '1') == '1']
 _SIDE_STREAMS = {}
 
 
@@ -180,10 +181,17 @@ def encode_group(model, group, contextual_model=True, device=None):
     # (cmhse_gru_pool_fwd_multi), then step t of both level-2 encoders.
     v_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
     t_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
+    # The visual chain (<= 80 frames) ends long before the text chain (paragraphs of hundreds of
+    # tokens, a handful of sequences per step by then): its attention pass starts right there on
+    # a side stream and runs beside the text tail instead of after it.
+    main = torch.cuda.current_stream(device)
+    side = _side_streams(device)[0] if EARLY_POOL[0] else None
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
         clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs),
         txt_rnn.request_ptrs(np.concatenate(len_cap + len_par), table.shape[1], device,
-                             tok_ptrs=t_ptrs, table=table)])
+                             tok_ptrs=t_ptrs, table=table)], pool_stream=side)
+    if side is not None:
+      main.wait_stream(side)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
 

@@ -382,26 +382,29 @@ def test_superbatch_equals_per_batch(dev):
 
 
 def test_stream_schedules_are_bit_identical(dev):
-  """The side-stream schedule of encode_group (the two towers on two streams) and the grouped
-  launches of cmhse_gru_pool_fwd_multi change launch order only, never a bit of the result."""
+  """The side-stream schedule of encode_group (the two towers on two streams), the grouped launches
+  of cmhse_gru_pool_fwd_multi and the early attention pass of the shorter chain on a side stream
+  change launch order only, never a bit of the result."""
   from cmhse_amd import synthetic, evaluation
   g = load_golden('model_attention.npz')
   opt, model = golden_model('attention', g)
   spec = synthetic.ragged_spec(37, seed=9)
   batches = synthetic.make_batches(spec, 8, opt.img_dim, opt.vocab_size, seed=2)
   keys = ('vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx')
-  saved = evaluation.TWO_STREAMS[0], evaluation.GROUP_TOWERS[0]
+  saved = evaluation.TWO_STREAMS[0], evaluation.GROUP_TOWERS[0], evaluation.EARLY_POOL[0]
   outs = []
   try:
-    for two, group in ((False, False), (True, False), (False, True)):
+    for two, group, early in ((False, False, False), (True, False, False), (False, True, False),
+                              (False, True, True)):
       evaluation.TWO_STREAMS[0], evaluation.GROUP_TOWERS[0] = two, group
+      evaluation.EARLY_POOL[0] = early
       for _ in range(3):   # repeat: a missing stream dependency shows up as a flaky mismatch
         with torch.no_grad():
           r = evaluation.encode_group(model, batches)
         torch.cuda.synchronize()
         outs.append({k: r[k].cpu().numpy() for k in keys})
   finally:
-    evaluation.TWO_STREAMS[0], evaluation.GROUP_TOWERS[0] = saved
+    evaluation.TWO_STREAMS[0], evaluation.GROUP_TOWERS[0], evaluation.EARLY_POOL[0] = saved
   for o in outs[1:]:
     for k in keys:
       assert np.array_equal(o[k], outs[0][k]), k
