@@ -42,7 +42,7 @@ class SeqBatch(ctypes.Structure):
 class GruJob(ctypes.Structure):
   _fields_ = [('seqs', ctypes.POINTER(SeqBatch)), ('weights', ctypes.POINTER(GruWeights)),
               ('pool_mode', c_int32), ('out', c_void_p), ('workspace', c_void_p),
-              ('workspace_bytes', c_size_t), ('pool_stream', c_void_p)]
+              ('workspace_bytes', c_size_t), ('tail_stream', c_void_p)]
 
 
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)

@@ -711,8 +711,8 @@ struct FwdJob {
   int64_t sum_T, off;
   int32_t pool_mode;
   bool vec, bf3, save;
-  hipStream_t pool_stream;   // optional side stream for an early attention pass (or nullptr)
-  bool pooled;               // attention already launched (early, on pool_stream)
+  hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
+  bool pooled;               // attention already launched (early, beside the others' tail)
 };
 
 int gru_msub() {
@@ -800,9 +800,12 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
 
 // Which step kernel serves job `j` at its current step: 0 = tiny, 1 = tiled fp32, 2 = tiled bf16x3;
 // bit 2 = scalar-load variant.  Jobs of equal kind share a launch.
-// active sequences at or below which the small-batch kernels split K over 8 waves instead of 4
+// Active sequences at or below which the small-batch FORWARD step splits K over 8 waves instead of
+// 4.  Off by default: the forward step gains nothing from it (its chain is not what bounds it), and
+// its 64 KB of LDS keeps the launch from slipping in beside an attention pass (tail_stream); the
+// BPTT step, whose K = 3H chain is twice as long, does use the 8-wave form (bwd.hip).
 static int tiny_nw8_max() {
-  static const int v = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
+  static const int v = [] { const char* e = getenv("CMHSE_TINY_FWD_NW8_MAX"); return e ? atoi(e) : 0; }();
   return v;
 }
 
@@ -862,8 +865,9 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
 int launch_attention(const FwdJob& job, hipStream_t stream);
 
-int launch_steps(FwdJob* jobs, int n, hipStream_t stream, Timer* timer) {
+int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;
+  hipStream_t stream = main_stream;   // where step launches go; moves to a tail stream at most once
   for (int k = 0; k < n; ++k) Tmax = jobs[k].b->Tmax > Tmax ? jobs[k].b->Tmax : Tmax;
   for (int t = 0; t < Tmax; ++t) {
     int kind[kMaxJobs];
@@ -913,19 +917,32 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t stream, Timer* timer) {
       }
       ++launches;
     }
-    // A request whose chain ends here while others go on: its attention pass starts now on its
-    // side stream and overlaps the others' remaining steps (few sequences, latency-bound).
+    // A request whose chain ends here while others go on: the others' remaining steps move to its
+    // tail stream and its attention pass starts now on the caller's stream, so the two overlap
+    // (the tail is a few sequences per step: latency-bound launches on an otherwise idle chip).
     for (int k = 0; k < n; ++k) {
       FwdJob& j = jobs[k];
-      if (j.pooled || j.pool_stream == nullptr || j.pool_stream == stream ||
-          j.pool_mode != CMHSE_POOL_ATTN || t != j.b->Tmax - 1 || t == Tmax - 1)
+      if (j.pooled || j.tail_stream == nullptr || j.tail_stream == main_stream ||
+          stream != main_stream || j.pool_mode != CMHSE_POOL_ATTN || t != j.b->Tmax - 1 ||
+          t == Tmax - 1)
         continue;
       hipEvent_t ev;
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
-      (void)hipEventRecord(ev, stream);
-      (void)hipStreamWaitEvent(j.pool_stream, ev, 0);
+      (void)hipEventRecord(ev, main_stream);
+      (void)hipStreamWaitEvent(j.tail_stream, ev, 0);
       (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
-      if (launch_attention(j, j.pool_stream) == CMHSE_OK) j.pooled = true;
+      stream = j.tail_stream;
+      if (launch_attention(j, main_stream) == CMHSE_OK) j.pooled = true;
+    }
+  }
+  if (stream != main_stream) {   // rejoin: everything after the steps is ordered on the caller's stream
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      (void)hipEventRecord(ev, stream);
+      (void)hipStreamWaitEvent(main_stream, ev, 0);
+      (void)hipEventDestroy(ev);
+    } else {
+      (void)hipStreamSynchronize(stream);
     }
   }
   return launches;
@@ -999,7 +1016,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     const int rc = prepare_job(reqs[k].seqs, reqs[k].weights, reqs[k].pool_mode, reqs[k].out,
                                reqs[k].workspace, reqs[k].workspace_bytes, stream, &jobs[k]);
     if (rc != CMHSE_OK) return rc;
-    jobs[k].pool_stream = static_cast<hipStream_t>(reqs[k].pool_stream);
+    jobs[k].tail_stream = static_cast<hipStream_t>(reqs[k].tail_stream);
     jobs[k].pooled = false;
   }
   // the first job's step_timer (if any) spans the step launches of the whole group
@@ -1028,7 +1045,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   req.out = out;
   req.workspace = workspace;
   req.workspace_bytes = workspace_bytes;
-  req.pool_stream = nullptr;
+  req.tail_stream = nullptr;
   return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
 }
 

@@ -93,6 +93,13 @@ EARLY_POOL = [os.environ.get('CMHSE_EARLY_POOL', '1') == '1']
 _SIDE_STREAMS = {}
 
 
+def _tail_stream(device):
+  key = (device.type, device.index, 'tail')
+  if key not in _SIDE_STREAMS:
+    _SIDE_STREAMS[key] = torch.cuda.Stream(device, priority=-1)   # above the default priority
+  return _SIDE_STREAMS[key]
+
+
 def _side_streams(device):
   key = (device.type, device.index)
   if key not in _SIDE_STREAMS:
@@ -182,16 +189,13 @@ def encode_group(model, group, contextual_model=True, device=None):
     v_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
     t_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
     # The visual chain (<= 80 frames) ends long before the text chain (paragraphs of hundreds of
-    # tokens, a handful of sequences per step by then): its attention pass starts right there on
-    # a side stream and runs beside the text tail instead of after it.
-    main = torch.cuda.current_stream(device)
-    side = _side_streams(device)[0] if EARLY_POOL[0] else None
+    # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
+    # side stream while the visual attention pass runs on this one, instead of after it.
+    tail = _tail_stream(device) if EARLY_POOL[0] else None
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
         clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs),
         txt_rnn.request_ptrs(np.concatenate(len_cap + len_par), table.shape[1], device,
-                             tok_ptrs=t_ptrs, table=table)], pool_stream=side)
-    if side is not None:
-      main.wait_stream(side)
+                             tok_ptrs=t_ptrs, table=table)], tail_stream=tail)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
 

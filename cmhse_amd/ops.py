@@ -215,13 +215,13 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, **kw):
                                   device=device, **kw)])[0]
 
 
-def gru_pool_fwd_multi(requests, pool_stream=None):
+def gru_pool_fwd_multi(requests, tail_stream=None):
   """cmhse_gru_pool_fwd_multi: `requests` is a list of keyword dicts (the arguments of
   gru_pool_fwd) for INDEPENDENT encoders; their time steps share launches.  Returns a list of
-  (out, ctx), bit-identical to separate gru_pool_fwd calls.  With `pool_stream` (a torch stream)
-  an attention-pooled request whose chain is shorter than the longest gets its pooling pass on
-  that stream, beside the others' remaining steps; the caller must `wait_stream(pool_stream)`
-  before it consumes the outputs."""
+  (out, ctx), bit-identical to separate gru_pool_fwd calls.  With `tail_stream` (a torch stream,
+  ideally high priority) the steps left over when an attention-pooled request's shorter chain
+  has ended continue there while that request's pooling pass runs on the current stream; the
+  call rejoins the current stream before it returns."""
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_fwd_multi takes 1..%d requests' % MAX_JOBS)
@@ -234,10 +234,10 @@ def gru_pool_fwd_multi(requests, pool_stream=None):
     jobs[k].out = job['out'].data_ptr()
     jobs[k].workspace = job['ws'].data_ptr()
     jobs[k].workspace_bytes = job['ws_bytes']
-    if pool_stream is not None and len(prepared) > 1:
-      jobs[k].pool_stream = ctypes.c_void_p(pool_stream.cuda_stream)
+    if tail_stream is not None and len(prepared) > 1:
+      jobs[k].tail_stream = ctypes.c_void_p(tail_stream.cuda_stream)
       for t in [job['out'], job['ws'], job['ctx']['sched'].meta] + job['ctx']['keep']:
-        t.record_stream(pool_stream)
+        t.record_stream(tail_stream)
   if StepTimers.active is not None:
     handle = lib.cmhse_timer_create()
     prepared[0][0]['b'].step_timer = handle

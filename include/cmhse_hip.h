@@ -127,12 +127,14 @@ typedef struct cmhse_gru_job {
   float* out;
   void* workspace;
   size_t workspace_bytes;
-  void* pool_stream;   /* optional second hipStream_t (or NULL).  When this request's last time
-                          step is launched while other requests of the call still have steps to
-                          go (a shorter chain beside a longer one), its attention projection +
-                          pooling are launched THERE, ordered after its steps by an event, and run
-                          beside the remaining (few-sequence, latency-bound) steps of the others.
-                          The caller orders its consumers after pool_stream. */
+  void* tail_stream;   /* optional second hipStream_t (or NULL), ideally of higher priority.  When
+                          this request's last time step is launched while other requests of the
+                          call still have steps to go (a short chain beside a long one), the
+                          REMAINING step launches of the call continue on tail_stream (ordered by
+                          an event) and this request's attention projection + pooling start at
+                          once on `stream`, beside that few-sequence, latency-bound tail.  The
+                          call rejoins `stream` (event wait) before its last launches, so the
+                          caller needs no extra ordering. */
 } cmhse_gru_job;
 int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
 
