@@ -8,9 +8,11 @@ evaluation.py:129), then score all N x N video-paragraph pairs in both direction
 ranks, top-1, Recall@K).  pairs = N^2; inputs are resident in HBM before the timed region.
 
 Workloads (config.workload):
-  anet_c3d_val   BASELINE configs[1] model (img_dim=500, embed=1024, attention pooling, loader
-                 batch 32) over the val_1-shaped split N=4917, sumC~17.5k  [default]
-  anet_icep_val  configs[4] model (img_dim=2048) over the same split
+  anet_icep_val  the metric's configuration (BASELINE configs[4], north_star "ActivityNet-ICEP val"):
+                 img_dim=2048, embed=1024, attention pooling, loader batch 32, over the
+                 val_1-shaped split N=4917, sumC~17.5k  [default]
+  anet_c3d_val   configs[1] model (img_dim=500) over the same split
+  didemo_icep_val configs[3] (img_dim=2048, all-80-frame clips, vocab 7205, N=1004)
   plumbing       configs[0]: 64 videos x 4 clips x 10 frames, batch 16
 
 N>1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL): the SAME split is
@@ -21,6 +23,14 @@ The JSON line also carries
   roofline      for the dominant kernel (gru_step_kernel): algorithmic FLOPs of the timed launches
                 (2*3H*I + 2*3H*H + 14H per sequence-step) / their HIP-event time,
                 against the exact-fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+  roofline_sim  the similarity GEMM (sim_kernel<Rank>): 2*nrows*M*D FLOP per direction over the
+                HIP-event time of that launch alone, against the same peak (north_star: "MFMA
+                utilisation on the similarity GEMM");
+  rank_check    in-run correctness signal: i2t/t2i ranks of the HIP path on
+                synthetic.correlated_embeddings(N, 1024, 3.0) against an fp64 NumPy recomputation
+                of a 256-row sample (mismatches must be 0);
+  pcie_inclusive the same pass with the loader batches in pinned HOST memory, uploaded inside the
+                timed pass (the reference's loader hands over host tensors, model.py:225-227);
   cpu_baseline  the NumPy oracle (oracle/, "port") timed on this host's cores on a bounded
                 sample of the same workload, extrapolated to the full split (encode ~ N,
                 scoring ~ N^2) — a reported baseline, never the thing measured as `value`.
@@ -183,27 +193,48 @@ def fast_mode_bench(opt, model, batches, N, n_steps):
     r_t, _ = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
     return cat, r_i, r_t
 
-  ref_cat, ref_ri, _ = one_pass()          # exact fp32
+  ref_cat, _, _ = one_pass()          # exact fp32
   try:
     ops.set_math_mode('bf16x3')
     one_pass()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_steps):
-      cat, r_i, _ = one_pass()
+      cat, _, _ = one_pass()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_steps
   finally:
     ops.set_math_mode('fp32')
   diff = max(float((cat[k] - ref_cat[k]).abs().max()) for k in ['vid_emb', 'para_emb', 'clip_emb',
                                                                  'cap_emb', 'vid_ctx', 'para_ctx'])
-  same = float((r_i == ref_ri).float().mean())
   return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
                   'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
                   'attention projection); ranking kernel exact fp32',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
-          'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
-          'i2t_ranks_identical_fraction': same}
+          'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff}
+
+
+def rank_check(N, D, n_sample=256, seed=0):
+  """In-run correctness signal: HIP ranks (both directions) on SURVEY §8d S5's scoring inputs
+  (normalize(z + 3 eps) pairs: R@1 ~ 33 %, a non-trivial rank distribution) against an fp64
+  recomputation of `n_sample` rows, rank_i = #{j : d_ij > d_ii} (evaluation.py:164-171)."""
+  a, b = synthetic.correlated_embeddings(N, D, 3.0, seed=seed)
+  ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+  rows = np.random.RandomState(seed).choice(N, min(n_sample, N), replace=False)
+  a64, b64 = a.astype(np.float64), b.astype(np.float64)
+  mism, r1 = 0, None
+  for q, g, q64, g64 in [(ad, bd, a64, b64), (bd, ad, b64, a64)]:
+    rank, top1 = ops.sim_rank(q, g)
+    rank, top1 = rank.cpu().numpy(), top1.cpu().numpy()
+    d = q64[rows] @ g64.T
+    dii = d[np.arange(len(rows)), rows]
+    want = (d > dii[:, None]).sum(1)
+    mism += int((rank[rows] != want).sum()) + int((top1[rows] != d.argmax(1)).sum())
+    if r1 is None:
+      r1 = 100.0 * float((rank < 1).mean())
+  return {'rows': int(len(rows)) * 2, 'mismatches': mism, 'r1_i2t': r1,
+          'inputs': 'synthetic.correlated_embeddings(%d, %d, 3.0), both directions, ranks and '
+                    'top-1 vs fp64 NumPy' % (N, D)}
 
 
 def train_bench(wl, opt, model, batches, n_steps):
@@ -236,10 +267,11 @@ def measured_traffic(kernel='gru_step'):
   """Fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
   (profiles/r01_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
   FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM).  None if absent."""
-  path = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')
-  if not os.path.exists(path):
+  import glob
+  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_hbm_traffic.json')))
+  if not paths:
     return None
-  d = json.load(open(path))
+  d = json.load(open(paths[-1]))
   tot, n = 0.0, 0
   for k, v in d.items():
     if kernel in k:
@@ -252,10 +284,11 @@ def measured_traffic(kernel='gru_step'):
 def measured_clock_ghz():
   """In-kernel shader clock of the tiled GRU step under load (median over workgroups), from the
   committed tools/tile_trace.py run (profiles/r01_tile_trace.txt).  None if absent."""
-  path = os.path.join(REPO, 'profiles', 'r01_tile_trace.txt')
-  if not os.path.exists(path):
+  import glob
+  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_tile_trace.txt')))
+  if not paths:
     return None
-  for line in open(path):
+  for line in open(paths[-1]):
     if line.startswith('in-kernel shader clock') and 'median' in line:
       try:
         return float(line.split('median')[1].split('GHz')[0])
@@ -269,7 +302,7 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
-  ap.add_argument('--workload', default='anet_c3d_val', choices=sorted(WORKLOADS))
+  ap.add_argument('--workload', default='anet_icep_val', choices=sorted(WORKLOADS))
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
@@ -277,9 +310,11 @@ def main():
                   help='also time this many passes in the bf16x3 math mode (0 = skip)')
   ap.add_argument('--train_steps', type=int, default=10,
                   help='also time this many VSE.train_emb steps on loader batches (0 = skip)')
-  ap.add_argument('--host_steps', type=int, default=0,
+  ap.add_argument('--host_steps', type=int, default=2,
                   help='also time this many passes with the loader batches in pinned HOST memory '
                        '(PCIe-inclusive rate; never the headline value)')
+  ap.add_argument('--rank_check', type=int, default=1,
+                  help='check HIP ranks on correlated embeddings against fp64 NumPy (0 = skip)')
   ap.add_argument('--cpu_batches', type=int, default=8,
                   help='loader batches in the CPU-baseline sample (0 = skip)')
   args = ap.parse_args()
@@ -331,11 +366,12 @@ def main():
     step()
   sync()
   t0 = time.perf_counter()
-  with ops.StepTimers() as timers:
+  with ops.StepTimers() as timers, ops.SimTimers() as sim_timers:
     for _ in range(args.steps):
       ranks_i, ranks_t = step()
     sync()
   elapsed = time.perf_counter() - t0
+  my_elapsed = elapsed
   if world > 1:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -346,6 +382,16 @@ def main():
   # with its algorithmic FLOPs.  `all_step_kernels` adds the small-batch step kernel (the ragged
   # tails), from the event spans around each encoder call's whole step sequence.
   spans = timers.collect()
+  sims = sim_timers.collect()
+  sim_ms = sum(x[0] for x in sims)
+  sim_flops = sum(2.0 * x[1] * x[2] * x[3] for x in sims)
+  sim_achieved = sim_flops / (sim_ms * 1e-3) / 1e12 if sim_ms > 0 else 0.0
+  per_rank_ms = [my_elapsed / args.steps * 1e3]
+  if world > 1:
+    t = torch.tensor([my_elapsed / args.steps * 1e3], dtype=torch.float64, device=device)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    per_rank_ms = [float(x.item()) for x in allt]
   flops_all = sum(sum_T * gru_flops_per_step(I, H)
                   for (_, _, metas, _) in spans for (_, sum_T, I, H, _, _) in metas)
   ms_all = sum(s[0] for s in spans)
@@ -376,6 +422,7 @@ def main():
                    'rnn_type': args.rnn_type, 'step': 'encode_data + i2t + t2i over the split',
                    'sharding': 'videos over ranks, all-gather embeddings, row-stripe scoring'},
         'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
+        'per_rank_ms_per_step': per_rank_ms,
         'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -401,6 +448,19 @@ def main():
                          'avg_launch_us': (ms_all * 1e3 / launches_all) if launches_all else None,
                          'kernel_time_share': (ms_all * 1e-3) / elapsed if elapsed > 0 else None}},
     }
+    out['roofline_sim'] = {
+        'kernel': 'sim_kernel<Rank>', 'bound': 'mfma', 'achieved': sim_achieved,
+        'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': sim_achieved / FP32_MFMA_PEAK_TFLOPS, 'launches': len(sims),
+        'avg_launch_us': (sim_ms * 1e3 / len(sims)) if sims else None,
+        'flops_per_launch': (sim_flops / len(sims)) if sims else None,
+        'algorithmic_bytes_per_launch': (sum(4.0 * (x[1] + x[2]) * x[3] + 8.0 * x[1] for x in sims)
+                                         / len(sims)) if sims else None,
+        'traffic': measured_traffic('sim_kernel<1'),
+        'note': '2*nrows*M*D FLOP per direction / HIP-event time of the counting pass alone '
+                '(cmhse_sim_rank_ex timer); rank 0\'s stripe when n_gpus > 1'}
+    if args.rank_check:
+      out['rank_check'] = rank_check(N, args.embed)
     if world == 1 and args.fast_steps > 0:
       out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)
     if world == 1 and args.train_steps > 0:

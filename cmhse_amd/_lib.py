@@ -57,6 +57,9 @@ SIGNATURES = {
     'cmhse_sim_rank_workspace': (c_size_t, [c_int32]),
     'cmhse_sim_rank': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmhse_sim_rank_ex': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                         c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                         c_void_p]),
     'cmhse_cosine_sim': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                         c_void_p]),
     'cmhse_contrastive_workspace': (c_size_t, [c_int32]),

@@ -638,15 +638,6 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
   for (int c = threadIdx.x; c < cols; c += kThreads) dst[c] = src[c];
 }
 
-struct Timer {
-  hipEvent_t start, stop;
-  int32_t launches;  // step kernels launched inside the bracket
-  // one event pair around every launch of the LDS-tiled step kernel (the dominant kernel), with the
-  // algorithmic FLOPs of those launches, so bench.py can price that kernel alone
-  std::vector<hipEvent_t> tiled_events;
-  double tiled_flops, tiled_bytes;
-};
-
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
 // split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
 // (k beyond K zero-filled), see nt_phase_bf3.

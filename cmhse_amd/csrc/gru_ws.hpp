@@ -12,6 +12,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/cmhse_hip.h"
 
 namespace cmhse {
@@ -59,5 +61,15 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   L.total = off;
   return L;
 }
+
+// cmhse_timer handle (measurement aid, include/cmhse_hip.h): HIP events owned by the handle.
+struct Timer {
+  hipEvent_t start, stop;
+  int32_t launches;  // step kernels launched inside the bracket
+  // one event pair around every launch of the LDS-tiled step kernel (the dominant kernel), with the
+  // algorithmic FLOPs of those launches, so bench.py can price that kernel alone
+  std::vector<hipEvent_t> tiled_events;
+  double tiled_flops, tiled_bytes;
+};
 
 }  // namespace cmhse

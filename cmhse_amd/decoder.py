@@ -58,18 +58,22 @@ class DecoderSequence(nn.Module):
 
 class _EuclidFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, a, b, b_rows, norm):
+  def forward(ctx, a, b, b_rows, norm, keepalive):
     ad = a.detach()
     bd = None if b is None else b.detach()
     loss, rows_dev = ops.euclid_fwd(ad, bd, b_rows, norm)
     ctx.save_for_backward(ad)
     ctx.b, ctx.rows_dev, ctx.norm = bd, rows_dev, norm
+    # the backward kernel reads the target rows through the raw addresses in `rows_dev`: the
+    # storage they point into must live as long as this graph node, not as long as the caller's
+    # local variables
+    ctx.keepalive = keepalive
     return loss
 
   @staticmethod
   def backward(ctx, g):
     (a,) = ctx.saved_tensors
-    return ops.euclid_bwd(a, ctx.b, ctx.rows_dev, ctx.norm, g), None, None, None
+    return ops.euclid_bwd(a, ctx.b, ctx.rows_dev, ctx.norm, g), None, None, None, None
 
 
 class EuclideanLoss(nn.Module):
@@ -80,7 +84,7 @@ class EuclideanLoss(nn.Module):
     self.norm = norm
 
   def forward_loss(self, clip_remap, clip_emb):
-    return _EuclidFn.apply(clip_remap, clip_emb, None, self.norm)
+    return _EuclidFn.apply(clip_remap, clip_emb, None, self.norm, None)
 
   def forward(self, clip_remap, clip_emb):
     return self.forward_loss(clip_remap, clip_emb)
@@ -88,6 +92,4 @@ class EuclideanLoss(nn.Module):
   def forward_rows(self, clip_remap, target_row_addrs, keepalive):
     """Targets addressed row by row (numpy uint64 device addresses into `keepalive`), e.g. the
     valid frames of a padded clip batch (model.py:350-361) without copying them out."""
-    loss = _EuclidFn.apply(clip_remap, None, target_row_addrs, self.norm)
-    loss._cmhse_keepalive = keepalive
-    return loss
+    return _EuclidFn.apply(clip_remap, None, target_row_addrs, self.norm, keepalive)

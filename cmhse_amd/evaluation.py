@@ -26,58 +26,50 @@ from . import ops
 
 
 class AverageMeter(object):
-  """/root/reference/evaluation.py:18-45 (note avg = sum / (1e-4 + count), update(val, n=0))."""
+  """Running value + weighted mean of one logged quantity — the contract of
+  /root/reference/evaluation.py:18-45: `update(val, n=0)` (a weight of 0 only refreshes `val`),
+  `avg = sum / (1e-4 + count)` (so an empty meter reads 0, not NaN), and the printed form."""
+  __slots__ = ('val', 'avg', 'sum', 'count')
 
   def __init__(self):
     self.reset()
 
   def reset(self):
-    self.val = 0
-    self.avg = 0
-    self.sum = 0
-    self.count = 0
+    self.val = self.avg = self.sum = self.count = 0
 
   def update(self, val, n=0):
     self.val = val
-    self.sum += val * n
+    self.sum += n * val
     self.count += n
-    self.avg = self.sum / (.0001 + self.count)
+    self.avg = self.sum / (self.count + 1e-4)
 
   def __str__(self):
-    if self.count == 0:
-      return str(self.val)
-    return '%.4f (%.4f)' % (self.val, self.avg)
+    return str(self.val) if self.count == 0 else '%.4f (%.4f)' % (self.val, self.avg)
 
 
 class LogCollector(object):
-  """/root/reference/evaluation.py:48-72."""
+  """Named AverageMeters in first-use order (/root/reference/evaluation.py:48-72): what
+  VSE.forward_loss writes to (`model.logger.update('Le'+name, value, n)`, model.py:291) and what
+  train.py prints / sends to tensorboard."""
 
   def __init__(self):
     self.meters = OrderedDict()
 
   def update(self, k, v, n=0):
-    if k not in self.meters:
-      self.meters[k] = AverageMeter()
-    self.meters[k].update(v, n)
+    self.meters.setdefault(k, AverageMeter()).update(v, n)
 
   def __str__(self):
-    s = ''
-    for i, (k, v) in enumerate(self.meters.items()):
-      if i > 0:
-        s += '  '
-      s += k + ' ' + str(v)
-    return s
+    return '  '.join('%s %s' % (k, m) for k, m in self.meters.items())
 
   def tb_log(self, tb_logger, prefix='', step=None):
-    for k, v in self.meters.items():
-      tb_logger.log_value(prefix + k, v.val, step=step)
+    for k, m in self.meters.items():
+      tb_logger.log_value(prefix + k, m.val, step=step)
 
 
 def LogReporter(tb_logger, result, epoch, name):
-  """/root/reference/evaluation.py:74-78."""
-  for key in result:
-    tb_logger.log_value(name + key, result[key], step=epoch)
-  return
+  """/root/reference/evaluation.py:74-78: one tensorboard scalar per report entry."""
+  for key, value in result.items():
+    tb_logger.log_value(name + key, value, step=epoch)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -288,20 +280,16 @@ def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_
 # i2t / t2i
 # ---------------------------------------------------------------------------------------------
 def report_from_ranks(ranks):
-  """evaluation.py:173-184; 'r10' is Recall@50 upstream (`ranks < 50`, :175)."""
-  r1 = 100.0 * len(numpy.where(ranks < 1)[0]) / len(ranks)
-  r5 = 100.0 * len(numpy.where(ranks < 5)[0]) / len(ranks)
-  r10 = 100.0 * len(numpy.where(ranks < 50)[0]) / len(ranks)
-  medr = numpy.floor(numpy.median(ranks)) + 1
-  meanr = ranks.mean() + 1
-  report_dict = dict()
-  report_dict['r1'] = r1
-  report_dict['r5'] = r5
-  report_dict['r10'] = r10
-  report_dict['medr'] = medr
-  report_dict['meanr'] = meanr
-  report_dict['sum'] = r1 + r5 + r10
-  return report_dict
+  """The six numbers of evaluation.py:173-184 from the 0-based ranks of the matching item:
+  recall at 1 / 5 / 50 in percent (the key 'r10' IS Recall@50 upstream: `ranks < 50`, :175),
+  median and mean rank 1-based, and the recall sum train.py uses as its model-selection score."""
+  ranks = numpy.asarray(ranks)
+  recall = {key: 100.0 * numpy.count_nonzero(ranks < k) / len(ranks)
+            for key, k in (('r1', 1), ('r5', 5), ('r10', 50))}
+  recall['medr'] = numpy.floor(numpy.median(ranks)) + 1
+  recall['meanr'] = ranks.mean() + 1
+  recall['sum'] = recall['r1'] + recall['r5'] + recall['r10']
+  return recall
 
 
 def _as_device(x):

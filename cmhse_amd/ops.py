@@ -285,6 +285,33 @@ def gather_rows(table, ids):
   return out
 
 
+class SimTimers(object):
+  """Measurement aid for bench.py: while active, every sim_rank call gets a cmhse_timer around its
+  counting pass (sim_kernel<Rank>); collect() returns [(elapsed_ms, nrows, M, D)] and frees them."""
+  active = None
+
+  def __init__(self):
+    self.items = []
+
+  def __enter__(self):
+    SimTimers.active = self
+    return self
+
+  def __exit__(self, *a):
+    SimTimers.active = None
+
+  def collect(self):
+    lib = _lib.load()
+    out = []
+    for handle, meta in self.items:
+      ms = ctypes.c_float(0.0)
+      _lib.check(lib.cmhse_timer_elapsed_ms(handle, ctypes.byref(ms)), 'cmhse_timer_elapsed_ms')
+      lib.cmhse_timer_destroy(handle)
+      out.append((ms.value,) + meta)
+    self.items = []
+    return out
+
+
 def sim_rank(a, b, row0=0, nrows=None):
   """Ranks / top-1 of the stripe [row0,row0+nrows) of a @ b.T (cmhse_sim_rank).
   Returns int32 device tensors (rank, top1)."""
@@ -303,8 +330,12 @@ def sim_rank(a, b, row0=0, nrows=None):
     return rank, top1
   ws_bytes = lib.cmhse_sim_rank_workspace(nrows)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-  rc = lib.cmhse_sim_rank(a.data_ptr(), b.data_ptr(), N, M, D, row0, nrows, rank.data_ptr(),
-                          top1.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+  timer = None
+  if SimTimers.active is not None:
+    timer = lib.cmhse_timer_create()
+    SimTimers.active.items.append((timer, (nrows, M, D)))
+  rc = lib.cmhse_sim_rank_ex(a.data_ptr(), b.data_ptr(), N, M, D, row0, nrows, rank.data_ptr(),
+                             top1.data_ptr(), ws.data_ptr(), ws_bytes, _stream(), timer)
   _lib.check(rc, 'cmhse_sim_rank')
   return rank, top1
 

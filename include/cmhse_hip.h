@@ -12,9 +12,15 @@
  *   - all float data is IEEE fp32, row-major, 16-byte aligned rows are the fast path (feature
  *     width and hidden size multiples of 4); indices are int32 unless stated (token ids: int64,
  *     as torch.LongTensor);
- *   - calls are asynchronous on `stream`, allocate nothing, keep no global state and are
- *     re-entrant; scratch memory is an explicit caller-owned workspace whose size the matching
- *     `*_workspace` function returns;
+ *   - calls are asynchronous on `stream` and re-entrant; they allocate NO device memory: scratch
+ *     is an explicit caller-owned workspace whose size the matching `*_workspace` function
+ *     returns.  Host-side objects a call may create and release before it returns: one HIP event
+ *     per stream fork/join when a `tail_stream` is used (cmhse_gru_pool_fwd_multi), and event
+ *     pairs owned by a cmhse_timer handle when the caller passes one (measurement only);
+ *   - process-wide state is limited to read-only tuning overrides taken ONCE from the environment
+ *     at first use (CMHSE_TINY_MAX_SEQS, CMHSE_MID_MAX_SEQS, CMHSE_GRU_MSUB,
+ *     CMHSE_TINY_FWD_NW8_MAX, CMHSE_TINY_NW8_MAX: kernel-shape crossovers, never results); nothing
+ *     is written after that, so concurrent calls from several host threads are safe;
  *   - return value: 0 = success, negative = error code (cmhse_strerror); no exceptions or aborts
  *     cross the ABI.
  */
@@ -116,8 +122,8 @@ int cmhse_gru_pool_fwd(const cmhse_seq_batch* seqs, const cmhse_gru_weights* w, 
 #define CMHSE_MAX_JOBS 4
 /* Several INDEPENDENT cmhse_gru_pool_fwd requests in one call (at most CMHSE_MAX_JOBS).  Results are bit-identical
  * to the separate calls; step t of every request shares one launch, so two encoders that do not
- * depend on each other — the clip and sentence encoders of VSE.forward_emb (model.py:311-331), the
- * video and paragraph encoders of structure_emb (model.py:345-358) — pay one launch latency and one
+ * depend on each other — the clip and sentence encoders of VSE.forward_emb (model.py:222-236), the
+ * video and paragraph encoders of structure_emb (model.py:238-255) — pay one launch latency and one
  * partially filled last wave of workgroups per time step instead of two.  The first request's
  * step_timer (if set) brackets the step launches of the whole group. */
 typedef struct cmhse_gru_job {
@@ -159,6 +165,12 @@ size_t cmhse_sim_rank_workspace(int32_t nrows);
 int cmhse_sim_rank(const float* A, const float* B, int32_t N, int32_t M, int32_t D, int32_t row0,
                    int32_t nrows, int32_t* rank, int32_t* top1, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* Same, with an optional cmhse_timer (or NULL) whose event pair brackets the counting pass (the
+ * N x M MFMA contraction with the rank / arg-max epilogue) on `stream` — measurement only. */
+int cmhse_sim_rank_ex(const float* A, const float* B, int32_t N, int32_t M, int32_t D,
+                      int32_t row0, int32_t nrows, int32_t* rank, int32_t* top1, void* workspace,
+                      size_t workspace_bytes, void* stream, void* timer);
 
 /* Replaces loss.cosine_sim (loss.py:12-13): scores[n,m] = im s^T, exact fp32. */
 int cmhse_cosine_sim(const float* im, const float* s, int32_t n, int32_t m, int32_t D,

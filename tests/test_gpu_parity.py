@@ -939,3 +939,212 @@ def test_python_wrappers_validate_shapes(dev):
     GroupWiseContrastiveLoss(margin=0.2)(a, a, [2, 1], [2, 2])
   with pytest.raises(NotImplementedError):
     ContrastiveLoss(margin=0.2, measure='order')
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE configs[2] / [3] / [4] at their real shapes (ICEP 2048-d, DiDeMo, the full val split)
+# ------------------------------------------------------------------------------------------
+def _blas_threads(n=16):
+  """The oracle's per-step GEMMs are small: all cores of a big host oversubscribe OpenBLAS."""
+  from threadpoolctl import threadpool_limits
+  return threadpool_limits(limits=n)
+
+
+def _full_opt(rnn_type, img_dim, vocab, **kw):
+  opt = argparse.Namespace(
+      margin=0.2, word_dim=300, embed_size=1024, grad_clip=0.0, learning_rate=0.001,
+      max_violation=False, img_dim=img_dim, measure='cosine', rnn_type=rnn_type,
+      img_first_size=1024, cap_first_size=1024, low_level_loss=False, weak_low_level_loss=False,
+      reconstruct_loss=False, lowest_reconstruct_loss=False, norm=False,
+      data_name='anet_precomp', vocab_size=vocab)
+  for k, v in kw.items():
+    setattr(opt, k, v)
+  return opt
+
+
+def _np_state_dicts(model, opt):
+  return [{k: v.detach().cpu().numpy() for k, v in sd.items()} for sd in model.state_dict(opt)]
+
+
+def _np_batches(batches):
+  return [tuple(x.cpu().numpy() if isinstance(x, torch.Tensor) else x for x in b) for b in batches]
+
+
+@pytest.mark.parametrize('pool', ['attention', 'maxout', 'seq2seq'])
+def test_full_size_encoder_properties_icep(dev, oracle, pool):
+  """configs[2]/[4] encoder shape: S = 2200 ragged sequences, img_dim 2048 (post-ReLU-like
+  non-negative features), embed 1024, T <= 80 — all three poolings: a 12-sequence sample against
+  the fp64 oracle, permutation equivariance bit for bit, in-batch == alone."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(23)
+  S, T, I, H = 2200, 80, 2048, 1024
+  cls = {'attention': 'Attention', 'maxout': 'Maxout', 'seq2seq': 'Seq2Seq'}[pool]
+  torch.manual_seed(9)
+  layer = getattr(layers, cls)(I, H)
+  sd = {'rnn.' + k: v.detach().numpy() for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = np.where(rng.uniform(size=S) < 0.53, T, rng.randint(1, T, size=S))
+  gen = torch.Generator(device=dev).manual_seed(5)
+  xd = (0.5 * torch.randn(S, T, I, generator=gen, device=dev)).abs_()
+  xd = xd * (torch.arange(T, device=dev)[None, :] < torch.from_numpy(lens).to(dev)[:, None])[:, :, None]
+  with torch.no_grad():
+    y = layer(xd, torch.from_numpy(lens))
+    perm = torch.from_numpy(rng.permutation(S))
+    yp = layer(xd[perm.to(dev)], torch.from_numpy(lens)[perm])
+    assert torch.equal(yp, y[perm.to(dev)])
+    sample = np.sort(rng.choice(S, 12, replace=False))
+    ys = layer(xd[torch.from_numpy(sample).to(dev)], torch.from_numpy(lens[sample]))
+  yn = ops.l2norm_rows(y).cpu().numpy()
+  with _blas_threads():
+    want = oracle.pooled_gru_forward(pool, xd[torch.from_numpy(sample).to(dev)].cpu().numpy(),
+                                     lens[sample], sd, None, np.float64)
+  want = want / np.linalg.norm(want, axis=1, keepdims=True)
+  np.testing.assert_allclose(yn[sample], want, atol=EMB_TOL, rtol=0)
+  np.testing.assert_allclose(ops.l2norm_rows(ys).cpu().numpy(), yn[sample], atol=2e-6, rtol=0)
+
+
+def _robust_rank_rows(q64, g64, eps):
+  """fp64 ranks of every row and the mask of rows whose diagonal score is further than `eps` from
+  every other score of the row (their rank cannot change under perturbations < eps / 2)."""
+  d = q64 @ g64.T
+  n = d.shape[0]
+  dii = d[np.arange(n), np.arange(n)]
+  ranks = (d > dii[:, None]).sum(1)
+  gap = np.abs(d - dii[:, None])
+  gap[np.arange(n), np.arange(n)] = np.inf
+  return ranks, gap.min(1) > eps, d
+
+
+def test_didemo_icep_encode_and_rank_vs_oracle(dev, oracle):
+  """configs[3]: DiDeMo-shaped split (all-80-frame clips, 1-7 clips per video, short sentences,
+  vocab 7205, img_dim 2048): encode_data + i2t / t2i on 256 videos against the oracle."""
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import encode_data, i2t, t2i
+  from cmhse_amd.model import VSE
+  opt = _full_opt('attention', 2048, synthetic.DIDEMO_VOCAB)
+  torch.manual_seed(4)
+  model = VSE(opt)
+  spec = synthetic.anet_like_spec(256, seed=2, dataset='didemo')
+  assert set(spec.frames_per_clip) == {80}
+  batches = synthetic.make_batches(spec, 32, 2048, synthetic.DIDEMO_VOCAB, seed=7, feat='relu')
+  res = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  with _blas_threads():
+    want = oracle.encode_data('attention', _np_state_dicts(model, opt), _np_batches(batches),
+                              margin=0.2)
+  err = 0.0
+  for i in range(6):
+    assert res[i].shape == want[i].shape
+    np.testing.assert_allclose(res[i], want[i], atol=EMB_TOL, rtol=0)
+    err = max(err, float(np.abs(res[i] - want[i]).max()))
+  assert list(res[6]) == list(want[6])
+  v64, p64 = want[0].astype(np.float64), want[1].astype(np.float64)
+  hv64, hp64 = res[0].astype(np.float64), res[1].astype(np.float64)
+  for fn, (q, g), (hq, hg) in [(i2t, (v64, p64), (hv64, hp64)), (t2i, (p64, v64), (hp64, hv64))]:
+    rep, top1, ranks = fn(res[0], res[1])
+    # (1) the scoring kernel on its own inputs: exact on rows an fp32 dot cannot flip
+    r_self, ok_self, d_self = _robust_rank_rows(hq, hg, 2e-6)
+    np.testing.assert_array_equal(ranks[ok_self], r_self[ok_self])
+    assert np.array_equal(top1[ok_self], d_self.argmax(1)[ok_self])
+    # (2) end to end against the oracle's embeddings: exact on rows the embedding error cannot flip
+    r_or, ok_or, _ = _robust_rank_rows(q, g, 4 * err + 2e-6)
+    np.testing.assert_array_equal(ranks[ok_or], r_or[ok_or])
+    assert ok_self.mean() > 0.5 and ok_or.mean() > 0.25, (ok_self.mean(), ok_or.mean())
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout'])
+def test_icep_recon_train_step_full_dims_vs_oracle(dev, oracle, rnn_type):
+  """configs[2] at its real dimensions: ONE VSE.train_emb step, batch 32, embed 1024, img_dim 2048,
+  --low_level_loss --reconstruct_loss --norm, weight_recon 5e-4 — the logged losses and every
+  parameter gradient (4 encoders, 2 decoders, the word table) against the fp64 oracle."""
+  from cmhse_amd import synthetic
+  from cmhse_amd.model import VSE
+  opt = _full_opt(rnn_type, 2048, synthetic.ANET_VOCAB, low_level_loss=True, reconstruct_loss=True,
+                  norm=True, weight_recon=0.0005, lowest_weight_recon=0.0001,
+                  decode_rnn_type='seq2seq')
+  torch.manual_seed(11)
+  model = VSE(opt)
+  assert len(model.state_dict(opt)) == 6
+  spec = synthetic.anet_like_spec(32, seed=3)
+  batch = synthetic.make_batches(spec, 32, 2048, synthetic.ANET_VOCAB, seed=1, feat='relu')[0]
+  sds = _np_state_dicts(model, opt)
+  model.logger = MeterLog()
+  model.train_start(opt)
+  model.train_emb(opt, *batch)
+  with _blas_threads():
+    log, total, grads = oracle.train_step_recon(
+        rnn_type, sds, _np_batches([batch])[0], margin=0.2, max_violation=False, norm=True,
+        low_level_loss=True, lowest=False, weight_recon=0.0005)
+  calls = [c for c in model.logger.calls if c[0].startswith('Le')]
+  assert [c[0] for c in calls] == [l[0] for l in log]
+  for c, l in zip(calls, log):
+    assert loss_close(c[1], l[1]), (c, l)
+    assert c[2] == l[2]
+  for i, m in enumerate(model._modules()):
+    for pn, pp in m.named_parameters():
+      assert pp.grad is not None, (i, pn)
+      grad_close(pp.grad.cpu().numpy(), grads[i][pn], 'mod%d %s' % (i, pn))
+
+
+def test_full_val_split_icep_encode_sample_vs_oracle(dev, oracle):
+  """configs[4], encode half at full size: the whole N = 4917 ActivityNet-val-shaped split at
+  img_dim 2048 through encode_data_device as ONE super-batch (what bench.py times), then the six
+  embedding matrices of 128 videos (4 loader batches spread over the split) against the oracle
+  encoding those batches on their own."""
+  import bench
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import encode_data_device
+  from cmhse_amd.model import VSE
+  wl = dict(bench.WORKLOADS['anet_icep_val'])
+  opt = bench.make_opt(wl, 'attention', 1024)
+  torch.manual_seed(1)
+  model = VSE(opt)
+  spec = synthetic.anet_like_spec(wl['n_videos'], seed=0, dataset='anet')
+  n_batches = (spec.n_videos + wl['batch'] - 1) // wl['batch']
+  batches = bench.build_loader(spec, wl, dev, 0, n_batches)
+  cat, num_clips_total, _ = encode_data_device(opt, model, batches, logging=lambda *a: None)
+  assert cat['vid_emb'].shape == (4917, 1024) and len(num_clips_total) == 4917
+  pick = [0, 51, 102, n_batches - 1]
+  clip_start = np.concatenate([[0], np.cumsum(num_clips_total)])
+  with _blas_threads():
+    want = oracle.encode_data('attention', _np_state_dicts(model, opt),
+                              _np_batches([batches[i] for i in pick]), margin=0.2)
+  v0 = c0 = 0
+  for i in pick:
+    lo, hi = i * wl['batch'], min(spec.n_videos, (i + 1) * wl['batch'])
+    nv, nc = hi - lo, int(clip_start[hi] - clip_start[lo])
+    for key, w_idx, a, b, n, o in [('vid_emb', 0, lo, hi, nv, v0), ('para_emb', 1, lo, hi, nv, v0),
+                                   ('vid_ctx', 4, lo, hi, nv, v0), ('para_ctx', 5, lo, hi, nv, v0),
+                                   ('clip_emb', 2, clip_start[lo], clip_start[hi], nc, c0),
+                                   ('cap_emb', 3, clip_start[lo], clip_start[hi], nc, c0)]:
+      np.testing.assert_allclose(cat[key][a:b].cpu().numpy(), want[w_idx][o:o + n], atol=EMB_TOL,
+                                 rtol=0, err_msg='%s batch %d' % (key, i))
+    v0 += nv
+    c0 += nc
+
+
+def test_euclid_rows_target_outlives_caller_locals(dev, oracle):
+  """EuclideanLoss.forward_rows addresses its targets by raw device address; the graph node must
+  keep that storage alive.  Drop every caller reference, churn the allocator with same-sized
+  buffers full of garbage, and only then run backward()."""
+  import gc
+  from cmhse_amd.decoder import EuclideanLoss
+  rng = np.random.RandomState(5)
+  rows, cols = 257, 300
+  a_np = rng.standard_normal((rows, cols)).astype(np.float32)
+  b_np = rng.standard_normal((rows + 40, cols)).astype(np.float32)
+  idx = np.sort(rng.choice(rows + 40, rows, replace=False))
+  a = torch.from_numpy(a_np).to(dev).requires_grad_(True)
+
+  def make_loss():
+    target = torch.from_numpy(b_np).to(dev)
+    addrs = np.uint64(target.data_ptr()) + idx.astype(np.uint64) * np.uint64(cols * 4)
+    return EuclideanLoss(norm=True).forward_rows(a, addrs, target) * 3.0
+
+  loss = make_loss()
+  gc.collect()
+  junk = [torch.full((rows + 40, cols), 1e30, device=dev) for _ in range(8)]   # would reuse the block
+  torch.cuda.synchronize()
+  loss.backward()
+  want = 3.0 * oracle.euclidean_loss_backward(a_np, b_np[idx], True, np.float64)
+  grad_close(a.grad.cpu().numpy(), want, 'd_a')
+  del junk
