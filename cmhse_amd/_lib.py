@@ -36,7 +36,7 @@ class SeqBatch(ctypes.Structure):
               ('emb_table', c_void_p),
               ('vocab', c_int32), ('h0_rows', c_void_p), ('lens', c_void_p),
               ('out_row', c_void_p), ('step_off', c_void_p), ('step_count_host', c_void_p),
-              ('step_timer', c_void_p)]
+              ('step_timer', c_void_p), ('step_events_host', c_void_p)]
 
 
 class GruJob(ctypes.Structure):
@@ -51,6 +51,8 @@ SIGNATURES = {
     'cmhse_gru_pool_fwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),
                                           c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cmhse_gru_pool_fwd_multi': (ctypes.c_int, [ctypes.POINTER(GruJob), c_int32, c_void_p]),
+    'cmhse_pull_steps': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                        c_int32, c_void_p]),
     'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     'cmhse_gather_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                          c_void_p]),

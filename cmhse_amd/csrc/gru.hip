@@ -56,6 +56,7 @@ struct GruStepParams {
   float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
   int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
   int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
+  int32_t raster;   // N tiles per XCD group of the tiled step's workgroup rasterisation (0 = default)
   int64_t off_prev, off_cur;
 };
 
@@ -131,8 +132,19 @@ void gru_step_kernel(const GruStepGroup grp) {
 #endif
   // 1-D grid, N tile fastest: blocks b and b+8 land on the same XCD (round-robin dispatch), so
   // with H/BU a multiple of 8 every XCD's L2 keeps re-serving the same two weight-row slices.
-  const int u0 = (wg % p.n_tiles) * BU;
-  const int m0 = (wg / p.n_tiles) * BM;
+  int nt_ = wg % p.n_tiles, mt_ = wg / p.n_tiles;
+  if (p.raster > 1) {
+    // experiment (tools/ab_pass.py, CMHSE_GRU_RASTER): XCD label x = wg % 8 owns R consecutive N
+    // tiles (a weight slice of R x 3 x 64 rows) for every C-th M tile instead of 2 N tiles for all
+    // M tiles: the A rows are then pulled through 8 / C = n_tiles / R L2s instead of all 8.
+    const int R = p.raster, G = p.n_tiles / R, C = 8 / G;
+    const int x = wg & 7, q = wg >> 3;
+    nt_ = R * (x % G) + q % R;
+    mt_ = C * (q / R) + x / G;
+  }
+  const int u0 = nt_ * BU;
+  const int m0 = mt_ * BM;
+  if (m0 >= p.S_t) return;   // padding workgroups of a rasterisation with C > 1
   const int srow = tid >> 2;
   const int I = p.I, H = p.H;
 
@@ -638,6 +650,49 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
   for (int c = threadIdx.x; c < cols; c += kThreads) dst[c] = src[c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Host -> HBM upload of time steps [t0, t1) of every still-active sequence, straight out of the
+// loader's pinned host tensors (device-readable, zero-copy over PCIe): the unit the step pipeline
+// consumes.  Padding rows (t >= len) are never read on the host side nor written here.
+// 57 GB/s measured with a few hundred workgroups (tools/microbench/h2d_chunked.hip), so the grid is
+// capped: the kernel runs beside the MFMA-bound step kernels and should not crowd their CUs.
+// ---------------------------------------------------------------------------------------------
+struct PullParams {
+  const uint64_t* src_rows;   // [S] host (pinned) address of step 0 of sorted sequence s
+  const uint64_t* dst_rows;   // [S] device address of step 0 of sorted sequence s
+  const int32_t* lens;        // [S] non-increasing
+  int32_t n_active, row_floats, t0, t1;
+};
+
+__global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p) {
+  for (int s = blockIdx.x; s < p.n_active; s += gridDim.x) {
+    const int len = p.lens[s];
+    const int te = (p.t1 < len) ? p.t1 : len;
+    if (te <= p.t0) break;     // sorted longest first: every later sequence is shorter still
+    const size_t off = static_cast<size_t>(p.t0) * p.row_floats * 4u;
+    const size_t n = static_cast<size_t>(te - p.t0) * p.row_floats;
+    const rowaddr_t src = p.src_rows[s] + off, dst = p.dst_rows[s] + off;
+    if (((src | dst) & 15u) == 0 && (n & 3u) == 0) {
+      const float4* sp = reinterpret_cast<const float4*>(src);
+      float4* dp = reinterpret_cast<float4*>(dst);
+      const size_t n4 = n >> 2;
+      size_t i = threadIdx.x;
+      for (; i + 3 * kThreads < n4; i += 4 * kThreads) {   // four 16-byte PCIe reads in flight per lane
+        const float4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
+        dp[i] = a;
+        dp[i + kThreads] = b;
+        dp[i + 2 * kThreads] = c;
+        dp[i + 3 * kThreads] = d;
+      }
+      for (; i < n4; i += kThreads) dp[i] = sp[i];
+    } else {
+      const float* sp = reinterpret_cast<const float*>(src);
+      float* dp = reinterpret_cast<float*>(dst);
+      for (size_t i = threadIdx.x; i < n; i += kThreads) dp[i] = sp[i];
+    }
+  }
+}
+
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
 // split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
 // (k beyond K zero-filled), see nt_phase_bf3.
@@ -711,6 +766,16 @@ int gru_msub() {
   return msub;
 }
 
+// CMHSE_GRU_RASTER=<R> (read per call: A/B runs switch it inside one process): N tiles per XCD
+// group, valid when it divides the N-tile count and leaves 1, 2, 4 or 8 groups.
+int gru_raster(int n_tiles) {
+  const char* e = getenv("CMHSE_GRU_RASTER");
+  const int R = e ? atoi(e) : 0;
+  if (R <= 1 || n_tiles % R != 0) return 0;
+  const int G = n_tiles / R;
+  return (G == 1 || G == 2 || G == 4 || G == 8) ? R : 0;
+}
+
 int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode, float* out,
                 void* workspace, size_t workspace_bytes, hipStream_t stream, FwdJob* job) {
   if (!b || !w || !out || !workspace) return CMHSE_ERR_ARG;
@@ -772,6 +837,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   p.pool_mode = pool_mode;
   p.x_step = b->x_step_floats;
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
+  p.raster = gru_raster(p.n_tiles);
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
   job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
@@ -850,7 +916,12 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   if ((kind & 3) == 0)
     return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
   const int bm = ((kind & 3) == 2 || gru_msub() == 2) ? 128 : 64;
-  return static_cast<unsigned>(j.p.n_tiles) * ((S_t + bm - 1) / bm);
+  int m_tiles = (S_t + bm - 1) / bm;
+  if (j.p.raster > 1) {
+    const int C = 8 / (j.p.n_tiles / j.p.raster);
+    m_tiles = (m_tiles + C - 1) / C * C;
+  }
+  return static_cast<unsigned>(j.p.n_tiles) * m_tiles;
 }
 
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
@@ -868,6 +939,8 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (done[k]) continue;
       FwdJob& j = jobs[k];
       const int S_t = j.b->step_count_host[t];
+      if (j.b->step_events_host != nullptr && j.b->step_events_host[t] != nullptr)
+        (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[t])), 0);
       j.p.t = t;
       j.p.S_t = S_t;
       j.p.off_prev = j.off - (t > 0 ? j.b->step_count_host[t - 1] : 0);
@@ -1038,6 +1111,26 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   req.workspace_bytes = workspace_bytes;
   req.tail_stream = nullptr;
   return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
+}
+
+extern "C" int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t* dst_rows,
+                                const int32_t* lens, int32_t n_active, int32_t row_floats,
+                                int32_t t0, int32_t t1, void* stream_) {
+  if (!src_rows_pinned || !dst_rows || !lens || n_active < 0 || row_floats <= 0 || t0 < 0 || t1 < t0)
+    return CMHSE_ERR_ARG;
+  if (n_active == 0 || t1 == t0) return CMHSE_OK;
+  PullParams p;
+  p.src_rows = src_rows_pinned;
+  p.dst_rows = dst_rows;
+  p.lens = lens;
+  p.n_active = n_active;
+  p.row_floats = row_floats;
+  p.t0 = t0;
+  p.t1 = t1;
+  const unsigned grid = static_cast<unsigned>(n_active < 512 ? n_active : 512);
+  hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream_), p);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
 extern "C" int cmhse_l2norm_rows(const float* x, float* y, int32_t rows, int32_t cols, int64_t ld,

@@ -99,6 +99,22 @@ def _side_streams(device):
   return _SIDE_STREAMS[key]
 
 
+PIPELINE_UPLOAD = [os.environ.get('CMHSE_PIPELINE_UPLOAD', '1') == '1']
+UPLOAD_CHUNK = [int(os.environ.get('CMHSE_UPLOAD_CHUNK', '8'))]
+
+
+def _copy_stream(device):
+  key = (device.type, device.index, 'copy')
+  if key not in _SIDE_STREAMS:
+    _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+  return _SIDE_STREAMS[key]
+
+
+def _pinned_f32(t):
+  return (isinstance(t, torch.Tensor) and not t.is_cuda and t.dtype == torch.float32 and
+          t.is_contiguous() and t.is_pinned())
+
+
 def encode_group(model, group, contextual_model=True, device=None):
   """Encode a list of loader batches (12-tuples) as ONE super-batch.  Returns a dict of device
   tensors: the six un-normalised embedding matrices plus their L2-normalised versions, rows in
@@ -108,10 +124,23 @@ def encode_group(model, group, contextual_model=True, device=None):
   clips_l, caps_l, vids_l, pars_l = [], [], [], []
   len_clip, len_cap, len_vid, len_par = [], [], [], []
   num_clips, num_caps = [], []
+  # The loader hands over pinned HOST tensors (activity_net/data.py:157-162, pin_memory=True).  In
+  # the grouped schedule their features are not copied up front: device buffers are only allocated
+  # here, and the rows travel time-chunk by time-chunk on a copy stream while earlier GRU steps
+  # already compute (ops.pull_steps; only valid steps cross PCIe, padding stays uninitialised and
+  # is never read).
+  pull = (PIPELINE_UPLOAD[0] and GROUP_TOWERS[0] and not TWO_STREAMS[0] and
+          all(_pinned_f32(b[0]) and _pinned_f32(b[2]) for b in group))
+  host_feats = []
   for b in group:
-    clips_l.append(_to_dev(b[0], device).float().contiguous())
+    if pull:
+      host_feats.append((b[0], b[2]))
+      clips_l.append(torch.empty(b[0].shape, dtype=torch.float32, device=device))
+      vids_l.append(torch.empty(b[2].shape, dtype=torch.float32, device=device))
+    else:
+      clips_l.append(_to_dev(b[0], device).float().contiguous())
+      vids_l.append(_to_dev(b[2], device).float().contiguous())
     caps_l.append(_to_dev(b[1], device).long().contiguous())
-    vids_l.append(_to_dev(b[2], device).float().contiguous())
     pars_l.append(_to_dev(b[3], device).long().contiguous())
     len_clip.append(np.asarray(b[4], dtype=np.int64))
     len_cap.append(np.asarray(b[5], dtype=np.int64))
@@ -184,8 +213,20 @@ def encode_group(model, group, contextual_model=True, device=None):
     # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
     # side stream while the visual attention pass runs on this one, instead of after it.
     tail = _tail_stream(device) if EARLY_POOL[0] else None
+    v_sched = v_events = None
+    if pull:
+      main, copy = torch.cuda.current_stream(device), _copy_stream(device)
+      src = np.concatenate([ops.padded_row_ptrs(h) for h in [c for c, _ in host_feats] +
+                            [v for _, v in host_feats]])
+      v_sched = ops.SeqSchedule(np.concatenate(len_clip + len_vid), device, x_ptrs=v_ptrs,
+                                src_ptrs=src)
+      copy.wait_stream(main)         # the fresh device buffers may recycle blocks still in use
+      v_events = ops.pull_steps(v_sched, img_dim, copy, UPLOAD_CHUNK[0])
+      for t in clips_l + vids_l:
+        t.record_stream(copy)
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
-        clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs),
+        clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs,
+                              sched=v_sched, step_events=v_events),
         txt_rnn.request_ptrs(np.concatenate(len_cap + len_par), table.shape[1], device,
                              tok_ptrs=t_ptrs, table=table)], tail_stream=tail)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]

@@ -218,12 +218,13 @@ class _GRUPoolBase(nn.Module):
     return out
 
   def request_ptrs(self, lens, in_dim, device, x_ptrs=None, tok_ptrs=None, table=None,
-                   h0_ptrs=None, out=None):
+                   h0_ptrs=None, out=None, sched=None, step_events=None):
     """The arguments of forward_ptrs as one request of ops.gru_pool_fwd_multi, which runs
     independent encoders (the visual and the text tower) in shared per-step launches."""
     return dict(weights=self._weights(), pool_mode=self.POOL, lens=lens, I=in_dim,
                 H=self.rnn.weight_hh_l0.shape[1], device=device, x_ptrs=x_ptrs,
-                tok_ptrs=tok_ptrs, emb_table=table, h0_ptrs=h0_ptrs, out=out)
+                tok_ptrs=tok_ptrs, emb_table=table, h0_ptrs=h0_ptrs, out=out, sched=sched,
+                step_events=step_events)
 
   def forward_tokens(self, tokens, q_len, table):
     """Fused embedding-lookup + encoder (model.EncoderText.forward, model.py:92-99): the word

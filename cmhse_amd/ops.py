@@ -67,7 +67,7 @@ class SeqSchedule(object):
   """
 
   def __init__(self, lens, device, x_ptrs=None, tok_ptrs=None, h0_ptrs=None,
-               out_rows_are_starts=False):
+               out_rows_are_starts=False, src_ptrs=None):
     lens = np.asarray(lens, dtype=np.int64).reshape(-1)
     if lens.size == 0 or lens.min() < 1:
       raise ValueError('all sequence lengths must be >= 1 (pack_padded_sequence contract)')
@@ -87,8 +87,9 @@ class SeqSchedule(object):
     self.step_count_host = np.ascontiguousarray(step_count)
     self.lens_sorted = ls
 
-    # one packed metadata buffer: [x_rows u64 | h0_rows u64 | lens i32 | out_row i32 | step_off i32]
-    n64 = 2 * S
+    # one packed metadata buffer:
+    #   [x_rows u64 | h0_rows u64 | (src_rows u64) | lens i32 | out_row i32 | step_off i32]
+    n64 = (3 if src_ptrs is not None else 2) * S
     n32 = 2 * S + (Tmax + 1)
     buf = np.zeros(n64 * 8 + n32 * 4, dtype=np.uint8)
     v64 = buf[:n64 * 8].view(np.uint64)
@@ -97,6 +98,8 @@ class SeqSchedule(object):
     v64[:S] = np.asarray(src, dtype=np.uint64)[order]
     if h0_ptrs is not None:
       v64[S:2 * S] = np.asarray(h0_ptrs, dtype=np.uint64)[order]
+    if src_ptrs is not None:   # pinned-host source of every sequence (pull_steps)
+      v64[2 * S:3 * S] = np.asarray(src_ptrs, dtype=np.uint64)[order]
     v32[:S] = ls
     if out_rows_are_starts:
       # CMHSE_POOL_ALL: sequence i (input order) owns output rows [start_i, start_i + len_i)
@@ -109,6 +112,7 @@ class SeqSchedule(object):
     base = self.meta.data_ptr()
     self.p_rows = base
     self.p_h0 = base + S * 8 if h0_ptrs is not None else None
+    self.p_src = base + 2 * S * 8 if src_ptrs is not None else None
     self.p_lens = base + n64 * 8
     self.p_out_row = self.p_lens + S * 4
     self.p_step_off = self.p_out_row + S * 4
@@ -157,13 +161,42 @@ class StepTimers(object):
     return out
 
 
+def pull_steps(sched, row_floats, copy_stream, chunk=8):
+  """Queue the host -> HBM hand-over of a schedule built with `src_ptrs` (pinned host rows) on
+  `copy_stream` and return {t0: torch event}: the event of the chunk that starts at step t0 (what
+  cmhse_seq_batch.step_events_host takes).  Chunks grow 1, 1, 2, 4, ... up to `chunk` steps, so the
+  first step's rows arrive after one step's worth of PCIe time, not after a whole chunk's."""
+  lib = _lib.load()
+  if sched.p_src is None:
+    raise ValueError('schedule was built without src_ptrs')
+  events = {}
+  sched.meta.record_stream(copy_stream)
+  bounds, t, c = [], 0, 1
+  while t < sched.Tmax:
+    bounds.append((t, min(sched.Tmax, t + c)))
+    t += c
+    c = min(chunk, c * 2) if t > 1 else 1
+  for t0, t1 in bounds:
+    rc = lib.cmhse_pull_steps(sched.p_src, sched.p_rows, sched.p_lens,
+                              int(sched.step_count_host[t0]), row_floats, t0, t1,
+                              ctypes.c_void_p(copy_stream.cuda_stream))
+    _lib.check(rc, 'cmhse_pull_steps')
+    ev = torch.cuda.Event()
+    ev.record(copy_stream)
+    events[t0] = ev
+  return events
+
+
 def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
-                 constant_input=False):
-  """Build the ctypes request of one cmhse_gru_pool_fwd call.  Returns (job dict, timer meta)."""
+                 constant_input=False, sched=None, step_events=None):
+  """Build the ctypes request of one cmhse_gru_pool_fwd call.  Returns (job dict, timer meta).
+  `sched`: a prebuilt SeqSchedule for these sequences (else built here); `step_events`:
+  {step: torch.cuda.Event} the step's launch must wait for (chunked upload, pull_steps)."""
   lib = _lib.load()
-  sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs,
-                      out_rows_are_starts=(pool_mode == POOL_ALL))
+  if sched is None:
+    sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs,
+                        out_rows_are_starts=(pool_mode == POOL_ALL))
   S = sched.S
   if out is None:
     n_out = sched.sum_T if pool_mode == POOL_ALL else S
@@ -199,6 +232,13 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
   b.h0_rows = sched.p_h0
   b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
   b.step_count_host = sched.step_count_host.ctypes.data
+  ev_arr = None
+  if step_events:
+    ev_arr = (ctypes.c_void_p * sched.Tmax)()
+    for t, ev in step_events.items():
+      ev_arr[t] = ev.cuda_event
+    b.step_events_host = ctypes.cast(ev_arr, ctypes.c_void_p)
+    keep.append((ev_arr, step_events))
   ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
              device=device)
   job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx)
@@ -237,7 +277,8 @@ def gru_pool_fwd_multi(requests, tail_stream=None):
     if tail_stream is not None and len(prepared) > 1:
       jobs[k].tail_stream = ctypes.c_void_p(tail_stream.cuda_stream)
       for t in [job['out'], job['ws'], job['ctx']['sched'].meta] + job['ctx']['keep']:
-        t.record_stream(tail_stream)
+        if isinstance(t, torch.Tensor):
+          t.record_stream(tail_stream)
   if StepTimers.active is not None:
     handle = lib.cmhse_timer_create()
     prepared[0][0]['b'].step_timer = handle

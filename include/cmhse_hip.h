@@ -103,6 +103,10 @@ typedef struct cmhse_seq_batch {
   const int32_t* step_count_host; /* HOST [Tmax] #{s : lens[s] > t} (sizes the per-step grids) */
   void* step_timer;         /* optional cmhse_timer (or NULL): brackets the per-step GRU kernels of
                                this call on `stream` — measurement only, no effect on results */
+  const void* const* step_events_host; /* optional HOST [Tmax] of hipEvent_t (NULL entries allowed), or
+                               NULL: before step t's kernel is launched, its stream waits on entry t.
+                               Lets the caller feed x rows chunk by chunk (cmhse_pull_steps on a copy
+                               stream) while earlier steps compute */
 } cmhse_seq_batch;
 
 /* Bytes of workspace cmhse_gru_pool_fwd needs for this batch: the time-major packed hidden states
@@ -143,6 +147,17 @@ typedef struct cmhse_gru_job {
                           caller needs no extra ordering. */
 } cmhse_gru_job;
 int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
+
+/* Host -> HBM hand-over of the loader's feature tensors (the `.cuda()` of model.py:225-227,
+ * evaluation.py:97-104), in the unit the step pipeline consumes: time steps [t0, t1) of the first
+ * n_active sequences of a length-sorted batch.  src_rows_pinned[s] is the HOST address of step 0 of
+ * sequence s inside page-locked memory (the DataLoader's pin_memory=True tensors,
+ * activity_net/data.py:157-162; it must be device-readable, as hipHostMalloc / torch pinned memory
+ * is), dst_rows[s] its device address; rows are row_floats floats apart in both.  Only valid steps
+ * (t < lens[s]) are moved: zero padding never crosses PCIe.  Runs as a kernel on `stream` (give it a
+ * stream of its own, record an event, hand it to the consumer via step_events_host). */
+int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t* dst_rows, const int32_t* lens,
+                     int32_t n_active, int32_t row_floats, int32_t t0, int32_t t1, void* stream);
 
 /* torch.nn.functional.normalize(x) (p=2, dim=1, eps=1e-12) — call sites model.py:333-343,
  * evaluation.py:111-116.  y may alias x.  Rows have stride `ld` floats. */

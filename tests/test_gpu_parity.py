@@ -1148,3 +1148,56 @@ def test_euclid_rows_target_outlives_caller_locals(dev, oracle):
   want = 3.0 * oracle.euclidean_loss_backward(a_np, b_np[idx], True, np.float64)
   grad_close(a.grad.cpu().numpy(), want, 'd_a')
   del junk
+
+
+# ------------------------------------------------------------------------------------------
+# host hand-over (§8f-3): chunked pull of the loader's pinned tensors under the step pipeline
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('I', [24, 7])
+def test_pull_steps_moves_exactly_the_valid_rows(dev, I):
+  """cmhse_pull_steps: every valid (sequence, step) row of the pinned source lands in the device
+  buffer, chunk by chunk; padding rows are neither read nor written (sentinel survives)."""
+  from cmhse_amd import ops
+  rng = np.random.RandomState(I)
+  S, T = 37, 11
+  lens = rng.randint(1, T + 1, size=S)
+  lens[3] = T
+  src = torch.from_numpy(rng.standard_normal((S, T, I)).astype(np.float32)).pin_memory()
+  dst = torch.full((S, T, I), -7.0, device=dev)
+  sched = ops.SeqSchedule(lens, dev, x_ptrs=ops.padded_row_ptrs(dst),
+                          src_ptrs=ops.padded_row_ptrs(src))
+  copy = torch.cuda.Stream(dev)
+  copy.wait_stream(torch.cuda.current_stream())
+  events = ops.pull_steps(sched, I, copy, chunk=4)
+  assert sorted(events) == [0, 1, 2, 4, 8]
+  for ev in events.values():
+    ev.synchronize()
+  got = dst.cpu().numpy()
+  for s in range(S):
+    np.testing.assert_array_equal(got[s, :lens[s]], src.numpy()[s, :lens[s]])
+    assert (got[s, lens[s]:] == -7.0).all()
+
+
+@pytest.mark.parametrize('chunk', [2, 8])
+def test_pinned_host_batches_encode_bit_identically(dev, chunk, monkeypatch):
+  """encode_data_device fed the loader's pinned HOST tensors (features pulled chunk by chunk on a
+  copy stream while earlier steps compute) == the same batches resident on the device."""
+  from cmhse_amd import evaluation, synthetic
+  g = load_golden('model_attention.npz')
+  opt, model = golden_model('attention', g)
+  spec = synthetic.ragged_spec(23, seed=9, max_frames=13, max_video=17)
+  batches = synthetic.make_batches(spec, 6, opt.img_dim, opt.vocab_size, seed=4)
+  pinned = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
+  on_dev = [tuple(t.to(dev) if isinstance(t, torch.Tensor) and t.dim() > 1 else t for t in b)
+            for b in batches]
+  monkeypatch.setattr(evaluation, 'UPLOAD_CHUNK', [chunk])
+  quiet = lambda *a, **k: None
+  want, nc_w, _ = evaluation.encode_data_device(opt, model, on_dev, logging=quiet)
+  monkeypatch.setattr(evaluation, 'PIPELINE_UPLOAD', [True])
+  got, nc_g, _ = evaluation.encode_data_device(opt, model, pinned, logging=quiet)
+  monkeypatch.setattr(evaluation, 'PIPELINE_UPLOAD', [False])
+  plain, _, _ = evaluation.encode_data_device(opt, model, pinned, logging=quiet)
+  assert nc_w == nc_g
+  for k in want:
+    assert torch.equal(got[k], want[k]), k
+    assert torch.equal(plain[k], want[k]), k
