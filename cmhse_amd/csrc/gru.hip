@@ -654,8 +654,8 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
 // Host -> HBM upload of time steps [t0, t1) of every still-active sequence, straight out of the
 // loader's pinned host tensors (device-readable, zero-copy over PCIe): the unit the step pipeline
 // consumes.  Padding rows (t >= len) are never read on the host side nor written here.
-// 57 GB/s measured with a few hundred workgroups (tools/microbench/h2d_chunked.hip), so the grid is
-// capped: the kernel runs beside the MFMA-bound step kernels and should not crowd their CUs.
+// A few dozen waves saturate PCIe (tools/microbench/h2d_chunked.hip), so the grid is small: the
+// kernel runs beside the MFMA-bound step kernels and must not crowd their CUs.
 // ---------------------------------------------------------------------------------------------
 struct PullParams {
   const uint64_t* src_rows;   // [S] host (pinned) address of step 0 of sorted sequence s
@@ -665,6 +665,7 @@ struct PullParams {
 };
 
 __global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p) {
+  const unsigned nthr = blockDim.x;
   for (int s = blockIdx.x; s < p.n_active; s += gridDim.x) {
     const int len = p.lens[s];
     const int te = (p.t1 < len) ? p.t1 : len;
@@ -677,18 +678,20 @@ __global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p
       float4* dp = reinterpret_cast<float4*>(dst);
       const size_t n4 = n >> 2;
       size_t i = threadIdx.x;
-      for (; i + 3 * kThreads < n4; i += 4 * kThreads) {   // four 16-byte PCIe reads in flight per lane
-        const float4 a = sp[i], b = sp[i + kThreads], c = sp[i + 2 * kThreads], d = sp[i + 3 * kThreads];
-        dp[i] = a;
-        dp[i + kThreads] = b;
-        dp[i + 2 * kThreads] = c;
-        dp[i + 3 * kThreads] = d;
+      // eight 16-byte PCIe reads in flight per lane: few waves must keep the link busy, because
+      // every resident pull wave costs the MFMA-bound step kernel beside it a workgroup slot
+      for (; i + 7 * nthr < n4; i += 8 * nthr) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = sp[i + q * nthr];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dp[i + q * nthr] = v[q];
       }
-      for (; i < n4; i += kThreads) dp[i] = sp[i];
+      for (; i < n4; i += nthr) dp[i] = sp[i];
     } else {
       const float* sp = reinterpret_cast<const float*>(src);
       float* dp = reinterpret_cast<float*>(dst);
-      for (size_t i = threadIdx.x; i < n; i += kThreads) dp[i] = sp[i];
+      for (size_t i = threadIdx.x; i < n; i += nthr) dp[i] = sp[i];
     }
   }
 }
@@ -1127,8 +1130,16 @@ extern "C" int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t*
   p.row_floats = row_floats;
   p.t0 = t0;
   p.t1 = t1;
-  const unsigned grid = static_cast<unsigned>(n_active < 512 ? n_active : 512);
-  hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(kThreads), 0,
+  const char* ge = getenv("CMHSE_PULL_GRID");   // experiments (tools/ab_host.py)
+  const char* te = getenv("CMHSE_PULL_THREADS");
+  // 32 single-wave workgroups, 8 x 16 B in flight per lane: 57 GB/s alone (the PCIe Gen5 x16 rate),
+  // and the smallest footprint that does it — beside the step kernel every resident pull wave
+  // takes a SIMD's free registers, i.e. one of that CU's three step-workgroup slots (sweep in
+  // profiles/r02_upload_pipeline.txt: 16 x 256 threads 358 ms / pass, 128 x 64 422, 32 x 64 330)
+  const int cap = (ge && atoi(ge) > 0) ? atoi(ge) : 32;
+  const int thr = (te && (atoi(te) == 128 || atoi(te) == 256)) ? atoi(te) : 64;
+  const unsigned grid = static_cast<unsigned>(n_active < cap ? n_active : cap);
+  hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(thr), 0,
                      static_cast<hipStream_t>(stream_), p);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }

@@ -106,7 +106,11 @@ UPLOAD_CHUNK = [int(os.environ.get('CMHSE_UPLOAD_CHUNK', '8'))]
 def _copy_stream(device):
   key = (device.type, device.index, 'copy')
   if key not in _SIDE_STREAMS:
-    _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    # high priority: its few, short workgroups should be dispatched as soon as a slot frees, and
+    # priority streams live on hardware queues of their own (a copy stream that shares the compute
+    # stream's hardware queue runs in submission order with it: no overlap at all, measured)
+    prio = int(os.environ.get('CMHSE_COPY_PRIO', '-1'))
+    _SIDE_STREAMS[key] = torch.cuda.Stream(device, priority=prio)
   return _SIDE_STREAMS[key]
 
 
@@ -131,13 +135,28 @@ def encode_group(model, group, contextual_model=True, device=None):
   # is never read).
   pull = (PIPELINE_UPLOAD[0] and GROUP_TOWERS[0] and not TWO_STREAMS[0] and
           all(_pinned_f32(b[0]) and _pinned_f32(b[2]) for b in group))
-  host_feats = []
-  for b in group:
-    if pull:
-      host_feats.append((b[0], b[2]))
+  v_sched = v_events = None
+  if pull:
+    # features first: the copy stream starts pulling step 0 before anything else of this group is
+    # queued (schedule metadata travels on the copy stream too; step 0's event orders it)
+    for b in group:
       clips_l.append(torch.empty(b[0].shape, dtype=torch.float32, device=device))
       vids_l.append(torch.empty(b[2].shape, dtype=torch.float32, device=device))
-    else:
+    main, copy = torch.cuda.current_stream(device), _copy_stream(device)
+    copy.wait_stream(main)         # the fresh device buffers may recycle blocks still in use
+    with torch.cuda.stream(copy):
+      v_sched = ops.SeqSchedule(
+          np.concatenate([np.asarray(b[4], dtype=np.int64) for b in group] +
+                         [np.asarray(b[6], dtype=np.int64) for b in group]), device,
+          x_ptrs=np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l]),
+          src_ptrs=np.concatenate([ops.padded_row_ptrs(b[0]) for b in group] +
+                                  [ops.padded_row_ptrs(b[2]) for b in group]))
+      v_events = ops.pull_steps(v_sched, int(group[0][0].shape[2]), copy, UPLOAD_CHUNK[0])
+    for t in clips_l + vids_l:
+      t.record_stream(copy)        # allocated on the caller's stream, written on the copy stream
+    v_sched.meta.record_stream(main)   # the other way round
+  for b in group:
+    if not pull:
       clips_l.append(_to_dev(b[0], device).float().contiguous())
       vids_l.append(_to_dev(b[2], device).float().contiguous())
     caps_l.append(_to_dev(b[1], device).long().contiguous())
@@ -213,17 +232,6 @@ def encode_group(model, group, contextual_model=True, device=None):
     # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
     # side stream while the visual attention pass runs on this one, instead of after it.
     tail = _tail_stream(device) if EARLY_POOL[0] else None
-    v_sched = v_events = None
-    if pull:
-      main, copy = torch.cuda.current_stream(device), _copy_stream(device)
-      src = np.concatenate([ops.padded_row_ptrs(h) for h in [c for c, _ in host_feats] +
-                            [v for _, v in host_feats]])
-      v_sched = ops.SeqSchedule(np.concatenate(len_clip + len_vid), device, x_ptrs=v_ptrs,
-                                src_ptrs=src)
-      copy.wait_stream(main)         # the fresh device buffers may recycle blocks still in use
-      v_events = ops.pull_steps(v_sched, img_dim, copy, UPLOAD_CHUNK[0])
-      for t in clips_l + vids_l:
-        t.record_stream(copy)
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
         clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs,
                               sched=v_sched, step_events=v_events),

@@ -161,29 +161,36 @@ class StepTimers(object):
     return out
 
 
+PULL_EVENT_TIMING = [False]     # tools/ab_host.py: timed events to see when each chunk landed
+LAST_PULL_EVENTS = [None]
+
+
 def pull_steps(sched, row_floats, copy_stream, chunk=8):
   """Queue the host -> HBM hand-over of a schedule built with `src_ptrs` (pinned host rows) on
   `copy_stream` and return {t0: torch event}: the event of the chunk that starts at step t0 (what
-  cmhse_seq_batch.step_events_host takes).  Chunks grow 1, 1, 2, 4, ... up to `chunk` steps, so the
-  first step's rows arrive after one step's worth of PCIe time, not after a whole chunk's."""
+  cmhse_seq_batch.step_events_host takes).  Chunks grow from single steps up to `chunk` steps, so
+  the first step's rows arrive after one step's worth of PCIe time, not after a whole chunk's."""
   lib = _lib.load()
   if sched.p_src is None:
     raise ValueError('schedule was built without src_ptrs')
   events = {}
   sched.meta.record_stream(copy_stream)
-  bounds, t, c = [], 0, 1
+  bounds, t = [], 0
   while t < sched.Tmax:
+    # a consumer trails the copy by one chunk, and it can only stall while the pipeline fills:
+    # single steps first, the full chunk once the copy is safely ahead
+    c = min(chunk, 1 if t < 8 else (2 if t < 16 else (4 if t < 32 else chunk)))
     bounds.append((t, min(sched.Tmax, t + c)))
     t += c
-    c = min(chunk, c * 2) if t > 1 else 1
   for t0, t1 in bounds:
     rc = lib.cmhse_pull_steps(sched.p_src, sched.p_rows, sched.p_lens,
                               int(sched.step_count_host[t0]), row_floats, t0, t1,
                               ctypes.c_void_p(copy_stream.cuda_stream))
     _lib.check(rc, 'cmhse_pull_steps')
-    ev = torch.cuda.Event()
+    ev = torch.cuda.Event(enable_timing=PULL_EVENT_TIMING[0])
     ev.record(copy_stream)
     events[t0] = ev
+  LAST_PULL_EVENTS[0] = events
   return events
 
 

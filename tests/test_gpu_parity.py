@@ -1169,7 +1169,7 @@ def test_pull_steps_moves_exactly_the_valid_rows(dev, I):
   copy = torch.cuda.Stream(dev)
   copy.wait_stream(torch.cuda.current_stream())
   events = ops.pull_steps(sched, I, copy, chunk=4)
-  assert sorted(events) == [0, 1, 2, 4, 8]
+  assert sorted(events) == [0, 1, 2, 3, 4, 5, 6, 7, 8, 10]   # single steps first, then <= chunk
   for ev in events.values():
     ev.synchronize()
   got = dst.cpu().numpy()

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Kernel-time sum against wall for the timed region of a rocprofv3 --kernel-trace CSV: the region
+after the LAST idle gap of >= 200 ms (tools/train_profile.py sleeps there).
+
+  python tools/trace_busy.py <kernel_trace.csv> [steps]
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def main():
+  rows = []
+  for r in csv.DictReader(open(sys.argv[1])):
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'],
+                 int(r['Stream_Id'])))
+  steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+  rows.sort()
+  cut, cur_e = 0, rows[0][1]
+  for i, (s, e, n, st) in enumerate(rows):
+    if s - cur_e >= 200e6:
+      cut = i
+    cur_e = max(cur_e, e)
+  sel = rows[cut:]
+  t0, t1 = sel[0][0], max(r[1] for r in sel)
+  busy_sum = sum(e - s for s, e, n, st in sel)
+  union, cur_e, gaps = 0, t0, []
+  for s, e, n, st in sel:
+    if s > cur_e:
+      gaps.append(s - cur_e)
+      cur_s = s
+    else:
+      cur_s = cur_e
+    if e > cur_s:
+      union += e - cur_s
+    cur_e = max(cur_e, e)
+  wall = t1 - t0
+  print('timed region: %d launches, wall %.3f ms (%.3f ms / step over %d steps)'
+        % (len(sel), wall / 1e6, wall / 1e6 / steps, steps))
+  print('kernel time sum %.3f ms (%.3f / step); union over streams %.3f ms (%.1f %% of wall); '
+        'idle %.3f ms in %d gaps (%.1f us avg)'
+        % (busy_sum / 1e6, busy_sum / 1e6 / steps, union / 1e6, 100.0 * union / wall,
+           (wall - union) / 1e6, len(gaps), (sum(gaps) / max(1, len(gaps))) / 1e3))
+  per = defaultdict(lambda: [0, 0])
+  for s, e, n, st in sel:
+    key = n.split('(')[0][-60:]
+    per[key][0] += e - s
+    per[key][1] += 1
+  print('\n| kernel | launches / step | ms / step | avg us |')
+  print('|---|---|---|---|')
+  for k, (b, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:28]:
+    print('| `%s` | %.1f | %.3f | %.1f |' % (k, c / steps, b / 1e6 / steps, b / c / 1e3))
+  streams = defaultdict(int)
+  for s, e, n, st in sel:
+    streams[st] += e - s
+  print('\nper stream busy ms / step: ' + ', '.join('%d: %.3f' % (k, v / 1e6 / steps)
+                                                      for k, v in sorted(streams.items())))
+
+
+if __name__ == '__main__':
+  main()

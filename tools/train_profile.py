@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""K timed VSE.train_emb steps after a warm-up and a 300 ms idle gap (the gap lets
+tools/trace_busy.py find the timed region in a rocprofv3 kernel trace of this script).
+
+  python tools/train_profile.py --config icep_recon --steps 10
+  rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/train_profile.py ...
+"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import bench  # noqa: E402
+from cmhse_amd import synthetic  # noqa: E402
+from cmhse_amd.evaluation import LogCollector  # noqa: E402
+from cmhse_amd.model import VSE  # noqa: E402
+
+CONFIGS = {
+    # BASELINE configs[1]: ActivityNet C3D, HSE tau=0, batch 32 (bench.py's train_step line)
+    'c3d': dict(workload='anet_c3d_val', low_level_loss=True, norm=True),
+    # BASELINE configs[2]: ActivityNet ICEP, tau=5e-4, --low_level_loss --reconstruct_loss --norm
+    'icep_recon': dict(workload='anet_icep_val', low_level_loss=True, norm=True,
+                       reconstruct_loss=True, weight_recon=0.0005, decode_rnn_type='seq2seq'),
+    'icep': dict(workload='anet_icep_val', low_level_loss=True, norm=True),
+}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--config', default='icep_recon', choices=sorted(CONFIGS))
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--rnn_type', default='attention')
+  args = ap.parse_args()
+  cfg = dict(CONFIGS[args.config])
+  wl = dict(bench.WORKLOADS[cfg.pop('workload')])
+  opt = bench.make_opt(wl, args.rnn_type, 1024)
+  for k, v in cfg.items():
+    setattr(opt, k, v)
+  torch.cuda.set_device(0)
+  torch.manual_seed(1)
+  model = VSE(opt)
+  spec = synthetic.anet_like_spec(32 * 4, seed=0, dataset=wl['dataset'])
+  batches = synthetic.make_batches(spec, 32, wl['img_dim'], wl['vocab'], seed=0, feat=wl['feat'])
+  batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
+  model.logger = LogCollector()
+  model.train_start(opt)
+  use = [batches[i % len(batches)] for i in range(args.steps + 3)]
+  for b in use[:3]:
+    model.train_emb(opt, *b)
+  torch.cuda.synchronize()
+  time.sleep(0.3)
+  t0 = time.perf_counter()
+  for b in use[3:]:
+    model.train_emb(opt, *b)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / args.steps
+  print('%s: %.2f ms per train_emb step (%d steps, batch 32, img_dim %d, %s)'
+        % (args.config, dt * 1e3, args.steps, wl['img_dim'], args.rnn_type))
+  print(str(model.logger))
+
+
+if __name__ == '__main__':
+  main()
