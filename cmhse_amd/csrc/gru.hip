@@ -57,6 +57,12 @@ struct GruStepParams {
   int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
   int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
   int32_t raster;   // N tiles per XCD group of the tiled step's workgroup rasterisation (0 = default)
+  // mid-size step (gru_step_mid_kernel): hoisted input projection x W_ih^T of the small-batch steps,
+  // row (off_cur + m - gx_p0) for an ordinary input, row m (the sorted sequence) for a
+  // time-constant one
+  const float* gx;
+  int64_t gx_p0;
+  int32_t gx_per_seq;
   int64_t off_prev, off_cur;
 };
 
@@ -443,6 +449,271 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mid-size GRU step: 1 <= S_t <= ~1k active sequences (every step of a training batch, the level-2
+// encoders, the long few-sequence tails of paragraphs).  Such a step is one [S_t, K] x [K, 3H]
+// product with S_t far too small to fill 256 CUs from LDS-tiled 64-row tiles, and the 32 x 8-unit
+// tiles of gru_step_tiny_kernel pull every operand row through L2 once per tile (~220 MB per step
+// at S_t = 152: that kernel is L2-bandwidth-bound, not latency-bound).  Two changes:
+//   * the input projection x_t W_ih^T has no time dependence: for all these steps together it is
+//     ONE well-shaped GEMM (xproj_kernel, tiled like the attention projection) into gx[rows, 3H];
+//     the sequential part keeps only K = H;
+//   * tile = 32 sequences x 16 hidden units x {r, z, n}: 2 x 3 blocks of v_mfma_f32_16x16x4_f32
+//     (no idle MFMA columns, 64 contiguous bytes per operand row per load), 8 waves split K,
+//     operands global -> registers in MFMA layout through a 4-deep ring, fixed-order LDS combine;
+//     H/16 x ceil(S_t/32) workgroups (320 at S_t = 152, H = 1024).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kMidBM = 32;
+constexpr int kMidBU = 16;
+constexpr int kMidNW = 8;
+constexpr int kMidRing = 4;
+
+__device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[2], const rowaddr_t (&brow)[3],
+                                          int K, int wave, int kq, f32x4v (&acc)[2][3]) {
+  constexpr int NW = kMidNW, D = kMidRing;
+  const int nkb = (K + 15) / 16;                       // k-blocks of 16 (4 per lane quarter)
+  const int nmine = (nkb - wave + NW - 1) / NW;        // this wave takes blocks wave, wave + NW, ...
+  if (nmine <= 0) return;
+  float4 ra[D][2], rb[D][3];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int k = (wave + NW * d) * 16 + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[d][i] = issue_row4<true>(arow[i], k, K);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rb[d][i] = issue_row4<true>(brow[i], k, K);
+  }
+  auto mfmas = [&](const float4 (&a)[2], const float4 (&b)[3]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float av = (j == 0) ? a[mb].x : (j == 1) ? a[mb].y : (j == 2) ? a[mb].z : a[mb].w;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const float bv = (j == 0) ? b[g].x : (j == 1) ? b[g].y : (j == 2) ? b[g].z : b[g].w;
+          acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mb][g], 0, 0, 0);
+        }
+      }
+    }
+  };
+  int it = 0;
+  // lean steady state: every k this trip consumes or prefetches lies inside K for all waves
+  {
+    constexpr unsigned kSlot = NW * 16u * 4u;            // bytes between ring slots
+    constexpr unsigned kAhead = kSlot * D;
+    rowaddr_t pa[2], pb[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pa[i] = arow[i] + static_cast<rowaddr_t>(wave * 16 + 4 * kq) * 4u + kAhead;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pb[i] = brow[i] + static_cast<rowaddr_t>(wave * 16 + 4 * kq) * 4u + kAhead;
+    for (; 16 * NW * (it + 2 * D) <= K; it += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        float4 a[2], b[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = ra[d][i];
+          const f32x4 g = *(gptr_f32x4)(pa[i] + kSlot * d);
+          ra[d][i] = make_float4(g.x, g.y, g.z, g.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          b[i] = rb[d][i];
+          const f32x4 g = *(gptr_f32x4)(pb[i] + kSlot * d);
+          rb[d][i] = make_float4(g.x, g.y, g.z, g.w);
+        }
+        mfmas(a, b);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pa[i] += kSlot * D;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pb[i] += kSlot * D;
+    }
+  }
+  for (; it < nmine; it += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int k = (wave + NW * (it + d)) * 16 + 4 * kq;
+      const int kn = k + NW * D * 16;
+      float4 a[2], b[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = finish_row4<true>(ra[d][i], true, k, K);
+        ra[d][i] = issue_row4<true>(arow[i], kn, K);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        b[i] = finish_row4<true>(rb[d][i], true, k, K);
+        rb[d][i] = issue_row4<true>(brow[i], kn, K);
+      }
+      mfmas(a, b);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStepGroup grp) {
+  constexpr int NW = kMidNW;
+  unsigned wg;
+  const GruStepParams& p = grp.j[group_job(grp, &wg)];
+  __shared__ f32x4v red[NW][6][64];       // [wave][M block x gate][lane], 48 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H;
+  const int u_tiles = (H + kMidBU - 1) / kMidBU;
+  const int u0 = (wg % u_tiles) * kMidBU;    // unit tile fastest: b, b+8 share an XCD's L2
+  const int m0 = (wg / u_tiles) * kMidBM;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
+  if (have_h) {
+    rowaddr_t arow[2], brow[3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int m = m0 + 16 * mb + r16;
+      const int mc = (m < p.S_t) ? m : (p.S_t - 1);   // rows past S_t are never stored
+      arow[mb] = (p.t > 0) ? row_addr(p.hs + (p.off_prev + mc) * H) : p.h0_rows[mc];
+    }
+    const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) brow[g] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
+    f32x4v acc[2][3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[mb][g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mid_phase(arow, brow, H, wave, kq, acc);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) red[wave][mb * 3 + g][lane] = acc[mb][g];
+    __syncthreads();
+  }
+
+  // epilogue: one (sequence, unit) per thread.  Element (row r, col c) of a 16x16 block sits in
+  // lane (r >> 2) * 16 + c, register r & 3.
+  const int er = tid >> 4, eu = tid & 15;
+  const int em = m0 + er, u = u0 + eu;
+  if (em >= p.S_t || u >= H) return;
+  float hr = 0.f, hz = 0.f, hn_ = 0.f;
+  if (have_h) {
+    const int mb = er >> 4, rr = er & 15;
+    const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      hr += reinterpret_cast<const float*>(&red[w][mb * 3 + 0][sl])[reg];
+      hz += reinterpret_cast<const float*>(&red[w][mb * 3 + 1][sl])[reg];
+      hn_ += reinterpret_cast<const float*>(&red[w][mb * 3 + 2][sl])[reg];
+    }
+  }
+  const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(em) : (p.off_cur + em - p.gx_p0);
+  const float* gxr = p.gx + gxrow * 3 * H;
+  const float xr = gxr[u], xz = gxr[H + u], xn = gxr[2 * H + u];
+  float hp = 0.f;
+  if (p.t > 0)
+    hp = p.hs[(p.off_prev + em) * H + u];
+  else if (p.h0_rows != nullptr)
+    hp = reinterpret_cast<const float*>(p.h0_rows[em])[u];
+  const float rg = sigmoidf_(xr + hr + p.b_ih[u] + p.b_hh[u]);
+  const float zg = sigmoidf_(xz + hz + p.b_ih[H + u] + p.b_hh[H + u]);
+  const float ghn = hn_ + p.b_hh[2 * H + u];
+  const float ng = tanhf_(xn + p.b_ih[2 * H + u] + rg * ghn);
+  const float hn = (1.0f - zg) * ng + zg * hp;
+  p.hs[(p.off_cur + em) * H + u] = hn;
+  if (p.gates != nullptr) {
+    float* gp = p.gates + (p.off_cur + em) * 4 * H + u;
+    gp[0] = rg;
+    gp[H] = zg;
+    gp[2 * H] = ng;
+    gp[3 * H] = ghn;
+  }
+  if (p.pool_mode == CMHSE_POOL_MAX) {
+    float* o = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
+    if (p.t == 0 || hn > *o) {
+      *o = hn;
+      if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(em) * H + u] = p.t;
+    }
+  } else if (p.pool_mode == CMHSE_POOL_LAST) {
+    if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
+  } else if (p.pool_mode == CMHSE_POOL_ALL) {
+    p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
+  }
+}
+
+// Hoisted input projection of the mid-size steps: gx[m][n] = sum_k x_row(m)[k] W_ih[n][k] for the
+// packed rows p0 + m of steps >= t_first (or, for a time-constant input, for the sequences
+// themselves), 64 x 192 tiles on the shared exact-fp32 NT tile loop.
+struct XprojParams {
+  const uint64_t* x_rows;
+  const uint64_t* tok_rows;
+  const float* emb;
+  const int32_t* step_off;
+  const float* w_ih;
+  float* gx;
+  int64_t p0, rows;
+  int32_t I, N, vocab, x_step, Tmax, t_first, n_tiles, per_seq;
+};
+
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3)))
+void xproj_kernel(const XprojParams p) {
+  constexpr int BM = 64, BN = 192, NS = 3;   // the step kernel's tile shape (3 x 32 columns per wave)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = (blockIdx.x % p.n_tiles) * BN;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
+  const int srow = tid >> 2;
+  rowaddr_t ar[1], br[BN / 64];
+  bool av[1], bv[BN / 64];
+  {
+    int64_t m = m0 + srow;
+    av[0] = m < p.rows;
+    if (!av[0]) m = p.rows - 1;
+    int t = 0;
+    int64_t sidx = m;
+    if (!p.per_seq) {
+      // packed row -> (step, sorted sequence): the last step whose first row is <= the row
+      const int64_t pr = p.p0 + m;
+      int lo = p.t_first, hi = p.Tmax - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (static_cast<int64_t>(p.step_off[mid]) <= pr) lo = mid; else hi = mid - 1;
+      }
+      t = lo;
+      sidx = pr - p.step_off[t];
+    }
+    if (p.tok_rows != nullptr) {
+      long long tok = reinterpret_cast<const long long*>(p.tok_rows[sidx])[t];
+      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
+      ar[0] = row_addr(p.emb + tok * p.I);
+    } else {
+      ar[0] = p.x_rows[sidx] + static_cast<rowaddr_t>(t) * p.x_step * 4u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 64; ++i) {
+    const int n = n0 + srow + 64 * i;
+    bv[i] = n < p.N;
+    br[i] = row_addr(p.w_ih + static_cast<int64_t>(bv[i] ? n : (p.N - 1)) * p.I);
+  }
+  f32x16 acc[1][NS];
+#pragma unroll
+  for (int a = 0; a < NS; ++a) acc[0][a] = zero16();
+  int b_row0[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
+  nt_phase<BM, BN, 1, NS, NS, NS - 1, true>(smem, ar, av, br, bv, p.I, wm * 32, b_row0, acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = m0 + wm * 32 + acc_row(r, lane);
+    if (m >= p.rows) continue;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int n = n0 + b_row0[ns] + acc_col(lane);
+      if (n < p.N) p.gx[m * p.N + n] = acc[0][ns][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
 // ---------------------------------------------------------------------------------------------
 struct AttnEnergyParams {
@@ -736,15 +1007,22 @@ static int tiny_max_seqs() {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int mid_max_seqs() {
+  static const int v = [] {
+    const char* e = getenv("CMHSE_MID_MAX_SEQS");
+    return e ? atoi(e) : 1024;
+  }();
+  return v;
+}
+
 }  // namespace cmhse
 
 using namespace cmhse;
 
 extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I,
                                            int32_t H, int32_t pool_mode) {
-  (void)Tmax;
   if (sum_T <= 0 || H <= 0 || S <= 0 || I <= 0) return 0;
-  return gru_ws_layout(S, sum_T, H, pool_mode, I).total;
+  return gru_ws_layout(S, sum_T, H, pool_mode, I, Tmax).total;
 }
 
 namespace {
@@ -760,6 +1038,7 @@ struct FwdJob {
   int64_t sum_T, off;
   int32_t pool_mode;
   bool vec, bf3, save;
+  int32_t t_mid;             // first step served by the mid-size kernel (Tmax: none)
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
   bool pooled;               // attention already launched (early, beside the others' tail)
 };
@@ -810,7 +1089,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   job->b = b;
   job->w = w;
   job->out = out;
-  job->L = gru_ws_layout(b->S, sum_T, b->H, mode_flags, b->I);
+  job->L = gru_ws_layout(b->S, sum_T, b->H, mode_flags, b->I, b->Tmax);
   job->wsb = static_cast<char*>(workspace);
   job->sum_T = sum_T;
   job->off = 0;
@@ -845,6 +1124,24 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
   job->bf3 = bf3 && job->vec && (b->S > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
+  // steps with few active sequences: mid-size kernel on a hoisted input projection
+  job->t_mid = b->Tmax;
+  p.gx = nullptr;
+  p.gx_p0 = 0;
+  p.gx_per_seq = 0;
+  if (job->vec && mid_max_seqs() > 0) {
+    int64_t p0 = 0;
+    for (int t = 0; t < b->Tmax; ++t) {
+      if (b->step_count_host[t] <= mid_max_seqs()) {
+        job->t_mid = t;
+        break;
+      }
+      p0 += b->step_count_host[t];
+    }
+    p.gx = reinterpret_cast<float*>(wsb + L.gx);
+    p.gx_p0 = p0;
+    p.gx_per_seq = (b->x_rows != nullptr && b->x_step_floats == 0) ? 1 : 0;
+  }
   p.w_ih_s = nullptr;
   p.w_hh_s = nullptr;
   if (job->bf3) {
@@ -870,15 +1167,44 @@ static int tiny_nw8_max() {
 }
 
 int step_kind(const FwdJob& j, int S_t) {
+  if (j.p.t >= j.t_mid) return 3;   // mid-size kernel (vec shapes only, see prepare_job)
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
   return k | (j.vec ? 0 : 4);
+}
+
+// The input projection of every step >= t_mid of a job, launched once before the first of them.
+void launch_xproj(const FwdJob& j, hipStream_t stream) {
+  const cmhse_seq_batch* b = j.b;
+  XprojParams q;
+  q.x_rows = b->x_rows;
+  q.tok_rows = b->tok_rows;
+  q.emb = b->emb_table;
+  q.step_off = b->step_off;
+  q.w_ih = j.w->w_ih;
+  q.gx = const_cast<float*>(j.p.gx);
+  q.p0 = j.p.gx_p0;
+  q.per_seq = j.p.gx_per_seq;
+  q.rows = q.per_seq ? b->step_count_host[j.t_mid] : (j.sum_T - j.p.gx_p0);
+  q.I = b->I;
+  q.N = 3 * b->H;
+  q.vocab = b->vocab;
+  q.x_step = b->x_step_floats;
+  q.Tmax = b->Tmax;
+  q.t_first = j.t_mid;
+  q.n_tiles = (q.N + 191) / 192;
+  const int64_t grid = static_cast<int64_t>(q.n_tiles) * ((q.rows + 63) / 64);
+  const size_t smem = TileSmem<64, 192>::kBytes;
+  hipLaunchKernelGGL(xproj_kernel, dim3(static_cast<unsigned>(grid)), dim3(kThreads), smem, stream, q);
 }
 
 void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t stream) {
   const bool vec = (kind & 4) == 0;
   const int msub = gru_msub();
   switch (kind & 3) {
+    case 3:
+      hipLaunchKernelGGL(gru_step_mid_kernel, dim3(grid), dim3(64 * kMidNW), 0, stream, g);
+      break;
     case 0:
       if ((kind & 16) != 0) {
         if (vec)
@@ -916,6 +1242,8 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
 
 unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   const int H = j.b->H;
+  if ((kind & 3) == 3)
+    return static_cast<unsigned>((H + kMidBU - 1) / kMidBU) * ((S_t + kMidBM - 1) / kMidBM);
   if ((kind & 3) == 0)
     return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
   const int bm = ((kind & 3) == 2 || gru_msub() == 2) ? 128 : 64;
@@ -944,6 +1272,14 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       const int S_t = j.b->step_count_host[t];
       if (j.b->step_events_host != nullptr && j.b->step_events_host[t] != nullptr)
         (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[t])), 0);
+      if (t == j.t_mid) {
+        // the hoisted projection reads the inputs of ALL remaining steps: wait for their uploads
+        if (j.b->step_events_host != nullptr)
+          for (int q = t + 1; q < j.b->Tmax; ++q)
+            if (j.b->step_events_host[q] != nullptr)
+              (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[q])), 0);
+        launch_xproj(j, stream);
+      }
       j.p.t = t;
       j.p.S_t = S_t;
       j.p.off_prev = j.off - (t > 0 ? j.b->step_count_host[t - 1] : 0);

@@ -6,7 +6,8 @@
 //   gates   [sumT, 4H]    r, z, n, (W_hn h + b_hn) per packed row
 //   argmax  [S, H] int32  step of the maximum (CMHSE_POOL_MAX)
 //   v       [sumT, H]     tanh(W_lin h + b_lin) (CMHSE_POOL_ATTN)
-// and, with CMHSE_MATH_BF16X3: the hi/lo pre-split copies of W_ih, W_hh (and W_lin).
+// with CMHSE_MATH_BF16X3: the hi/lo pre-split copies of W_ih, W_hh (and W_lin);
+// and last   gx  [rows of the small-batch steps, 3H]   their hoisted input projection x W_ih^T.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -24,8 +25,23 @@ namespace cmhse {
 constexpr int kAttBN = CMHSE_ATT_BN;  // columns of W_lin per attention-energy workgroup (128 or 256)
 
 struct GruWs {
-  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, total;
+  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, gx, total;
 };
+
+// Active sequences at or below which a step runs on the mid-size kernel (gru_step_mid_kernel: the
+// input projection of those steps hoisted into one GEMM, split-K 16x16x4 MFMA tiles for the
+// recurrent part).  CMHSE_MID_MAX_SEQS overrides (0 disables the kernel), read once.
+int mid_max_seqs();
+
+// Upper bound of the packed rows whose input projection is hoisted (the rows of the steps with at
+// most mid_max_seqs() active sequences): all of them when the whole batch is that small.
+static inline int64_t gx_rows_bound(int32_t S, int32_t Tmax, int64_t sum_T) {
+  const int64_t mm = mid_max_seqs();
+  if (mm <= 0) return 0;
+  if (S <= mm || Tmax <= 0) return sum_T;
+  const int64_t b = mm * static_cast<int64_t>(Tmax);
+  return b < sum_T ? b : sum_T;
+}
 
 constexpr int32_t kModeMask = ~(CMHSE_SAVE_FOR_BACKWARD | CMHSE_MATH_BF16X3);
 
@@ -35,7 +51,7 @@ __host__ __device__ static inline int64_t split_ld(int K) { return (static_cast<
 static inline size_t ws_align(size_t v) { return (v + 255) / 256 * 256; }
 
 static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t mode_flags,
-                                  int32_t I = 0) {
+                                  int32_t I = 0, int32_t Tmax = 0) {
   const bool save = (mode_flags & CMHSE_SAVE_FOR_BACKWARD) != 0;
   const bool bf3 = (mode_flags & CMHSE_MATH_BF16X3) != 0;
   const int mode = mode_flags & kModeMask;
@@ -58,6 +74,9 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   if (bf3) off += ws_align(static_cast<size_t>(3) * H * split_ld(H) * sizeof(float));
   L.wlin_s = off;
   if (bf3 && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(H) * split_ld(H) * sizeof(float));
+  L.gx = off;   // last region: the backward pass never looks at it (it calls this without Tmax)
+  if (I % 4 == 0 && H % 4 == 0)
+    off += ws_align(static_cast<size_t>(gx_rows_bound(S, Tmax, sum_T)) * 3 * H * sizeof(float));
   L.total = off;
   return L;
 }

@@ -98,6 +98,19 @@ def _tower_streams(device):
   return _TOWER_STREAMS[key]
 
 
+# tools/train_timeline.py sets this to a list: (name, host perf_counter, event on the current
+# stream) at the phase boundaries of a training step.  None (default) = no instrumentation.
+TRACE = None
+
+
+def _tick(name):
+  if TRACE is not None:
+    import time
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    TRACE.append((name, time.perf_counter(), ev))
+
+
 class VSE(object):
   """/root/reference/model.py:102-369."""
 
@@ -245,9 +258,12 @@ class VSE(object):
     lw = np.asarray(lengths_cap, dtype=np.int64)
 
     def visual_tower():
+      _tick('vis:start')
       vis = self.clip_enc.rnn.forward_multi([clips, videos], [lengths_clip, lengths_video])
+      _tick('vis:level1')
       clip_emb, vid_context = vis[:n_clip], vis[n_clip:]
       vid_emb = self._level2(self.vid_seq_enc, clip_emb, num_clips, vid_context)
+      _tick('vis:level2')
       clip_recon = frame_recon = None
       if self.reconstruct_loss:
         clip_recon = self.vid_seq_dec.forward_repeat(vid_emb, num_clips)
@@ -256,9 +272,11 @@ class VSE(object):
       return clip_emb, vid_context, vid_emb, clip_recon, frame_recon
 
     def text_tower():
+      _tick('txt:start')
       txt = self.txt_enc.rnn.forward_tokens_multi([captions, paragraphs],
                                                   [lengths_cap, lengths_paragraph],
                                                   self.txt_enc.embed.weight)
+      _tick('txt:level1')
       cap_emb, para_context = txt[:n_cap], txt[n_cap:]
       word = (ops.gather_rows(self.txt_enc.embed.weight.detach(), captions)
               if self.lowest_reconstruct_loss else None)
@@ -297,6 +315,7 @@ class VSE(object):
       out_t = text_tower()
     clip_emb, vid_context, vid_emb, clip_recon, frame_recon = out_v
     cap_emb, para_context, para_emb, cap_recon, sent_recon, word = out_t
+    _tick('towers:joined')
     n = normalize
     nv, npar = n(vid_emb), n(para_emb)
     loss_1 = self.forward_loss(nv, npar, '_vid')
@@ -341,9 +360,13 @@ class VSE(object):
     self.logger.update('Eit', self.Eiters)
     self.logger.update('lr', self.optimizer.param_groups[0]['lr'])
     self.optimizer.zero_grad()
+    _tick('step:start')
     loss = self.train_losses(opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
                              lengths_video, lengths_paragraph, num_clips, num_caps, ind, cur_vid)
+    _tick('losses:done')
     loss.backward()
+    _tick('backward:done')
     if self.grad_clip > 0:
       torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
     self.optimizer.step()
+    _tick('adam:done')

@@ -36,6 +36,7 @@ def main():
   ap.add_argument('--config', default='icep_recon', choices=sorted(CONFIGS))
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--rnn_type', default='attention')
+  ap.add_argument('--timeline', type=int, default=0, help='host (h) / GPU (g) ms at phase marks')
   args = ap.parse_args()
   cfg = dict(CONFIGS[args.config])
   wl = dict(bench.WORKLOADS[cfg.pop('workload')])
@@ -62,6 +63,17 @@ def main():
   dt = (time.perf_counter() - t0) / args.steps
   print('%s: %.2f ms per train_emb step (%d steps, batch 32, img_dim %d, %s)'
         % (args.config, dt * 1e3, args.steps, wl['img_dim'], args.rnn_type))
+  if args.timeline:
+    from cmhse_amd import model as model_mod
+    for b in use[3:6]:
+      torch.cuda.synchronize()
+      model_mod.TRACE = []
+      model.train_emb(opt, *b)
+      torch.cuda.synchronize()
+      tr, model_mod.TRACE = model_mod.TRACE, None
+      h0, e0 = tr[0][1], tr[0][2]
+      print('  ' + '  '.join('%s h%.2f g%.2f' % (n, (h - h0) * 1e3, e0.elapsed_time(e))
+                             for n, h, e in tr))
   print(str(model.logger))
 
 
