@@ -106,16 +106,18 @@ def device_batch(spec, b0, b1, clip_pos, img_dim, vocab, feat, gen, device):
           tuple(range(b0, b1)), tuple('v_%06d' % k for k in range(b0, b1)))
 
 
-def build_loader(spec, wl, device, own_lo, own_hi, seed=0):
-  """All loader batches of the split; only batches [own_lo, own_hi) are materialised (the others
-  carry just num_clips, which is all parallel_eval needs from them)."""
+def build_loader(spec, wl, device, own_lo, own_hi=None, seed=0):
+  """All loader batches of the split; only the batches this rank owns — [own_lo, own_hi), or the
+  index collection `own_lo` when `own_hi` is None — are materialised (the others carry just
+  num_clips, which is all parallel_eval needs from them)."""
+  own = set(range(own_lo, own_hi)) if own_hi is not None else set(own_lo)
   gen = torch.Generator(device=device)
   batches, clip_pos = [], 0
   n, bs = spec.n_videos, wl['batch']
   for bi, b0 in enumerate(range(0, n, bs)):
     b1 = min(n, b0 + bs)
     nclips = spec.num_clips[b0:b1]
-    if own_lo <= bi < own_hi:
+    if bi in own:
       gen.manual_seed(seed * 100003 + bi)
       batches.append(device_batch(spec, b0, b1, clip_pos, wl['img_dim'], wl['vocab'], wl['feat'],
                                   gen, device))
@@ -125,6 +127,10 @@ def build_loader(spec, wl, device, own_lo, own_hi, seed=0):
       batches.append(tuple(stub))
     clip_pos += sum(nclips)
   return batches
+
+
+def costs_sum(costs, idx):
+  return float(sum(costs[i][0] for i in idx))
 
 
 def gru_flops_per_step(I, H):
@@ -341,11 +347,16 @@ def main():
     spec = synthetic.uniform_spec(wl['n_videos'], clips=4, frames=10, words=12)
   else:
     spec = synthetic.anet_like_spec(wl['n_videos'], seed=0, dataset=wl['dataset'])
-  n_batches = (spec.n_videos + wl['batch'] - 1) // wl['batch']
-  lo, hi = parallel_eval.shard_range(n_batches, rank, world)
-  batches = build_loader(spec, wl, device, lo, hi)
+  # batches are dealt to ranks by work (GRU FLOPs of their frame / word steps), longest paragraph
+  # first: every rank derives the same assignment from the split's sizes alone
+  costs = [parallel_eval.batch_cost(lc, lv, lw, lp, wl['img_dim'], 300, args.embed)
+           for lc, lv, lw, lp in synthetic.batch_lengths(spec, wl['batch'])]
+  assignment = parallel_eval.assign_batches(costs, world)
+  batches = build_loader(spec, wl, device, assignment[rank])
   N = spec.n_videos
   quiet = lambda *a, **k: None
+
+  phase_ms, phase_sum = {}, {}
 
   def step():
     if world == 1:
@@ -353,7 +364,10 @@ def main():
       r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
       return r_i, r_t
-    res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed)
+    res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed,
+                                         assignment=assignment, timings=phase_ms)
+    for k, v in phase_ms.items():
+      phase_sum[k] = phase_sum.get(k, 0.0) + v
     return res[2], res[3]
 
   def sync():
@@ -386,12 +400,18 @@ def main():
   sim_ms = sum(x[0] for x in sims)
   sim_flops = sum(2.0 * x[1] * x[2] * x[3] for x in sims)
   sim_achieved = sim_flops / (sim_ms * 1e-3) / 1e12 if sim_ms > 0 else 0.0
-  per_rank_ms = [my_elapsed / args.steps * 1e3]
+  per_rank = [{'ms_per_step': my_elapsed / args.steps * 1e3}]
   if world > 1:
-    t = torch.tensor([my_elapsed / args.steps * 1e3], dtype=torch.float64, device=device)
+    # per-rank phase times of the TIMED passes (warm-up passes are subtracted out by resetting)
+    mine = [my_elapsed / args.steps * 1e3] + [phase_sum.get(k, 0.0) / max(1, args.steps + args.warmup)
+                                               for k in ('encode_ms', 'exchange_ms', 'score_ms')] + \
+        [float(phase_ms.get('videos', 0)), costs_sum(costs, assignment[rank])]
+    t = torch.tensor(mine, dtype=torch.float64, device=device)
     allt = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allt, t)
-    per_rank_ms = [float(x.item()) for x in allt]
+    per_rank = [{'ms_per_step': float(x[0]), 'encode_ms': float(x[1]), 'exchange_ms': float(x[2]),
+                 'score_ms': float(x[3]), 'videos': int(x[4]), 'gru_tflop': float(x[5]) / 1e12}
+                for x in allt]
   flops_all = sum(sum_T * gru_flops_per_step(I, H)
                   for (_, _, metas, _) in spans for (_, sum_T, I, H, _, _) in metas)
   ms_all = sum(s[0] for s in spans)
@@ -420,9 +440,9 @@ def main():
         'config': {'workload': args.workload, 'n_videos': N, 'n_clips': len(spec.frames_per_clip),
                    'loader_batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': args.embed,
                    'rnn_type': args.rnn_type, 'step': 'encode_data + i2t + t2i over the split',
-                   'sharding': 'videos over ranks, all-gather embeddings, row-stripe scoring'},
+                   'sharding': 'loader batches dealt to ranks by GRU work (longest paragraph first), one all-gather of the embeddings, row-stripe scoring'},
         'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
-        'per_rank_ms_per_step': per_rank_ms,
+        'per_rank': per_rank,
         'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -464,7 +484,7 @@ def main():
     if world == 1 and args.fast_steps > 0:
       out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)
     if world == 1 and args.train_steps > 0:
-      out['train_step'] = train_bench(wl, opt, model, batches[lo:hi], args.train_steps)
+      out['train_step'] = train_bench(wl, opt, model, batches, args.train_steps)
     if world == 1 and args.host_steps > 0:
       # the reference's loader contract hands over host tensors (activity_net/data.py:114-150):
       # same pass, inputs uploaded inside the timed region (one H2D per loader tensor, no overlap)

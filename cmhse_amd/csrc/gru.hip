@@ -457,37 +457,50 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 //   * the input projection x_t W_ih^T has no time dependence: for all these steps together it is
 //     ONE well-shaped GEMM (xproj_kernel, tiled like the attention projection) into gx[rows, 3H];
 //     the sequential part keeps only K = H;
-//   * tile = 32 sequences x 16 hidden units x {r, z, n}: 2 x 3 blocks of v_mfma_f32_16x16x4_f32
-//     (no idle MFMA columns, 64 contiguous bytes per operand row per load), 8 waves split K,
-//     operands global -> registers in MFMA layout through a 4-deep ring, fixed-order LDS combine;
-//     H/16 x ceil(S_t/32) workgroups (320 at S_t = 152, H = 1024).
+//   * tile = 32 (or 16) sequences x 16 hidden units x {r, z, n}: 2 (1) x 3 blocks of
+//     v_mfma_f32_16x16x4_f32 (no idle MFMA columns), 4 waves split K, operands global -> registers
+//     in MFMA layout through a ring of two 128-byte line pairs, fixed-order LDS combine, the
+//     epilogue's operands requested before the K loop; H/16 x ceil(S_t/32) workgroups of 256
+//     threads (320 at S_t = 152, H = 1024: all resident at once).
+// In-kernel stamps (tools/mid_trace.py) put the loop at the per-CU L2 bandwidth (~70 GB/s): a
+// 32 x 16 tile needs 320 KB of operands.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-constexpr int kMidBM = 32;
 constexpr int kMidBU = 16;
-constexpr int kMidNW = 8;
-constexpr int kMidRing = 4;
+constexpr int kMidNW = 4;      // waves per workgroup, splitting K
+constexpr int kMidRing = 4;    // 16-k blocks in flight per wave (two 128-byte line pairs)
 
-__device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[2], const rowaddr_t (&brow)[3],
-                                          int K, int wave, int kq, f32x4v (&acc)[2][3]) {
+// One wave's share of the K = H contraction for MB x 3 blocks of 16 x 16 outputs.  Blocks of 16 k
+// are owned in ADJACENT PAIRS (wave w: blocks 2w, 2w+1, then 2w + 2 NW, ...): a lane quarter loads
+// 16 bytes, so one load instruction covers 64 contiguous bytes of each of its 16 rows, and the
+// pair, issued back to back, the whole 128-byte line — per-CU L2 bandwidth (~70 GB/s) is what
+// bounds this loop, and half-used lines halve it.
+template <int MB>
+__device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[MB], const rowaddr_t (&brow)[3],
+                                          int K, int wave, int kq, f32x4v (&acc)[MB][3]) {
   constexpr int NW = kMidNW, D = kMidRing;
-  const int nkb = (K + 15) / 16;                       // k-blocks of 16 (4 per lane quarter)
-  const int nmine = (nkb - wave + NW - 1) / NW;        // this wave takes blocks wave, wave + NW, ...
+  static_assert(D % 2 == 0, "ring holds whole block pairs");
+  const int nkb = (K + 15) / 16;
+  // ring position i of this wave -> block index
+  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };
+  // positions this wave owns: all i with block_of(i) < nkb (monotone in i)
+  int nmine = 0;
+  while (block_of(nmine) < nkb) ++nmine;
   if (nmine <= 0) return;
-  float4 ra[D][2], rb[D][3];
+  float4 ra[D][MB], rb[D][3];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    const int k = (wave + NW * d) * 16 + 4 * kq;
+    const int k = block_of(d) * 16 + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[d][i] = issue_row4<true>(arow[i], k, K);
+    for (int i = 0; i < MB; ++i) ra[d][i] = issue_row4<true>(arow[i], k, K);
 #pragma unroll
     for (int i = 0; i < 3; ++i) rb[d][i] = issue_row4<true>(brow[i], k, K);
   }
-  auto mfmas = [&](const float4 (&a)[2], const float4 (&b)[3]) {
+  auto mfmas = [&](const float4 (&a)[MB], const float4 (&b)[3]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
+      for (int mb = 0; mb < MB; ++mb) {
         const float av = (j == 0) ? a[mb].x : (j == 1) ? a[mb].y : (j == 2) ? a[mb].z : a[mb].w;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -498,47 +511,51 @@ __device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[2], const rowa
     }
   };
   int it = 0;
-  // lean steady state: every k this trip consumes or prefetches lies inside K for all waves
   {
-    constexpr unsigned kSlot = NW * 16u * 4u;            // bytes between ring slots
-    constexpr unsigned kAhead = kSlot * D;
-    rowaddr_t pa[2], pb[3];
+    // lean steady state: every block this trip consumes or prefetches lies wholly inside K for all
+    // waves (uniform bound): no masks, no clamps, running pointers with immediate offsets.
+    // Ring slot d holds block_of(it + d); slots d, d+1 of a pair are 64 bytes apart, pairs 2 NW blocks.
+    constexpr unsigned kPair = 2u * NW * 16u * 4u;        // bytes between consecutive pairs
+    constexpr unsigned kAhead = kPair * (D / 2);
+    rowaddr_t pa[MB], pb[3];
+    const rowaddr_t lane_off = static_cast<rowaddr_t>(2 * wave * 16 + 4 * kq) * 4u + kAhead;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) pa[i] = arow[i] + static_cast<rowaddr_t>(wave * 16 + 4 * kq) * 4u + kAhead;
+    for (int i = 0; i < MB; ++i) pa[i] = arow[i] + lane_off;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) pb[i] = brow[i] + static_cast<rowaddr_t>(wave * 16 + 4 * kq) * 4u + kAhead;
-    for (; 16 * NW * (it + 2 * D) <= K; it += D) {
+    for (int i = 0; i < 3; ++i) pb[i] = brow[i] + lane_off;
+    for (; 16 * 2 * NW * ((it + 2 * D) / 2) <= K; it += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        float4 a[2], b[3];
+        const unsigned off = kPair * (d >> 1) + 64u * (d & 1);
+        float4 a[MB], b[3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MB; ++i) {
           a[i] = ra[d][i];
-          const f32x4 g = *(gptr_f32x4)(pa[i] + kSlot * d);
+          const f32x4 g = *(gptr_f32x4)(pa[i] + off);
           ra[d][i] = make_float4(g.x, g.y, g.z, g.w);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           b[i] = rb[d][i];
-          const f32x4 g = *(gptr_f32x4)(pb[i] + kSlot * d);
+          const f32x4 g = *(gptr_f32x4)(pb[i] + off);
           rb[d][i] = make_float4(g.x, g.y, g.z, g.w);
         }
         mfmas(a, b);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) pa[i] += kSlot * D;
+      for (int i = 0; i < MB; ++i) pa[i] += kPair * (D / 2);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) pb[i] += kSlot * D;
+      for (int i = 0; i < 3; ++i) pb[i] += kPair * (D / 2);
     }
   }
   for (; it < nmine; it += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const int k = (wave + NW * (it + d)) * 16 + 4 * kq;
-      const int kn = k + NW * D * 16;
-      float4 a[2], b[3];
+      const int k = block_of(it + d) * 16 + 4 * kq;
+      const int kn = block_of(it + d + D) * 16 + 4 * kq;
+      float4 a[MB], b[3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < MB; ++i) {
         a[i] = finish_row4<true>(ra[d][i], true, k, K);
         ra[d][i] = issue_row4<true>(arow[i], kn, K);
       }
@@ -552,22 +569,60 @@ __device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[2], const rowa
   }
 }
 
+// MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active
+template <int MB>
 __global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStepGroup grp) {
-  constexpr int NW = kMidNW;
+  constexpr int NW = kMidNW, BM = 16 * MB, NOUT = MB * 256 / (64 * NW);   // outputs per thread
   unsigned wg;
   const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  __shared__ f32x4v red[NW][6][64];       // [wave][M block x gate][lane], 48 KB
+  __shared__ f32x4v red[NW][MB * 3][64];       // [wave][M block x gate][lane]: 12 KB per M block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H;
   const int u_tiles = (H + kMidBU - 1) / kMidBU;
   const int u0 = (wg % u_tiles) * kMidBU;    // unit tile fastest: b, b+8 share an XCD's L2
-  const int m0 = (wg / u_tiles) * kMidBM;
+  const int m0 = (wg / u_tiles) * BM;
   const int r16 = lane & 15, kq = lane >> 4;
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-  if (have_h) {
-    rowaddr_t arow[2], brow[3];
+#ifdef CMHSE_TRACE
+  // tools/mid_trace.py: stamps of step t, workgroup wg at g_trace[(t * gridDim.x + blockIdx.x) * 8 + i]
+#define MID_MARK(i)                                                                       \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && g_trace)                                                      \
+      g_trace[(static_cast<size_t>(p.t) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define MID_MARK(i) do {} while (0)
+#endif
+  MID_MARK(0);
+  // The epilogue's own operands do not depend on the K loop: request them first (branch-free,
+  // clamped), so their memory round trip hides under it.  Output o of this thread: tile row
+  // er = o >> 4, unit eu = o & 15, o = tid + 256 q.
+  float e_gx[NOUT][3], e_hp[NOUT], e_b[NOUT][4];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+  for (int q = 0; q < NOUT; ++q) {
+    const int o = tid + 64 * NW * q;
+    const int em = m0 + (o >> 4), u = u0 + (o & 15);
+    const int emc = (em < p.S_t) ? em : (p.S_t - 1), uc = (u < H) ? u : (H - 1);
+    const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(emc) : (p.off_cur + emc - p.gx_p0);
+    const float* gxr = p.gx + gxrow * 3 * H;
+    e_gx[q][0] = gxr[uc];
+    e_gx[q][1] = gxr[H + uc];
+    e_gx[q][2] = gxr[2 * H + uc];
+    if (p.t > 0)
+      e_hp[q] = p.hs[(p.off_prev + emc) * H + uc];
+    else if (p.h0_rows != nullptr)
+      e_hp[q] = reinterpret_cast<const float*>(p.h0_rows[emc])[uc];
+    else
+      e_hp[q] = 0.f;
+    e_b[q][0] = p.b_ih[uc] + p.b_hh[uc];
+    e_b[q][1] = p.b_ih[H + uc] + p.b_hh[H + uc];
+    e_b[q][2] = p.b_ih[2 * H + uc];
+    e_b[q][3] = p.b_hh[2 * H + uc];
+  }
+  if (have_h) {
+    rowaddr_t arow[MB], brow[3];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
       const int m = m0 + 16 * mb + r16;
       const int mc = (m < p.S_t) ? m : (p.S_t - 1);   // rows past S_t are never stored
       arow[mb] = (p.t > 0) ? row_addr(p.hs + (p.off_prev + mc) * H) : p.h0_rows[mc];
@@ -575,67 +630,69 @@ __global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStep
     const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
 #pragma unroll
     for (int g = 0; g < 3; ++g) brow[g] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
-    f32x4v acc[2][3];
+    f32x4v acc[MB][3];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[mb][g] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    mid_phase(arow, brow, H, wave, kq, acc);
+    MID_MARK(1);
+    mid_phase<MB>(arow, brow, H, wave, kq, acc);
+    MID_MARK(2);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int g = 0; g < 3; ++g) red[wave][mb * 3 + g][lane] = acc[mb][g];
     __syncthreads();
+    MID_MARK(3);
   }
 
-  // epilogue: one (sequence, unit) per thread.  Element (row r, col c) of a 16x16 block sits in
-  // lane (r >> 2) * 16 + c, register r & 3.
-  const int er = tid >> 4, eu = tid & 15;
-  const int em = m0 + er, u = u0 + eu;
-  if (em >= p.S_t || u >= H) return;
-  float hr = 0.f, hz = 0.f, hn_ = 0.f;
-  if (have_h) {
-    const int mb = er >> 4, rr = er & 15;
-    const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
+  // epilogue.  Element (row r, col c) of a 16x16 block sits in lane (r >> 2) * 16 + c, register r & 3.
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      hr += reinterpret_cast<const float*>(&red[w][mb * 3 + 0][sl])[reg];
-      hz += reinterpret_cast<const float*>(&red[w][mb * 3 + 1][sl])[reg];
-      hn_ += reinterpret_cast<const float*>(&red[w][mb * 3 + 2][sl])[reg];
+  for (int q = 0; q < NOUT; ++q) {
+    const int o = tid + 64 * NW * q;
+    const int er = o >> 4, eu = o & 15;
+    const int em = m0 + er, u = u0 + eu;
+    if (em >= p.S_t || u >= H) continue;
+    float hr = 0.f, hz = 0.f, hn_ = 0.f;
+    if (have_h) {
+      const int mb = er >> 4, rr = er & 15;
+      const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        hr += reinterpret_cast<const float*>(&red[w][mb * 3 + 0][sl])[reg];
+        hz += reinterpret_cast<const float*>(&red[w][mb * 3 + 1][sl])[reg];
+        hn_ += reinterpret_cast<const float*>(&red[w][mb * 3 + 2][sl])[reg];
+      }
+    }
+    const float rg = sigmoidf_(e_gx[q][0] + hr + e_b[q][0]);
+    const float zg = sigmoidf_(e_gx[q][1] + hz + e_b[q][1]);
+    const float ghn = hn_ + e_b[q][3];
+    const float ng = tanhf_(e_gx[q][2] + e_b[q][2] + rg * ghn);
+    const float hn = (1.0f - zg) * ng + zg * e_hp[q];
+    p.hs[(p.off_cur + em) * H + u] = hn;
+    if (p.gates != nullptr) {
+      float* gp = p.gates + (p.off_cur + em) * 4 * H + u;
+      gp[0] = rg;
+      gp[H] = zg;
+      gp[2 * H] = ng;
+      gp[3 * H] = ghn;
+    }
+    if (p.pool_mode == CMHSE_POOL_MAX) {
+      float* op = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
+      if (p.t == 0 || hn > *op) {
+        *op = hn;
+        if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(em) * H + u] = p.t;
+      }
+    } else if (p.pool_mode == CMHSE_POOL_LAST) {
+      if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
+    } else if (p.pool_mode == CMHSE_POOL_ALL) {
+      p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
     }
   }
-  const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(em) : (p.off_cur + em - p.gx_p0);
-  const float* gxr = p.gx + gxrow * 3 * H;
-  const float xr = gxr[u], xz = gxr[H + u], xn = gxr[2 * H + u];
-  float hp = 0.f;
-  if (p.t > 0)
-    hp = p.hs[(p.off_prev + em) * H + u];
-  else if (p.h0_rows != nullptr)
-    hp = reinterpret_cast<const float*>(p.h0_rows[em])[u];
-  const float rg = sigmoidf_(xr + hr + p.b_ih[u] + p.b_hh[u]);
-  const float zg = sigmoidf_(xz + hz + p.b_ih[H + u] + p.b_hh[H + u]);
-  const float ghn = hn_ + p.b_hh[2 * H + u];
-  const float ng = tanhf_(xn + p.b_ih[2 * H + u] + rg * ghn);
-  const float hn = (1.0f - zg) * ng + zg * hp;
-  p.hs[(p.off_cur + em) * H + u] = hn;
-  if (p.gates != nullptr) {
-    float* gp = p.gates + (p.off_cur + em) * 4 * H + u;
-    gp[0] = rg;
-    gp[H] = zg;
-    gp[2 * H] = ng;
-    gp[3 * H] = ghn;
-  }
-  if (p.pool_mode == CMHSE_POOL_MAX) {
-    float* o = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
-    if (p.t == 0 || hn > *o) {
-      *o = hn;
-      if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(em) * H + u] = p.t;
-    }
-  } else if (p.pool_mode == CMHSE_POOL_LAST) {
-    if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
-  } else if (p.pool_mode == CMHSE_POOL_ALL) {
-    p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
-  }
+#ifdef CMHSE_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  MID_MARK(5);
+#endif
 }
 
 // Hoisted input projection of the mid-size steps: gx[m][n] = sum_k x_row(m)[k] W_ih[n][k] for the
@@ -1007,12 +1064,9 @@ static int tiny_max_seqs() {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int mid_max_seqs() {
-  static const int v = [] {
-    const char* e = getenv("CMHSE_MID_MAX_SEQS");
-    return e ? atoi(e) : 1024;
-  }();
-  return v;
+int mid_max_seqs() {   // read per call, so one process can A/B it (tools/step_sweep.py)
+  const char* e = getenv("CMHSE_MID_MAX_SEQS");
+  return e ? atoi(e) : 1024;
 }
 
 }  // namespace cmhse
@@ -1167,7 +1221,7 @@ static int tiny_nw8_max() {
 }
 
 int step_kind(const FwdJob& j, int S_t) {
-  if (j.p.t >= j.t_mid) return 3;   // mid-size kernel (vec shapes only, see prepare_job)
+  if (j.p.t >= j.t_mid) return 3 | (S_t <= 16 ? 32 : 0);   // mid-size kernel (vec shapes only)
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
   return k | (j.vec ? 0 : 4);
@@ -1203,7 +1257,10 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   const int msub = gru_msub();
   switch (kind & 3) {
     case 3:
-      hipLaunchKernelGGL(gru_step_mid_kernel, dim3(grid), dim3(64 * kMidNW), 0, stream, g);
+      if ((kind & 32) != 0)
+        hipLaunchKernelGGL(gru_step_mid_kernel<1>, dim3(grid), dim3(64 * kMidNW), 0, stream, g);
+      else
+        hipLaunchKernelGGL(gru_step_mid_kernel<2>, dim3(grid), dim3(64 * kMidNW), 0, stream, g);
       break;
     case 0:
       if ((kind & 16) != 0) {
@@ -1242,8 +1299,10 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
 
 unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   const int H = j.b->H;
-  if ((kind & 3) == 3)
-    return static_cast<unsigned>((H + kMidBU - 1) / kMidBU) * ((S_t + kMidBM - 1) / kMidBM);
+  if ((kind & 3) == 3) {
+    const int bm = (kind & 32) != 0 ? 16 : 32;
+    return static_cast<unsigned>((H + kMidBU - 1) / kMidBU) * ((S_t + bm - 1) / bm);
+  }
   if ((kind & 3) == 0)
     return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
   const int bm = ((kind & 3) == 2 || gru_msub() == 2) ? 128 : 64;
@@ -1301,7 +1360,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         done[m] = true;
       }
       for (int m = g.n; m < kMaxJobs; ++m) g.start[m] = 0xffffffffu;
-      const bool stamp = timer != nullptr && (kind[k] & 3) != 0;
+      const bool stamp = timer != nullptr && ((kind[k] & 3) == 1 || (kind[k] & 3) == 2);
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (stamp && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         (void)hipEventRecord(e0, stream);

@@ -30,7 +30,7 @@ struct GruWs {
 
 // Active sequences at or below which a step runs on the mid-size kernel (gru_step_mid_kernel: the
 // input projection of those steps hoisted into one GEMM, split-K 16x16x4 MFMA tiles for the
-// recurrent part).  CMHSE_MID_MAX_SEQS overrides (0 disables the kernel), read once.
+// recurrent part).  CMHSE_MID_MAX_SEQS overrides (0 disables the kernel).
 int mid_max_seqs();
 
 // Upper bound of the packed rows whose input projection is hoisted (the rows of the steps with at

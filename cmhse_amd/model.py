@@ -160,6 +160,7 @@ class VSE(object):
     self.optimizer = torch.optim.Adam(params, lr=opt.learning_rate)
     self.Eiters = 0
     self.logger = None
+    self._pending_log = None
 
   # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
   def _modules(self):
@@ -223,22 +224,40 @@ class VSE(object):
     word_emb = self.sent_seq_dec.forward_repeat(para_emb, num_caps)
     return frame_emb, word_emb
 
+  # -- logger protocol (model.py:291: `self.logger.update('Le'+name, loss.item(), n)`) -------------
+  # The reference pays one host sync per loss (3-9 per step).  Inside train_emb the values are only
+  # needed by the time the step returns, so the (name, device scalar, n) triples are queued and
+  # replayed in the reference's order after ONE device-to-host copy of all of them, issued once the
+  # backward pass and the Adam update have been queued: the host never waits mid-step.
+  def _log(self, key, loss, n):
+    if self._pending_log is not None:
+      self._pending_log.append((key, loss.detach(), n))
+    else:
+      self.logger.update(key, loss.item(), n)
+
+  def _flush_log(self):
+    pending, self._pending_log = self._pending_log, None
+    if pending:
+      values = torch.stack([v.reshape(()) for _, v, _ in pending]).cpu().tolist()
+      for (key, _, n), v in zip(pending, values):
+        self.logger.update(key, v, n)
+
   def forward_weak_loss(self, clip_emb, cap_emb, num_clips, num_caps, name, **kwargs):
     """model.py:294-299."""
     loss = self.weak_criterion(clip_emb, cap_emb, num_clips, num_caps)
-    self.logger.update('Le' + name, loss.item(), clip_emb.size(0))
+    self._log('Le' + name, loss, clip_emb.size(0))
     return loss
 
   def forward_reconstruct_loss(self, clip_recon, clip_emb, name, **kwargs):
     """model.py:301-306."""
     loss = self.criterion_Euclid_Distance(clip_recon, clip_emb)
-    self.logger.update('Le' + name, loss.item(), clip_emb.size(0))
+    self._log('Le' + name, loss, clip_emb.size(0))
     return loss
 
   def forward_loss(self, clip_emb, cap_emb, name, **kwargs):
     """model.py:287-292."""
     loss = self.criterion(clip_emb, cap_emb)
-    self.logger.update('Le' + name, loss.item(), clip_emb.size(0))
+    self._log('Le' + name, loss, clip_emb.size(0))
     return loss
 
   def train_losses(self, opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
@@ -346,9 +365,9 @@ class VSE(object):
       word_c = word.detach().contiguous()
       crit = self.criterion_Euclid_Distance
       l_fr = crit.forward_rows(frame_recon, valid_rows(clips_c, lc), clips_c)
-      self.logger.update('Le_reconstruct_frame_hier', l_fr.item(), int(lc.sum()))
+      self._log('Le_reconstruct_frame_hier', l_fr, int(lc.sum()))
       l_wd = crit.forward_rows(sent_recon, valid_rows(word_c, lw), word_c)
-      self.logger.update('Le_reconstruct_word_hier', l_wd.item(), int(lw.sum()))
+      self._log('Le_reconstruct_word_hier', l_wd, int(lw.sum()))
       loss = loss + (l_fr + l_wd) * opts.lowest_weight_recon
     return loss
 
@@ -361,12 +380,17 @@ class VSE(object):
     self.logger.update('lr', self.optimizer.param_groups[0]['lr'])
     self.optimizer.zero_grad()
     _tick('step:start')
-    loss = self.train_losses(opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
-                             lengths_video, lengths_paragraph, num_clips, num_caps, ind, cur_vid)
-    _tick('losses:done')
-    loss.backward()
-    _tick('backward:done')
-    if self.grad_clip > 0:
-      torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-    self.optimizer.step()
-    _tick('adam:done')
+    self._pending_log = []
+    try:
+      loss = self.train_losses(opts, clips, captions, videos, paragraphs, lengths_clip,
+                               lengths_cap, lengths_video, lengths_paragraph, num_clips, num_caps,
+                               ind, cur_vid)
+      _tick('losses:done')
+      loss.backward()
+      _tick('backward:done')
+      if self.grad_clip > 0:
+        torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+      self.optimizer.step()
+      _tick('adam:done')
+    finally:
+      self._flush_log()

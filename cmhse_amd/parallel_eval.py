@@ -3,20 +3,27 @@
 The reference is single-GPU (train.py:101) and has no collective anywhere; this is the one
 data-parallel sharding the path offers: videos/paragraphs are independent units.
 
-  1. rank r encodes a contiguous slice of the loader's batches (replicated weights);
+  1. the loader's batches are dealt to ranks by WORK, not by count (`assign_batches`): the cost of a
+     batch is its frame steps and word steps priced by the GRU step they feed, the batches are
+     placed longest-paragraph-first on the least-loaded rank, so the long few-sequence tails of the
+     text chain (which do not shrink with the world size) are spread over the ranks; rank r encodes
+     its batches with replicated weights;
   2. ONE exchange step: all-gather of the L2-normalised [n_r, D] video and paragraph embeddings
-     (RCCL over xGMI under backend "nccl"; shards are padded to the largest n_r);
+     (RCCL over xGMI under backend "nccl"; `all_gather_into_tensor`, shards padded to the largest);
   3. rank r scores its own ROW STRIPE: V[stripe] . P^T for i2t and P[stripe] . V^T for t2i with the
      fused rank/top-1 epilogue — every row's diagonal lies inside its stripe's columns, so no
      further data-path communication is needed;
-  4. all-gather of the int32 ranks / top-1 (a few KB) and the Recall@K report on every rank,
-     computed exactly as evaluation.py:173-184.
+  4. all-gather of the int32 ranks / top-1 (a few KB), un-permuted to loader order, and the
+     Recall@K report on every rank, computed exactly as evaluation.py:173-184.
 
-Ranks do not depend on the partition (each row is computed independently), so the result is
-identical for any world size.  `encode_fn` / `rank_fn` exist so the partition/merge logic can be
-exercised on CPU with gloo in tests; the defaults are the HIP path and have no fallback.
+Ranks do not depend on the partition (each row is computed independently, and a common permutation
+of videos and paragraphs keeps every diagonal pair together), so the result is identical for any
+world size.  `encode_fn` / `rank_fn` exist so the partition/merge logic can be exercised on CPU
+with gloo in tests; the defaults are the HIP path and have no fallback.
 """
 from __future__ import annotations
+
+import time
 
 import numpy as np
 import torch
@@ -32,6 +39,44 @@ def shard_range(n_items, rank, world):
   return lo, lo + base + (1 if rank < rem else 0)
 
 
+def batch_cost(len_clip, len_vid, len_cap, len_par, img_dim, word_dim=300, hidden=1024):
+  """(work, chain) of one loader batch: work = GRU FLOPs of its level-1 steps (SURVEY §8d:
+  2*3H*(I+H) per sequence-step, frames at I = img_dim, words at I = word_dim); chain = its longest
+  paragraph, the length of the dependent tail it brings to whichever rank encodes it."""
+  fv = 6.0 * hidden * (img_dim + hidden)
+  ft = 6.0 * hidden * (word_dim + hidden)
+  work = fv * (float(np.sum(len_clip)) + float(np.sum(len_vid))) + \
+      ft * (float(np.sum(len_cap)) + float(np.sum(len_par)))
+  return work, int(np.max(len_par)) if len(len_par) else 0
+
+
+def assign_batches(costs, world):
+  """Deal batches to ranks: longest chain first (ties: most work first), each onto the rank with
+  the least work so far (ties: lowest rank).  `costs` = [(work, chain)] per batch.  Returns a list
+  of `world` ascending batch-index lists; deterministic, so every rank computes the same one."""
+  order = sorted(range(len(costs)), key=lambda i: (-costs[i][1], -costs[i][0], i))
+  load = [0.0] * world
+  out = [[] for _ in range(world)]
+  for i in order:
+    r = min(range(world), key=lambda q: (load[q], q))
+    out[r].append(i)
+    load[r] += max(costs[i][0], 1e-9)
+  return [sorted(o) for o in out]
+
+
+def costs_of(batches, img_dim=None):
+  """Per-batch (work, chain) from the loader's own length tensors (slots 4-7 of the 12-tuple); a
+  batch that carries none (a stub that only says how many videos it has) counts its videos."""
+  out = []
+  for b in batches:
+    if b[4] is None or b[7] is None:
+      out.append((float(len(b[8])), 0))
+      continue
+    I = img_dim if img_dim is not None else (int(b[0].shape[2]) if hasattr(b[0], 'shape') else 1024)
+    out.append(batch_cost(np.asarray(b[4]), np.asarray(b[6]), np.asarray(b[5]), np.asarray(b[7]), I))
+  return out
+
+
 def _default_encode(opt, model, batches):
   if not batches:
     return None
@@ -44,34 +89,49 @@ def _default_rank(queries, gallery, row0, nrows):
 
 
 def all_gather_rows(local, counts, group=None):
-  """All-gather row blocks of unequal height: pad to max(counts), gather, drop the padding."""
+  """All-gather row blocks of unequal height into one tensor: pad to max(counts), ONE
+  all_gather_into_tensor, drop the padding."""
   world = dist.get_world_size(group)
-  width = local.shape[1:]
-  mx = max(counts)
-  padded = torch.zeros((mx,) + tuple(width), dtype=local.dtype, device=local.device)
+  width = tuple(local.shape[1:])
+  mx = max(max(counts), 1)
+  padded = torch.zeros((mx,) + width, dtype=local.dtype, device=local.device)
   padded[:local.shape[0]] = local
-  bufs = [torch.empty_like(padded) for _ in range(world)]
-  dist.all_gather(bufs, padded, group=group)
-  return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+  out = torch.empty((world * mx,) + width, dtype=local.dtype, device=local.device)
+  dist.all_gather_into_tensor(out, padded, group=group)
+  if all(c == mx for c in counts):
+    return out
+  return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)], 0)
 
 
 def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_fn=None,
-                     device=None, dim=None):
+                     device=None, dim=None, assignment=None, timings=None):
   """Sharded counterpart of train.validate's encode_data + i2t + t2i (train.py:223-236).
-  Returns (report_i2t, report_t2i, ranks_i2t, ranks_t2i, top1_i2t, top1_t2i) on every rank."""
+  Returns (report_i2t, report_t2i, ranks_i2t, ranks_t2i, top1_i2t, top1_t2i) on every rank, rows in
+  loader order.  `assignment`: per-rank batch-index lists (default: assign_batches on the loader's
+  lengths).  `timings`: a dict that receives this rank's encode_ms / exchange_ms / score_ms (host
+  clock around device syncs) — measurement only."""
   encode_fn = encode_fn or _default_encode
   rank_fn = rank_fn or _default_rank
   world = dist.get_world_size(group)
   me = dist.get_rank(group)
   batches = list(data_loader)
-  lo, hi = shard_range(len(batches), me, world)
-  mine = batches[lo:hi]
-  # videos per rank follow from the loader alone, so every rank can compute all counts locally
-  counts = []
-  for r in range(world):
-    a, b = shard_range(len(batches), r, world)
-    counts.append(sum(len(bb[8]) for bb in batches[a:b]))
-  enc = encode_fn(opt, model, mine)
+  if assignment is None:
+    assignment = assign_batches(costs_of(batches), world)
+  sizes = [len(b[8]) for b in batches]
+  starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+  # global (loader-order) video index of every row of the gathered matrices, rank after rank
+  perm = np.concatenate([np.arange(starts[i], starts[i + 1]) for r in range(world)
+                         for i in assignment[r]] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+  counts = [int(sum(sizes[i] for i in assignment[r])) for r in range(world)]
+
+  def sync():
+    if timings is not None and torch.cuda.is_available() and device is not None and \
+        torch.device(device).type == 'cuda':
+      torch.cuda.synchronize()
+    return time.perf_counter()
+
+  t0 = sync()
+  enc = encode_fn(opt, model, [batches[i] for i in assignment[me]])
   if enc is None:
     if device is None or dim is None:
       raise ValueError('a rank with an empty shard needs `device` and `dim`')
@@ -79,15 +139,26 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
     p_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
   else:
     v_loc, p_loc = enc
+  t1 = sync()
   V = all_gather_rows(v_loc, counts, group)
   P = all_gather_rows(p_loc, counts, group)
+  t2 = sync()
   row0 = sum(counts[:me])
   nrows = counts[me]
   r_i, t_i = rank_fn(V, P, row0, nrows)
   r_t, t_t = rank_fn(P, V, row0, nrows)
   packed = torch.stack([r_i, t_i, r_t, t_t], 1).to(torch.int32)
+  t3 = sync()
   full = all_gather_rows(packed, counts, group).cpu().numpy()
-  ranks_i, top1_i = full[:, 0].astype(np.float64), full[:, 1].astype(np.float64)
-  ranks_t, top1_t = full[:, 2].astype(np.float64), full[:, 3].astype(np.float64)
+  if timings is not None:
+    timings.update(encode_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3,
+                   score_ms=(t3 - t2) * 1e3, videos=nrows)
+  # rows are in rank-major (permuted) order: put them back in loader order; a top-1 is an index
+  # into the permuted gallery and maps through the same permutation
+  n = len(perm)
+  ranks_i, ranks_t = np.empty(n, np.float64), np.empty(n, np.float64)
+  top1_i, top1_t = np.empty(n, np.float64), np.empty(n, np.float64)
+  ranks_i[perm], ranks_t[perm] = full[:, 0], full[:, 2]
+  top1_i[perm], top1_t[perm] = perm[full[:, 1]], perm[full[:, 3]]
   return (evaluation.report_from_ranks(ranks_i), evaluation.report_from_ranks(ranks_t),
           ranks_i, ranks_t, top1_i, top1_t)

@@ -104,6 +104,26 @@ def ragged_spec(n_videos, seed=0, max_clips=5, max_frames=9, max_words=7, max_vi
   return SplitSpec(nclips, fpc, fpv, wps)
 
 
+def batch_lengths(spec, batch_size):
+  """Per loader batch: (lengths_clip, lengths_video, lengths_cap, lengths_paragraph) as the
+  collate_fn would report them — the sizes alone, without materialising any feature."""
+  out, clip_pos = [], 0
+  for b0 in range(0, spec.n_videos, batch_size):
+    b1 = min(spec.n_videos, b0 + batch_size)
+    nclips = spec.num_clips[b0:b1]
+    sumC = sum(nclips)
+    fpc = spec.frames_per_clip[clip_pos:clip_pos + sumC]
+    wps = spec.words_per_sent[clip_pos:clip_pos + sumC]
+    clip_pos += sumC
+    par, j = [], 0
+    for c in nclips:
+      par.append(sum(wps[j:j + c]))
+      j += c
+    out.append((np.asarray(fpc), np.asarray(spec.frames_per_video[b0:b1]), np.asarray(wps),
+                np.asarray(par)))
+  return out
+
+
 def make_batches(spec, batch_size, img_dim, vocab_size, seed=0, feat='normal',
                  device='cpu', dtype=torch.float32):
   """Materialise `spec` as a list of 12-tuples (one per loader batch).

@@ -22,7 +22,7 @@ def _free_port():
   return p
 
 
-def _worker(rank, world, port, n_videos, batch, out_dir):
+def _worker(rank, world, port, n_videos, batch, out_dir, scramble=False):
   sys.path.insert(0, REPO)
   sys.path.insert(0, os.path.join(REPO, 'oracle'))
   import cmhse_oracle as oracle
@@ -52,19 +52,27 @@ def _worker(rank, world, port, n_videos, batch, out_dir):
     return (torch.from_numpy((d > diag).sum(1).astype(np.int32)),
             torch.from_numpy(d.argmax(1).astype(np.int32)))
 
+  assignment = None
+  if scramble:   # a non-contiguous deal: exercises the permutation back to loader order
+    nb = len(batches)
+    assignment = [[i for i in range(nb) if (i * 7 + 3) % world == r] for r in range(world)]
   res = parallel_eval.validate_sharded(None, None, batches, encode_fn=encode_fn, rank_fn=rank_fn,
-                                       device='cpu', dim=48)
+                                       device='cpu', dim=48, assignment=assignment)
   np.savez(os.path.join(out_dir, 'r%d.npz' % rank), ranks_i=res[2], ranks_t=res[3],
            top1_i=res[4], top1_t=res[5], rep_i=np.array(sorted(res[0].items()), dtype=object)[:, 1]
            .astype(np.float64))
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_videos,batch', [(2, 37, 5), (3, 10, 4), (2, 3, 4)])
-def test_sharded_validation_matches_single_process(tmp_path, oracle, world, n_videos, batch):
+@pytest.mark.parametrize('world,n_videos,batch,scramble',
+                         [(2, 37, 5, False), (3, 10, 4, False), (2, 3, 4, False), (2, 37, 5, True),
+                          (3, 41, 4, True)])
+def test_sharded_validation_matches_single_process(tmp_path, oracle, world, n_videos, batch,
+                                                   scramble):
   from cmhse_amd import synthetic
   port = _free_port()
-  mp.spawn(_worker, args=(world, port, n_videos, batch, str(tmp_path)), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, port, n_videos, batch, str(tmp_path), scramble), nprocs=world,
+           join=True)
   a, b = synthetic.correlated_embeddings(n_videos, 48, 2.0, seed=11)
   _, top1_i, ranks_i = oracle.i2t(a, b, np.float64)
   _, top1_t, ranks_t = oracle.t2i(a, b, np.float64)
@@ -85,3 +93,35 @@ def test_shard_range_is_a_partition():
       assert all(pieces[i][1] == pieces[i + 1][0] for i in range(w - 1))
       sizes = [b - a for a, b in pieces]
       assert max(sizes) - min(sizes) <= 1
+
+
+def test_assign_batches_balances_work_and_spreads_the_long_chains():
+  """The deal is a partition, deterministic, balanced by work to within one batch, and puts the
+  batches with the longest paragraphs (the tails that do not shrink with the world size) on
+  different ranks."""
+  from cmhse_amd import parallel_eval, synthetic
+  spec = synthetic.anet_like_spec(4917, seed=0)
+  costs = [parallel_eval.batch_cost(lc, lv, lw, lp, 2048)
+           for lc, lv, lw, lp in synthetic.batch_lengths(spec, 32)]
+  assert len(costs) == 154
+  for world in (1, 2, 3, 4, 8):
+    a = parallel_eval.assign_batches(costs, world)
+    assert a == parallel_eval.assign_batches(list(costs), world)
+    flat = sorted(i for r in a for i in r)
+    assert flat == list(range(len(costs)))
+    load = [sum(costs[i][0] for i in r) for r in a]
+    assert max(load) - min(load) <= max(c[0] for c in costs) + 1e-6
+    top = sorted(range(len(costs)), key=lambda i: -costs[i][1])[:world]
+    owners = {r for r in range(world) for i in a[r] if i in top}
+    assert len(owners) == world
+
+
+def test_batch_lengths_match_the_materialised_batches():
+  from cmhse_amd import synthetic
+  spec = synthetic.ragged_spec(11, seed=3)
+  lens = synthetic.batch_lengths(spec, 4)
+  batches = synthetic.make_batches(spec, 4, 8, 50, seed=0)
+  assert len(lens) == len(batches)
+  for (lc, lv, lw, lp), b in zip(lens, batches):
+    assert list(lc) == b[4].tolist() and list(lw) == b[5].tolist()
+    assert list(lv) == b[6].tolist() and list(lp) == b[7].tolist()
