@@ -331,11 +331,19 @@ def main():
   if world != args.gpus:
     raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with '
                      'torch.distributed.run)' % (args.gpus, world))
+  # CMHSE_BENCH_BACKEND=gloo: debugging aid — exercises the N-rank path (deal, gathers, merge,
+  # per-rank report) with every rank on GPU 0 of a box that has fewer GPUs than ranks
+  backend = os.environ.get('CMHSE_BENCH_BACKEND', 'nccl')
+  if backend == 'gloo':
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group('nccl', device_id=device)
+    if backend == 'gloo':
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=device)
 
   wl = dict(WORKLOADS[args.workload])
   if args.n_videos:
@@ -387,7 +395,7 @@ def main():
   elapsed = time.perf_counter() - t0
   my_elapsed = elapsed
   if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -406,7 +414,7 @@ def main():
     mine = [my_elapsed / args.steps * 1e3] + [phase_sum.get(k, 0.0) / max(1, args.steps + args.warmup)
                                                for k in ('encode_ms', 'exchange_ms', 'score_ms')] + \
         [float(phase_ms.get('videos', 0)), costs_sum(costs, assignment[rank])]
-    t = torch.tensor(mine, dtype=torch.float64, device=device)
+    t = torch.tensor(mine, dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
     allt = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(allt, t)
     per_rank = [{'ms_per_step': float(x[0]), 'encode_ms': float(x[1]), 'exchange_ms': float(x[2]),

@@ -638,17 +638,31 @@ __global__ __launch_bounds__(kThreads) void euclid_rows_kernel(const EuclidParam
     if (threadIdx.x == 0) q.dist[r] = dist;
     return;
   }
+  // d sqrt(ss) / d a = (a - b) / dist: no epsilon, like autograd through torch.sqrt upstream
+  // (decoder/loss.py:21) — an exactly reconstructed row (dist == 0) gives NaN there and here
   float sc = *q.gout / dist;
   if (q.norm) sc /= static_cast<float>(q.rows);
   for (int c = threadIdx.x; c < q.cols; c += kThreads) q.d_a[r * q.cols + c] = (ar[c] - br[c]) * sc;
 }
 
-__global__ void euclid_final_kernel(const EuclidParams q) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Sum of the row distances in a FIXED order (bitwise reproducible): thread i adds rows i, i + 256,
+// ... in double, then a pairwise LDS tree.  (--lowest_reconstruct_loss sums one row per frame /
+// word of the batch, 1e4 and more: a single-thread dependent load chain took milliseconds.)
+__global__ __launch_bounds__(kThreads) void euclid_final_kernel(const EuclidParams q) {
+  __shared__ double part[kThreads];
   double t = 0.0;
-  for (int r = 0; r < q.rows; ++r) t += q.dist[r];
-  if (q.norm) t /= q.rows;
-  *q.loss = static_cast<float>(t);
+  for (int r = threadIdx.x; r < q.rows; r += kThreads) t += q.dist[r];
+  part[threadIdx.x] = t;
+  __syncthreads();
+  for (int w = kThreads / 2; w >= 1; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double total = part[0];
+    if (q.norm) total /= q.rows;
+    *q.loss = static_cast<float>(total);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -974,7 +988,7 @@ extern "C" int cmhse_euclid_fwd(const float* a, const float* b, const uint64_t* 
   q.a = a; q.b = b; q.b_rows = b_rows; q.dist = row_dist; q.d_a = nullptr; q.gout = nullptr;
   q.loss = loss; q.rows = rows; q.cols = cols; q.norm = norm;
   hipLaunchKernelGGL(euclid_rows_kernel, dim3(rows), dim3(kThreads), 0, st, q, 0);
-  hipLaunchKernelGGL(euclid_final_kernel, dim3(1), dim3(64), 0, st, q);
+  hipLaunchKernelGGL(euclid_final_kernel, dim3(1), dim3(kThreads), 0, st, q);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 

@@ -1362,8 +1362,13 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       for (int m = g.n; m < kMaxJobs; ++m) g.start[m] = 0xffffffffu;
       const bool stamp = timer != nullptr && ((kind[k] & 3) == 1 || (kind[k] & 3) == 2);
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (stamp && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-        (void)hipEventRecord(e0, stream);
+      if (stamp) {
+        if (hipEventCreate(&e0) != hipSuccess) e0 = nullptr;
+        if (e0 && hipEventCreate(&e1) != hipSuccess) {   // no pair: release the first, time nothing
+          (void)hipEventDestroy(e0);
+          e0 = e1 = nullptr;
+        }
+        if (e0 && e1) (void)hipEventRecord(e0, stream);
       }
       launch_group(g, kind[k], grid, stream);
       if (stamp && e0 && e1) {

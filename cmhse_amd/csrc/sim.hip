@@ -31,6 +31,7 @@ struct SimParams {
   const float* A;  // [N, D]
   const float* B;  // [M, D]
   int32_t N, M, D, row0, nrows, n_tiles;
+  int32_t m_tiles8;             // counting pass: 1 = quad rasterisation (see sim_kernel), 0 = plain
   float* diag;                  // [nrows]
   int32_t* rank;                // [nrows]
   unsigned long long* top1key;  // [nrows]
@@ -73,6 +74,20 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
   if (MODE == kSimDiag) {
     i0 = blockIdx.x * BM;
     j0 = p.row0 + i0;  // the column block that holds this row block's diagonal
+  } else if (MODE == kSimRank && p.m_tiles8 > 0) {
+    // Counting pass, XCD-aware: blocks b, b + 8 share an XCD (round-robin dispatch), whose 4 MB L2
+    // holds neither operand (2 x 20 MB at N = 4917).  The tiles are dealt in QUADS — four
+    // consecutive row tiles x one column tile — quad Q to XCD label Q % 8, its four workgroups
+    // back to back in that XCD's order: they run together and pull their B tile through the
+    // fabric once instead of four times, the four A tiles of a row group (2 MB) stay L2-resident
+    // while the group's quads stream by, and every XCD gets the same number of quads (a deal by
+    // row tile left one XCD in eight with a third round of workgroups: 0.70 instead of 0.45 ms).
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int Q = (q >> 2) * 8 + x;
+    const int it = 4 * (Q / p.n_tiles) + (q & 3);
+    j0 = (Q % p.n_tiles) * BN;
+    i0 = it * BM;
+    if (i0 >= p.nrows) return;     // padding: quads beyond the last row group, rows of a partial group
   } else {
     j0 = (blockIdx.x % p.n_tiles) * BN;
     i0 = (blockIdx.x / p.n_tiles) * BM;
@@ -274,6 +289,7 @@ static int launch_sim_store(const float* A, const float* B, int n, int m, int D,
   p.row0 = 0;
   p.nrows = n;
   p.n_tiles = (m + kSimBN - 1) / kSimBN;
+  p.m_tiles8 = 0;
   p.diag = nullptr;
   p.rank = nullptr;
   p.top1key = nullptr;
@@ -331,7 +347,10 @@ extern "C" int cmhse_sim_rank_ex(const float* A, const float* B, int32_t N, int3
   p.blk_off = nullptr;
   p.blk_stride = 0;
   const int m_tiles = (nrows + kSimBM - 1) / kSimBM;
-  const int64_t blocks = static_cast<int64_t>(p.n_tiles) * m_tiles;
+  // quads (4 row tiles x 1 column tile) dealt round-robin to the 8 XCD labels (see sim_kernel)
+  p.m_tiles8 = 1;
+  const int64_t quads = static_cast<int64_t>((m_tiles + 3) / 4) * p.n_tiles;
+  const int64_t blocks = (quads + 7) / 8 * 8 * 4;
   if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
   if (hipMemsetAsync(rank, 0, sizeof(int32_t) * nrows, stream) != hipSuccess) return CMHSE_ERR_LAUNCH;
   if (hipMemsetAsync(p.top1key, 0, sizeof(unsigned long long) * nrows, stream) != hipSuccess)
@@ -436,6 +455,7 @@ extern "C" int cmhse_contrastive_blocks_fwd(const float* im, const float* s,
   p.D = D;
   p.row0 = 0;
   p.n_tiles = (max_n + kSimBN - 1) / kSimBN;
+  p.m_tiles8 = 0;
   p.diag = nullptr;
   p.rank = nullptr;
   p.top1key = nullptr;

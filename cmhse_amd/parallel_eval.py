@@ -94,10 +94,16 @@ def all_gather_rows(local, counts, group=None):
   world = dist.get_world_size(group)
   width = tuple(local.shape[1:])
   mx = max(max(counts), 1)
-  padded = torch.zeros((mx,) + width, dtype=local.dtype, device=local.device)
+  # (a gloo group moves device tensors through the host: debugging runs of the N-rank path on a
+  # box with fewer GPUs than ranks; RCCL gathers in place)
+  via_host = local.is_cuda and dist.get_backend(group) == 'gloo'
+  dev = torch.device('cpu') if via_host else local.device
+  padded = torch.zeros((mx,) + width, dtype=local.dtype, device=dev)
   padded[:local.shape[0]] = local
-  out = torch.empty((world * mx,) + width, dtype=local.dtype, device=local.device)
+  out = torch.empty((world * mx,) + width, dtype=local.dtype, device=dev)
   dist.all_gather_into_tensor(out, padded, group=group)
+  if via_host:
+    out = out.to(local.device)
   if all(c == mx for c in counts):
     return out
   return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)], 0)
