@@ -31,7 +31,7 @@ struct SimParams {
   const float* A;  // [N, D]
   const float* B;  // [M, D]
   int32_t N, M, D, row0, nrows, n_tiles;
-  int32_t m_tiles8;             // counting pass: 1 = quad rasterisation (see sim_kernel), 0 = plain
+  int32_t m_tiles8;             // counting pass: row tiles per rasterisation group (see sim_kernel), 0 = plain
   float* diag;                  // [nrows]
   int32_t* rank;                // [nrows]
   unsigned long long* top1key;  // [nrows]
@@ -76,18 +76,22 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
     j0 = p.row0 + i0;  // the column block that holds this row block's diagonal
   } else if (MODE == kSimRank && p.m_tiles8 > 0) {
     // Counting pass, XCD-aware: blocks b, b + 8 share an XCD (round-robin dispatch), whose 4 MB L2
-    // holds neither operand (2 x 20 MB at N = 4917).  The tiles are dealt in QUADS — four
-    // consecutive row tiles x one column tile — quad Q to XCD label Q % 8, its four workgroups
-    // back to back in that XCD's order: they run together and pull their B tile through the
-    // fabric once instead of four times, the four A tiles of a row group (2 MB) stay L2-resident
-    // while the group's quads stream by, and every XCD gets the same number of quads (a deal by
-    // row tile left one XCD in eight with a third round of workgroups: 0.70 instead of 0.45 ms).
+    // holds neither operand (2 x 20 MB at N = 4917).  The tiles are dealt in GROUPS — G consecutive
+    // row tiles x one column tile — group Q to XCD label Q % 8, its G workgroups back to back in
+    // that XCD's order: they run together and pull their B tile through the fabric once instead of
+    // G times, and the G A tiles of a row group stay L2-resident while the group's column tiles
+    // stream by (931 -> 424 MB per launch at N = 4917, rocprofv3 FETCH_SIZE).  G is the largest of
+    // 4, 3, 2 that keeps every XCD within the rounds of resident workgroups a perfectly even deal
+    // needs: a launch is two rounds at N = 4917, and one XCD with a handful of workgroups in a
+    // third round costs a third of the launch (0.70 ms with a deal by row tile, 0.49 with G = 4,
+    // against 0.45 ms).
+    const int G = p.m_tiles8;      // row tiles per group (2..4), chosen by the launcher
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int Q = (q >> 2) * 8 + x;
-    const int it = 4 * (Q / p.n_tiles) + (q & 3);
+    const int Q = (q / G) * 8 + x;
+    const int it = G * (Q / p.n_tiles) + (q % G);
     j0 = (Q % p.n_tiles) * BN;
     i0 = it * BM;
-    if (i0 >= p.nrows) return;     // padding: quads beyond the last row group, rows of a partial group
+    if (i0 >= p.nrows) return;     // padding: groups beyond the last row group, rows of a partial group
   } else {
     j0 = (blockIdx.x % p.n_tiles) * BN;
     i0 = (blockIdx.x / p.n_tiles) * BM;
@@ -347,10 +351,18 @@ extern "C" int cmhse_sim_rank_ex(const float* A, const float* B, int32_t N, int3
   p.blk_off = nullptr;
   p.blk_stride = 0;
   const int m_tiles = (nrows + kSimBM - 1) / kSimBM;
-  // quads (4 row tiles x 1 column tile) dealt round-robin to the 8 XCD labels (see sim_kernel)
-  p.m_tiles8 = 1;
-  const int64_t quads = static_cast<int64_t>((m_tiles + 3) / 4) * p.n_tiles;
-  const int64_t blocks = (quads + 7) / 8 * 8 * 4;
+  // groups of G row tiles x 1 column tile dealt round-robin to the 8 XCD labels (see sim_kernel);
+  // 96 = workgroups resident per XCD (3 per CU at 41 KB of LDS)
+  const int64_t tiles = static_cast<int64_t>(m_tiles) * p.n_tiles;
+  const int64_t ideal_rounds = (tiles + 767) / 768;
+  int G = 0;
+  for (int g = 4; g >= 2 && G == 0; --g) {
+    const int64_t groups = static_cast<int64_t>((m_tiles + g - 1) / g) * p.n_tiles;
+    if (((groups + 7) / 8 * g + 95) / 96 <= ideal_rounds) G = g;
+  }
+  p.m_tiles8 = G;
+  int64_t blocks = tiles;
+  if (G > 0) blocks = (static_cast<int64_t>((m_tiles + G - 1) / G) * p.n_tiles + 7) / 8 * 8 * G;
   if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
   if (hipMemsetAsync(rank, 0, sizeof(int32_t) * nrows, stream) != hipSuccess) return CMHSE_ERR_LAUNCH;
   if (hipMemsetAsync(p.top1key, 0, sizeof(unsigned long long) * nrows, stream) != hipSuccess)

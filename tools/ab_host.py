@@ -87,8 +87,9 @@ def main():
               % (i, bool(torch.equal(cat['vid_emb'], ref)), pull_only()))
         continue
       res[i].append(timed(host))
-      if rnd == 1:   # when did the chunks land, relative to the start of a pass?
+      if rnd == 1 and evaluation.PIPELINE_UPLOAD[0]:   # when did the chunks land in a pass?
         ops.PULL_EVENT_TIMING[0] = True
+        ops.LAST_PULL_EVENTS[0] = None
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
