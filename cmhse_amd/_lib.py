@@ -45,6 +45,13 @@ class GruJob(ctypes.Structure):
               ('workspace_bytes', c_size_t), ('tail_stream', c_void_p)]
 
 
+class GruBwdJob(ctypes.Structure):
+  _fields_ = [('seqs', ctypes.POINTER(SeqBatch)), ('weights', ctypes.POINTER(GruWeights)),
+              ('pool_mode', c_int32), ('dout', c_void_p), ('fwd_workspace', c_void_p),
+              ('grads', ctypes.POINTER(GruGrads)), ('dx_rows', c_void_p), ('d_emb_table', c_void_p),
+              ('dh0', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_size_t)]
+
+
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
@@ -78,6 +85,7 @@ SIGNATURES = {
                                           c_int32, c_void_p, c_void_p, ctypes.POINTER(GruGrads),
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                           c_void_p]),
+    'cmhse_gru_pool_bwd_multi': (ctypes.c_int, [ctypes.POINTER(GruBwdJob), c_int32, c_void_p]),
     'cmhse_l2norm_rows_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                              c_void_p]),
     'cmhse_contrastive_bwd_workspace': (c_size_t, [c_int32]),

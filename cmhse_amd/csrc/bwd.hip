@@ -387,13 +387,27 @@ struct BwdStepParams {
   int64_t off_cur, off_prev;
 };
 
+// Up to CMHSE_MAX_JOBS independent BPTT chains share one launch per step (cmhse_gru_pool_bwd_multi):
+// workgroups [start[k], start[k+1]) belong to job k, like GruStepGroup in the forward pass.
+struct BwdStepGroup {
+  BwdStepParams j[CMHSE_MAX_JOBS];
+  uint32_t start[CMHSE_MAX_JOBS];
+  int32_t n;
+};
+
 template <bool VEC, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void gru_bwd_step_kernel(const BwdStepParams q) {
+__global__ __launch_bounds__(64 * NW) void gru_bwd_step_kernel(const BwdStepGroup grp) {
   __shared__ float red[NW][16][64];
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < CMHSE_MAX_JOBS; ++k)
+    if (k < grp.n && blockIdx.x >= grp.start[k]) ji = k;
+  const BwdStepParams& q = grp.j[ji];
+  const unsigned wg = blockIdx.x - grp.start[ji];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = q.H, K = 3 * H;
   const int u_tiles = (H + 31) / 32;
-  const int u0 = (blockIdx.x % u_tiles) * 32, m0 = (blockIdx.x / u_tiles) * 32;
+  const int u0 = (wg % u_tiles) * 32, m0 = (wg / u_tiles) * 32;
   const int row = lane & 31, hi = lane >> 5;
   f32x16 acc = zero16();
   if (q.S_next > 0) {
@@ -774,11 +788,30 @@ extern "C" size_t cmhse_gru_pool_bwd_workspace(int32_t S, int32_t Tmax, int64_t 
   return bwd_ws_layout(S, sum_T, I, H, pool_mode & ~CMHSE_SAVE_FOR_BACKWARD).total;
 }
 
-extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
-                                  int32_t pool_mode, const float* dout, const void* fwd_workspace,
-                                  const cmhse_gru_grads* g, const uint64_t* dx_rows,
-                                  float* d_emb_table, float* dh0, void* workspace,
-                                  size_t workspace_bytes, void* stream_) {
+namespace {
+
+// One validated cmhse_gru_pool_bwd request with its workspace carved up.
+struct BwdJob {
+  const cmhse_seq_batch* b;
+  const cmhse_gru_weights* w;
+  const cmhse_gru_grads* g;
+  const float* dout;
+  const uint64_t* dx_rows;
+  float* d_emb_table;
+  float* dh0;
+  const char* fws;
+  char* ws;
+  GruWs F;
+  BwdWs L;
+  int64_t sum_T, off;     // off: running step offset of the BPTT walk (starts at sum_T)
+  int32_t pool_mode;
+  BwdStepParams sp;
+};
+
+int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode,
+                const float* dout, const void* fwd_workspace, const cmhse_gru_grads* g,
+                const uint64_t* dx_rows, float* d_emb_table, float* dh0, void* workspace,
+                size_t workspace_bytes, BwdJob* job) {
   if (!b || !w || !dout || !fwd_workspace || !g || !workspace) return CMHSE_ERR_ARG;
   pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
   if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX &&
@@ -797,32 +830,43 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
       workspace_bytes < cmhse_gru_pool_bwd_workspace(S, Tmax, sum_T, I, H, pool_mode))
     return CMHSE_ERR_WORKSPACE;
-  hipStream_t st = static_cast<hipStream_t>(stream_);
-  const GruWs F = gru_ws_layout(S, sum_T, H, pool_mode | CMHSE_SAVE_FOR_BACKWARD);
-  const char* fws = static_cast<const char*>(fwd_workspace);
+  job->b = b; job->w = w; job->g = g; job->dout = dout; job->dx_rows = dx_rows;
+  job->d_emb_table = d_emb_table; job->dh0 = dh0;
+  job->fws = static_cast<const char*>(fwd_workspace);
+  job->ws = static_cast<char*>(workspace);
+  job->F = gru_ws_layout(S, sum_T, H, pool_mode | CMHSE_SAVE_FOR_BACKWARD);
+  job->L = bwd_ws_layout(S, sum_T, I, H, pool_mode);
+  job->sum_T = sum_T;
+  job->off = sum_T;
+  job->pool_mode = pool_mode;
+  return CMHSE_OK;
+}
+
+// Phase 1 (pooling backward -> dpool) and the W_hh transpose the BPTT steps read.
+void bwd_begin(BwdJob& j, hipStream_t st) {
+  const cmhse_seq_batch* b = j.b;
+  const cmhse_gru_weights* w = j.w;
+  const cmhse_gru_grads* g = j.g;
+  const int S = b->S, I = b->I, H = b->H;
+  const int64_t sum_T = j.sum_T;
+  const GruWs& F = j.F;
+  const BwdWs& L = j.L;
+  const char* fws = j.fws;
+  char* ws = j.ws;
   const float* hs = reinterpret_cast<const float*>(fws + F.hs);
-  const float* gates = reinterpret_cast<const float*>(fws + F.gates);
-  const BwdWs L = bwd_ws_layout(S, sum_T, I, H, pool_mode);
-  char* ws = static_cast<char*>(workspace);
-  float* dgx = reinterpret_cast<float*>(ws + L.dgx);
-  float* dgh = reinterpret_cast<float*>(ws + L.dgh);
   float* dpool = reinterpret_cast<float*>(ws + L.dpool);
   float* carry = reinterpret_cast<float*>(ws + L.carry);
   float* whh_t = reinterpret_cast<float*>(ws + L.whh_t);
-  float* wih_t = reinterpret_cast<float*>(ws + L.wih_t);
-  uint64_t* xaddr = reinterpret_cast<uint64_t*>(ws + L.xaddr);
-  uint64_t* hpaddr = reinterpret_cast<uint64_t*>(ws + L.hpaddr);
-  int32_t* p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
   float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
   float* cs_scratch = reinterpret_cast<float*>(ws + L.colsum);
   float* t_a = reinterpret_cast<float*>(ws + L.t_a);
   float* t_b = reinterpret_cast<float*>(ws + L.t_b);
   const int64_t kp = (sum_T + 3) / 4 * 4;  // packed-row count padded for dwordx4 rows
-  const bool vec = (I % 4 == 0) && (H % 4 == 0);
+  const float* dout = j.dout;
+  const int pool_mode = j.pool_mode;
 
   (void)hipMemsetAsync(zero_row, 0, static_cast<size_t>(H > I ? H : I) * 4, st);
   (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
-
   // ---- 1. pooling backward -> dpool ----
   if (pool_mode == CMHSE_POOL_ATTN) {
     float* du = reinterpret_cast<float*>(ws + L.du);
@@ -855,37 +899,99 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
     hipLaunchKernelGGL(pool_scatter_bwd_kernel, dim3(S), dim3(kThreads), 0, st, pp);
   }
 
-  // ---- 2. BPTT over the packed steps, last to first ----
   launch_transpose(w->w_hh, whh_t, 3 * H, H, st);
-  BwdStepParams sp;
-  sp.whh_t = whh_t; sp.dpool = dpool; sp.gates = gates; sp.hs = hs; sp.h0_rows = b->h0_rows;
-  sp.out_row = b->out_row; sp.carry = carry; sp.dgx = dgx; sp.dgh = dgh; sp.dh0 = dh0; sp.H = H;
-  const int u_tiles = (H + 31) / 32;
-  int64_t off = sum_T;
-  for (int t = Tmax - 1; t >= -1; --t) {
-    if (t < 0 && !dh0) break;
-    const int S_t = (t >= 0) ? b->step_count_host[t] : S;
-    const int S_next = (t + 1 < Tmax) ? b->step_count_host[t + 1] : 0;
-    const int64_t off_next = off;           // step_off[t+1]
-    if (t >= 0) off -= S_t;                  // step_off[t]
-    sp.t = t; sp.S_t = S_t; sp.S_next = S_next;
-    sp.dgh_next = dgh + off_next * 3 * H;
-    sp.off_cur = off;
-    sp.off_prev = (t > 0) ? off - b->step_count_host[t - 1] : 0;
-    const unsigned grid = static_cast<unsigned>(u_tiles) * ((S_t + 31) / 32);
-    // few active sequences: a pure latency chain on an under-filled chip -> 8 waves split K
-    static const int nw8_max = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
-    if (S_t <= nw8_max) {
-      if (H % 4 == 0)
-        hipLaunchKernelGGL((gru_bwd_step_kernel<true, 8>), dim3(grid), dim3(512), 0, st, sp);
-      else
-        hipLaunchKernelGGL((gru_bwd_step_kernel<false, 8>), dim3(grid), dim3(512), 0, st, sp);
-    } else if (H % 4 == 0) {
-      hipLaunchKernelGGL((gru_bwd_step_kernel<true, 4>), dim3(grid), dim3(kThreads), 0, st, sp);
-    } else {
-      hipLaunchKernelGGL((gru_bwd_step_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, st, sp);
+  BwdStepParams& sp = j.sp;
+  sp.whh_t = whh_t; sp.dpool = dpool;
+  sp.gates = reinterpret_cast<const float*>(fws + F.gates);
+  sp.hs = hs; sp.h0_rows = b->h0_rows;
+  sp.out_row = b->out_row; sp.carry = carry;
+  sp.dgx = reinterpret_cast<float*>(ws + L.dgx);
+  sp.dgh = reinterpret_cast<float*>(ws + L.dgh);
+  sp.dh0 = j.dh0; sp.H = H;
+}
+
+// Phase 2: BPTT of all jobs, last step first.  Launch i serves step Tmax_k - 1 - i of every job k
+// that still has one (and the extra t = -1 launch of a job that wants d h0); jobs of equal block
+// size share the launch.
+void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
+  static const int nw8_max = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
+  int longest = 0;
+  for (int k = 0; k < n; ++k) longest = jobs[k].b->Tmax > longest ? jobs[k].b->Tmax : longest;
+  for (int i = 0; i <= longest; ++i) {
+    int kind[CMHSE_MAX_JOBS];      // 0 = not in this launch, 1 = 4 waves, 2 = 8 waves; +4 = scalar loads
+    unsigned grid_k[CMHSE_MAX_JOBS];
+    for (int k = 0; k < n; ++k) {
+      BwdJob& j = jobs[k];
+      const cmhse_seq_batch* b = j.b;
+      const int t = b->Tmax - 1 - i;
+      kind[k] = 0;
+      if (t < -1 || (t < 0 && !j.dh0)) continue;
+      const int S_t = (t >= 0) ? b->step_count_host[t] : b->S;
+      const int S_next = (t + 1 < b->Tmax) ? b->step_count_host[t + 1] : 0;
+      const int64_t off_next = j.off;          // step_off[t+1]
+      if (t >= 0) j.off -= S_t;                // step_off[t]
+      BwdStepParams& sp = j.sp;
+      sp.t = t; sp.S_t = S_t; sp.S_next = S_next;
+      sp.dgh_next = sp.dgh + off_next * 3 * b->H;
+      sp.off_cur = j.off;
+      sp.off_prev = (t > 0) ? j.off - b->step_count_host[t - 1] : 0;
+      grid_k[k] = static_cast<unsigned>((b->H + 31) / 32) * ((S_t + 31) / 32);
+      // few active sequences: a pure latency chain on an under-filled chip -> 8 waves split K
+      kind[k] = ((S_t <= nw8_max) ? 2 : 1) | ((b->H % 4 == 0) ? 0 : 4);
+    }
+    for (int k = 0; k < n; ++k) {
+      if (kind[k] == 0) continue;
+      BwdStepGroup g;
+      g.n = 0;
+      unsigned grid = 0;
+      const int kd = kind[k];
+      for (int m = k; m < n; ++m) {
+        if (kind[m] != kd) continue;
+        g.j[g.n] = jobs[m].sp;
+        g.start[g.n] = grid;
+        grid += grid_k[m];
+        ++g.n;
+        kind[m] = 0;
+      }
+      for (int m = g.n; m < CMHSE_MAX_JOBS; ++m) g.start[m] = 0xffffffffu;
+      const bool vec = (kd & 4) == 0;
+      if ((kd & 3) == 2) {
+        if (vec)
+          hipLaunchKernelGGL((gru_bwd_step_kernel<true, 8>), dim3(grid), dim3(512), 0, st, g);
+        else
+          hipLaunchKernelGGL((gru_bwd_step_kernel<false, 8>), dim3(grid), dim3(512), 0, st, g);
+      } else if (vec) {
+        hipLaunchKernelGGL((gru_bwd_step_kernel<true, 4>), dim3(grid), dim3(kThreads), 0, st, g);
+      } else {
+        hipLaunchKernelGGL((gru_bwd_step_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, st, g);
+      }
     }
   }
+}
+
+// Phases 3 and 4: weight gradients over all packed rows, d(input).
+void bwd_finish(BwdJob& j, hipStream_t st) {
+  const cmhse_seq_batch* b = j.b;
+  const cmhse_gru_weights* w = j.w;
+  const cmhse_gru_grads* g = j.g;
+  const int Tmax = b->Tmax, I = b->I, H = b->H;
+  const int64_t sum_T = j.sum_T;
+  const BwdWs& L = j.L;
+  char* ws = j.ws;
+  const float* hs = reinterpret_cast<const float*>(j.fws + j.F.hs);
+  float* dgx = reinterpret_cast<float*>(ws + L.dgx);
+  float* dgh = reinterpret_cast<float*>(ws + L.dgh);
+  float* wih_t = reinterpret_cast<float*>(ws + L.wih_t);
+  uint64_t* xaddr = reinterpret_cast<uint64_t*>(ws + L.xaddr);
+  uint64_t* hpaddr = reinterpret_cast<uint64_t*>(ws + L.hpaddr);
+  int32_t* p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
+  float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
+  float* cs_scratch = reinterpret_cast<float*>(ws + L.colsum);
+  float* t_a = reinterpret_cast<float*>(ws + L.t_a);
+  float* t_b = reinterpret_cast<float*>(ws + L.t_b);
+  const int64_t kp = (sum_T + 3) / 4 * 4;
+  const uint64_t* dx_rows = j.dx_rows;
+  float* d_emb_table = j.d_emb_table;
 
   // ---- 3. weight gradients over all packed rows ----
   RowAddrParams rp;
@@ -930,7 +1036,38 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
                     2, st);
     }
   }
+}
+
+}  // namespace
+
+extern "C" int cmhse_gru_pool_bwd_multi(const cmhse_gru_bwd_job* reqs, int32_t n_jobs,
+                                        void* stream_) {
+  if (!reqs || n_jobs <= 0 || n_jobs > CMHSE_MAX_JOBS) return CMHSE_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  BwdJob jobs[CMHSE_MAX_JOBS];
+  for (int k = 0; k < n_jobs; ++k) {
+    const cmhse_gru_bwd_job& r = reqs[k];
+    const int rc = bwd_prepare(r.seqs, r.weights, r.pool_mode, r.dout, r.fwd_workspace, r.grads,
+                               r.dx_rows, r.d_emb_table, r.dh0, r.workspace, r.workspace_bytes,
+                               &jobs[k]);
+    if (rc != CMHSE_OK) return rc;
+  }
+  for (int k = 0; k < n_jobs; ++k) bwd_begin(jobs[k], st);
+  bwd_steps(jobs, n_jobs, st);
+  for (int k = 0; k < n_jobs; ++k) bwd_finish(jobs[k], st);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weights* w,
+                                  int32_t pool_mode, const float* dout, const void* fwd_workspace,
+                                  const cmhse_gru_grads* g, const uint64_t* dx_rows,
+                                  float* d_emb_table, float* dh0, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+  cmhse_gru_bwd_job r;
+  r.seqs = b; r.weights = w; r.pool_mode = pool_mode; r.dout = dout;
+  r.fwd_workspace = fwd_workspace; r.grads = g; r.dx_rows = dx_rows; r.d_emb_table = d_emb_table;
+  r.dh0 = dh0; r.workspace = workspace; r.workspace_bytes = workspace_bytes;
+  return cmhse_gru_pool_bwd_multi(&r, 1, stream_);
 }
 
 extern "C" int cmhse_l2norm_rows_bwd(const float* x, const float* g, float* dx, int32_t rows,

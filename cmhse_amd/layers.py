@@ -36,101 +36,178 @@ class SeqInput(object):
     self.need_grad = False
 
 
+class _Saved(object):
+  """What one request's backward needs from its forward (lives on the autograd ctx)."""
+  __slots__ = ('fctx', 'spec', 'keep', 'x_shape', 'table_shape', 'has_hidden', 'saved_for_bwd',
+               'row_starts')
+
+
+def _fwd_request(spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w_att):
+  """The ops.gru_pool_fwd_multi request of one encoder call + its _Saved record."""
+  pool = spec.pool
+  weights = dict(w_ih=w_ih.detach(), w_hh=w_hh.detach(), b_ih=b_ih.detach(), b_hh=b_hh.detach())
+  if pool == ops.POOL_ATTN:
+    weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
+  H = w_hh.shape[1]
+  sv = _Saved()
+  sv.row_starts = None
+  keep, x_ptrs, tok_ptrs, emb = [], None, None, None
+  if spec.kind == 'tokens' or (spec.kind == 'multi' and spec.tokens is not None):
+    toks = spec.tokens if spec.kind == 'multi' else [spec.tokens]
+    ptr_list = []
+    for tok in toks:
+      ops._require_cuda(tok, 'tokens')
+      tok = tok.detach().contiguous()
+      if tok.dtype != torch.int64:
+        tok = tok.long()
+      keep.append(tok)
+      ptr_list.append(ops.padded_row_ptrs(tok))
+    emb = table.detach().float().contiguous()
+    I = emb.shape[1]
+    tok_ptrs = np.concatenate(ptr_list)
+    device = keep[0].device
+    keep.append(emb)
+  elif spec.kind == 'multi':
+    ptr_list = []
+    for t in spec.tensors:
+      ops._require_cuda(t, 'x')
+      tc = t.detach().float().contiguous()
+      keep.append(tc)
+      ptr_list.append(ops.padded_row_ptrs(tc))
+    I = keep[0].shape[2]
+    x_ptrs = np.concatenate(ptr_list)
+    device = keep[0].device
+  else:
+    ops._require_cuda(x, 'x')
+    xc = x.detach().float().contiguous()
+    device = xc.device
+    keep.append(xc)
+    if spec.kind == 'padded':
+      I = xc.shape[2]
+      x_ptrs = ops.padded_row_ptrs(xc)
+    elif spec.kind == 'repeat':
+      I = xc.shape[1]
+      x_ptrs = ops.padded_row_ptrs(xc)
+    else:
+      I = xc.shape[1]
+      counts = np.asarray(spec.counts, dtype=np.int64)
+      starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+      x_ptrs = np.uint64(xc.data_ptr()) + starts * np.uint64(I * 4)
+      sv.row_starts = starts
+  h0_ptrs = None
+  if hidden is not None:
+    ops._require_cuda(hidden, 'hidden')
+    h0 = hidden.detach().float().contiguous()
+    keep.append(h0)
+    h0_ptrs = ops.padded_row_ptrs(h0)
+  need_grad = spec.need_grad   # decided by the caller: grad mode is off inside Function.forward
+  req = dict(weights=weights, pool_mode=pool, lens=spec.lens, I=I, H=H, device=device,
+             x_ptrs=x_ptrs, tok_ptrs=tok_ptrs, emb_table=emb, h0_ptrs=h0_ptrs,
+             save_for_backward=need_grad, constant_input=(spec.kind == 'repeat'))
+  sv.spec, sv.keep = spec, keep
+  sv.x_shape = None if x is None else tuple(x.shape)
+  sv.table_shape = None if table is None else tuple(table.shape)
+  sv.has_hidden = hidden is not None
+  sv.saved_for_bwd = need_grad
+  return req, sv
+
+
+def _bwd_request(sv, grad_out, need):
+  """The ops.gru_pool_bwd_multi request of one encoder call; `need` = needs_input_grad of its ten
+  inputs (x, hidden, table, weights...).  Returns (request, dx, dtable)."""
+  if not sv.saved_for_bwd:
+    raise RuntimeError('cmhse_amd: forward ran without saving state for backward')
+  spec, fctx = sv.spec, sv.fctx
+  device = fctx['device']
+  dx = dtable = dx_ptrs = None
+  if spec.kind not in ('tokens', 'multi') and need[0]:
+    dx = torch.zeros(sv.x_shape, dtype=torch.float32, device=device)
+    if spec.kind in ('padded', 'repeat'):
+      dx_ptrs = ops.padded_row_ptrs(dx)      # 'repeat': the kernel accumulates over the steps
+    else:
+      dx_ptrs = np.uint64(dx.data_ptr()) + sv.row_starts * np.uint64(sv.x_shape[1] * 4)
+  if sv.table_shape is not None and need[2]:
+    dtable = torch.zeros(sv.table_shape, dtype=torch.float32, device=device)
+  req = dict(fctx=fctx, dout=grad_out, dx_ptrs=dx_ptrs, d_emb_table=dtable,
+             want_dh0=sv.has_hidden and need[1])
+  return req, dx, dtable
+
+
+def _grads_tuple(grads, dx, dh0, dtable):
+  w_att_g = grads.get('w_att')
+  return (dx, dh0, dtable, grads['w_ih'], grads['w_hh'], grads['b_ih'], grads['b_hh'],
+          grads.get('w_lin'), grads.get('b_lin'), None if w_att_g is None else w_att_g.reshape(1, -1))
+
+
 class _PackedGRUPoolFn(torch.autograd.Function):
   """Forward = cmhse_gru_pool_fwd, backward = cmhse_gru_pool_bwd (BPTT on the HIP path)."""
 
   @staticmethod
   def forward(ctx, spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w_att):
-    pool = spec.pool
-    weights = dict(w_ih=w_ih.detach(), w_hh=w_hh.detach(), b_ih=b_ih.detach(),
-                   b_hh=b_hh.detach())
-    if pool == ops.POOL_ATTN:
-      weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
-    H = w_hh.shape[1]
-    keep, x_ptrs, tok_ptrs, emb = [], None, None, None
-    if spec.kind == 'tokens' or (spec.kind == 'multi' and spec.tokens is not None):
-      toks = spec.tokens if spec.kind == 'multi' else [spec.tokens]
-      ptr_list = []
-      for tok in toks:
-        ops._require_cuda(tok, 'tokens')
-        tok = tok.detach().contiguous()
-        if tok.dtype != torch.int64:
-          tok = tok.long()
-        keep.append(tok)
-        ptr_list.append(ops.padded_row_ptrs(tok))
-      emb = table.detach().float().contiguous()
-      I = emb.shape[1]
-      tok_ptrs = np.concatenate(ptr_list)
-      device = keep[0].device
-      keep.append(emb)
-    elif spec.kind == 'multi':
-      ptr_list = []
-      for t in spec.tensors:
-        ops._require_cuda(t, 'x')
-        tc = t.detach().float().contiguous()
-        keep.append(tc)
-        ptr_list.append(ops.padded_row_ptrs(tc))
-      I = keep[0].shape[2]
-      x_ptrs = np.concatenate(ptr_list)
-      device = keep[0].device
-    else:
-      ops._require_cuda(x, 'x')
-      xc = x.detach().float().contiguous()
-      device = xc.device
-      keep.append(xc)
-      if spec.kind == 'padded':
-        I = xc.shape[2]
-        x_ptrs = ops.padded_row_ptrs(xc)
-      elif spec.kind == 'repeat':
-        I = xc.shape[1]
-        x_ptrs = ops.padded_row_ptrs(xc)
-      else:
-        I = xc.shape[1]
-        counts = np.asarray(spec.counts, dtype=np.int64)
-        starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
-        x_ptrs = np.uint64(xc.data_ptr()) + starts * np.uint64(I * 4)
-        ctx.row_starts = starts
-    h0_ptrs = None
-    if hidden is not None:
-      ops._require_cuda(hidden, 'hidden')
-      h0 = hidden.detach().float().contiguous()
-      keep.append(h0)
-      h0_ptrs = ops.padded_row_ptrs(h0)
-    need_grad = spec.need_grad   # decided by the caller: grad mode is off inside Function.forward
-    out, fctx = ops.gru_pool_fwd(weights, pool, spec.lens, I, H, device, x_ptrs=x_ptrs,
-                                 tok_ptrs=tok_ptrs, emb_table=emb, h0_ptrs=h0_ptrs,
-                                 save_for_backward=need_grad,
-                                 constant_input=(spec.kind == 'repeat'))
-    ctx.fctx, ctx.spec, ctx.keep = fctx, spec, keep
-    ctx.x_shape = None if x is None else tuple(x.shape)
-    ctx.table_shape = None if table is None else tuple(table.shape)
-    ctx.has_hidden = hidden is not None
-    ctx.saved_for_bwd = need_grad
+    req, sv = _fwd_request(spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w_att)
+    out, sv.fctx = ops.gru_pool_fwd(**req)
+    ctx.sv = sv
     return out
 
   @staticmethod
   def backward(ctx, grad_out):
-    if not ctx.saved_for_bwd:
-      raise RuntimeError('cmhse_amd: forward ran without saving state for backward')
-    spec, fctx = ctx.spec, ctx.fctx
+    req, dx, dtable = _bwd_request(ctx.sv, grad_out, ctx.needs_input_grad[1:])
+    (grads, dh0), = ops.gru_pool_bwd_multi([req])
+    return (None,) + _grads_tuple(grads, dx, dh0, dtable)
+
+
+class _GroupedGRUPoolFn(torch.autograd.Function):
+  """Several INDEPENDENT encoder calls as one autograd node: forward = cmhse_gru_pool_fwd_multi,
+  backward = cmhse_gru_pool_bwd_multi — step t of every encoder shares one launch in both
+  directions (the two towers of VSE.train_emb).  Inputs: `specs` (list of SeqInput), then the ten
+  tensors of _PackedGRUPoolFn per spec, flattened; outputs: one tensor per spec."""
+
+  @staticmethod
+  def forward(ctx, specs, *flat):
+    reqs, svs = [], []
+    for i, spec in enumerate(specs):
+      req, sv = _fwd_request(spec, *flat[10 * i:10 * i + 10])
+      reqs.append(req)
+      svs.append(sv)
+    results = ops.gru_pool_fwd_multi(reqs)
+    for sv, (_, fctx) in zip(svs, results):
+      sv.fctx = fctx
+    ctx.svs = svs
+    return tuple(out for out, _ in results)
+
+  @staticmethod
+  def backward(ctx, *grad_outs):
     need = ctx.needs_input_grad
-    device = fctx['device']
-    dx = dtable = None
-    dx_ptrs = None
-    if spec.kind not in ('tokens', 'multi') and need[1]:
-      dx = torch.zeros(ctx.x_shape, dtype=torch.float32, device=device)
-      if spec.kind in ('padded', 'repeat'):
-        dx_ptrs = ops.padded_row_ptrs(dx)      # 'repeat': the kernel accumulates over the steps
-      else:
-        dx_ptrs = np.uint64(dx.data_ptr()) + ctx.row_starts * np.uint64(ctx.x_shape[1] * 4)
-    if ctx.table_shape is not None and need[3]:
-      dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=device)
-    grads, dh0 = ops.gru_pool_bwd(fctx, grad_out, dx_ptrs=dx_ptrs, d_emb_table=dtable,
-                                  want_dh0=ctx.has_hidden and need[2])
-    w_att_g = grads.get('w_att')
-    return (None, dx, dh0, dtable, grads['w_ih'], grads['w_hh'], grads['b_ih'], grads['b_hh'],
-            grads.get('w_lin'), grads.get('b_lin'),
-            None if w_att_g is None else w_att_g.reshape(1, -1))
+    reqs, extra = [], []
+    for i, (sv, g) in enumerate(zip(ctx.svs, grad_outs)):
+      if g is None:      # this encoder's output did not reach the loss
+        fctx = sv.fctx
+        n_out = fctx['sched'].sum_T if fctx['pool_mode'] == ops.POOL_ALL else fctx['sched'].S
+        g = torch.zeros(n_out, fctx['H'], dtype=torch.float32, device=fctx['device'])
+      req, dx, dtable = _bwd_request(sv, g, need[1 + 10 * i:1 + 10 * i + 10])
+      reqs.append(req)
+      extra.append((dx, dtable))
+    out = [None]
+    for (grads, dh0), (dx, dtable) in zip(ops.gru_pool_bwd_multi(reqs), extra):
+      out.extend(_grads_tuple(grads, dx, dh0, dtable))
+    return tuple(out)
+
+
+def run_grouped(calls):
+  """`calls`: list of (layer, SeqInput, x, hidden, table) for independent encoders; runs them as
+  ONE autograd node with shared per-step launches and returns their outputs in order."""
+  flat, specs = [], []
+  for layer, spec, x, hidden, table in calls:
+    w_lin, b_lin, w_att = layer._extra_weights()
+    tensors = (x, hidden, table, layer.rnn.weight_ih_l0, layer.rnn.weight_hh_l0,
+               layer.rnn.bias_ih_l0, layer.rnn.bias_hh_l0, w_lin, b_lin, w_att)
+    spec.need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                     for t in tensors)
+    specs.append(spec)
+    flat.extend(tensors)
+  if len({s.need_grad for s in specs}) > 1:    # mixed: keep them apart (not a training-step case)
+    return [_PackedGRUPoolFn.apply(spec, *flat[10 * i:10 * i + 10]) for i, spec in enumerate(specs)]
+  return list(_GroupedGRUPoolFn.apply(specs, *flat))
 
 
 def _lens_numpy(q_len):
@@ -194,6 +271,23 @@ class _GRUPoolBase(nn.Module):
     if self.POOL == ops.POOL_ATTN:
       weights.update(w_lin=w_lin.detach(), b_lin=b_lin.detach(), w_att=w_att.detach().reshape(-1))
     return weights
+
+  # -- call descriptions for run_grouped(): (layer, SeqInput, x, hidden, table) -------------------
+  def call_multi(self, tensors, lens_list):
+    lens = np.concatenate([_lens_numpy(l) for l in lens_list])
+    return (self, SeqInput('multi', lens, self.POOL, tensors=list(tensors)), None, None, None)
+
+  def call_tokens_multi(self, token_tensors, lens_list, table):
+    lens = np.concatenate([_lens_numpy(l) for l in lens_list])
+    return (self, SeqInput('multi', lens, self.POOL, tokens=list(token_tensors)), None, None, table)
+
+  def call_rows(self, rows, counts, hidden=None):
+    counts = np.asarray(counts, dtype=np.int64)
+    return (self, SeqInput('rows', counts, self.POOL, counts=counts), rows, hidden, None)
+
+  def call_repeat(self, rows, counts):
+    counts = np.asarray(counts, dtype=np.int64)
+    return (self, SeqInput('repeat', counts, self.POOL), rows, None, None)
 
   def forward_multi(self, tensors, lens_list):
     """Several padded feature batches [S_i, T_i, I] through this encoder in one packed pass;

@@ -86,7 +86,12 @@ class EncoderText(nn.Module):
     return outputs, cap_emb
 
 
-# the two towers of a training step on two HIP streams (23.4 -> 18.8 ms per step at batch 32)
+# A training step's two towers are independent until the losses.  Default: GROUPED — step t of
+# the visual and the text encoder shares one launch, forward (cmhse_gru_pool_fwd_multi) and backward
+# (cmhse_gru_pool_bwd_multi), one autograd node per level: half the dependent launches, twice the
+# workgroups in each.  CMHSE_TRAIN_GROUPED=0 falls back to the two towers on two HIP streams
+# (CMHSE_TRAIN_STREAMS=1, round 1) or on one.
+TRAIN_GROUPED = [os.environ.get('CMHSE_TRAIN_GROUPED', '1') == '1']
 TRAIN_TWO_STREAMS = [os.environ.get('CMHSE_TRAIN_STREAMS', '1') == '1']
 _TOWER_STREAMS = {}
 
@@ -307,7 +312,38 @@ class VSE(object):
         sent_recon = self.sent_seq_dec.forward_repeat(cap_recon, lw)
       return cap_emb, para_context, para_emb, cap_recon, sent_recon, word
 
-    if TRAIN_TWO_STREAMS[0]:
+    def grouped_towers():
+      from .layers import run_grouped
+      _tick('vis:start')
+      vis, txt = run_grouped([
+          self.clip_enc.rnn.call_multi([clips, videos], [lengths_clip, lengths_video]),
+          self.txt_enc.rnn.call_tokens_multi([captions, paragraphs],
+                                             [lengths_cap, lengths_paragraph],
+                                             self.txt_enc.embed.weight)])
+      _tick('vis:level1')
+      clip_emb, vid_context = vis[:n_clip], vis[n_clip:]
+      cap_emb, para_context = txt[:n_cap], txt[n_cap:]
+      vid_emb, para_emb = run_grouped([
+          self.vid_seq_enc.rnn.call_rows(clip_emb, num_clips, vid_context),
+          self.txt_seq_enc.rnn.call_rows(cap_emb, num_caps, para_context)])
+      _tick('vis:level2')
+      word = (ops.gather_rows(self.txt_enc.embed.weight.detach(), captions)
+              if self.lowest_reconstruct_loss else None)
+      clip_recon = cap_recon = frame_recon = sent_recon = None
+      if self.reconstruct_loss:
+        clip_recon, cap_recon = run_grouped([
+            self.vid_seq_dec.rnn.call_repeat(vid_emb, num_clips),
+            self.txt_seq_dec.rnn.call_repeat(para_emb, num_caps)])
+      if self.lowest_reconstruct_loss:
+        frame_recon, sent_recon = run_grouped([
+            self.clip_seq_dec.rnn.call_repeat(clip_recon, lc),
+            self.sent_seq_dec.rnn.call_repeat(cap_recon, lw)])
+      return ((clip_emb, vid_context, vid_emb, clip_recon, frame_recon),
+              (cap_emb, para_context, para_emb, cap_recon, sent_recon, word))
+
+    if TRAIN_GROUPED[0]:
+      out_v, out_t = grouped_towers()
+    elif TRAIN_TWO_STREAMS[0]:
       # The two towers (encoders and decoders alike) meet only in the losses.  At training batch
       # sizes every GRU time step is a short launch; on two HIP streams the launches of one tower
       # fill the ramps and tails of the other's.  autograd runs each backward node on its forward's

@@ -450,6 +450,41 @@ def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
   """cmhse_gru_pool_bwd for a forward run with save_for_backward=True.
   dx_ptrs: numpy uint64 [S] (input order) addresses receiving d x of step 0 of each sequence.
   Returns (grads dict of fresh tensors, dh0 [S,H] or None)."""
+  return gru_pool_bwd_multi([dict(fctx=fctx, dout=dout, dx_ptrs=dx_ptrs, d_emb_table=d_emb_table,
+                                  want_dh0=want_dh0)])[0]
+
+
+def gru_pool_bwd_multi(requests):
+  """cmhse_gru_pool_bwd_multi: `requests` = keyword dicts of gru_pool_bwd for INDEPENDENT encoders
+  (the two towers of a training step); their BPTT steps share launches.  Returns [(grads, dh0)]."""
+  lib = _lib.load()
+  if not 1 <= len(requests) <= MAX_JOBS:
+    raise ValueError('gru_pool_bwd_multi takes 1..%d requests' % MAX_JOBS)
+  jobs = (_lib.GruBwdJob * len(requests))()
+  keep, out = [], []
+  for k, r in enumerate(requests):
+    grads, dh0, g, dx_dev, ws, ws_bytes, dout = _prepare_bwd(**r)
+    fctx = r['fctx']
+    jobs[k].seqs = ctypes.pointer(fctx['batch'])
+    jobs[k].weights = ctypes.pointer(fctx['weights'])
+    jobs[k].pool_mode = fctx['pool_mode']
+    jobs[k].dout = dout.data_ptr()
+    jobs[k].fwd_workspace = fctx['ws'].data_ptr()
+    jobs[k].grads = ctypes.pointer(g)
+    jobs[k].dx_rows = dx_dev.data_ptr() if dx_dev is not None else None
+    d_emb = r.get('d_emb_table')
+    jobs[k].d_emb_table = d_emb.data_ptr() if d_emb is not None else None
+    jobs[k].dh0 = dh0.data_ptr() if dh0 is not None else None
+    jobs[k].workspace = ws.data_ptr()
+    jobs[k].workspace_bytes = ws_bytes
+    keep.append((g, dx_dev, ws, dout))
+    out.append((grads, dh0))
+  rc = lib.cmhse_gru_pool_bwd_multi(jobs, len(requests), _stream())
+  _lib.check(rc, 'cmhse_gru_pool_bwd_multi')
+  return out
+
+
+def _prepare_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
   lib = _lib.load()
   sched, b, w = fctx['sched'], fctx['batch'], fctx['weights']
   H, I, device, pool_mode = fctx['H'], fctx['I'], fctx['device'], fctx['pool_mode']
@@ -473,14 +508,7 @@ def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
   dh0 = torch.empty(S, H, dtype=torch.float32, device=device) if want_dh0 else None
   ws_bytes = lib.cmhse_gru_pool_bwd_workspace(S, sched.Tmax, sched.sum_T, I, H, pool_mode)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-  rc = lib.cmhse_gru_pool_bwd(ctypes.byref(b), ctypes.byref(w), pool_mode, dout.data_ptr(),
-                              fctx['ws'].data_ptr(), ctypes.byref(g),
-                              dx_dev.data_ptr() if dx_dev is not None else None,
-                              d_emb_table.data_ptr() if d_emb_table is not None else None,
-                              dh0.data_ptr() if dh0 is not None else None, ws.data_ptr(),
-                              ws_bytes, _stream())
-  _lib.check(rc, 'cmhse_gru_pool_bwd')
-  return grads, dh0
+  return grads, dh0, g, dx_dev, ws, ws_bytes, dout
 
 
 def l2norm_rows_bwd(x, g):

@@ -242,6 +242,26 @@ int cmhse_gru_pool_bwd(const cmhse_seq_batch* seqs, const cmhse_gru_weights* w, 
                        const uint64_t* dx_rows, float* d_emb_table, float* dh0, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Several INDEPENDENT cmhse_gru_pool_bwd requests in one call (at most CMHSE_MAX_JOBS), the
+ * backward counterpart of cmhse_gru_pool_fwd_multi: the BPTT step of every request shares one
+ * launch (chains are aligned at their LAST step), so the two towers of a training step
+ * (model.py:319-321: clip_enc / txt_enc, then vid_seq_enc / txt_seq_enc) pay one dependent
+ * launch per step instead of two.  Results are bit-identical to the separate calls. */
+typedef struct cmhse_gru_bwd_job {
+  const cmhse_seq_batch* seqs;
+  const cmhse_gru_weights* weights;
+  int32_t pool_mode;
+  const float* dout;
+  const void* fwd_workspace;
+  const cmhse_gru_grads* grads;
+  const uint64_t* dx_rows;
+  float* d_emb_table;
+  float* dh0;
+  void* workspace;
+  size_t workspace_bytes;
+} cmhse_gru_bwd_job;
+int cmhse_gru_pool_bwd_multi(const cmhse_gru_bwd_job* jobs, int32_t n_jobs, void* stream);
+
 /* Backward of F.normalize (model.py:333-343): dx from x [rows, cols] (contiguous) and g = d/dy. */
 int cmhse_l2norm_rows_bwd(const float* x, const float* g, float* dx, int32_t rows, int32_t cols,
                           void* stream);

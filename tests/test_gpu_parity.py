@@ -496,14 +496,16 @@ def test_loss_backward_vs_golden(dev, n):
       grad_close(a2.grad.cpu().numpy(), g[tag + '.da_self'], tag + '.da_self')
 
 
-@pytest.mark.parametrize('two_streams', [True, False])
+@pytest.mark.parametrize('schedule', ['grouped', 'two_streams', 'one_stream'])
 @pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
-def test_train_emb_gradients_vs_golden(dev, rnn_type, two_streams, monkeypatch):  # noqa: C901
+def test_train_emb_gradients_vs_golden(dev, rnn_type, schedule, monkeypatch):  # noqa: C901
   """One full VSE.train_emb step (forward, 7 losses, backward, Adam): the parameter gradients
   left in .grad equal the reference's for every encoder, and the parameters moved — with the two
-  towers on two HIP streams (default) and on one."""
+  towers grouped into shared per-step launches in both directions (default), on two HIP streams,
+  and on one."""
   from cmhse_amd import model as model_mod
-  monkeypatch.setattr(model_mod, 'TRAIN_TWO_STREAMS', [two_streams])
+  monkeypatch.setattr(model_mod, 'TRAIN_GROUPED', [schedule == 'grouped'])
+  monkeypatch.setattr(model_mod, 'TRAIN_TWO_STREAMS', [schedule == 'two_streams'])
   g = load_golden('model_%s.npz' % rnn_type)
   batch = torch_batches(golden_batches(g))[1]
   for mv in (0, 1):
@@ -1266,3 +1268,50 @@ def test_sharded_validation_two_gpus_rccl(dev, tmp_path):
     np.testing.assert_array_equal(got['ranks_t'], ranks_t)
     np.testing.assert_array_equal(got['top1_i'], top1_i)
     np.testing.assert_array_equal(got['top1_t'], top1_t)
+
+
+def test_grouped_backward_equals_separate_calls(dev):
+  """cmhse_gru_pool_bwd_multi (BPTT steps of independent encoders in shared launches, chains of
+  different lengths aligned at their last step) == one cmhse_gru_pool_bwd per encoder, bit for
+  bit: every parameter gradient, d input, d h0, d embedding table."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(12)
+  torch.manual_seed(5)
+  H = 64
+  enc_a = layers.Attention(24, H).to(dev)
+  enc_b = layers.Maxout(20, H).to(dev)
+  enc_c = layers.Seq2Seq(H, H).to(dev)
+  table = torch.randn(50, 20, device=dev, requires_grad=True)
+  xa = torch.randn(37, 9, 24, device=dev)
+  la = rng.randint(1, 10, size=37)
+  tok = torch.from_numpy(rng.randint(0, 50, size=(21, 17))).to(dev)
+  lb = rng.randint(1, 18, size=21)
+  rows = torch.randn(30, H, device=dev, requires_grad=True)
+  counts = [5, 1, 9, 3, 12]
+  h0 = torch.randn(5, H, device=dev, requires_grad=True)
+
+  def calls():
+    return [enc_a.call_multi([xa], [la]), enc_b.call_tokens_multi([tok], [lb], table),
+            enc_c.call_rows(rows, counts, h0)]
+
+  def grads_of(outs):
+    params = [p for e in (enc_a, enc_b, enc_c) for p in e.parameters()] + [table, rows, h0]
+    for p in params:
+      p.grad = None
+    w = [torch.linspace(-1, 1, o.numel(), device=dev).reshape(o.shape) for o in outs]
+    sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+    return [p.grad.clone() for p in params], [o.detach().clone() for o in outs]
+
+  g_grp, o_grp = grads_of(layers.run_grouped(calls()))
+  g_sep, o_sep = grads_of([layers._PackedGRUPoolFn.apply(c[1], c[2], c[3], c[4],
+                                                         c[0].rnn.weight_ih_l0, c[0].rnn.weight_hh_l0,
+                                                         c[0].rnn.bias_ih_l0, c[0].rnn.bias_hh_l0,
+                                                         *c[0]._extra_weights())
+                           for c in [tuple(x) for x in calls()] if c[1].__setattr__('need_grad', True) is None])
+  for a, b in zip(o_grp, o_sep):
+    assert torch.equal(a, b)
+  for i, (a, b) in enumerate(zip(g_grp, g_sep)):
+    if i == len(g_grp) - 3:     # the embedding table: float atomics (order-dependent last bits)
+      np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    else:
+      assert torch.equal(a, b), i
