@@ -781,7 +781,8 @@ struct AttnEnergyParams {
   const float* w_att;
   float* e_part;  // [n_tiles, rows]
   float* v;       // [rows, H] tanh(W_lin h + b) kept for the backward pass, or NULL
-  int64_t rows;
+  int64_t rows;   // all packed rows (stride of e_part)
+  int64_t row_begin, row_end;   // the rows this launch computes
   int32_t H, n_tiles;
 };
 
@@ -795,7 +796,7 @@ void attn_energy_kernel(const AttnEnergyParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int nt = blockIdx.x % p.n_tiles;
   const int n0 = nt * BN;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
+  const int64_t m0 = p.row_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
   const int srow = tid >> 2;
   const int H = p.H;
 
@@ -805,8 +806,8 @@ void attn_energy_kernel(const AttnEnergyParams p) {
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i) {
     const int64_t m = m0 + srow + 64 * i;
-    av[i] = m < p.rows;
-    ar[i] = row_addr(p.hs + (av[i] ? m : (p.rows - 1)) * H);
+    av[i] = m < p.row_end;
+    ar[i] = row_addr(p.hs + (av[i] ? m : (p.row_end - 1)) * H);
   }
 #pragma unroll
   for (int i = 0; i < BN / 64; ++i) {
@@ -849,7 +850,7 @@ void attn_energy_kernel(const AttnEnergyParams p) {
         const float tv = tanhf_(acc[ms][ns][r] + bl[ns]);
         s += wa[ns] * tv;
         const int n = n0 + b_row0[ns] + acc_col(lane);
-        if (p.v != nullptr && vm < p.rows && n < H) p.v[vm * H + n] = tv;
+        if (p.v != nullptr && vm < p.row_end && n < H) p.v[vm * H + n] = tv;
       }
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
@@ -859,7 +860,7 @@ void attn_energy_kernel(const AttnEnergyParams p) {
   __syncthreads();
   if (tid < BM) {
     const int64_t m = m0 + tid;
-    if (m < p.rows) p.e_part[static_cast<int64_t>(nt) * p.rows + m] = red[tid] + red[BM + tid];
+    if (m < p.row_end) p.e_part[static_cast<int64_t>(nt) * p.rows + m] = red[tid] + red[BM + tid];
   }
 }
 
@@ -1095,6 +1096,7 @@ struct FwdJob {
   int32_t t_mid;             // first step served by the mid-size kernel (Tmax: none)
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
   bool pooled;               // attention already launched (early, beside the others' tail)
+  int64_t att_rows_done;     // packed rows whose attention energies are already launched
 };
 
 int gru_msub() {
@@ -1315,7 +1317,7 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 }
 
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
-int launch_attention(const FwdJob& job, hipStream_t stream);
+int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool);
 
 int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;
@@ -1399,7 +1401,15 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       (void)hipStreamWaitEvent(j.tail_stream, ev, 0);
       (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
       stream = j.tail_stream;
-      if (launch_attention(j, main_stream) == CMHSE_OK) j.pooled = true;
+      if (launch_attention(j, main_stream, j.sum_T, true) == CMHSE_OK) j.pooled = true;
+      // ... and behind it the attention projection of what the OTHER attention-pooled chains have
+      // produced so far (their steps <= t were launched on the caller's stream): only the rows of
+      // their remaining tail steps are left for after the tail
+      for (int m = 0; m < n; ++m) {
+        FwdJob& o = jobs[m];
+        if (m != k && o.pool_mode == CMHSE_POOL_ATTN && !o.pooled && t < o.b->Tmax - 1 && o.off > 0)
+          (void)launch_attention(o, main_stream, o.off, false);
+      }
     }
   }
   if (stream != main_stream) {   // rejoin: everything after the steps is ordered on the caller's stream
@@ -1415,7 +1425,9 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   return launches;
 }
 
-int launch_attention(const FwdJob& job, hipStream_t stream) {
+// Attention energies of packed rows [job.att_rows_done, row_end) and, with `pool`, the pooling
+// pass over all rows (row_end must then be sum_T).
+int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool) {
   const cmhse_seq_batch* b = job.b;
   const cmhse_gru_weights* w = job.w;
   const GruWs& L = job.L;
@@ -1432,17 +1444,22 @@ int launch_attention(const FwdJob& job, hipStream_t stream) {
   ep.e_part = e_part;
   ep.v = job.save ? reinterpret_cast<float*>(wsb + L.v) : nullptr;
   ep.rows = sum_T;
+  ep.row_begin = job.att_rows_done;
+  ep.row_end = row_end;
   ep.H = b->H;
   ep.n_tiles = att_tiles;
   const bool att_bf3 = job.bf3 && sum_T > tiny_max_seqs();
   const int att_bm = att_bf3 ? 128 : 64 * msub;
-  const int64_t m_tiles = (sum_T + att_bm - 1) / att_bm;
+  const int64_t m_tiles = (row_end - job.att_rows_done + att_bm - 1) / att_bm;
+  job.att_rows_done = row_end;
   if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
   const unsigned att_grid = static_cast<unsigned>(m_tiles * att_tiles);
   ep.w_lin_s = nullptr;
-  if (att_bf3) {
+  if (att_grid == 0) {
+    // nothing left to project (every row was served by an earlier partial launch)
+  } else if (att_bf3) {
     float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
-    launch_split(w->w_lin, wlin_s, b->H, b->H, stream);
+    if (ep.row_begin == 0) launch_split(w->w_lin, wlin_s, b->H, b->H, stream);
     ep.w_lin_s = wlin_s;
     const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
     hipLaunchKernelGGL((attn_energy_kernel<true, 2, true>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
@@ -1459,6 +1476,7 @@ int launch_attention(const FwdJob& job, hipStream_t stream) {
     else
       hipLaunchKernelGGL((attn_energy_kernel<false, 1, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
   }
+  if (!pool) return CMHSE_OK;
   AttnPoolParams pp;
   pp.hs = job.p.hs;
   pp.e_part = e_part;
@@ -1485,6 +1503,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     if (rc != CMHSE_OK) return rc;
     jobs[k].tail_stream = static_cast<hipStream_t>(reqs[k].tail_stream);
     jobs[k].pooled = false;
+    jobs[k].att_rows_done = 0;
   }
   // the first job's step_timer (if any) spans the step launches of the whole group
   Timer* timer = static_cast<Timer*>(jobs[0].b->step_timer);
@@ -1496,7 +1515,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
   }
   for (int k = 0; k < n_jobs; ++k) {
     if (jobs[k].pool_mode != CMHSE_POOL_ATTN || jobs[k].pooled) continue;
-    const int rc = launch_attention(jobs[k], stream);
+    const int rc = launch_attention(jobs[k], stream, jobs[k].sum_T, true);
     if (rc != CMHSE_OK) return rc;
   }
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;

@@ -86,12 +86,14 @@ class EncoderText(nn.Module):
     return outputs, cap_emb
 
 
-# A training step's two towers are independent until the losses.  Default: GROUPED — step t of
-# the visual and the text encoder shares one launch, forward (cmhse_gru_pool_fwd_multi) and backward
-# (cmhse_gru_pool_bwd_multi), one autograd node per level: half the dependent launches, twice the
-# workgroups in each.  CMHSE_TRAIN_GROUPED=0 falls back to the two towers on two HIP streams
-# (CMHSE_TRAIN_STREAMS=1, round 1) or on one.
-TRAIN_GROUPED = [os.environ.get('CMHSE_TRAIN_GROUPED', '1') == '1']
+# A training step's two towers are independent until the losses.  Default: the two towers on two
+# HIP streams (23.4 -> 18.8 ms per step in round 1).  CMHSE_TRAIN_GROUPED=1 instead groups step t
+# of the visual and the text encoder into one launch, forward (cmhse_gru_pool_fwd_multi) and
+# backward (cmhse_gru_pool_bwd_multi), one autograd node per level: half the dependent launches,
+# twice the workgroups in each — measured 15.4 against 14.9 ms per step: at a training batch the
+# step kernels are bound by operand bandwidth per CU, not by launch latency, so a launch with
+# twice the workgroups takes twice as long.  Bit-identical either way (tested).
+TRAIN_GROUPED = [os.environ.get('CMHSE_TRAIN_GROUPED', '0') == '1']
 TRAIN_TWO_STREAMS = [os.environ.get('CMHSE_TRAIN_STREAMS', '1') == '1']
 _TOWER_STREAMS = {}
 
