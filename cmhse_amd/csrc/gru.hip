@@ -53,6 +53,9 @@ struct GruStepParams {
   float* out;
   const float* w_ih_s;  // bf16x3 pre-split weights (rows of split_ld(K) float units) or NULL
   const float* w_hh_s;
+  const float* xs;      // bf16x3: pre-split input rows, packed row p at xs + p * split_ld(I)
+  float* hs_s;          // bf16x3: pre-split hidden states, packed row p at hs_s + p * split_ld(H)
+  const float* h0_s;    // bf16x3: pre-split initial hidden states, sorted sequence s at h0_s + s * split_ld(H)
   float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
   int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
   int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
@@ -164,7 +167,9 @@ void gru_step_kernel(const GruStepGroup grp) {
     const int m = m0 + srow + 64 * i;
     av[i] = m < p.S_t;
     const int mc = av[i] ? m : (p.S_t - 1);
-    if (p.tok_rows != nullptr) {
+    if (BF3) {
+      ax[i] = row_addr(p.xs + (p.off_cur + mc) * split_ld(I));   // (token lookups included)
+    } else if (p.tok_rows != nullptr) {
       long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
       tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
       ax[i] = row_addr(p.emb + tok * I);
@@ -172,9 +177,10 @@ void gru_step_kernel(const GruStepGroup grp) {
       ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * p.x_step * 4u;
     }
     if (p.t > 0)
-      ah[i] = row_addr(p.hs + (p.off_prev + mc) * H);
+      ah[i] = BF3 ? row_addr(p.hs_s + (p.off_prev + mc) * split_ld(H))
+                  : row_addr(p.hs + (p.off_prev + mc) * H);
     else if (p.h0_rows != nullptr)
-      ah[i] = p.h0_rows[mc];
+      ah[i] = BF3 ? row_addr(p.h0_s + static_cast<int64_t>(mc) * split_ld(H)) : p.h0_rows[mc];
     else
       ah[i] = row_addr(p.w_hh);  // unused: the h phase is skipped
   }
@@ -221,8 +227,9 @@ void gru_step_kernel(const GruStepGroup grp) {
   if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime();
 #endif
   if (BF3) {
-    nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
-    if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
+    // pre-split A operands: xs, then hs_s of the previous step (or the pre-split initial states)
+    nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2, true>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   } else {
     nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
@@ -276,6 +283,21 @@ void gru_step_kernel(const GruStepGroup grp) {
       const float ghn = acc[ms][3][r] + b_hn;
       const float ng = tanhf_(acc[ms][2][r] + b_in + rg * ghn);
       hn[r] = (1.0f - zg) * ng + zg * hp[r];
+      if (BF3) {
+        // the state once more in pre-split form for the next step's / the attention's A operand:
+        // units u, u+1 sit in neighbouring lanes; even lanes store the (hi, lo) bf16 pairs
+        const float other = __shfl_xor(hn[r], 1, 64);
+        if (uv && m < S_t && (lane & 1) == 0) {
+          const float o1 = (u + 1 < H) ? other : 0.f;
+          const uint32_t hi = pack_bf16(hn[r], o1);
+          const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
+          const uint32_t lo = pack_bf16(hn[r] - f0, o1 - f1);
+          uint32_t* dst = reinterpret_cast<uint32_t*>(p.hs_s) + (off_cur + m) * split_ld(H) +
+                          (u >> 4) * 16 + ((u & 15) >> 1);
+          dst[0] = hi;
+          dst[8] = lo;
+        }
+      }
       if (uv && m < S_t) {
         hs[(off_cur + m) * H + u] = hn[r];
         if (gates != nullptr) {
@@ -774,6 +796,7 @@ void xproj_kernel(const XprojParams p) {
 // attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
 // ---------------------------------------------------------------------------------------------
 struct AttnEnergyParams {
+  const float* hs_s;   // bf16x3: pre-split hidden states (rows of split_ld(H) units) or NULL
   const float* hs;     // [rows, H]
   const float* w_lin;  // [H, H]
   const float* w_lin_s;  // bf16x3 pre-split copy or NULL
@@ -787,7 +810,7 @@ struct AttnEnergyParams {
 };
 
 
-template <bool VEC, int MSUB, bool BF3>
+template <bool VEC, int MSUB, bool BF3, bool ASPLIT = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void attn_energy_kernel(const AttnEnergyParams p) {
   constexpr int BM = 64 * MSUB, BN = kAttBN;
@@ -807,7 +830,8 @@ void attn_energy_kernel(const AttnEnergyParams p) {
   for (int i = 0; i < BM / 64; ++i) {
     const int64_t m = m0 + srow + 64 * i;
     av[i] = m < p.row_end;
-    ar[i] = row_addr(p.hs + (av[i] ? m : (p.row_end - 1)) * H);
+    ar[i] = ASPLIT ? row_addr(p.hs_s + (av[i] ? m : (p.row_end - 1)) * split_ld(H))
+                   : row_addr(p.hs + (av[i] ? m : (p.row_end - 1)) * H);
   }
 #pragma unroll
   for (int i = 0; i < BN / 64; ++i) {
@@ -826,7 +850,7 @@ void attn_energy_kernel(const AttnEnergyParams p) {
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
   if (BF3)
-    nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+    nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1, ASPLIT>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
   else
     nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
 
@@ -1054,13 +1078,56 @@ static void launch_split(const float* W, float* out, int R, int K, hipStream_t s
                      dim3(kThreads), 0, st, W, reinterpret_cast<uint32_t*>(out), R, K);
 }
 
-// Tuning override (benchmarks / tests): CMHSE_TINY_MAX_SEQS=<n> moves the tiny/tiled crossover.
+// bf16x3 pre-split of the INPUT rows of the packed steps [0, rows): row p of `out` (split_ld(I)
+// float units, same chunk layout as split_bf16x3_kernel) = split(x row of packed row p), the token
+// lookup included.  One workgroup per packed row; one pass over the inputs at HBM speed.
+struct SplitRowsParams {
+  const uint64_t* x_rows;
+  const uint64_t* tok_rows;
+  const float* emb;
+  const int32_t* step_off;
+  uint32_t* out;
+  int32_t I, vocab, x_step, Tmax;
+};
+
+__global__ __launch_bounds__(kThreads) void split_rows_kernel(const SplitRowsParams p) {
+  const int64_t pr = blockIdx.x;
+  __shared__ rowaddr_t s_src;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = p.Tmax - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (static_cast<int64_t>(p.step_off[mid]) <= pr) lo = mid; else hi = mid - 1;
+    }
+    const int64_t sidx = pr - p.step_off[lo];
+    if (p.tok_rows != nullptr) {
+      long long tok = reinterpret_cast<const long long*>(p.tok_rows[sidx])[lo];
+      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
+      s_src = row_addr(p.emb + tok * p.I);
+    } else {
+      s_src = p.x_rows[sidx] + static_cast<rowaddr_t>(lo) * p.x_step * 4u;
+    }
+  }
+  __syncthreads();
+  const float* src = reinterpret_cast<const float*>(s_src);
+  const int64_t ld = split_ld(p.I);
+  uint32_t* o = p.out + pr * ld;
+  for (int pp = threadIdx.x; pp < ld / 2; pp += kThreads) {
+    const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
+    const float x0 = (k < p.I) ? src[k] : 0.f;
+    const float x1 = (k + 1 < p.I) ? src[k + 1] : 0.f;
+    const uint32_t hi = pack_bf16(x0, x1);
+    const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
+    o[c * 16 + q] = hi;
+    o[c * 16 + 8 + q] = pack_bf16(x0 - f0, x1 - f1);
+  }
+}
+
+// Tuning override (benchmarks / tests): CMHSE_TINY_MAX_SEQS=<n> moves the small-batch / tiled
+// crossover (read per call, so tests can force the tiled kernels onto small fixtures).
 static int tiny_max_seqs() {
-  static const int v = [] {
-    const char* e = getenv("CMHSE_TINY_MAX_SEQS");
-    return e ? atoi(e) : kTinyMaxSeqs;
-  }();
-  return v;
+  const char* e = getenv("CMHSE_TINY_MAX_SEQS");
+  return e ? atoi(e) : kTinyMaxSeqs;
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1094,6 +1161,7 @@ struct FwdJob {
   int32_t pool_mode;
   bool vec, bf3, save;
   int32_t t_mid;             // first step served by the mid-size kernel (Tmax: none)
+  int64_t rows_split;        // bf16x3: packed rows of the steps the tiled bf16x3 kernel serves
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
   bool pooled;               // attention already launched (early, beside the others' tail)
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
@@ -1200,6 +1268,10 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   }
   p.w_ih_s = nullptr;
   p.w_hh_s = nullptr;
+  p.xs = nullptr;
+  p.hs_s = nullptr;
+  p.h0_s = nullptr;
+  job->rows_split = 0;
   if (job->bf3) {
     float* wih_s = reinterpret_cast<float*>(wsb + L.wih_s);
     float* whh_s = reinterpret_cast<float*>(wsb + L.whh_s);
@@ -1207,6 +1279,37 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
     launch_split(w->w_hh, whh_s, 3 * b->H, b->H, stream);
     p.w_ih_s = wih_s;
     p.w_hh_s = whh_s;
+    // the steps the tiled bf16x3 kernel serves are a prefix (S_t is non-increasing)
+    for (int t = 0; t < b->Tmax && t < job->t_mid && b->step_count_host[t] > tiny_max_seqs(); ++t)
+      job->rows_split += b->step_count_host[t];
+    p.xs = reinterpret_cast<float*>(wsb + L.xs);
+    p.hs_s = reinterpret_cast<float*>(wsb + L.hs_s);
+    p.h0_s = reinterpret_cast<float*>(wsb + L.h0_s);
+    if (job->rows_split > 0) {
+      // their input rows pre-split in one pass (an upload still in flight must land first)
+      if (b->step_events_host != nullptr)
+        for (int t = 0; t < b->Tmax; ++t)
+          if (b->step_events_host[t] != nullptr)
+            (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(b->step_events_host[t])), 0);
+      SplitRowsParams sr;
+      sr.x_rows = b->x_rows; sr.tok_rows = b->tok_rows; sr.emb = b->emb_table;
+      sr.step_off = b->step_off;
+      sr.out = reinterpret_cast<uint32_t*>(wsb + L.xs);
+      sr.I = b->I; sr.vocab = b->vocab; sr.x_step = b->x_step_floats; sr.Tmax = b->Tmax;
+      hipLaunchKernelGGL(split_rows_kernel, dim3(static_cast<unsigned>(job->rows_split)),
+                         dim3(kThreads), 0, stream, sr);
+      if (b->h0_rows != nullptr) {   // the caller's initial states, one row per sorted sequence
+        SplitRowsParams sh = sr;
+        sh.x_rows = b->h0_rows; sh.tok_rows = nullptr;
+        sh.out = reinterpret_cast<uint32_t*>(wsb + L.h0_s);
+        sh.I = b->H; sh.x_step = 0; sh.Tmax = 1;
+        hipLaunchKernelGGL(split_rows_kernel, dim3(static_cast<unsigned>(b->S)), dim3(kThreads), 0,
+                           stream, sh);
+      }
+      if (b->H % 16 != 0)   // the epilogue writes whole (hi, lo) pairs; the chunk padding must read 0
+        (void)hipMemsetAsync(wsb + L.hs_s, 0,
+                             static_cast<size_t>(job->rows_split) * split_ld(b->H) * sizeof(float), stream);
+    }
   }
   return CMHSE_OK;
 }
@@ -1437,6 +1540,7 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
   float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
   AttnEnergyParams ep;
+  ep.hs_s = nullptr;
   ep.hs = job.p.hs;
   ep.w_lin = w->w_lin;
   ep.b_lin = w->b_lin;
@@ -1461,8 +1565,24 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
     float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
     if (ep.row_begin == 0) launch_split(w->w_lin, wlin_s, b->H, b->H, stream);
     ep.w_lin_s = wlin_s;
+    ep.hs_s = job.p.hs_s;
     const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
-    hipLaunchKernelGGL((attn_energy_kernel<true, 2, true>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
+    // rows the tiled bf16x3 steps produced exist in pre-split form (no conversion in the loop);
+    // the rows of the small-batch steps behind them are fp32 only
+    const int64_t lo = ep.row_begin, hi = ep.row_end;
+    const int64_t cut = job.rows_split < lo ? lo : (job.rows_split > hi ? hi : job.rows_split);
+    if (cut > lo) {
+      ep.row_begin = lo;
+      ep.row_end = cut;
+      const unsigned g1 = static_cast<unsigned>(((cut - lo + 127) / 128) * att_tiles);
+      hipLaunchKernelGGL((attn_energy_kernel<true, 2, true, true>), dim3(g1), dim3(kThreads), att_smem, stream, ep);
+    }
+    if (hi > cut) {
+      ep.row_begin = cut;
+      ep.row_end = hi;
+      const unsigned g2 = static_cast<unsigned>(((hi - cut + 127) / 128) * att_tiles);
+      hipLaunchKernelGGL((attn_energy_kernel<true, 2, true, false>), dim3(g2), dim3(kThreads), att_smem, stream, ep);
+    }
   } else if (msub == 2) {
     const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
     if (job.vec)

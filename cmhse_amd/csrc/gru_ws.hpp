@@ -6,7 +6,8 @@
 //   gates   [sumT, 4H]    r, z, n, (W_hn h + b_hn) per packed row
 //   argmax  [S, H] int32  step of the maximum (CMHSE_POOL_MAX)
 //   v       [sumT, H]     tanh(W_lin h + b_lin) (CMHSE_POOL_ATTN)
-// with CMHSE_MATH_BF16X3: the hi/lo pre-split copies of W_ih, W_hh (and W_lin);
+// with CMHSE_MATH_BF16X3: the hi/lo pre-split copies of W_ih, W_hh (and W_lin), of the input rows
+// (xs [sumT, split_ld(I)]) and of the hidden states (hs_s [sumT, split_ld(H)]);
 // and last   gx  [rows of the small-batch steps, 3H]   their hoisted input projection x W_ih^T.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,7 +26,7 @@ namespace cmhse {
 constexpr int kAttBN = CMHSE_ATT_BN;  // columns of W_lin per attention-energy workgroup (128 or 256)
 
 struct GruWs {
-  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, gx, total;
+  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, total;
 };
 
 // Active sequences at or below which a step runs on the mid-size kernel (gru_step_mid_kernel: the
@@ -74,6 +75,13 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   if (bf3) off += ws_align(static_cast<size_t>(3) * H * split_ld(H) * sizeof(float));
   L.wlin_s = off;
   if (bf3 && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(H) * split_ld(H) * sizeof(float));
+  // bf16x3: the inputs and the hidden states of the LDS-tiled steps in pre-split (hi | lo) rows
+  L.xs = off;
+  if (bf3) off += ws_align(static_cast<size_t>(sum_T) * split_ld(I) * sizeof(float));
+  L.hs_s = off;
+  if (bf3) off += ws_align(static_cast<size_t>(sum_T) * split_ld(H) * sizeof(float));
+  L.h0_s = off;  // ... and of the caller's initial hidden states
+  if (bf3) off += ws_align(static_cast<size_t>(S) * split_ld(H) * sizeof(float));
   L.gx = off;   // last region: the backward pass never looks at it (it calls this without Tmax)
   if (I % 4 == 0 && H % 4 == 0)
     off += ws_align(static_cast<size_t>(gx_rows_bound(S, Tmax, sum_T)) * 3 * H * sizeof(float));

@@ -367,7 +367,11 @@ __device__ __forceinline__ void split8(const float4& lo4, const float4& hi4, uin
   l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
 }
 
-template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST>
+// ASPLIT: the A rows are PRE-SPLIT like the weights (rows of split_ld(K) float units, per 16-k chunk
+// 16 bf16 hi then 16 bf16 lo; written once by split_rows_kernel for the inputs and by the step
+// epilogue for the hidden states): no conversion in the loop, the A fragments are read exactly like
+// the B fragments, one chunk ahead of the MFMAs that consume them.
+template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST, bool ASPLIT = false>
 __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow)[BM / 64],
                                              const bool (&aval)[BM / 64],
                                              const rowaddr_t (&brow)[BNR / 64],
@@ -381,16 +385,18 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
   const int sk = (tid & 3) * 4;
   const int nchunks = (K + kBK - 1) / kBK;
   if (nchunks == 0) return;
-  const int Kp = nchunks * kBK;  // B rows are zero-padded to whole chunks by the split kernel
+  const int Kp = nchunks * kBK;  // pre-split rows are zero-padded to whole chunks by their producers
+  const int Ka = ASPLIT ? Kp : K;
   const int frow = lane & 31;
   const int fk = (lane >> 5) * 8;  // this lane-half's 8 k inside the 16-k chunk
   float4 ra[AP], rb[BP];
-  float4 xa[MSUB][2];               // raw fp32 A fragments of the chunk just read
+  float4 xa[MSUB][2];               // raw fp32 A fragments of the chunk just read (!ASPLIT)
+  uint4 an[MSUB], aln[MSUB];        // pre-split A fragments of the chunk just read (ASPLIT)
   uint4 ah[MSUB], al[MSUB], bh[NSUB], bl[NSUB];   // operands of the chunk being multiplied
 
   auto issue_global = [&](int kn) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<true>(arow[i], kn, K);
+    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<true>(arow[i], kn, Ka);
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = issue_row4<true>(brow[i], kn, Kp);
   };
@@ -398,7 +404,7 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
 #pragma unroll
     for (int i = 0; i < AP; ++i)
       *reinterpret_cast<float4*>(SM::a(smem, buf) + (srow + 64 * i) * kLdsLd + sk) =
-          finish_row4<true>(ra[i], aval[i], kn, K);
+          finish_row4<true>(ra[i], aval[i], kn, Ka);
 #pragma unroll
     for (int i = 0; i < BP; ++i)
       *reinterpret_cast<float4*>(SM::b(smem, buf) + (srow + 64 * i) * kLdsLd + sk) =
@@ -407,9 +413,15 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
   auto read_a = [&](int buf) {
 #pragma unroll
     for (int ms = 0; ms < MSUB; ++ms) {
-      const float* p = SM::a(smem, buf) + (a_row0 + ms * 32 + frow) * kLdsLd + fk;
-      xa[ms][0] = *reinterpret_cast<const float4*>(p);
-      xa[ms][1] = *reinterpret_cast<const float4*>(p + 4);
+      if (ASPLIT) {
+        const float* p = SM::a(smem, buf) + (a_row0 + ms * 32 + frow) * kLdsLd;
+        an[ms] = *reinterpret_cast<const uint4*>(p + (fk >> 1));
+        aln[ms] = *reinterpret_cast<const uint4*>(p + 8 + (fk >> 1));
+      } else {
+        const float* p = SM::a(smem, buf) + (a_row0 + ms * 32 + frow) * kLdsLd + fk;
+        xa[ms][0] = *reinterpret_cast<const float4*>(p);
+        xa[ms][1] = *reinterpret_cast<const float4*>(p + 4);
+      }
     }
   };
   auto read_b = [&](int buf) {
@@ -423,7 +435,14 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
   };
   auto convert_a = [&]() {
 #pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) split8(xa[ms][0], xa[ms][1], ah[ms], al[ms]);
+    for (int ms = 0; ms < MSUB; ++ms) {
+      if (ASPLIT) {
+        ah[ms] = an[ms];
+        al[ms] = aln[ms];
+      } else {
+        split8(xa[ms][0], xa[ms][1], ah[ms], al[ms]);
+      }
+    }
   };
   auto mfma_chunk = [&]() {
 #pragma unroll
@@ -460,7 +479,7 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
     const int cur = c & 1;
     const int kn = (c + 1) * kBK + sk;
     __syncthreads();                 // chunk c complete in LDS; everyone holds chunk c-1 operands
-    read_a(cur);                     // raw A of chunk c (into xa; ah/al still hold chunk c-1)
+    read_a(cur);                     // A of chunk c (into xa / an; ah/al still hold chunk c-1)
     issue_global(kn);
     __builtin_amdgcn_sched_barrier(0);
     mfma_chunk();                    // chunk c-1

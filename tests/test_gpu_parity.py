@@ -1315,3 +1315,36 @@ def test_grouped_backward_equals_separate_calls(dev):
       np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=1e-5)
     else:
       assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, monkeypatch):
+  """The optional bf16x3 math mode where parity means something: the REFERENCE's own outputs.
+  The golden fixtures are small, so the LDS-tiled kernels (the only ones the mode touches) are
+  forced onto them; encode_data then has to reproduce the reference's embeddings within the 1e-4
+  bar and the reference's integer ranks / top-1 exactly, with pre-split inputs, hidden states,
+  initial states (level 2) and weights all in play."""
+  from cmhse_amd import ops, synthetic
+  from cmhse_amd.evaluation import encode_data, i2t, t2i
+  g = load_golden('model_%s.npz' % rnn_type)
+  opt, model = golden_model(rnn_type, g)
+  batches = torch_batches(golden_batches(g))
+  monkeypatch.setenv('CMHSE_TINY_MAX_SEQS', '0')
+  monkeypatch.setenv('CMHSE_MID_MAX_SEQS', '0')
+  exact = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  try:
+    ops.set_math_mode('bf16x3')
+    res = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
+  finally:
+    ops.set_math_mode('fp32')
+  engaged = False
+  for i, nm in enumerate(['vid_embs', 'para_embs', 'clip_embs', 'cap_embs', 'vid_contexts',
+                          'para_contexts']):
+    np.testing.assert_allclose(res[i], g['enc.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+    np.testing.assert_allclose(exact[i], g['enc.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+    engaged = engaged or not np.array_equal(res[i], exact[i])
+  assert engaged, 'bf16x3 mode did not engage'
+  for nm, fn in [('i2t', i2t), ('t2i', t2i)]:
+    rep, top1, ranks = fn(res[0], res[1])
+    np.testing.assert_array_equal(ranks, g['enc.%s.ranks' % nm])
+    np.testing.assert_array_equal(top1, g['enc.%s.top1' % nm])
