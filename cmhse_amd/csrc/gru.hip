@@ -1422,18 +1422,59 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
 int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool);
 
+// Orders `waiter` behind everything queued on `signal` so far.
+static void stream_after(hipStream_t waiter, hipStream_t signal) {
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+    (void)hipEventRecord(ev, signal);
+    (void)hipStreamWaitEvent(waiter, ev, 0);
+    (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
+  } else {
+    (void)hipStreamSynchronize(signal);
+  }
+}
+
 int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;
-  hipStream_t stream = main_stream;   // where step launches go; moves to a tail stream at most once
+  // Every chain starts on the caller's stream; a chain moves to the call's side stream (at most
+  // once, ordered by an event) when it should run BESIDE the others instead of between them:
+  //   (a) it has dropped to small-batch steps while another chain still launches LDS-tiled steps
+  //       that do not fill the chip (a rank's share of the split: 28-44 row tiles x 16 < 768
+  //       workgroup slots) — its short launches, and later its long few-sequence tail, then hide
+  //       under the other chain's steps instead of following each of them;
+  //   (b) another chain has ended and starts its attention pass on the caller's stream.
+  hipStream_t side = nullptr;
+  for (int k = 0; k < n; ++k)
+    if (jobs[k].tail_stream != nullptr && jobs[k].tail_stream != main_stream) side = jobs[k].tail_stream;
+  hipStream_t js[kMaxJobs];
+  for (int k = 0; k < kMaxJobs; ++k) js[k] = main_stream;
+  bool forked = false;
+  auto fork = [&](int k) {
+    if (side == nullptr || js[k] != main_stream) return;
+    stream_after(side, main_stream);
+    js[k] = side;
+    forked = true;
+  };
   for (int k = 0; k < n; ++k) Tmax = jobs[k].b->Tmax > Tmax ? jobs[k].b->Tmax : Tmax;
   for (int t = 0; t < Tmax; ++t) {
     int kind[kMaxJobs];
     bool done[kMaxJobs];
+    bool any_tiled = false;
     for (int k = 0; k < n; ++k) {
       done[k] = t >= jobs[k].b->Tmax;
       if (done[k]) continue;
       FwdJob& j = jobs[k];
+      j.p.t = t;
+      kind[k] = step_kind(j, j.b->step_count_host[t]);
+      any_tiled = any_tiled || (kind[k] & 3) == 1 || (kind[k] & 3) == 2;
+    }
+    for (int k = 0; k < n; ++k) {
+      if (done[k]) continue;
+      FwdJob& j = jobs[k];
       const int S_t = j.b->step_count_host[t];
+      const bool small = (kind[k] & 3) == 0 || (kind[k] & 3) == 3;
+      if (small && any_tiled) fork(k);                                       // (a)
+      hipStream_t stream = js[k];
       if (j.b->step_events_host != nullptr && j.b->step_events_host[t] != nullptr)
         (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[t])), 0);
       if (t == j.t_mid) {
@@ -1444,20 +1485,19 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
               (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[q])), 0);
         launch_xproj(j, stream);
       }
-      j.p.t = t;
       j.p.S_t = S_t;
       j.p.off_prev = j.off - (t > 0 ? j.b->step_count_host[t - 1] : 0);
       j.p.off_cur = j.off;
       j.off += S_t;
-      kind[k] = step_kind(j, S_t);
     }
     for (int k = 0; k < n; ++k) {
       if (done[k]) continue;
       GruStepGroup g;
       g.n = 0;
       unsigned grid = 0;
-      for (int m = k; m < n; ++m) {
-        if (done[m] || kind[m] != kind[k]) continue;
+      hipStream_t stream = js[k];
+      for (int m = k; m < n; ++m) {   // same kernel, same stream: one launch
+        if (done[m] || kind[m] != kind[k] || js[m] != stream) continue;
         g.j[g.n] = jobs[m].p;
         g.start[g.n] = grid;
         grid += step_grid(jobs[m], kind[m], jobs[m].p.S_t);
@@ -1489,42 +1529,34 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       }
       ++launches;
     }
-    // A request whose chain ends here while others go on: the others' remaining steps move to its
-    // tail stream and its attention pass starts now on the caller's stream, so the two overlap
-    // (the tail is a few sequences per step: latency-bound launches on an otherwise idle chip).
+    // (b) A request whose chain ends here while others go on: the others continue on the side
+    // stream and its attention pass starts now on the caller's stream, so the two overlap (the
+    // tail is a few sequences per step: latency-bound launches on an otherwise idle chip).
     for (int k = 0; k < n; ++k) {
       FwdJob& j = jobs[k];
-      if (j.pooled || j.tail_stream == nullptr || j.tail_stream == main_stream ||
-          stream != main_stream || j.pool_mode != CMHSE_POOL_ATTN || t != j.b->Tmax - 1 ||
-          t == Tmax - 1)
+      if (j.pooled || side == nullptr || js[k] != main_stream || j.pool_mode != CMHSE_POOL_ATTN ||
+          t != j.b->Tmax - 1 || t == Tmax - 1)
         continue;
-      hipEvent_t ev;
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
-      (void)hipEventRecord(ev, main_stream);
-      (void)hipStreamWaitEvent(j.tail_stream, ev, 0);
-      (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
-      stream = j.tail_stream;
+      bool others = false;
+      for (int m = 0; m < n; ++m)
+        if (m != k && t < jobs[m].b->Tmax - 1) {
+          fork(m);
+          others = true;
+        }
+      if (!others) continue;
       if (launch_attention(j, main_stream, j.sum_T, true) == CMHSE_OK) j.pooled = true;
       // ... and behind it the attention projection of what the OTHER attention-pooled chains have
-      // produced so far (their steps <= t were launched on the caller's stream): only the rows of
-      // their remaining tail steps are left for after the tail
+      // produced so far: only the rows of their remaining tail steps are left for after the tail
       for (int m = 0; m < n; ++m) {
         FwdJob& o = jobs[m];
-        if (m != k && o.pool_mode == CMHSE_POOL_ATTN && !o.pooled && t < o.b->Tmax - 1 && o.off > 0)
-          (void)launch_attention(o, main_stream, o.off, false);
+        if (m == k || o.pool_mode != CMHSE_POOL_ATTN || o.pooled || t >= o.b->Tmax - 1 || o.off <= 0)
+          continue;
+        if (js[m] != main_stream) stream_after(main_stream, js[m]);   // its steps <= t
+        (void)launch_attention(o, main_stream, o.off, false);
       }
     }
   }
-  if (stream != main_stream) {   // rejoin: everything after the steps is ordered on the caller's stream
-    hipEvent_t ev;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-      (void)hipEventRecord(ev, stream);
-      (void)hipStreamWaitEvent(main_stream, ev, 0);
-      (void)hipEventDestroy(ev);
-    } else {
-      (void)hipStreamSynchronize(stream);
-    }
-  }
+  if (forked) stream_after(main_stream, side);   // rejoin: what follows is ordered on the caller's stream
   return launches;
 }
 

@@ -1348,3 +1348,30 @@ def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, monkeypatch):
     rep, top1, ranks = fn(res[0], res[1])
     np.testing.assert_array_equal(ranks, g['enc.%s.ranks' % nm])
     np.testing.assert_array_equal(top1, g['enc.%s.top1' % nm])
+
+
+def test_small_batch_chain_beside_tiled_chain_is_bit_identical(dev, monkeypatch):
+  """cmhse_gru_pool_fwd_multi moves a chain that has dropped to small-batch steps onto the side
+  stream while the other chain still launches LDS-tiled steps (a rank's share of the split on 8
+  GPUs), and projects the still-running chain's rows early when the other one ends.  With the
+  small / tiled crossover lowered so that both happen on a small fixture, the result must not
+  change by a bit against the one-stream schedule — repeated, because a missing stream dependency
+  shows up as a flaky mismatch."""
+  from cmhse_amd import synthetic, evaluation
+  g = load_golden('model_attention.npz')
+  opt, model = golden_model('attention', g)
+  spec = synthetic.ragged_spec(41, seed=13, max_frames=14, max_words=5, max_video=16)
+  batches = synthetic.make_batches(spec, 8, opt.img_dim, opt.vocab_size, seed=3)
+  monkeypatch.setenv('CMHSE_TINY_MAX_SEQS', '40')
+  monkeypatch.setenv('CMHSE_MID_MAX_SEQS', '40')
+  keys = ('vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx')
+  outs = []
+  for early in (False, True, True, True):
+    monkeypatch.setattr(evaluation, 'EARLY_POOL', [early])
+    with torch.no_grad():
+      r = evaluation.encode_group(model, batches)
+    torch.cuda.synchronize()
+    outs.append({k: r[k].cpu().numpy() for k in keys})
+  for o in outs[1:]:
+    for k in keys:
+      assert np.array_equal(o[k], outs[0][k]), k
