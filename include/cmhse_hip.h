@@ -17,10 +17,12 @@
  *     returns.  Host-side objects a call may create and release before it returns: one HIP event
  *     per stream fork/join when a `tail_stream` is used (cmhse_gru_pool_fwd_multi), and event
  *     pairs owned by a cmhse_timer handle when the caller passes one (measurement only);
- *   - process-wide state is limited to read-only tuning overrides taken ONCE from the environment
- *     at first use (CMHSE_TINY_MAX_SEQS, CMHSE_MID_MAX_SEQS, CMHSE_GRU_MSUB,
- *     CMHSE_TINY_FWD_NW8_MAX, CMHSE_TINY_NW8_MAX: kernel-shape crossovers, never results); nothing
- *     is written after that, so concurrent calls from several host threads are safe;
+ *   - the library keeps no mutable process-wide state.  It READS optional tuning overrides from
+ *     the environment — kernel-shape crossovers and launch footprints, never results:
+ *     CMHSE_MID_MAX_SEQS, CMHSE_TINY_MAX_SEQS, CMHSE_GRU_RASTER, CMHSE_PULL_GRID,
+ *     CMHSE_PULL_THREADS per call; CMHSE_GRU_MSUB, CMHSE_TINY_FWD_NW8_MAX, CMHSE_TINY_NW8_MAX once,
+ *     at first use — so concurrent calls from several host threads are safe as long as nobody
+ *     rewrites those variables between a `*_workspace` query and the call it sizes;
  *   - return value: 0 = success, negative = error code (cmhse_strerror); no exceptions or aborts
  *     cross the ABI.
  */
@@ -144,7 +146,10 @@ typedef struct cmhse_gru_job {
                           an event) and this request's attention projection + pooling start at
                           once on `stream`, beside that few-sequence, latency-bound tail.  The
                           call rejoins `stream` (event wait) before its last launches, so the
-                          caller needs no extra ordering. */
+                          caller needs no extra ordering.  The same side stream also takes a
+                          request whose chain has dropped to small-batch steps while another
+                          request still launches LDS-tiled steps that do not fill the chip, so
+                          that its short launches run beside those instead of between them. */
 } cmhse_gru_job;
 int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
 
