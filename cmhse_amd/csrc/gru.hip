@@ -908,6 +908,7 @@ __global__ __launch_bounds__(kThreads) void attn_pool_kernel(const AttnPoolParam
   const int len = p.lens[s];
   const int tid = threadIdx.x;
   __shared__ float s_w[kThreads];
+  __shared__ int64_t s_row[kThreads];
   __shared__ float s_den;
   // pass 1: denominator sum_t exp(e_t) + 1e-4 (each exp evaluated by exactly one thread)
   float part = 0.f;
@@ -928,9 +929,13 @@ __global__ __launch_bounds__(kThreads) void attn_pool_kernel(const AttnPoolParam
   const float den = s_den;
   const int H = p.H;
   float* o = p.out + static_cast<int64_t>(p.out_row[s]) * H;
-  // pass 2: weighted sum; the weights of 256 steps at a time are staged in LDS
+  const bool vec = (H % 4 == 0) && aligned16(p.hs) && aligned16(o);
+  // pass 2: weighted sum over the sequence's rows; the weights AND the packed row numbers of 256
+  // steps at a time are staged in LDS, so the row loads of consecutive steps are independent of any
+  // other global load and pipeline freely (HBM-bound: each hidden row is read once, 16 B per lane)
   for (int ub = 0; ub < H; ub += 4 * kThreads) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int u = ub + 4 * tid;
     for (int t0 = 0; t0 < len; t0 += kThreads) {
       __syncthreads();
       if (t0 + tid < len) {
@@ -938,24 +943,39 @@ __global__ __launch_bounds__(kThreads) void attn_pool_kernel(const AttnPoolParam
         float e = 0.f;
         for (int q = 0; q < p.n_tiles; ++q) e += p.e_part[q * p.rows + row];
         s_w[tid] = expf(e) / den;
+        s_row[tid] = row;
       }
       __syncthreads();
       const int cnt = (len - t0 < kThreads) ? (len - t0) : kThreads;
-      for (int j = 0; j < cnt; ++j) {
-        const float* hrow = p.hs + (static_cast<int64_t>(p.step_off[t0 + j]) + s) * H;
-        const float wgt = s_w[j];
-        const int u = ub + tid;
-        if (u < H) a0 += wgt * hrow[u];
-        if (u + kThreads < H) a1 += wgt * hrow[u + kThreads];
-        if (u + 2 * kThreads < H) a2 += wgt * hrow[u + 2 * kThreads];
-        if (u + 3 * kThreads < H) a3 += wgt * hrow[u + 3 * kThreads];
+      if (vec && u + 3 < H) {
+#pragma unroll 4
+        for (int j = 0; j < cnt; ++j) {
+          const float4 h = *reinterpret_cast<const float4*>(p.hs + s_row[j] * H + u);
+          const float wgt = s_w[j];
+          a0 += wgt * h.x;
+          a1 += wgt * h.y;
+          a2 += wgt * h.z;
+          a3 += wgt * h.w;
+        }
+      } else {
+        for (int j = 0; j < cnt; ++j) {
+          const float* hrow = p.hs + s_row[j] * H;
+          const float wgt = s_w[j];
+          if (u < H) a0 += wgt * hrow[u];
+          if (u + 1 < H) a1 += wgt * hrow[u + 1];
+          if (u + 2 < H) a2 += wgt * hrow[u + 2];
+          if (u + 3 < H) a3 += wgt * hrow[u + 3];
+        }
       }
     }
-    const int u = ub + tid;
-    if (u < H) o[u] = a0;
-    if (u + kThreads < H) o[u + kThreads] = a1;
-    if (u + 2 * kThreads < H) o[u + 2 * kThreads] = a2;
-    if (u + 3 * kThreads < H) o[u + 3 * kThreads] = a3;
+    if (vec && u + 3 < H) {
+      *reinterpret_cast<float4*>(o + u) = make_float4(a0, a1, a2, a3);
+    } else {
+      if (u < H) o[u] = a0;
+      if (u + 1 < H) o[u + 1] = a1;
+      if (u + 2 < H) o[u + 2] = a2;
+      if (u + 3 < H) o[u + 3] = a3;
+    }
   }
 }
 
