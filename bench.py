@@ -368,9 +368,11 @@ def main():
 
   def step():
     if world == 1:
-      cat, _, _ = encode_data_device(opt, model, batches, logging=quiet)
+      cat, _, _, finish_log = encode_data_device(opt, model, batches, logging=quiet,
+                                                 defer_logging=True)
       r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
+      finish_log()     # the per-batch 'Letest' meters (evaluation.py:129), after the ranking is queued
       return r_i, r_t
     res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed,
                                          assignment=assignment, timings=phase_ms)

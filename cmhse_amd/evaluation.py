@@ -276,9 +276,13 @@ def _group_batches(batches, max_bytes):
 
 
 def encode_data_device(opt, model, data_loader, log_step=10, logging=print, contextual_model=True,
-                       superbatch_bytes=48 << 30):
+                       superbatch_bytes=48 << 30, defer_logging=False):
   """Device-resident core of encode_data: returns (dict of six [N,*] normalised embedding tensors
-  on the GPU, num_clips_total, cur_vid_total)."""
+  on the GPU, num_clips_total, cur_vid_total).  With `defer_logging` the per-batch 'Letest' values
+  travel to the host asynchronously and a fourth return value, `finish()`, replays the logger
+  updates: a caller that scores the embeddings right away (bench.py, parallel_eval) queues its
+  ranking kernels first and calls finish() afterwards, so the GPU does not idle through that
+  device-to-host round trip."""
   batch_time = AverageMeter()
   val_logger = LogCollector()
   model.val_start(opt)
@@ -287,7 +291,24 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
   num_clips_total, cur_vid_total = [], []
   batches = list(data_loader)
   n_loader = len(batches)
-  i = 0
+  pending, state = [], {'i': 0, 'end': end}
+
+  def flush():
+    """Replay model.logger.update('Letest', value, batch size) (model.py:291) for the groups whose
+    loss values have reached the host, batch by batch in loader order."""
+    while pending:
+      group, sizes, host, ev, _keep = pending.pop(0)
+      if ev is not None:
+        ev.synchronize()
+      for b, bs, lv in zip(group, sizes, host.tolist()):
+        val_logger.update('Letest', lv, bs)
+        batch_time.update(time.time() - state['end'])
+        state['end'] = time.time()
+        if state['i'] % log_step == 0:
+          logging('Test: [{0}/{1}]\t{e_log}\tTime {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                  .format(state['i'], n_loader, batch_time=batch_time, e_log=str(val_logger)))
+        state['i'] += 1
+
   with torch.no_grad():
     for group in _group_batches(batches, superbatch_bytes):
       model.logger = val_logger                     # evaluation.py:99
@@ -296,20 +317,23 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
         outs[k].append(enc[k])
       # per-loader-batch 'Letest' loss (evaluation.py:129), all on device, one sync per group
       crit = model.criterion
-      loss_vals = ops.contrastive_blocks_fwd(enc['vid_emb'], enc['para_emb'], enc['batch_sizes'],
-                                             crit.margin, crit.max_violation,
-                                             crit.norm).cpu().tolist()
-      for b, bs, lv in zip(group, enc['batch_sizes'], loss_vals):
+      loss_dev = ops.contrastive_blocks_fwd(enc['vid_emb'], enc['para_emb'], enc['batch_sizes'],
+                                            crit.margin, crit.max_violation, crit.norm)
+      for b in group:
         num_clips_total.extend(b[8])
         cur_vid_total.extend(b[11])
-        model.logger.update('Letest', lv, bs)       # model.py:291
-        batch_time.update(time.time() - end)
-        end = time.time()
-        if i % log_step == 0:
-          logging('Test: [{0}/{1}]\t{e_log}\tTime {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
-                  .format(i, n_loader, batch_time=batch_time, e_log=str(model.logger)))
-        i += 1
+      if defer_logging:
+        host = torch.empty(loss_dev.shape, dtype=loss_dev.dtype, pin_memory=True)
+        host.copy_(loss_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((group, enc['batch_sizes'], host, ev, loss_dev))
+      else:
+        pending.append((group, enc['batch_sizes'], loss_dev.cpu(), None, None))
+        flush()
   cat = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in outs.items()}
+  if defer_logging:
+    return cat, num_clips_total, cur_vid_total, flush
   return cat, num_clips_total, cur_vid_total
 
 

@@ -81,7 +81,7 @@ def _default_encode(opt, model, batches):
   if not batches:
     return None
   cat, _, _ = evaluation.encode_data_device(opt, model, batches, logging=lambda *a: None)
-  return cat['vid_emb'], cat['para_emb']
+  return cat['vid_emb'], cat['para_emb']   # (logging flushed inside: the exchange step follows)
 
 
 def _default_rank(queries, gallery, row0, nrows):
