@@ -1375,3 +1375,48 @@ def test_small_batch_chain_beside_tiled_chain_is_bit_identical(dev, monkeypatch)
   for o in outs[1:]:
     for k in keys:
       assert np.array_equal(o[k], outs[0][k]), k
+
+
+def test_deferred_logging_reports_the_same_meters(dev):
+  """encode_data_device(defer_logging=True): same embeddings, and after finish() the same
+  'Letest' meter (last value, weighted average, count) as the immediate form."""
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import encode_data_device
+  g = load_golden('model_maxout.npz')
+  opt, model = golden_model('maxout', g)
+  spec = synthetic.ragged_spec(26, seed=2)
+  batches = synthetic.make_batches(spec, 7, opt.img_dim, opt.vocab_size, seed=5)
+  quiet = lambda *a, **k: None
+  cat_a, nc_a, cv_a = encode_data_device(opt, model, batches, logging=quiet)
+  meter_a = model.logger.meters['Letest']
+  ref = (meter_a.val, meter_a.avg, meter_a.count)
+  cat_b, nc_b, cv_b, finish = encode_data_device(opt, model, batches, logging=quiet,
+                                                 defer_logging=True)
+  assert 'Letest' not in model.logger.meters      # nothing logged before finish()
+  finish()
+  meter_b = model.logger.meters['Letest']
+  assert (meter_b.val, meter_b.avg, meter_b.count) == ref
+  assert nc_a == nc_b and cv_a == cv_b
+  for k in cat_a:
+    assert torch.equal(cat_a[k], cat_b[k]), k
+
+
+def test_pinned_host_batches_at_icep_width(dev):
+  """The chunked pull at the real feature width (2048 floats = 8 KB rows, every chunk size of the
+  schedule in play: 80-frame clips) == the resident pass, bit for bit."""
+  from cmhse_amd import evaluation, synthetic
+  from cmhse_amd.model import VSE
+  opt = _full_opt('attention', 2048, 500, embed_size=128, img_first_size=128, cap_first_size=128)
+  torch.manual_seed(3)
+  model = VSE(opt)
+  spec = synthetic.anet_like_spec(48, seed=4)
+  batches = synthetic.make_batches(spec, 16, 2048, 500, seed=6, feat='relu')
+  pinned = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
+  on_dev = [tuple(t.to(dev) if isinstance(t, torch.Tensor) and t.dim() > 1 else t for t in b)
+            for b in batches]
+  quiet = lambda *a, **k: None
+  want, _, _ = evaluation.encode_data_device(opt, model, on_dev, logging=quiet)
+  for _ in range(2):
+    got, _, _ = evaluation.encode_data_device(opt, model, pinned, logging=quiet)
+    for k in want:
+      assert torch.equal(got[k], want[k]), k
