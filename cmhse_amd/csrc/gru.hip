@@ -118,7 +118,14 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
-template <bool VEC, int MSUB, bool BF3>
+// HOIST (experiment, CMHSE_HOIST_MAX_SEQS, off by default): the input projection of this job was
+// hoisted into xproj_kernel (gx[row, 3H]): the tile loop keeps only K = H and the epilogue adds the
+// three input terms.  Meant for steps whose grids do not fill the chip for several rounds (a
+// rank's share of the split): two thirds of the work then run as ONE filled GEMM instead of in 80
+// under-filled launches.  Measured: the under-filled steps were not that inefficient (workgroups
+// with fewer co-runners run faster) and the big projection runs at 94 TFLOP/s, so the pass moves
+// by +2 % (615 videos) ... -3 % (1230 videos): not enabled.
+template <bool VEC, int MSUB, bool BF3, bool HOIST = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_kernel(const GruStepGroup grp) {
   constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
@@ -167,7 +174,9 @@ void gru_step_kernel(const GruStepGroup grp) {
     const int m = m0 + srow + 64 * i;
     av[i] = m < p.S_t;
     const int mc = av[i] ? m : (p.S_t - 1);
-    if (BF3) {
+    if (HOIST) {
+      ax[i] = 0;   // no x phase
+    } else if (BF3) {
       ax[i] = row_addr(p.xs + (p.off_cur + mc) * split_ld(I));   // (token lookups included)
     } else if (p.tok_rows != nullptr) {
       long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
@@ -231,7 +240,7 @@ void gru_step_kernel(const GruStepGroup grp) {
     nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2, true>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   } else {
-    nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    if (!HOIST) nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   }
   TRACE_MARK(3);
@@ -274,6 +283,30 @@ void gru_step_kernel(const GruStepGroup grp) {
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) hp[r] = 0.f;
+    }
+    if (HOIST) {
+      // the hoisted input terms of this lane's 16 (sequence, unit) elements: one round trip
+      // (four rows at a time: all sixteen at once cost the third wave per SIMD)
+#pragma unroll
+      for (int r4 = 0; r4 < 16; r4 += 4) {
+        float gr[4], gz[4], gn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = mrow0 + acc_row(r4 + i, lane);
+          const int mc = m < S_t ? m : (S_t - 1);
+          const float* gxr = p.gx + (p.gx_per_seq ? static_cast<int64_t>(mc) : (off_cur + mc - p.gx_p0)) * 3 * H + uc;
+          gr[i] = gxr[0];
+          gz[i] = gxr[H];
+          gn[i] = gxr[2 * H];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[ms][0][r4 + i] += gr[i];
+          acc[ms][1][r4 + i] += gz[i];
+          acc[ms][2][r4 + i] = gn[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -780,15 +813,40 @@ void xproj_kernel(const XprojParams p) {
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
   nt_phase<BM, BN, 1, NS, NS, NS - 1, true>(smem, ar, av, br, bv, p.I, wm * 32, b_row0, acc);
+  // Epilogue.  48 dword stores per lane (one per accumulator element) made this kernel
+  // store-ISSUE-bound (65 % MFMA-busy against 86 % for the step kernel on the same tile loop): the
+  // tile goes through the now idle LDS, 32 rows at a time, and leaves as 16-byte stores of whole
+  // row segments (6 per thread and half).
+  constexpr int kLd = BN + 4;                  // row stride of the staging image, floats
+  float* stage = smem;                         // 32 x 196 x 4 B = 25 KB of the 40 KB tile buffers
+  const bool vec_out = (p.N % 4 == 0) && (n0 + BN <= p.N);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t m = m0 + wm * 32 + acc_row(r, lane);
-    if (m >= p.rows) continue;
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) {
-      const int n = n0 + b_row0[ns] + acc_col(lane);
-      if (n < p.N) p.gx[m * p.N + n] = acc[0][ns][r];
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          stage[acc_row(r, lane) * kLd + b_row0[ns] + acc_col(lane)] = acc[0][ns][r];
     }
+    __syncthreads();
+    const int64_t mh = m0 + 32 * half;
+    if (vec_out) {
+#pragma unroll
+      for (int i = 0; i < (32 * BN / 4) / kThreads; ++i) {
+        const int idx = tid + kThreads * i;
+        const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+        if (mh + row < p.rows)
+          *reinterpret_cast<float4*>(p.gx + (mh + row) * p.N + n0 + 4 * c4) =
+              *reinterpret_cast<const float4*>(stage + row * kLd + 4 * c4);
+      }
+    } else {
+      for (int idx = tid; idx < 32 * BN; idx += kThreads) {
+        const int row = idx / BN, c = idx % BN;
+        if (mh + row < p.rows && n0 + c < p.N) p.gx[(mh + row) * p.N + n0 + c] = stage[row * kLd + c];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1152,6 +1210,11 @@ static int tiny_max_seqs() {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int hoist_max_seqs() {   // read per call.  Off by default: measured +2 % at 615 videos, -3 % at 1230
+  const char* e = getenv("CMHSE_HOIST_MAX_SEQS");
+  return e ? atoi(e) : 0;
+}
+
 int mid_max_seqs() {   // read per call, so one process can A/B it (tools/step_sweep.py)
   const char* e = getenv("CMHSE_MID_MAX_SEQS");
   return e ? atoi(e) : 1024;
@@ -1181,6 +1244,7 @@ struct FwdJob {
   int32_t pool_mode;
   bool vec, bf3, save;
   int32_t t_mid;             // first step served by the mid-size kernel (Tmax: none)
+  bool hoist_all;            // the input projection of EVERY step is hoisted (xproj at t = 0)
   int64_t rows_split;        // bf16x3: packed rows of the steps the tiled bf16x3 kernel serves
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
   bool pooled;               // attention already launched (early, beside the others' tail)
@@ -1286,6 +1350,15 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
     p.gx_p0 = p0;
     p.gx_per_seq = (b->x_rows != nullptr && b->x_step_floats == 0) ? 1 : 0;
   }
+  // a batch too small to fill the chip with its tiled steps: hoist the projection of all steps
+  // (not while the inputs are still arriving chunk by chunk: the GEMM would wait for all of them)
+  job->hoist_all = job->vec && !bf3 && job->t_mid > 0 && b->S <= hoist_max_seqs() &&
+                   b->step_events_host == nullptr;
+  if (job->hoist_all) {
+    p.gx = reinterpret_cast<float*>(wsb + L.gx);
+    p.gx_p0 = 0;
+    p.gx_per_seq = (b->x_rows != nullptr && b->x_step_floats == 0) ? 1 : 0;
+  }
   p.w_ih_s = nullptr;
   p.w_hh_s = nullptr;
   p.xs = nullptr;
@@ -1349,12 +1422,14 @@ int step_kind(const FwdJob& j, int S_t) {
   if (j.p.t >= j.t_mid) return 3 | (S_t <= 16 ? 32 : 0);   // mid-size kernel (vec shapes only)
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
+  if (k == 1 && j.hoist_all) k |= 64;   // tiled step on the hoisted projection (K = H only)
   return k | (j.vec ? 0 : 4);
 }
 
 // The input projection of every step >= t_mid of a job, launched once before the first of them.
 void launch_xproj(const FwdJob& j, hipStream_t stream) {
   const cmhse_seq_batch* b = j.b;
+  const int t_first = j.hoist_all ? 0 : j.t_mid;
   XprojParams q;
   q.x_rows = b->x_rows;
   q.tok_rows = b->tok_rows;
@@ -1364,13 +1439,13 @@ void launch_xproj(const FwdJob& j, hipStream_t stream) {
   q.gx = const_cast<float*>(j.p.gx);
   q.p0 = j.p.gx_p0;
   q.per_seq = j.p.gx_per_seq;
-  q.rows = q.per_seq ? b->step_count_host[j.t_mid] : (j.sum_T - j.p.gx_p0);
+  q.rows = q.per_seq ? b->step_count_host[t_first] : (j.sum_T - j.p.gx_p0);
   q.I = b->I;
   q.N = 3 * b->H;
   q.vocab = b->vocab;
   q.x_step = b->x_step_floats;
   q.Tmax = b->Tmax;
-  q.t_first = j.t_mid;
+  q.t_first = t_first;
   q.n_tiles = (q.N + 191) / 192;
   const int64_t grid = static_cast<int64_t>(q.n_tiles) * ((q.rows + 63) / 64);
   const size_t smem = TileSmem<64, 192>::kBytes;
@@ -1414,7 +1489,9 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
           hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads), smem, stream, g);
       } else {
         const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
-        if (vec)
+        if ((kind & 64) != 0)
+          hipLaunchKernelGGL((gru_step_kernel<true, 1, false, true>), dim3(grid), dim3(kThreads), smem, stream, g);
+        else if (vec)
           hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
         else
           hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
@@ -1497,7 +1574,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       hipStream_t stream = js[k];
       if (j.b->step_events_host != nullptr && j.b->step_events_host[t] != nullptr)
         (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[t])), 0);
-      if (t == j.t_mid) {
+      if (t == (j.hoist_all ? 0 : j.t_mid)) {
         // the hoisted projection reads the inputs of ALL remaining steps: wait for their uploads
         if (j.b->step_events_host != nullptr)
           for (int q = t + 1; q < j.b->Tmax; ++q)
@@ -1541,7 +1618,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         timer->tiled_events.push_back(e0);
         timer->tiled_events.push_back(e1);
         for (int q = 0; q < g.n; ++q) {
-          const double I = g.j[q].I, H = g.j[q].H;
+          const double I = (kind[k] & 64) != 0 ? 0.0 : g.j[q].I, H = g.j[q].H;   // hoisted: K = H only
           timer->tiled_flops += g.j[q].S_t * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
           // x_t in, h_{t-1} in, h_t out per sequence; the weights once per launch
           timer->tiled_bytes += g.j[q].S_t * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);

@@ -34,10 +34,15 @@ struct GruWs {
 // recurrent part).  CMHSE_MID_MAX_SEQS overrides (0 disables the kernel).
 int mid_max_seqs();
 
+// Experiment (default 0 = off): batches of at most CMHSE_HOIST_MAX_SEQS sequences hoist the input
+// projection of ALL their steps, so that their under-filled tiled steps keep only K = H.
+int hoist_max_seqs();
+
 // Upper bound of the packed rows whose input projection is hoisted (the rows of the steps with at
-// most mid_max_seqs() active sequences): all of them when the whole batch is that small.
+// most mid_max_seqs() active sequences; all rows when the whole batch is small enough).
 static inline int64_t gx_rows_bound(int32_t S, int32_t Tmax, int64_t sum_T) {
   const int64_t mm = mid_max_seqs();
+  if (S <= hoist_max_seqs()) return sum_T;
   if (mm <= 0) return 0;
   if (S <= mm || Tmax <= 0) return sum_T;
   const int64_t b = mm * static_cast<int64_t>(Tmax);

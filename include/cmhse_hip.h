@@ -19,8 +19,8 @@
  *     pairs owned by a cmhse_timer handle when the caller passes one (measurement only);
  *   - the library keeps no mutable process-wide state.  It READS optional tuning overrides from
  *     the environment — kernel-shape crossovers and launch footprints, never results:
- *     CMHSE_MID_MAX_SEQS, CMHSE_TINY_MAX_SEQS, CMHSE_GRU_RASTER, CMHSE_PULL_GRID,
- *     CMHSE_PULL_THREADS per call; CMHSE_GRU_MSUB, CMHSE_TINY_FWD_NW8_MAX, CMHSE_TINY_NW8_MAX once,
+ *     CMHSE_MID_MAX_SEQS, CMHSE_TINY_MAX_SEQS, CMHSE_HOIST_MAX_SEQS, CMHSE_GRU_RASTER,
+ *     CMHSE_PULL_GRID, CMHSE_PULL_THREADS per call; CMHSE_GRU_MSUB, CMHSE_TINY_FWD_NW8_MAX, CMHSE_TINY_NW8_MAX once,
  *     at first use — so concurrent calls from several host threads are safe as long as nobody
  *     rewrites those variables between a `*_workspace` query and the call it sizes;
  *   - return value: 0 = success, negative = error code (cmhse_strerror); no exceptions or aborts

@@ -1420,3 +1420,33 @@ def test_pinned_host_batches_at_icep_width(dev):
     got, _, _ = evaluation.encode_data_device(opt, model, pinned, logging=quiet)
     for k in want:
       assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize('pool', ['attention', 'seq2seq'])
+def test_hoisted_projection_variant_matches(dev, oracle, pool, monkeypatch):
+  """CMHSE_HOIST_MAX_SEQS (experiment, off by default): the tiled step kernel on a fully hoisted
+  input projection (K = H only, input terms added in the epilogue) against the oracle and against
+  the default path."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(31)
+  S, T, I, H = 2300, 4, 36, 128
+  cls = {'attention': 'Attention', 'seq2seq': 'Seq2Seq'}[pool]
+  torch.manual_seed(6)
+  layer = getattr(layers, cls)(I, H)
+  sd = {'rnn.' + k: v.detach().numpy() for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[:1200] = T
+  x = rng.standard_normal((S, T, I)).astype(np.float32)
+  for i, l in enumerate(lens):
+    x[i, l:] = 0
+  xd = torch.from_numpy(x).to(dev)
+  with torch.no_grad():
+    base = layer(xd, torch.from_numpy(lens)).cpu().numpy()
+    monkeypatch.setenv('CMHSE_HOIST_MAX_SEQS', '100000')
+    hoisted = layer(xd, torch.from_numpy(lens)).cpu().numpy()
+  sample = np.sort(rng.choice(S, 40, replace=False))
+  want = oracle.pooled_gru_forward(pool, x[sample], lens[sample], sd, None, np.float64)
+  np.testing.assert_allclose(hoisted[sample], want, atol=EMB_TOL, rtol=0)
+  np.testing.assert_allclose(hoisted, base, atol=2e-6, rtol=0)
+  assert not np.array_equal(hoisted, base), 'the hoisted variant did not engage'
