@@ -271,7 +271,7 @@ def train_bench(wl, opt, model, batches, n_steps):
 
 def measured_traffic(kernel='gru_step'):
   """Fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-  (profiles/r01_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
+  (profiles/r*_pmc_hbm_traffic.json, newest round: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
   FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM).  None if absent."""
   import glob
   paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_hbm_traffic.json')))
@@ -289,7 +289,7 @@ def measured_traffic(kernel='gru_step'):
 
 def measured_clock_ghz():
   """In-kernel shader clock of the tiled GRU step under load (median over workgroups), from the
-  committed tools/tile_trace.py run (profiles/r01_tile_trace.txt).  None if absent."""
+  committed tools/tile_trace.py run (profiles/r*_tile_trace.txt, newest round).  None if absent."""
   import glob
   paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_tile_trace.txt')))
   if not paths:
@@ -458,7 +458,7 @@ def main():
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                      'traffic': traffic,
                      'traffic_unit': 'fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + '
-                                     'WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)',
+                                     'WRITE_SIZE, newest profiles/r*_pmc_hbm_traffic.json)',
                      'algorithmic_bytes_per_launch': (alg_bytes / launches) if launches else None,
                      # north_star: achieved GB/s of the GRU = PMC traffic / live launch duration
                      # (against ~8000 GB/s HBM; counts Infinity-Cache hits too — the kernel is

@@ -469,6 +469,119 @@ __global__ __launch_bounds__(64 * NW) void gru_bwd_step_kernel(const BwdStepGrou
 }
 
 // ---------------------------------------------------------------------------------------------
+// BPTT step for few active sequences (every step of a training batch): the same product on the
+// tile shape of the forward mid-size step (gru_step_mid_kernel): 32 (or 16) sequences x BU = 16, 8
+// or 4 hidden units per workgroup, one 16 x 16 x 4 MFMA column block, 8 waves split K = 3H with one
+// 128-byte line pair in flight each (mid_phase), fixed-order LDS combine, the epilogue's operands
+// requested before the K loop.  The 32 x 32 tiles above leave H/32 = 32 workgroups at S_t <= 32,
+// each pulling 768 KB of operands through one CU; here 64-256 workgroups pull 430-580 KB each.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBwdMidNW = 8, kBwdMidRing = 2;
+
+template <int MB, int BU>
+__global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const BwdStepGroup grp) {
+  constexpr int NW = kBwdMidNW, BM = 16 * MB;
+  constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);
+  __shared__ f32x4v red[NW][MB][64];
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < CMHSE_MAX_JOBS; ++k)
+    if (k < grp.n && blockIdx.x >= grp.start[k]) ji = k;
+  const BwdStepParams& q = grp.j[ji];
+  const unsigned wg = blockIdx.x - grp.start[ji];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = q.H, K = 3 * H;
+  const int u_tiles = (H + BU - 1) / BU;
+  const int u0 = (wg % u_tiles) * BU, m0 = (wg / u_tiles) * BM;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const bool final_launch = q.t < 0;
+
+  // epilogue operands first (clamped, branch-free): output o = tid + 512 q -> row o / BU, unit o % BU
+  float e_carry[NOUT], e_dpool[NOUT], e_g[NOUT][4], e_hp[NOUT];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int o = tid + 64 * NW * i;
+    const int m = m0 + (o / BU) % BM, u = u0 + (o % BU);
+    const int mc = (m < q.S_t) ? m : (q.S_t - 1), uc = (u < H) ? u : (H - 1);
+    const int mn = (mc < q.S_next) ? mc : 0;
+    e_carry[i] = (q.S_next > 0) ? q.carry[static_cast<int64_t>(mn) * H + uc] : 0.f;
+    e_dpool[i] = 0.f;
+    e_hp[i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e_g[i][g] = 0.f;
+    if (!final_launch) {
+      const int64_t p = q.off_cur + mc;
+      e_dpool[i] = q.dpool[p * H + uc];
+      const float* gp = q.gates + p * 4 * H + uc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_g[i][g] = gp[static_cast<int64_t>(g) * H];
+      if (q.t > 0)
+        e_hp[i] = q.hs[(q.off_prev + mc) * H + uc];
+      else if (q.h0_rows != nullptr)
+        e_hp[i] = reinterpret_cast<const float*>(q.h0_rows[mc])[uc];
+    }
+  }
+
+  const bool have_rec = m0 < q.S_next;   // (workgroup-uniform) some row of this block continues
+  if (have_rec) {
+    rowaddr_t arow[MB], brow[1];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = m0 + 16 * mb + r16;
+      const int mc = (m < q.S_next) ? m : (q.S_next - 1);   // rows past S_next: computed, never used
+      arow[mb] = row_addr(q.dgh_next + static_cast<int64_t>(mc) * K);
+    }
+    const int uu = u0 + ((r16 < BU) ? r16 : (BU - 1)), uc = (uu < H) ? uu : (H - 1);
+    brow[0] = row_addr(q.whh_t + static_cast<int64_t>(uc) * K);
+    f32x4v acc[MB][1];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb][0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mid_phase<MB, 1, NW, kBwdMidRing>(arow, brow, K, wave, kq, acc);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) red[wave][mb][lane] = acc[mb][0];
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int o = tid + 64 * NW * i;
+    if (o >= OUTS) continue;
+    const int er = o / BU, eu = o % BU;
+    const int m = m0 + er, u = u0 + eu;
+    if (m >= q.S_t || u >= H) continue;
+    float rec = 0.f;
+    if (m < q.S_next) {
+      const int mb = er >> 4, rr = er & 15;
+      const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
+      float part = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) part += reinterpret_cast<const float*>(&red[w][mb][sl])[reg];
+      rec = e_carry[i] + part;
+    }
+    if (final_launch) {  // d loss / d h0
+      q.dh0[static_cast<int64_t>(q.out_row[m]) * H + u] = rec;
+      continue;
+    }
+    const int64_t p = q.off_cur + m;
+    const float dh = rec + e_dpool[i];
+    const float rg = e_g[i][0], zg = e_g[i][1], ng = e_g[i][2], ghn = e_g[i][3];
+    const float hp = e_hp[i];
+    const float dn_pre = dh * (1.0f - zg) * (1.0f - ng * ng);
+    const float dz_pre = dh * (hp - ng) * zg * (1.0f - zg);
+    const float dr_pre = dn_pre * ghn * rg * (1.0f - rg);
+    float* gx = q.dgx + p * K + u;
+    float* gh = q.dgh + p * K + u;
+    gx[0] = dr_pre;
+    gx[H] = dz_pre;
+    gx[2 * H] = dn_pre;
+    gh[0] = dr_pre;
+    gh[H] = dz_pre;
+    gh[2 * H] = dn_pre * rg;
+    q.carry[static_cast<int64_t>(m) * H + u] = dh * zg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // F.normalize backward: dx = (g - y (y.g)) / max(||x||, eps), y = x / max(||x||, eps)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(const float* __restrict__ x,
@@ -910,6 +1023,25 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   sp.dh0 = j.dh0; sp.H = H;
 }
 
+// Active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel
+// (CMHSE_BWD_MID_MAX_SEQS, read per call; 0 = never), and its hidden units per workgroup
+// (CMHSE_BWD_MID_UNITS = 16 | 8 | 4 forces one).
+static int bwd_mid_max_seqs() {
+  const char* e = getenv("CMHSE_BWD_MID_MAX_SEQS");
+  return e ? atoi(e) : 512;
+}
+static int bwd_mid_units(int H, int m_blocks) {
+  const char* e = getenv("CMHSE_BWD_MID_UNITS");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 16 || forced == 8 || forced == 4) return forced;
+  // Unlike the forward step (K = H), narrower tiles LOSE here: the 32 dgh rows of K = 3H floats
+  // (384 KB) every workgroup pulls dominate, and 128-256 workgroups of them cost more L2 bandwidth
+  // than the spread gains (train_emb step, C3D: 16 units 12.8 ms, 8 units 16.0, 4 units 15.9).
+  (void)H;
+  (void)m_blocks;
+  return 16;
+}
+
 // Phase 2: BPTT of all jobs, last step first.  Launch i serves step Tmax_k - 1 - i of every job k
 // that still has one (and the extra t = -1 launch of a job that wants d h0); jobs of equal block
 // size share the launch.
@@ -918,7 +1050,7 @@ void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
   int longest = 0;
   for (int k = 0; k < n; ++k) longest = jobs[k].b->Tmax > longest ? jobs[k].b->Tmax : longest;
   for (int i = 0; i <= longest; ++i) {
-    int kind[CMHSE_MAX_JOBS];      // 0 = not in this launch, 1 = 4 waves, 2 = 8 waves; +4 = scalar loads
+    int kind[CMHSE_MAX_JOBS];      // 0 = not in this launch, 1 = 4 waves, 2 = 8 waves, +4 = scalar loads; 8 | shape bits = gru_bwd_step_mid_kernel
     unsigned grid_k[CMHSE_MAX_JOBS];
     for (int k = 0; k < n; ++k) {
       BwdJob& j = jobs[k];
@@ -938,6 +1070,12 @@ void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
       grid_k[k] = static_cast<unsigned>((b->H + 31) / 32) * ((S_t + 31) / 32);
       // few active sequences: a pure latency chain on an under-filled chip -> 8 waves split K
       kind[k] = ((S_t <= nw8_max) ? 2 : 1) | ((b->H % 4 == 0) ? 0 : 4);
+      if (b->H % 4 == 0 && S_t <= bwd_mid_max_seqs()) {   // the 16 x 16 x 4 tile shapes
+        const int bm = (S_t <= 16) ? 16 : 32;
+        const int bu = bwd_mid_units(b->H, (S_t + bm - 1) / bm);
+        kind[k] = 8 | (bm == 16 ? 16 : 0) | (bu == 8 ? 32 : 0) | (bu == 4 ? 64 : 0);
+        grid_k[k] = static_cast<unsigned>((b->H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
+      }
     }
     for (int k = 0; k < n; ++k) {
       if (kind[k] == 0) continue;
@@ -955,7 +1093,21 @@ void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
       }
       for (int m = g.n; m < CMHSE_MAX_JOBS; ++m) g.start[m] = 0xffffffffu;
       const bool vec = (kd & 4) == 0;
-      if ((kd & 3) == 2) {
+      if ((kd & 8) != 0) {
+        const int bu = (kd & 64) != 0 ? 4 : ((kd & 32) != 0 ? 8 : 16);
+#define CMHSE_BWD_MID_LAUNCH(MB, BU) \
+  hipLaunchKernelGGL((gru_bwd_step_mid_kernel<MB, BU>), dim3(grid), dim3(64 * kBwdMidNW), 0, st, g)
+        if ((kd & 16) != 0) {
+          if (bu == 4) CMHSE_BWD_MID_LAUNCH(1, 4);
+          else if (bu == 8) CMHSE_BWD_MID_LAUNCH(1, 8);
+          else CMHSE_BWD_MID_LAUNCH(1, 16);
+        } else {
+          if (bu == 4) CMHSE_BWD_MID_LAUNCH(2, 4);
+          else if (bu == 8) CMHSE_BWD_MID_LAUNCH(2, 8);
+          else CMHSE_BWD_MID_LAUNCH(2, 16);
+        }
+#undef CMHSE_BWD_MID_LAUNCH
+      } else if ((kd & 3) == 2) {
         if (vec)
           hipLaunchKernelGGL((gru_bwd_step_kernel<true, 8>), dim3(grid), dim3(512), 0, st, g);
         else

@@ -512,129 +512,55 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 //   * the input projection x_t W_ih^T has no time dependence: for all these steps together it is
 //     ONE well-shaped GEMM (xproj_kernel, tiled like the attention projection) into gx[rows, 3H];
 //     the sequential part keeps only K = H;
-//   * tile = 32 (or 16) sequences x 16 hidden units x {r, z, n}: 2 (1) x 3 blocks of
-//     v_mfma_f32_16x16x4_f32 (no idle MFMA columns), 4 waves split K, operands global -> registers
-//     in MFMA layout through a ring of two 128-byte line pairs, fixed-order LDS combine, the
-//     epilogue's operands requested before the K loop; H/16 x ceil(S_t/32) workgroups of 256
-//     threads (320 at S_t = 152, H = 1024: all resident at once).
-// In-kernel stamps (tools/mid_trace.py) put the loop at the per-CU L2 bandwidth (~70 GB/s): a
-// 32 x 16 tile needs 320 KB of operands.
+//   * tile = 32 (or 16) sequences x 16, 8 or 4 hidden units x {r, z, n}: blocks of
+//     v_mfma_f32_16x16x4_f32, 8 waves split K, operands global -> registers in MFMA layout through
+//     a ring of ONE 128-byte line pair per wave, fixed-order LDS combine, the epilogue's operands
+//     requested before the K loop; H/BU x ceil(S_t/32) workgroups of 512 threads.
+// In-kernel stamps (tools/mid_trace.py): the loop is bound by how fast ONE CU pulls its operands
+// through L1 (a 32 x 16 tile needs 320 KB; 40-50 GB/s per CU for a plain stream of an L2-resident
+// slice, tools/microbench/weights_reread.hip).  Measured (tools/step_sweep.py, us per step at
+// H = 1024): deeper rings are SLOWER (4 waves x 4 blocks in flight: 22.0 at S_t = 96; 8 x 2: 17.2;
+// 8 x 4: 19.9; 8 x 8 on the 4-unit tile: 21.5 against 9.5 at S_t = 16) — a lane quarter loads
+// 16 bytes, so an instruction touches 16 half lines, and more of them in flight than the 32 KB L1
+// holds evicts a line between its two halves.
 // ---------------------------------------------------------------------------------------------
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-constexpr int kMidBU = 16;
-constexpr int kMidNW = 4;      // waves per workgroup, splitting K
-constexpr int kMidRing = 4;    // 16-k blocks in flight per wave (two 128-byte line pairs)
+// MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active.
+// BU = hidden units per workgroup (16, 8 or 4).  The 3 BU gate columns (gate-major: column
+// f = gate * BU + unit) fill NB = ceil(3 BU / 16) MFMA column blocks.  A step with few sequences
+// has only H / 16 x ceil(S_t / 32) tiles of 16 units — 64 workgroups at S_t <= 32, H = 1024, each
+// pulling 320 KB through ONE CU's L2 port (~40-50 GB/s, tools/microbench/weights_reread.hip) while
+// three quarters of the chip idle; narrower unit tiles spread the same W_hh over up to 256 CUs
+// (176 KB per workgroup at BU = 4: the 32 h rows are then the larger part).  mid_units() picks BU.
+// Waves per workgroup (splitting K) and 16-k blocks in flight per wave, for the narrow (BU < 16)
+// and the 16-unit tiles; compile-time switches for experiments (CMHSE_HIPCC_FLAGS).
+#ifndef CMHSE_MID_NARROW_NW
+#define CMHSE_MID_NARROW_NW 8
+#endif
+#ifndef CMHSE_MID_NARROW_D
+#define CMHSE_MID_NARROW_D 2
+#endif
+#ifndef CMHSE_MID_WIDE_NW
+#define CMHSE_MID_WIDE_NW 8
+#endif
+#ifndef CMHSE_MID_WIDE_D
+#define CMHSE_MID_WIDE_D 2
+#endif
+template <int BU> struct MidShape {
+  static constexpr int NW = (BU == 16) ? CMHSE_MID_WIDE_NW : CMHSE_MID_NARROW_NW;
+  static constexpr int D = (BU == 16) ? CMHSE_MID_WIDE_D : CMHSE_MID_NARROW_D;
+};
 
-// One wave's share of the K = H contraction for MB x 3 blocks of 16 x 16 outputs.  Blocks of 16 k
-// are owned in ADJACENT PAIRS (wave w: blocks 2w, 2w+1, then 2w + 2 NW, ...): a lane quarter loads
-// 16 bytes, so one load instruction covers 64 contiguous bytes of each of its 16 rows, and the
-// pair, issued back to back, the whole 128-byte line — per-CU L2 bandwidth (~70 GB/s) is what
-// bounds this loop, and half-used lines halve it.
-template <int MB>
-__device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[MB], const rowaddr_t (&brow)[3],
-                                          int K, int wave, int kq, f32x4v (&acc)[MB][3]) {
-  constexpr int NW = kMidNW, D = kMidRing;
-  static_assert(D % 2 == 0, "ring holds whole block pairs");
-  const int nkb = (K + 15) / 16;
-  // ring position i of this wave -> block index
-  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };
-  // positions this wave owns: all i with block_of(i) < nkb (monotone in i)
-  int nmine = 0;
-  while (block_of(nmine) < nkb) ++nmine;
-  if (nmine <= 0) return;
-  float4 ra[D][MB], rb[D][3];
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const int k = block_of(d) * 16 + 4 * kq;
-#pragma unroll
-    for (int i = 0; i < MB; ++i) ra[d][i] = issue_row4<true>(arow[i], k, K);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rb[d][i] = issue_row4<true>(brow[i], k, K);
-  }
-  auto mfmas = [&](const float4 (&a)[MB], const float4 (&b)[3]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const float av = (j == 0) ? a[mb].x : (j == 1) ? a[mb].y : (j == 2) ? a[mb].z : a[mb].w;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const float bv = (j == 0) ? b[g].x : (j == 1) ? b[g].y : (j == 2) ? b[g].z : b[g].w;
-          acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mb][g], 0, 0, 0);
-        }
-      }
-    }
-  };
-  int it = 0;
-  {
-    // lean steady state: every block this trip consumes or prefetches lies wholly inside K for all
-    // waves (uniform bound): no masks, no clamps, running pointers with immediate offsets.
-    // Ring slot d holds block_of(it + d); slots d, d+1 of a pair are 64 bytes apart, pairs 2 NW blocks.
-    constexpr unsigned kPair = 2u * NW * 16u * 4u;        // bytes between consecutive pairs
-    constexpr unsigned kAhead = kPair * (D / 2);
-    rowaddr_t pa[MB], pb[3];
-    const rowaddr_t lane_off = static_cast<rowaddr_t>(2 * wave * 16 + 4 * kq) * 4u + kAhead;
-#pragma unroll
-    for (int i = 0; i < MB; ++i) pa[i] = arow[i] + lane_off;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pb[i] = brow[i] + lane_off;
-    for (; 16 * 2 * NW * ((it + 2 * D) / 2) <= K; it += D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const unsigned off = kPair * (d >> 1) + 64u * (d & 1);
-        float4 a[MB], b[3];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-          a[i] = ra[d][i];
-          const f32x4 g = *(gptr_f32x4)(pa[i] + off);
-          ra[d][i] = make_float4(g.x, g.y, g.z, g.w);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          b[i] = rb[d][i];
-          const f32x4 g = *(gptr_f32x4)(pb[i] + off);
-          rb[d][i] = make_float4(g.x, g.y, g.z, g.w);
-        }
-        mfmas(a, b);
-      }
-#pragma unroll
-      for (int i = 0; i < MB; ++i) pa[i] += kPair * (D / 2);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) pb[i] += kPair * (D / 2);
-    }
-  }
-  for (; it < nmine; it += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int k = block_of(it + d) * 16 + 4 * kq;
-      const int kn = block_of(it + d + D) * 16 + 4 * kq;
-      float4 a[MB], b[3];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        a[i] = finish_row4<true>(ra[d][i], true, k, K);
-        ra[d][i] = issue_row4<true>(arow[i], kn, K);
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        b[i] = finish_row4<true>(rb[d][i], true, k, K);
-        rb[d][i] = issue_row4<true>(brow[i], kn, K);
-      }
-      mfmas(a, b);
-    }
-  }
-}
-
-// MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active
-template <int MB>
-__global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStepGroup grp) {
-  constexpr int NW = kMidNW, BM = 16 * MB, NOUT = MB * 256 / (64 * NW);   // outputs per thread
+template <int MB, int BU>
+__global__ __launch_bounds__(64 * MidShape<BU>::NW) void gru_step_mid_kernel(const GruStepGroup grp) {
+  constexpr int NW = MidShape<BU>::NW, BM = 16 * MB, NB = (3 * BU + 15) / 16;
+  constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);   // outputs (per thread)
   unsigned wg;
   const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  __shared__ f32x4v red[NW][MB * 3][64];       // [wave][M block x gate][lane]: 12 KB per M block
+  __shared__ f32x4v red[NW][MB * NB][64];       // [wave][M block x column block][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H;
-  const int u_tiles = (H + kMidBU - 1) / kMidBU;
-  const int u0 = (wg % u_tiles) * kMidBU;    // unit tile fastest: b, b+8 share an XCD's L2
+  const int u_tiles = (H + BU - 1) / BU;
+  const int u0 = (wg % u_tiles) * BU;    // unit tile fastest: b, b+8 share an XCD's L2
   const int m0 = (wg / u_tiles) * BM;
   const int r16 = lane & 15, kq = lane >> 4;
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
@@ -651,12 +577,12 @@ __global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStep
   MID_MARK(0);
   // The epilogue's own operands do not depend on the K loop: request them first (branch-free,
   // clamped), so their memory round trip hides under it.  Output o of this thread: tile row
-  // er = o >> 4, unit eu = o & 15, o = tid + 256 q.
+  // er = o / BU, unit eu = o % BU, o = tid + 256 q.
   float e_gx[NOUT][3], e_hp[NOUT], e_b[NOUT][4];
 #pragma unroll
   for (int q = 0; q < NOUT; ++q) {
     const int o = tid + 64 * NW * q;
-    const int em = m0 + (o >> 4), u = u0 + (o & 15);
+    const int em = m0 + (o / BU) % BM, u = u0 + (o % BU);
     const int emc = (em < p.S_t) ? em : (p.S_t - 1), uc = (u < H) ? u : (H - 1);
     const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(emc) : (p.off_cur + emc - p.gx_p0);
     const float* gxr = p.gx + gxrow * 3 * H;
@@ -675,28 +601,33 @@ __global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStep
     e_b[q][3] = p.b_hh[2 * H + uc];
   }
   if (have_h) {
-    rowaddr_t arow[MB], brow[3];
+    rowaddr_t arow[MB], brow[NB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int m = m0 + 16 * mb + r16;
       const int mc = (m < p.S_t) ? m : (p.S_t - 1);   // rows past S_t are never stored
       arow[mb] = (p.t > 0) ? row_addr(p.hs + (p.off_prev + mc) * H) : p.h0_rows[mc];
     }
-    const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) brow[g] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
-    f32x4v acc[MB][3];
+    for (int j = 0; j < NB; ++j) {
+      // column 16 j + r16 of the gate-major tile; columns past 3 BU (and units past H) compute on
+      // a clamped row and are never read back
+      const int fc = (16 * j + r16 < 3 * BU) ? (16 * j + r16) : (3 * BU - 1);
+      const int uu = u0 + fc % BU, uc = (uu < H) ? uu : (H - 1);
+      brow[j] = row_addr(p.w_hh + (static_cast<int64_t>(fc / BU) * H + uc) * H);
+    }
+    f32x4v acc[MB][NB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int g = 0; g < 3; ++g) acc[mb][g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NB; ++j) acc[mb][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     MID_MARK(1);
-    mid_phase<MB>(arow, brow, H, wave, kq, acc);
+    mid_phase<MB, NB, NW, MidShape<BU>::D>(arow, brow, H, wave, kq, acc);
     MID_MARK(2);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int g = 0; g < 3; ++g) red[wave][mb * 3 + g][lane] = acc[mb][g];
+      for (int j = 0; j < NB; ++j) red[wave][mb * NB + j][lane] = acc[mb][j];
     __syncthreads();
     MID_MARK(3);
   }
@@ -705,20 +636,23 @@ __global__ __launch_bounds__(64 * kMidNW) void gru_step_mid_kernel(const GruStep
 #pragma unroll
   for (int q = 0; q < NOUT; ++q) {
     const int o = tid + 64 * NW * q;
-    const int er = o >> 4, eu = o & 15;
+    if (o >= OUTS) continue;
+    const int er = o / BU, eu = o % BU;
     const int em = m0 + er, u = u0 + eu;
     if (em >= p.S_t || u >= H) continue;
-    float hr = 0.f, hz = 0.f, hn_ = 0.f;
+    float hg[3] = {0.f, 0.f, 0.f};
     if (have_h) {
-      const int mb = er >> 4, rr = er & 15;
-      const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
+      const int mb = er >> 4, rr = er & 15, reg = rr & 3;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        hr += reinterpret_cast<const float*>(&red[w][mb * 3 + 0][sl])[reg];
-        hz += reinterpret_cast<const float*>(&red[w][mb * 3 + 1][sl])[reg];
-        hn_ += reinterpret_cast<const float*>(&red[w][mb * 3 + 2][sl])[reg];
+      for (int g = 0; g < 3; ++g) {
+        const int fc = g * BU + eu;
+        const int sl = (rr >> 2) * 16 + (fc & 15);
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+          hg[g] += reinterpret_cast<const float*>(&red[w][mb * NB + (fc >> 4)][sl])[reg];
       }
     }
+    const float hr = hg[0], hz = hg[1], hn_ = hg[2];
     const float rg = sigmoidf_(e_gx[q][0] + hr + e_b[q][0]);
     const float zg = sigmoidf_(e_gx[q][1] + hz + e_b[q][1]);
     const float ghn = hn_ + e_b[q][3];
@@ -1418,8 +1352,27 @@ static int tiny_nw8_max() {
   return v;
 }
 
-int step_kind(const FwdJob& j, int S_t) {
-  if (j.p.t >= j.t_mid) return 3 | (S_t <= 16 ? 32 : 0);   // mid-size kernel (vec shapes only)
+// Hidden units per workgroup of the mid-size step: the narrowest of 16, 8, 4 whose grid still
+// fits the chip in one round (more, smaller tiles = more CUs pulling operands; past one round the
+// replicated h rows cost more than the spread gains).  CMHSE_MID_UNITS = 16 | 8 | 4 forces one.
+constexpr int kChipCUs = 256;
+static int mid_m_blocks(int S_t) { return (S_t <= 16) ? 1 : (S_t + 31) / 32; }
+static int mid_units(int H, int m_blocks) {
+  const char* e = getenv("CMHSE_MID_UNITS");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 16 || forced == 8 || forced == 4) return forced;
+  for (int bu = 4; bu < 16; bu *= 2)
+    if (((H + bu - 1) / bu) * m_blocks <= kChipCUs) return bu;
+  return 16;
+}
+
+// `mid_blocks`: 16/32-sequence blocks of ALL requests of the call that run a mid-size step at this
+// time step (they share the chip, and a launch when their shapes agree).
+int step_kind(const FwdJob& j, int S_t, int mid_blocks) {
+  if (j.p.t >= j.t_mid) {   // mid-size kernel (vec shapes only)
+    const int bu = mid_units(j.b->H, mid_blocks);
+    return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0);
+  }
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
   if (k == 1 && j.hoist_all) k |= 64;   // tiled step on the hoisted projection (K = H only)
@@ -1456,12 +1409,22 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   const bool vec = (kind & 4) == 0;
   const int msub = gru_msub();
   switch (kind & 3) {
-    case 3:
-      if ((kind & 32) != 0)
-        hipLaunchKernelGGL(gru_step_mid_kernel<1>, dim3(grid), dim3(64 * kMidNW), 0, stream, g);
-      else
-        hipLaunchKernelGGL(gru_step_mid_kernel<2>, dim3(grid), dim3(64 * kMidNW), 0, stream, g);
+    case 3: {
+      const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
+#define CMHSE_MID_LAUNCH(MB, BU) \
+  hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU>), dim3(grid), dim3(64 * MidShape<BU>::NW), 0, stream, g)
+      if ((kind & 32) != 0) {
+        if (bu == 4) CMHSE_MID_LAUNCH(1, 4);
+        else if (bu == 8) CMHSE_MID_LAUNCH(1, 8);
+        else CMHSE_MID_LAUNCH(1, 16);
+      } else {
+        if (bu == 4) CMHSE_MID_LAUNCH(2, 4);
+        else if (bu == 8) CMHSE_MID_LAUNCH(2, 8);
+        else CMHSE_MID_LAUNCH(2, 16);
+      }
+#undef CMHSE_MID_LAUNCH
       break;
+    }
     case 0:
       if ((kind & 16) != 0) {
         if (vec)
@@ -1503,7 +1466,8 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   const int H = j.b->H;
   if ((kind & 3) == 3) {
     const int bm = (kind & 32) != 0 ? 16 : 32;
-    return static_cast<unsigned>((H + kMidBU - 1) / kMidBU) * ((S_t + bm - 1) / bm);
+    const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
+    return static_cast<unsigned>((H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
   }
   if ((kind & 3) == 0)
     return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
@@ -1557,12 +1521,15 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     int kind[kMaxJobs];
     bool done[kMaxJobs];
     bool any_tiled = false;
+    int mid_blocks = 0;
+    for (int k = 0; k < n; ++k)
+      if (t < jobs[k].b->Tmax && t >= jobs[k].t_mid) mid_blocks += mid_m_blocks(jobs[k].b->step_count_host[t]);
     for (int k = 0; k < n; ++k) {
       done[k] = t >= jobs[k].b->Tmax;
       if (done[k]) continue;
       FwdJob& j = jobs[k];
       j.p.t = t;
-      kind[k] = step_kind(j, j.b->step_count_host[t]);
+      kind[k] = step_kind(j, j.b->step_count_host[t], mid_blocks);
       any_tiled = any_tiled || (kind[k] & 3) == 1 || (kind[k] & 3) == 2;
     }
     for (int k = 0; k < n; ++k) {

@@ -560,6 +560,113 @@ __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mid_phase: the K loop of the mid-size (few-sequence) steps, forward (gru.hip) and BPTT (bwd.hip):
+// 16 x 16 x 4 MFMA blocks, operands global -> registers in MFMA layout, K split over NW waves.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// One wave's share of the K = H contraction for MB x 3 blocks of 16 x 16 outputs.  Blocks of 16 k
+// are owned in ADJACENT PAIRS (wave w: blocks 2w, 2w+1, then 2w + 2 NW, ...): a lane quarter loads
+// 16 bytes, so one load instruction covers 64 contiguous bytes of each of its 16 rows, and the
+// pair, issued back to back, the whole 128-byte line.
+template <int MB, int NB, int NW, int D>
+__device__ __forceinline__ void mid_phase(const rowaddr_t (&arow)[MB], const rowaddr_t (&brow)[NB],
+                                          int K, int wave, int kq, f32x4v (&acc)[MB][NB]) {
+  static_assert(D % 2 == 0, "ring holds whole block pairs");
+  const int nkb = (K + 15) / 16;
+  // ring position i of this wave -> block index
+  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };
+  // positions this wave owns: all i with block_of(i) < nkb (monotone in i)
+  int nmine = 0;
+  while (block_of(nmine) < nkb) ++nmine;
+  if (nmine <= 0) return;
+  float4 ra[D][MB], rb[D][NB];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d >= nmine) continue;   // (wave-uniform) nothing to fetch: the slot is never consumed
+    const int k = block_of(d) * 16 + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) ra[d][i] = issue_row4<true>(arow[i], k, K);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[d][i] = issue_row4<true>(brow[i], k, K);
+  }
+  auto mfmas = [&](const float4 (&a)[MB], const float4 (&b)[NB]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const float av = (j == 0) ? a[mb].x : (j == 1) ? a[mb].y : (j == 2) ? a[mb].z : a[mb].w;
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+          const float bv = (j == 0) ? b[g].x : (j == 1) ? b[g].y : (j == 2) ? b[g].z : b[g].w;
+          acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mb][g], 0, 0, 0);
+        }
+      }
+    }
+  };
+  int it = 0;
+  {
+    // lean steady state: every block this trip consumes or prefetches lies wholly inside K for all
+    // waves (uniform bound): no masks, no clamps, running pointers with immediate offsets.
+    // Ring slot d holds block_of(it + d); slots d, d+1 of a pair are 64 bytes apart, pairs 2 NW blocks.
+    constexpr unsigned kPair = 2u * NW * 16u * 4u;        // bytes between consecutive pairs
+    constexpr unsigned kAhead = kPair * (D / 2);
+    rowaddr_t pa[MB], pb[NB];
+    const rowaddr_t lane_off = static_cast<rowaddr_t>(2 * wave * 16 + 4 * kq) * 4u + kAhead;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) pa[i] = arow[i] + lane_off;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) pb[i] = brow[i] + lane_off;
+    for (; 16 * 2 * NW * ((it + 2 * D) / 2) <= K; it += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const unsigned off = kPair * (d >> 1) + 64u * (d & 1);
+        float4 a[MB], b[NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          a[i] = ra[d][i];
+          const f32x4 g = *(gptr_f32x4)(pa[i] + off);
+          ra[d][i] = make_float4(g.x, g.y, g.z, g.w);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          b[i] = rb[d][i];
+          const f32x4 g = *(gptr_f32x4)(pb[i] + off);
+          rb[d][i] = make_float4(g.x, g.y, g.z, g.w);
+        }
+        mfmas(a, b);
+      }
+#pragma unroll
+      for (int i = 0; i < MB; ++i) pa[i] += kPair * (D / 2);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) pb[i] += kPair * (D / 2);
+    }
+  }
+  for (; it < nmine; it += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (it + d >= nmine) continue;   // wave-uniform
+      const int k = block_of(it + d) * 16 + 4 * kq;
+      const int kn = block_of(it + d + D) * 16 + 4 * kq;
+      const bool more = it + d + D < nmine;
+      float4 a[MB], b[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        a[i] = finish_row4<true>(ra[d][i], true, k, K);
+        if (more) ra[d][i] = issue_row4<true>(arow[i], kn, K);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        b[i] = finish_row4<true>(rb[d][i], true, k, K);
+        if (more) rb[d][i] = issue_row4<true>(brow[i], kn, K);
+      }
+      mfmas(a, b);
+    }
+  }
+}
+
+
 // Row / column owned by accumulator register r of lane `lane` inside a 32x32 sub-tile.
 __device__ __forceinline__ int acc_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

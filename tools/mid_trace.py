@@ -27,7 +27,10 @@ def main():
   lib_path = os.path.join(ROOT, 'cmhse_amd', 'libcmhse_trace.so')
   cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-DCMHSE_TRACE', '-o', lib_path] + [os.path.join(csrc, f) for f in ('gru.hip', 'sim.hip', 'bwd.hip')]
-  if '--build-only' in sys.argv or not os.path.exists(lib_path):
+  srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
+  stale = not os.path.exists(lib_path) or \
+      os.path.getmtime(lib_path) < max(os.path.getmtime(p) for p in srcs)
+  if '--build-only' in sys.argv or stale:
     subprocess.check_call(cmd)
   if '--build-only' in sys.argv:
     return
@@ -48,7 +51,11 @@ def main():
            w_hh=torch.randn(3 * H, H, generator=g).mul_(0.05).to(dev),
            b_ih=torch.zeros(3 * H, device=dev), b_hh=torch.zeros(3 * H, device=dev))
   bm = 16 if S <= 16 else 32
-  n_wg = ((S + bm - 1) // bm) * ((H + 15) // 16)
+  m_blocks = (S + bm - 1) // bm
+  bu = int(os.environ.get('CMHSE_MID_UNITS', '0'))
+  if bu not in (4, 8, 16):   # mid_units() of gru.hip: narrowest unit tile whose grid fits 256 CUs
+    bu = next((b for b in (4, 8) if ((H + b - 1) // b) * m_blocks <= 256), 16)
+  n_wg = m_blocks * ((H + bu - 1) // bu)
   trace = torch.zeros(T * n_wg * 8, dtype=torch.int64, device=dev)
   ptrs = ops.padded_row_ptrs(x)
   for it in range(3):
@@ -58,9 +65,12 @@ def main():
     torch.cuda.synchronize()
   lib.cmhse_debug_set_trace(None)
   tr = trace.cpu().numpy().reshape(T, n_wg, 8).astype(np.float64) * 0.01   # us
-  print('S=%d T=%d I=%d H=%d: %d workgroups of 256 threads per step' % (S, T, I, H, n_wg))
-  names = ['entry -> addresses', 'MFMA loop (K = H)', 'LDS combine + barrier', 'epilogue loads + gates',
-           'stores drained']
+  print('S=%d T=%d I=%d H=%d: %d workgroups (%d hidden units each) per step' % (S, T, I, H, n_wg, bu))
+  # marks 0,1,2,3,5 (the epilogue operands are prefetched before the loop: no mark between the
+  # gate math and the drained stores)
+  names = ['entry -> addresses', 'MFMA loop (K = H)', 'LDS combine + barrier',
+           'epilogue gates + stores drained']
+  slots = [0, 1, 2, 3, 5]
   for t in range(1, T):      # step 0 has no h phase
     a = tr[t]
     start, end = a[:, 0].min(), a[:, 5].max()
@@ -68,17 +78,17 @@ def main():
     line = 'step %2d: gap after previous step %5.2f us | kernel span %6.2f us | ' % (
         t, start - prev_end, end - start)
     line += 'last wg entry +%.2f | ' % (a[:, 0].max() - start)
-    d = [a[:, i + 1] - a[:, i] for i in range(5)]
+    d = [a[:, slots[i + 1]] - a[:, slots[i]] for i in range(4)]
     line += '  '.join('%s %.2f' % (n.split()[0], x.mean()) for n, x in zip(names, d))
     print(line)
   a = tr[T // 2]
-  d = [a[:, i + 1] - a[:, i] for i in range(5)]
+  d = [a[:, slots[i + 1]] - a[:, slots[i]] for i in range(4)]
   print('\nmid step, per-workgroup phases [us]:')
   for n, x in zip(names, d):
-    print('  %-26s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' %
+    print('  %-32s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' %
           ((n, x.mean()) + tuple(np.percentile(x, [10, 50, 90])) + (x.max(),)))
   tot = a[:, 5] - a[:, 0]
-  print('  %-26s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' %
+  print('  %-32s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f' %
         (('whole workgroup', tot.mean()) + tuple(np.percentile(tot, [10, 50, 90])) + (tot.max(),)))
   print('  step = first entry -> last drain: %.2f us' % (a[:, 5].max() - a[:, 0].min()))
 

@@ -27,7 +27,10 @@ def main():
   cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-DCMHSE_TRACE'] + os.environ.get('TRACE_FLAGS', '').split() + ['-o', lib_path] + [os.path.join(csrc, f) for f in
                                               ('gru.hip', 'sim.hip', 'bwd.hip')]
-  if '--build-only' in sys.argv or not os.path.exists(lib_path):
+  srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
+  stale = not os.path.exists(lib_path) or \
+      os.path.getmtime(lib_path) < max(os.path.getmtime(p) for p in srcs)
+  if '--build-only' in sys.argv or stale:
     subprocess.check_call(cmd)
   if '--build-only' in sys.argv:
     return
