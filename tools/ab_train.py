@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.join(REPO, 'tools'))
 import bench  # noqa: E402
 from cmhse_amd import synthetic  # noqa: E402
 from cmhse_amd.evaluation import LogCollector  # noqa: E402
+from cmhse_amd import model as model_mod  # noqa: E402
 from cmhse_amd.model import VSE  # noqa: E402
 from train_profile import CONFIGS  # noqa: E402
 
@@ -52,6 +53,8 @@ def main():
     for k in keys:
       os.environ.pop(k, None)
     os.environ.update(arm)
+    # host-side switches of cmhse_amd.model (module-level lists), by the same names as their env
+    model_mod.TRAIN_GROUPED[0] = arm.get('CMHSE_TRAIN_GROUPED', '0') == '1'
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):

@@ -7,6 +7,6 @@ D=$R/gpurun_out/$OUT; mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
 for c in ${@:-c3d}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/train_$c -- python3 $R/tools/train_profile.py --config $c --steps 10 > $D/train_$c.txt 2>/dev/null
-  (cd $R && python tools/trace_busy.py $D/train_$c/*/*kernel_trace.csv 10 > $D/train_step_$c.md)
+  (cd $R && python tools/trace_busy.py $D/train_$c/*/*kernel_trace.csv 10 --timeline > $D/train_step_$c.md)
   rm -rf $D/train_$c
 done

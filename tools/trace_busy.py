@@ -2,7 +2,10 @@
 """Kernel-time sum against wall for the timed region of a rocprofv3 --kernel-trace CSV: the region
 after the LAST idle gap of >= 200 ms (tools/train_profile.py sleeps there).
 
-  python tools/trace_busy.py <kernel_trace.csv> [steps]
+  python tools/trace_busy.py <kernel_trace.csv> [steps] [--timeline]
+
+--timeline adds, for the LAST step of the region, each stream's launches collapsed into runs of one
+kernel: start and end (ms from the step's first launch), launches, busy ms.
 """
 import csv
 import sys
@@ -14,7 +17,8 @@ def main():
   for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'],
                  int(r['Stream_Id'])))
-  steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+  argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+  steps = int(argv[1]) if len(argv) > 1 else 1
   rows.sort()
   cut, cur_e = 0, rows[0][1]
   for i, (s, e, n, st) in enumerate(rows):
@@ -55,6 +59,28 @@ def main():
     streams[st] += e - s
   print('\nper stream busy ms / step: ' + ', '.join('%d: %.3f' % (k, v / 1e6 / steps)
                                                       for k, v in sorted(streams.items())))
+  if '--timeline' in sys.argv:
+    # last step = launches after the region's last gap of >= 0.25 of the mean step... simpler:
+    # the final 1/steps of the wall
+    t_lo = t1 - wall // steps
+    last = [r for r in sel if r[0] >= t_lo]
+    base = last[0][0]
+    by_stream = defaultdict(list)
+    for r in last:
+      by_stream[r[3]].append(r)
+    for st, rs in sorted(by_stream.items()):
+      print('\nstream %d (last step):' % st)
+      run = None
+      for s_, e_, n_, _ in rs:
+        key = n_.split('(')[0][-48:]
+        if run and run[0] == key and s_ - run[2] < 50e3:
+          run[2], run[3], run[4] = e_, run[3] + 1, run[4] + (e_ - s_)
+        else:
+          if run:
+            print('  %7.3f - %7.3f  %4d x %-48s busy %.3f' % ((run[1] - base) / 1e6, (run[2] - base) / 1e6, run[3], run[0], run[4] / 1e6))
+          run = [key, s_, e_, 1, e_ - s_]
+      if run:
+        print('  %7.3f - %7.3f  %4d x %-48s busy %.3f' % ((run[1] - base) / 1e6, (run[2] - base) / 1e6, run[3], run[0], run[4] / 1e6))
 
 
 if __name__ == '__main__':
