@@ -60,6 +60,8 @@ SIGNATURES = {
     'cmhse_gru_pool_fwd_multi': (ctypes.c_int, [ctypes.POINTER(GruJob), c_int32, c_void_p]),
     'cmhse_pull_steps': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                         c_int32, c_void_p]),
+    'cmhse_pad_rows': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                      c_void_p, c_void_p]),
     'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     'cmhse_gather_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                          c_void_p]),

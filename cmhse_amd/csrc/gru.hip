@@ -1142,6 +1142,35 @@ static int tiny_max_seqs() {
   return e ? atoi(e) : kTinyMaxSeqs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// collate_fn's padding (activity_net/data.py:114-150) as an index kernel: S ragged sequences stored
+// back to back (row r of sequence s at src + (first_row[s] + r) * row_bytes) -> the zero-padded
+// [S, Tmax, row] block.  One 16-byte (or 4-byte) word per thread, grid-stride; HBM-bound.
+// ---------------------------------------------------------------------------------------------
+struct PadRowsParams {
+  const char* src;
+  const int64_t* first_row;
+  const int32_t* lens;
+  char* dst;
+  int64_t words;       // S * Tmax * words_per_row
+  int32_t Tmax, words_per_row;
+};
+
+template <typename W>
+__global__ __launch_bounds__(kThreads) void pad_rows_kernel(const PadRowsParams q) {
+  const W* src = reinterpret_cast<const W*>(q.src);
+  W* dst = reinterpret_cast<W*>(q.dst);
+  const int64_t per_seq = static_cast<int64_t>(q.Tmax) * q.words_per_row;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(kThreads) + threadIdx.x; i < q.words;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t s = i / per_seq, r = i - s * per_seq;
+    const int t = static_cast<int>(r / q.words_per_row);
+    W v{};
+    if (t < q.lens[s]) v = src[q.first_row[s] * q.words_per_row + r];
+    dst[i] = v;
+  }
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int hoist_max_seqs() {   // read per call.  Off by default: measured +2 % at 615 videos, -3 % at 1230
@@ -1776,6 +1805,32 @@ extern "C" int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t*
   const unsigned grid = static_cast<unsigned>(n_active < cap ? n_active : cap);
   hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(thr), 0,
                      static_cast<hipStream_t>(stream_), p);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_pad_rows(const void* src, const int64_t* first_row, const int32_t* lens,
+                              int32_t S, int32_t Tmax, int32_t row_bytes, void* dst, void* stream_) {
+  if (!src || !first_row || !lens || !dst || S < 0 || Tmax < 0 || row_bytes <= 0 || row_bytes % 4 != 0)
+    return CMHSE_ERR_ARG;
+  if (S == 0 || Tmax == 0) return CMHSE_OK;
+  const bool wide = row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+  PadRowsParams q;
+  q.src = static_cast<const char*>(src);
+  q.first_row = first_row;
+  q.lens = lens;
+  q.dst = static_cast<char*>(dst);
+  q.Tmax = Tmax;
+  q.words_per_row = row_bytes / (wide ? 16 : 4);
+  q.words = static_cast<int64_t>(S) * Tmax * q.words_per_row;
+  const int64_t blocks = (q.words + kThreads - 1) / kThreads;
+  const unsigned grid = static_cast<unsigned>(blocks < 8192 ? blocks : 8192);
+  if (wide)
+    hipLaunchKernelGGL(pad_rows_kernel<uint4>, dim3(grid), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream_), q);
+  else
+    hipLaunchKernelGGL(pad_rows_kernel<uint32_t>, dim3(grid), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream_), q);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 

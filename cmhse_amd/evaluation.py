@@ -115,8 +115,22 @@ def _copy_stream(device):
 
 
 def _pinned_f32(t):
-  return (isinstance(t, torch.Tensor) and not t.is_cuda and t.dtype == torch.float32 and
-          t.is_contiguous() and t.is_pinned())
+  return (isinstance(t, (torch.Tensor, ops.Ragged)) and not t.is_cuda and t.dtype == torch.float32
+          and t.is_contiguous() and t.is_pinned())
+
+
+def _empty_like_on(t, device):
+  """Uninitialised device storage of the same layout as loader tensor `t` (padded or Ragged)."""
+  if isinstance(t, ops.Ragged):
+    return ops.Ragged(torch.empty(t.data.shape, dtype=torch.float32, device=device), t.lens)
+  return torch.empty(t.shape, dtype=torch.float32, device=device)
+
+
+def _dev_seq(t, device, dtype):
+  """Loader tensor (padded or Ragged; host or device) -> contiguous `dtype` storage on `device`."""
+  if isinstance(t, ops.Ragged):
+    return ops.seq_keep(t if t.is_cuda else t.to(device, non_blocking=True), dtype)
+  return ops.seq_keep(_to_dev(t, device), dtype)
 
 
 def encode_group(model, group, contextual_model=True, device=None):
@@ -140,27 +154,27 @@ def encode_group(model, group, contextual_model=True, device=None):
     # features first: the copy stream starts pulling step 0 before anything else of this group is
     # queued (schedule metadata travels on the copy stream too; step 0's event orders it)
     for b in group:
-      clips_l.append(torch.empty(b[0].shape, dtype=torch.float32, device=device))
-      vids_l.append(torch.empty(b[2].shape, dtype=torch.float32, device=device))
+      clips_l.append(_empty_like_on(b[0], device))
+      vids_l.append(_empty_like_on(b[2], device))
     main, copy = torch.cuda.current_stream(device), _copy_stream(device)
     copy.wait_stream(main)         # the fresh device buffers may recycle blocks still in use
     with torch.cuda.stream(copy):
       v_sched = ops.SeqSchedule(
           np.concatenate([np.asarray(b[4], dtype=np.int64) for b in group] +
                          [np.asarray(b[6], dtype=np.int64) for b in group]), device,
-          x_ptrs=np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l]),
-          src_ptrs=np.concatenate([ops.padded_row_ptrs(b[0]) for b in group] +
-                                  [ops.padded_row_ptrs(b[2]) for b in group]))
+          x_ptrs=np.concatenate([ops.seq_row_ptrs(t) for t in clips_l + vids_l]),
+          src_ptrs=np.concatenate([ops.seq_row_ptrs(b[0]) for b in group] +
+                                  [ops.seq_row_ptrs(b[2]) for b in group]))
       v_events = ops.pull_steps(v_sched, int(group[0][0].shape[2]), copy, UPLOAD_CHUNK[0])
     for t in clips_l + vids_l:
       t.record_stream(copy)        # allocated on the caller's stream, written on the copy stream
     v_sched.meta.record_stream(main)   # the other way round
   for b in group:
     if not pull:
-      clips_l.append(_to_dev(b[0], device).float().contiguous())
-      vids_l.append(_to_dev(b[2], device).float().contiguous())
-    caps_l.append(_to_dev(b[1], device).long().contiguous())
-    pars_l.append(_to_dev(b[3], device).long().contiguous())
+      clips_l.append(_dev_seq(b[0], device, torch.float32))
+      vids_l.append(_dev_seq(b[2], device, torch.float32))
+    caps_l.append(_dev_seq(b[1], device, torch.int64))
+    pars_l.append(_dev_seq(b[3], device, torch.int64))
     len_clip.append(np.asarray(b[4], dtype=np.int64))
     len_cap.append(np.asarray(b[5], dtype=np.int64))
     len_vid.append(np.asarray(b[6], dtype=np.int64))
@@ -190,7 +204,7 @@ def encode_group(model, group, contextual_model=True, device=None):
 
   def visual_tower():
     # level 1: clips of all batches, then whole-video streams of all batches (same weights)
-    ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
+    ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in clips_l + vids_l])
     lens = np.concatenate(len_clip + len_vid)
     vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
@@ -200,7 +214,7 @@ def encode_group(model, group, contextual_model=True, device=None):
 
   def text_tower():
     # level 1: sentences, then paragraphs (embedding lookup fused into the operand load)
-    ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
+    ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in caps_l + pars_l])
     lens = np.concatenate(len_cap + len_par)
     txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
@@ -226,8 +240,8 @@ def encode_group(model, group, contextual_model=True, device=None):
   elif GROUP_TOWERS[0]:
     # The two towers are independent: step t of both level-1 encoders shares one launch
     # (cmhse_gru_pool_fwd_multi), then step t of both level-2 encoders.
-    v_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in clips_l + vids_l])
-    t_ptrs = np.concatenate([ops.padded_row_ptrs(t) for t in caps_l + pars_l])
+    v_ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in clips_l + vids_l])
+    t_ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in caps_l + pars_l])
     # The visual chain (<= 80 frames) ends long before the text chain (paragraphs of hundreds of
     # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
     # side stream while the visual attention pass runs on this one, instead of after it.

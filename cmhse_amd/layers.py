@@ -55,13 +55,11 @@ def _fwd_request(spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w
   if spec.kind == 'tokens' or (spec.kind == 'multi' and spec.tokens is not None):
     toks = spec.tokens if spec.kind == 'multi' else [spec.tokens]
     ptr_list = []
-    for tok in toks:
+    for tok in toks:   # padded [S, L] ids, or ops.Ragged (a packed batch: no padding stored)
       ops._require_cuda(tok, 'tokens')
-      tok = tok.detach().contiguous()
-      if tok.dtype != torch.int64:
-        tok = tok.long()
+      tok = ops.seq_keep(tok, torch.int64)
       keep.append(tok)
-      ptr_list.append(ops.padded_row_ptrs(tok))
+      ptr_list.append(ops.seq_row_ptrs(tok))
     emb = table.detach().float().contiguous()
     I = emb.shape[1]
     tok_ptrs = np.concatenate(ptr_list)
@@ -69,11 +67,11 @@ def _fwd_request(spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w
     keep.append(emb)
   elif spec.kind == 'multi':
     ptr_list = []
-    for t in spec.tensors:
+    for t in spec.tensors:   # padded [S, T, I] features, or ops.Ragged
       ops._require_cuda(t, 'x')
-      tc = t.detach().float().contiguous()
+      tc = ops.seq_keep(t, torch.float32)
       keep.append(tc)
-      ptr_list.append(ops.padded_row_ptrs(tc))
+      ptr_list.append(ops.seq_row_ptrs(tc))
     I = keep[0].shape[2]
     x_ptrs = np.concatenate(ptr_list)
     device = keep[0].device
@@ -256,6 +254,10 @@ class _GRUPoolBase(nn.Module):
                                   self.rnn.bias_hh_l0, w_lin, b_lin, w_att)
 
   def forward(self, q_emb, q_len, hidden=None):
+    if isinstance(q_emb, ops.Ragged):   # a packed (un-padded) batch: plain data, no gradient wrt it
+      if hidden is not None:
+        raise ValueError('a Ragged input takes no initial hidden state (level-1 encoders only)')
+      return self.forward_multi([q_emb], [q_len])
     return self._run(SeqInput('padded', _lens_numpy(q_len), self.POOL), q_emb, hidden, None)
 
   def forward_rows(self, rows, counts, hidden=None):

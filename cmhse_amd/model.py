@@ -82,8 +82,16 @@ class EncoderText(nn.Module):
     outputs = self.rnn.forward_tokens(x, lengths, self.embed.weight)
     cap_emb = None
     if return_word:
-      cap_emb = ops.gather_rows(self.embed.weight.detach(), x)
+      cap_emb = _word_rows(self.embed.weight.detach(), x)
     return outputs, cap_emb
+
+
+def _word_rows(table, tokens):
+  """table[tokens]: [S, L, word_dim] for padded ids; for a packed batch (ops.Ragged) the word
+  vectors of the valid tokens only, back to back, as a Ragged of [sum(lens), word_dim]."""
+  if isinstance(tokens, ops.Ragged):
+    return ops.Ragged(ops.gather_rows(table, tokens.data), tokens.lens)
+  return ops.gather_rows(table, tokens)
 
 
 # A training step's two towers are independent until the losses.  Default: the two towers on two
@@ -304,7 +312,7 @@ class VSE(object):
                                                   self.txt_enc.embed.weight)
       _tick('txt:level1')
       cap_emb, para_context = txt[:n_cap], txt[n_cap:]
-      word = (ops.gather_rows(self.txt_enc.embed.weight.detach(), captions)
+      word = (_word_rows(self.txt_enc.embed.weight.detach(), captions)
               if self.lowest_reconstruct_loss else None)
       para_emb = self._level2(self.txt_seq_enc, cap_emb, num_caps, para_context)
       cap_recon = sent_recon = None
@@ -329,7 +337,7 @@ class VSE(object):
           self.vid_seq_enc.rnn.call_rows(clip_emb, num_clips, vid_context),
           self.txt_seq_enc.rnn.call_rows(cap_emb, num_caps, para_context)])
       _tick('vis:level2')
-      word = (ops.gather_rows(self.txt_enc.embed.weight.detach(), captions)
+      word = (_word_rows(self.txt_enc.embed.weight.detach(), captions)
               if self.lowest_reconstruct_loss else None)
       clip_recon = cap_recon = frame_recon = sent_recon = None
       if self.reconstruct_loss:
@@ -399,12 +407,19 @@ class VSE(object):
         row_bytes = t.shape[2] * 4
         idx = np.concatenate([i * T + np.arange(l) for i, l in enumerate(lens)])
         return np.uint64(t.data_ptr()) + idx.astype(np.uint64) * np.uint64(row_bytes)
-      clips_c = clips.detach().float().contiguous()
-      word_c = word.detach().contiguous()
+
+      def targets(t, lens):   # (addresses of the valid rows, the storage that owns them)
+        if isinstance(t, ops.Ragged):   # a packed batch holds exactly the valid rows, in order
+          d = ops.seq_keep(t, torch.float32).data
+          return (np.uint64(d.data_ptr()) +
+                  np.arange(d.shape[0], dtype=np.uint64) * np.uint64(d.shape[1] * 4)), d
+        d = t.detach().float().contiguous()
+        return valid_rows(d, lens), d
+      (clip_rows, clips_c), (word_rows, word_c) = targets(clips, lc), targets(word, lw)
       crit = self.criterion_Euclid_Distance
-      l_fr = crit.forward_rows(frame_recon, valid_rows(clips_c, lc), clips_c)
+      l_fr = crit.forward_rows(frame_recon, clip_rows, clips_c)
       self._log('Le_reconstruct_frame_hier', l_fr, int(lc.sum()))
-      l_wd = crit.forward_rows(sent_recon, valid_rows(word_c, lw), word_c)
+      l_wd = crit.forward_rows(sent_recon, word_rows, word_c)
       self._log('Le_reconstruct_word_hier', l_wd, int(lw.sum()))
       loss = loss + (l_fr + l_wd) * opts.lowest_weight_recon
     return loss

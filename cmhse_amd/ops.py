@@ -30,7 +30,7 @@ def upload(arr, device):
 
 
 def _require_cuda(t, name):
-  if not isinstance(t, torch.Tensor) or not t.is_cuda:
+  if not isinstance(t, (torch.Tensor, Ragged)) or not t.is_cuda:
     raise RuntimeError('cmhse_amd: `%s` must be a tensor on the GPU (no CPU fallback; the HIP '
                        'path is the only implementation)' % name)
 
@@ -124,6 +124,103 @@ def padded_row_ptrs(t):
   S = t.shape[0]
   stride = t.stride(0) * t.element_size()
   return (np.uint64(t.data_ptr()) + np.arange(S, dtype=np.uint64) * np.uint64(stride))
+
+
+class Ragged(object):
+  """S sequences stored back to back WITHOUT padding: `data` is [sum(lens), I] float32 (frame
+  features) or [sum(lens)] int64 (token ids); sequence s owns rows first[s] .. first[s]+lens[s].
+  Stands in for a padded [S, Tmax, ...] loader tensor wherever the encoders take one: they address
+  every sequence through its own base pointer (cmhse_seq_batch.x_rows / tok_rows), so the padding
+  the reference's collate_fn writes (activity_net/data.py:114-150) is neither uploaded nor read."""
+
+  def __init__(self, data, lens):
+    self.data = data
+    self.lens = np.asarray(lens, dtype=np.int64).reshape(-1)
+    self.first = np.concatenate([[0], np.cumsum(self.lens)[:-1]]).astype(np.int64)
+    if int(self.lens.sum()) != int(data.shape[0]):
+      raise ValueError('Ragged: sum(lens) != rows of data')
+
+  # the handful of tensor members the hot path uses on its big inputs
+  @property
+  def shape(self):
+    tmax = int(self.lens.max()) if len(self.lens) else 0
+    return (len(self.lens), tmax) + tuple(self.data.shape[1:])
+
+  @property
+  def is_cuda(self):
+    return self.data.is_cuda
+
+  @property
+  def device(self):
+    return self.data.device
+
+  @property
+  def dtype(self):
+    return self.data.dtype
+
+  def cuda(self, non_blocking=False):
+    return self if self.data.is_cuda else Ragged(self.data.cuda(non_blocking=non_blocking), self.lens)
+
+  def to(self, device, non_blocking=False):
+    return Ragged(self.data.to(device, non_blocking=non_blocking), self.lens)
+
+  def pin_memory(self):
+    return Ragged(self.data.pin_memory(), self.lens)
+
+  def is_pinned(self):
+    return self.data.is_pinned()
+
+  def is_contiguous(self):
+    return self.data.is_contiguous()
+
+  def numel(self):
+    return self.data.numel()       # stored elements (no padding)
+
+  def record_stream(self, stream):
+    self.data.record_stream(stream)
+
+  def row_bytes(self):
+    return int(np.prod(self.data.shape[1:], dtype=np.int64)) * self.data.element_size()
+
+  def row_ptrs(self):
+    """Base address of every sequence (what padded_row_ptrs is for a padded batch)."""
+    return np.uint64(self.data.data_ptr()) + self.first.astype(np.uint64) * np.uint64(self.row_bytes())
+
+  def padded(self):
+    """The reference's zero-padded [S, Tmax, ...] tensor: cmhse_pad_rows on the device; plain
+    slicing for a host tensor (what collate_fn itself does)."""
+    S, tmax = self.shape[0], self.shape[1]
+    out_shape = (S, tmax) + tuple(self.data.shape[1:])
+    if not self.data.is_cuda:
+      out = torch.zeros(out_shape, dtype=self.data.dtype)
+      for s in range(S):
+        out[s, :self.lens[s]] = self.data[self.first[s]:self.first[s] + self.lens[s]]
+      return out
+    lib = _lib.load()
+    data = self.data.contiguous()
+    out = torch.empty(out_shape, dtype=data.dtype, device=data.device)
+    first = upload(self.first, data.device)
+    lens32 = upload(self.lens.astype(np.int32), data.device)
+    rc = lib.cmhse_pad_rows(data.data_ptr(), first.data_ptr(), lens32.data_ptr(), S, tmax,
+                            self.row_bytes(), out.data_ptr(), _stream())
+    _lib.check(rc, 'cmhse_pad_rows')
+    return out
+
+
+def seq_row_ptrs(t):
+  """Per-sequence base addresses of a loader tensor: padded [S, T, ...] or Ragged."""
+  return t.row_ptrs() if isinstance(t, Ragged) else padded_row_ptrs(t)
+
+
+def seq_keep(t, dtype):
+  """The storage to keep alive / hand to the kernels for one loader tensor, as `dtype`, contiguous."""
+  if isinstance(t, Ragged):
+    d = t.data.detach()
+    d = d if d.dtype == dtype else d.to(dtype)
+    return Ragged(d.contiguous(), t.lens)
+  t = t.detach()
+  t = t if t.dtype == dtype else t.to(dtype)
+  return t.contiguous()
 
 
 class StepTimers(object):

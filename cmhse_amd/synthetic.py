@@ -206,3 +206,22 @@ def correlated_embeddings(n, dim=1024, sigma=3.0, seed=0):
   a /= np.linalg.norm(a, axis=1, keepdims=True)
   b /= np.linalg.norm(b, axis=1, keepdims=True)
   return a.astype(np.float32), b.astype(np.float32)
+
+
+def dataset_samples(seed, img_dim, n_videos, didemo=False):
+  """Per-video samples in the shape Dataset.__getitem__ returns them (activity_net/data.py:97-109):
+  ragged clips, float-typed token ids, a whole-video stream, counts; seeded."""
+  rng = np.random.RandomState(seed)
+  samples = []
+  for i in range(n_videos):
+    n = int(rng.randint(1, 5))
+    lc = rng.randint(1, 9, size=n)
+    lw = rng.randint(1, 7, size=n)
+    clips = [torch.from_numpy(rng.standard_normal((int(l), img_dim)).astype(np.float32)) for l in lc]
+    caps = [torch.Tensor(rng.randint(1, 50, size=int(l)).tolist()) for l in lw]   # float ids (:80)
+    video = torch.from_numpy(rng.standard_normal((int(rng.randint(2, 11)), img_dim)).astype(np.float32))
+    paragraph = torch.cat(caps, 0)
+    last = torch.full((n,), i, dtype=torch.int64) if didemo else 'v_%03d' % i
+    samples.append((clips, caps, video, paragraph, torch.Tensor(lc.tolist()).long(),
+                    torch.Tensor(lw.tolist()).long(), n, n, 100 + i, last))
+  return samples

@@ -164,6 +164,16 @@ int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* st
 int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t* dst_rows, const int32_t* lens,
                      int32_t n_active, int32_t row_floats, int32_t t0, int32_t t1, void* stream);
 
+/* The padding half of the loader's collate_fn (activity_net/data.py:114-150, didemo_dev/data.py:
+ * 133-165) as an index kernel: S ragged sequences stored back to back, row r of sequence s at
+ * src + (first_row[s] + r) * row_bytes (frame features: row_bytes = 4 * img_dim; token ids: 8), are
+ * written into the zero-padded block dst[S, Tmax, row_bytes].  The encoders do not need it (they
+ * address ragged storage through cmhse_seq_batch.x_rows / tok_rows directly, so a packed batch is
+ * uploaded without its padding and never padded); it exists for callers that want the reference's
+ * padded tensors on the device.  row_bytes must be a multiple of 4. */
+int cmhse_pad_rows(const void* src, const int64_t* first_row, const int32_t* lens, int32_t S,
+                   int32_t Tmax, int32_t row_bytes, void* dst, void* stream);
+
 /* torch.nn.functional.normalize(x) (p=2, dim=1, eps=1e-12) — call sites model.py:333-343,
  * evaluation.py:111-116.  y may alias x.  Rows have stride `ld` floats. */
 int cmhse_l2norm_rows(const float* x, float* y, int32_t rows, int32_t cols, int64_t ld,

@@ -1461,3 +1461,91 @@ def test_hoisted_projection_variant_matches(dev, oracle, pool, monkeypatch):
   np.testing.assert_allclose(hoisted[sample], want, atol=EMB_TOL, rtol=0)
   np.testing.assert_allclose(hoisted, base, atol=2e-6, rtol=0)
   assert not np.array_equal(hoisted, base), 'the hoisted variant did not engage'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('img_dim', [10, 2048])
+def test_pad_rows_kernel_rebuilds_collate_fn_tensors(dev, img_dim):
+  """collate_packed -> ONE upload -> cmhse_pad_rows on the device == the reference-golden-checked
+  collate_fn tensors, bit for bit (float rows on the 4-byte and on the 16-byte path, int64 ids)."""
+  from cmhse_amd import collate, ops, synthetic
+  samples = synthetic.dataset_samples(5, img_dim, 7)
+  ref = collate.collate_fn(samples)
+  pk = collate.upload_packed(collate.collate_packed(samples), dev)
+  for k in range(4):
+    assert isinstance(pk[k], ops.Ragged) and pk[k].is_cuda
+    got = pk[k].padded()
+    assert got.dtype == ref[k].dtype and tuple(got.shape) == tuple(ref[k].shape)
+    assert torch.equal(got.cpu(), ref[k]), k
+  # the four members are views of one device block
+  assert len({pk[k].data.untyped_storage().data_ptr() for k in range(4)}) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lowest', [0, 1])
+def test_train_step_on_a_packed_batch_is_bit_identical(dev, lowest):
+  """VSE.train_emb fed the collate_packed 12-tuple (no padding anywhere) == fed collate_fn's padded
+  12-tuple: the logged losses bit for bit (the kernels read the same rows through different base
+  pointers), every parameter gradient bit for bit where the backward pass is deterministic,
+  reconstruction losses included."""
+  import copy
+  from cmhse_amd import collate, synthetic
+  from cmhse_amd.model import VSE
+  opt = golden_opt('attention', reconstruct_loss=True, lowest_reconstruct_loss=bool(lowest),
+                   low_level_loss=True, norm=True, weight_recon=0.0005, lowest_weight_recon=0.0001,
+                   decode_rnn_type='seq2seq')
+  torch.manual_seed(5)
+  model_a = VSE(opt)
+  model_b = VSE(opt)
+  model_b.load_state_dict(copy.deepcopy(model_a.state_dict(opt)), opt)
+  spec = synthetic.ragged_spec(9, seed=2, max_frames=11, max_video=13)
+  padded = synthetic.make_batches(spec, 9, opt.img_dim, opt.vocab_size, seed=3)[0]
+  samples = collate.split_samples(padded)
+  packed = collate.upload_packed(collate.collate_packed(samples), dev)
+  again = collate.collate_fn(samples)
+  for k in range(8):
+    assert torch.equal(again[k], padded[k])
+  logs = []
+  for model, batch in [(model_a, padded), (model_b, packed)]:
+    model.logger = MeterLog()
+    model.train_start(opt)
+    model.train_emb(opt, *batch)
+    logs.append([c for c in model.logger.calls if c[0].startswith('Le')])
+  assert logs[0] == logs[1] and len(logs[0]) >= 9
+  for ma, mb in zip(model_a._modules(), model_b._modules()):
+    for (na, pa), (nb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+      assert na == nb and pa.grad is not None
+      # the forward pass is deterministic (logs equal above); two backward scatters use float
+      # atomics — the embedding-table gradient (repeated tokens) and the gradient of a decoder's
+      # time-constant input — so those and everything upstream of them vary in the last bits
+      # from run to run of the SAME batch
+      exact = na != 'embed.weight' and not lowest
+      if exact:
+        assert torch.equal(pa.grad, pb.grad), na
+      else:
+        scale = float(pa.grad.abs().max())
+        assert float((pa.grad - pb.grad).abs().max()) <= 1e-5 * scale + 1e-12, na
+
+
+@pytest.mark.gpu
+def test_packed_loader_encodes_bit_identically(dev, monkeypatch):
+  """evaluation.encode_data_device over a loader of collate_packed batches — pinned on the host
+  (features pulled step-chunk by step-chunk) and already resident on the device — == over the
+  padded batches."""
+  from cmhse_amd import collate, evaluation, synthetic
+  g = load_golden('model_attention.npz')
+  opt, model = golden_model('attention', g)
+  spec = synthetic.ragged_spec(23, seed=9, max_frames=13, max_video=17)
+  batches = synthetic.make_batches(spec, 6, opt.img_dim, opt.vocab_size, seed=4)
+  on_dev = [tuple(t.to(dev) if isinstance(t, torch.Tensor) and t.dim() > 1 else t for t in b)
+            for b in batches]
+  packed_host = [collate.collate_packed(collate.split_samples(b)) for b in batches]
+  packed_dev = [collate.upload_packed(b, dev) for b in packed_host]
+  quiet = lambda *a, **k: None
+  want, nc_w, _ = evaluation.encode_data_device(opt, model, on_dev, logging=quiet)
+  for pipe, loader in [(True, packed_host), (False, packed_host), (False, packed_dev)]:
+    monkeypatch.setattr(evaluation, 'PIPELINE_UPLOAD', [pipe])
+    got, nc_g, _ = evaluation.encode_data_device(opt, model, loader, logging=quiet)
+    assert nc_g == nc_w
+    for k in want:
+      assert torch.equal(got[k], want[k]), (pipe, k)

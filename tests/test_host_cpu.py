@@ -201,3 +201,62 @@ def test_profile_tools_reduce_rocprof_csvs(tmp_path):
                                 str(stats), 'title']).decode()
   assert 'total kernel time 10.000 ms' in md
   assert '| 4 | 8.000 | 2000.00 | 1000.00 | 3000.00 | 80.00 |' in md
+
+
+@pytest.mark.parametrize('tag,didemo', [('anet', False), ('didemo', True)])
+def test_collate_fn_vs_reference_golden(tag, didemo):
+  """collate.collate_fn against the 12-tuples the reference's own collate_fn produced on the same
+  seeded samples (tools/make_golden.py: activity_net/data.py:114-150, didemo_dev/data.py:127-165):
+  values, shapes, dtypes, member types — bit for bit."""
+  from cmhse_amd import collate, synthetic
+  g = load_golden('collate.npz')
+  samples = synthetic.dataset_samples(int(g[tag + '_seed']), int(g[tag + '_img_dim']), 5, didemo)
+  res = collate.collate_fn(samples)
+  assert len(res) == 12
+  names = ['clips', 'captions', 'videos', 'paragraphs', 'lengths_clip', 'lengths_cap',
+           'lengths_video', 'lengths_paragraph']
+  for k, name in enumerate(names):
+    want = g['%s_%s' % (tag, name)]
+    assert isinstance(res[k], torch.Tensor)
+    assert str(res[k].dtype) == str(g['%s_%s_dtype' % (tag, name)])
+    assert tuple(res[k].shape) == want.shape
+    np.testing.assert_array_equal(res[k].numpy(), want)
+  assert isinstance(res[8], tuple) and isinstance(res[9], tuple) and isinstance(res[10], tuple)
+  np.testing.assert_array_equal(np.asarray(res[8]), g[tag + '_num_clips'])
+  np.testing.assert_array_equal(np.asarray(res[9]), g[tag + '_num_caps'])
+  np.testing.assert_array_equal(np.asarray(res[10]), g[tag + '_index'])
+  if bool(g[tag + '_last_is_tensor']):
+    assert isinstance(res[11], torch.Tensor) and res[11].dtype == torch.int64
+    np.testing.assert_array_equal(res[11].numpy(), g[tag + '_last'])
+  else:
+    assert isinstance(res[11], tuple) and list(res[11]) == list(g[tag + '_last'])
+
+
+def test_collate_packed_holds_the_same_batch_without_padding():
+  """collate_packed: one host block, the sequences back to back; padding it (host path of
+  Ragged.padded) gives collate_fn's tensors exactly; split_samples inverts collate_fn."""
+  from cmhse_amd import collate, ops, synthetic
+  samples = synthetic.dataset_samples(3, 10, 6)
+  ref = collate.collate_fn(samples)
+  pk = collate.collate_packed(samples, pin=False)
+  base = pk[0].data.untyped_storage().data_ptr()
+  for k in range(4):
+    assert isinstance(pk[k], ops.Ragged)
+    assert pk[k].data.untyped_storage().data_ptr() == base          # ONE block
+    assert pk[k].shape == tuple(ref[k].shape)
+    assert torch.equal(pk[k].padded(), ref[k])
+    np.testing.assert_array_equal(pk[k].lens, np.asarray(ref[4 + [0, 1, 2, 3][k]]))
+  # no padding stored: the block is exactly the valid rows (plus < 8 bytes of alignment)
+  valid = int(ref[4].sum() + ref[6].sum()) * 10 * 4 + int(ref[5].sum() + ref[7].sum()) * 8
+  assert valid <= pk[0].data.untyped_storage().nbytes() < valid + 8
+  for k in range(4, 8):
+    assert torch.equal(pk[k], ref[k])
+  assert pk[8:] == ref[8:]
+  # round trip through the per-sample form
+  again = collate.collate_fn(collate.split_samples(ref))
+  for k in range(8):
+    assert torch.equal(again[k], ref[k])
+  # row pointers: sequence s starts first[s] rows into the block
+  ptrs = pk[0].row_ptrs()
+  assert int(ptrs[0]) == pk[0].data.data_ptr()
+  assert int(ptrs[1] - ptrs[0]) == int(pk[0].lens[0]) * 10 * 4

@@ -365,6 +365,37 @@ def golden_recon(ref_model, out):
   np.savez_compressed(os.path.join(out, 'model_recon.npz'), **cases)
 
 
+def golden_collate(out):
+  """collate_fn of activity_net/data.py:114-150 and didemo_dev/data.py:127-165 on seeded samples."""
+  import importlib
+  if 'PIL' not in sys.modules:
+    try:
+      importlib.import_module('PIL')
+    except ImportError:
+      sys.modules['PIL'] = types.ModuleType('PIL')
+      sys.modules['PIL'].Image = types.ModuleType('PIL.Image')
+      sys.modules['PIL.Image'] = sys.modules['PIL'].Image
+  rec = {}
+  for tag, modname, didemo, img_dim in [('anet', 'activity_net.data', False, 6),
+                                        ('didemo', 'didemo_dev.data', True, 2048)]:
+    ref_data = importlib.import_module(modname)
+    samples = synthetic.dataset_samples(7 if not didemo else 8, img_dim, 5, didemo)
+    res = ref_data.collate_fn(samples)
+    rec[tag + '_seed'] = np.int64(7 if not didemo else 8)
+    rec[tag + '_img_dim'] = np.int64(img_dim)
+    for k, name in enumerate(['clips', 'captions', 'videos', 'paragraphs', 'lengths_clip',
+                              'lengths_cap', 'lengths_video', 'lengths_paragraph']):
+      rec['%s_%s' % (tag, name)] = res[k].numpy()
+      rec['%s_%s_dtype' % (tag, name)] = np.array(str(res[k].dtype))
+    rec[tag + '_num_clips'] = np.asarray(res[8], dtype=np.int64)
+    rec[tag + '_num_caps'] = np.asarray(res[9], dtype=np.int64)
+    rec[tag + '_index'] = np.asarray(res[10], dtype=np.int64)
+    rec[tag + '_last'] = (res[11].numpy() if isinstance(res[11], torch.Tensor)
+                          else np.array(list(res[11])))
+    rec[tag + '_last_is_tensor'] = np.bool_(isinstance(res[11], torch.Tensor))
+  np.savez_compressed(os.path.join(out, 'collate.npz'), **rec)
+
+
 def main():
   out = os.path.join(REPO, 'tests', 'golden')
   os.makedirs(out, exist_ok=True)
@@ -375,6 +406,7 @@ def main():
   golden_rank(ref_eval, out)
   golden_model(ref_model, ref_eval, out)
   golden_recon(ref_model, out)
+  golden_collate(out)
   for f in sorted(os.listdir(out)):
     print(f, os.path.getsize(os.path.join(out, f)))
 
