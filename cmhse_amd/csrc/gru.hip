@@ -520,9 +520,9 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 // through L1 (a 32 x 16 tile needs 320 KB; 40-50 GB/s per CU for a plain stream of an L2-resident
 // slice, tools/microbench/weights_reread.hip).  Measured (tools/step_sweep.py, us per step at
 // H = 1024): deeper rings are SLOWER (4 waves x 4 blocks in flight: 22.0 at S_t = 96; 8 x 2: 17.2;
-// 8 x 4: 19.9; 8 x 8 on the 4-unit tile: 21.5 against 9.5 at S_t = 16) — a lane quarter loads
-// 16 bytes, so an instruction touches 16 half lines, and more of them in flight than the 32 KB L1
-// holds evicts a line between its two halves.
+// 8 x 4: 19.9; 8 x 8 on the 4-unit tile: 21.5 against 9.5 at S_t = 16), with non-temporal loads
+// too (slower still at every depth: the second half of a line does hit L1): the loop wants many
+// waves with little in flight each.
 // ---------------------------------------------------------------------------------------------
 // MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active.
 // BU = hidden units per workgroup (16, 8 or 4).  The 3 BU gate columns (gate-major: column

@@ -26,7 +26,7 @@ rm -rf $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE $D/pmc_FETCH_R4 $D/pmc_SQ
 python tools/summarize_rocprof.py $D/stats/*/*kernel_stats.csv "round 2, final kernels: rocprofv3 --kernel-trace --stats -- python3 $B (anet_icep_val, exact fp32)" > $D/kernel_stats.md
 python tools/trace_timeline.py $D/stats/*/*kernel_trace.csv > $D/pass_timeline.txt
 for c in c3d icep_recon; do
-  python tools/trace_busy.py $D/train_$c/*/*kernel_trace.csv 10 > $D/train_step_$c.md
+  python tools/trace_busy.py $D/train_$c/*/*kernel_trace.csv 10 --timeline > $D/train_step_$c.md
   python tools/train_profile.py --config $c --timeline 1 >> $D/train_$c.txt 2>/dev/null
   rm -rf $D/train_$c
 done
@@ -36,8 +36,12 @@ python bench.py --workload anet_c3d_val --host_steps 0 --cpu_batches 0 > $D/benc
 python bench.py --workload didemo_icep_val --host_steps 0 --cpu_batches 0 --fast_steps 0 --train_steps 0 > $D/bench_didemo.json 2>/dev/null
 python tools/ab_pass.py --modes "CMHSE_GRU_RASTER=0;CMHSE_GRU_RASTER=4;CMHSE_GRU_RASTER=8;CMHSE_GRU_RASTER=16" --rounds 3 > $D/raster_ab_icep.txt 2>&1
 python tools/ab_host.py --rounds 2 --modes "PIPE=0;PIPE=1;PIPE=1,CMHSE_PULL_GRID=16,CMHSE_PULL_THREADS=256;PIPE=1,CMHSE_PULL_GRID=128" > $D/upload_pipeline.txt 2>&1
-python tools/step_sweep.py --sizes 1,8,16,32,64,152,320,512,1024 --dims 500,300,1024 > $D/step_sweep.txt 2>&1
+python tools/step_sweep.py --sizes 1,8,16,32,64,152,320,512,1024 --dims 500,300,1024 --arms "CMHSE_MID_MAX_SEQS=0;CMHSE_MID_UNITS=16;CMHSE_MID_UNITS=0" > $D/step_sweep.txt 2>&1
+python tools/ab_train.py --config c3d --modes "CMHSE_BWD_MID_MAX_SEQS=0,CMHSE_MID_UNITS=16;CMHSE_BWD_MID_MAX_SEQS=0;CMHSE_MID_UNITS=16;CMHSE_X=1" > $D/train_ab.txt 2>&1
+python tools/ab_train.py --config icep_recon --modes "CMHSE_BWD_MID_MAX_SEQS=0,CMHSE_MID_UNITS=16;CMHSE_X=1" >> $D/train_ab.txt 2>&1
+timeout 60 tools/microbench/weights_reread.bin > $D/weights_reread.txt 2>&1
 python tools/mid_trace.py 152 12 > $D/mid_trace_S152.txt 2>&1
 python tools/mid_trace.py 8 12 > $D/mid_trace_S8.txt 2>&1
+python tools/mid_trace.py 32 12 > $D/mid_trace_S32.txt 2>&1
 python tools/tile_trace.py 22419 2048 1024 > $D/tile_trace.txt 2>&1
 ls -la $D
