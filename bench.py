@@ -366,13 +366,21 @@ def main():
 
   phase_ms, phase_sum = {}, {}
 
+  debug = os.environ.get('CMHSE_BENCH_DEBUG', '0') == '1'   # host-side marks of every pass on stderr
+
   def step():
     if world == 1:
+      h0 = time.perf_counter()
       cat, _, _, finish_log = encode_data_device(opt, model, batches, logging=quiet,
                                                  defer_logging=True)
+      h1 = time.perf_counter()
       r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
+      h2 = time.perf_counter()
       finish_log()     # the per-batch 'Letest' meters (evaluation.py:129), after the ranking is queued
+      if debug:
+        sys.stderr.write('pass host ms: encode queued %.1f, ranking queued %.1f, log flushed %.1f\n'
+                         % ((h1 - h0) * 1e3, (h2 - h1) * 1e3, (time.perf_counter() - h2) * 1e3))
       return r_i, r_t
     res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed,
                                          assignment=assignment, timings=phase_ms)
@@ -389,6 +397,13 @@ def main():
   for _ in range(args.warmup):
     step()
   sync()
+  if os.environ.get('CMHSE_BENCH_GC_FREEZE', '1') == '1':
+    # the loader batches, schedules and modules built so far are ~10^6 long-lived Python objects;
+    # an unlucky full collection walks them all in the middle of a pass (tens of ms of host stall
+    # before the next launch).  Park them in the permanent generation.
+    import gc
+    gc.collect()
+    gc.freeze()
   t0 = time.perf_counter()
   with ops.StepTimers() as timers, ops.SimTimers() as sim_timers:
     for _ in range(args.steps):

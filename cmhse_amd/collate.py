@@ -77,11 +77,14 @@ def collate_fn(samples):
           lengths_paragraph) + _tail(samples)
 
 
-def collate_packed(samples, pin=True):
+def collate_packed(samples, pin=False):
   """Same batch, no padding.  Layout of the one host block (8-byte aligned sections):
        [ clip frames | video frames ]  float32 rows of img_dim     [ caption ids | paragraph ids ]  int64
   Members 0-3 of the returned 12-tuple are ops.Ragged views into it; members 4-11 are exactly
-  collate_fn's.  A clip contributes its first lengths_clip steps, like collate_fn's copy."""
+  collate_fn's.  A clip contributes its first lengths_clip steps, like collate_fn's copy.
+  `pin=True` page-locks the block here (main-process loaders; it needs the HIP runtime, so not
+  inside DataLoader worker processes — there leave it False and let DataLoader(pin_memory=True)
+  pin the members through Ragged.pin_memory(), as it does for the reference's tensors)."""
   lengths_clip, lengths_cap, lengths_video, lengths_paragraph = _lengths(samples)
   img_dim = int(samples[0][0][0].shape[1])
   lc, lw = lengths_clip.numpy(), lengths_cap.numpy()

@@ -531,32 +531,29 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 // pulling 320 KB through ONE CU's L2 port (~40-50 GB/s, tools/microbench/weights_reread.hip) while
 // three quarters of the chip idle; narrower unit tiles spread the same W_hh over up to 256 CUs
 // (176 KB per workgroup at BU = 4: the 32 h rows are then the larger part).  mid_units() picks BU.
-// Waves per workgroup (splitting K) and 16-k blocks in flight per wave, for the narrow (BU < 16)
-// and the 16-unit tiles; compile-time switches for experiments (CMHSE_HIPCC_FLAGS).
-#ifndef CMHSE_MID_NARROW_NW
-#define CMHSE_MID_NARROW_NW 8
-#endif
-#ifndef CMHSE_MID_NARROW_D
-#define CMHSE_MID_NARROW_D 2
-#endif
-#ifndef CMHSE_MID_WIDE_NW
-#define CMHSE_MID_WIDE_NW 8
-#endif
-#ifndef CMHSE_MID_WIDE_D
-#define CMHSE_MID_WIDE_D 2
-#endif
-template <int BU> struct MidShape {
-  static constexpr int NW = (BU == 16) ? CMHSE_MID_WIDE_NW : CMHSE_MID_NARROW_NW;
-  static constexpr int D = (BU == 16) ? CMHSE_MID_WIDE_D : CMHSE_MID_NARROW_D;
-};
+// Waves per workgroup (NW, splitting K) and 16-k blocks in flight per wave (D).  8 x 2 is the
+// fastest shape for a chain that has the chip to itself (a training step's towers, the level-2
+// encoders).  A chain that runs BESIDE other kernels — the few-sequence tail of the text encoder
+// on the side stream while the visual encoder still launches LDS-tiled steps or runs its attention
+// pass — uses 4 waves: a 512-thread workgroup needs two free wave slots on every SIMD of one CU at
+// once and starves among 256-thread workgroups that refill slots one by one (615-video share of
+// the split: 50.2 ms per pass with 8 waves, 42.5 with 4).
+constexpr int kMidRing = 2;
 
-template <int MB, int BU>
-__global__ __launch_bounds__(64 * MidShape<BU>::NW) void gru_step_mid_kernel(const GruStepGroup grp) {
-  constexpr int NW = MidShape<BU>::NW, BM = 16 * MB, NB = (3 * BU + 15) / 16;
+// K is always cut into kMidSlices = 8 slices with one accumulator each, combined in slice order:
+// with 8 waves every wave owns one slice, with 4 waves wave w runs slices w and w + 4 one after
+// the other — the same arithmetic, so both shapes give bit-identical results and the choice
+// between them is free to follow the schedule.
+constexpr int kMidSlices = 8;
+
+template <int MB, int BU, int NW>
+__global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGroup grp) {
+  constexpr int BM = 16 * MB, NB = (3 * BU + 15) / 16, VS = kMidSlices / NW;
+  static_assert(NW * VS == kMidSlices, "4 or 8 waves");
   constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);   // outputs (per thread)
   unsigned wg;
   const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  __shared__ f32x4v red[NW][MB * NB][64];       // [wave][M block x column block][lane]
+  __shared__ f32x4v red[kMidSlices][MB * NB][64];   // [K slice][M block x column block][lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H;
   const int u_tiles = (H + BU - 1) / BU;
@@ -616,18 +613,22 @@ __global__ __launch_bounds__(64 * MidShape<BU>::NW) void gru_step_mid_kernel(con
       const int uu = u0 + fc % BU, uc = (uu < H) ? uu : (H - 1);
       brow[j] = row_addr(p.w_hh + (static_cast<int64_t>(fc / BU) * H + uc) * H);
     }
-    f32x4v acc[MB][NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int j = 0; j < NB; ++j) acc[mb][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     MID_MARK(1);
-    mid_phase<MB, NB, NW, MidShape<BU>::D>(arow, brow, H, wave, kq, acc);
+#pragma unroll
+    for (int v = 0; v < VS; ++v) {
+      const int slice = wave + NW * v;
+      f32x4v acc[MB][NB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[mb][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      mid_phase<MB, NB, kMidSlices, kMidRing>(arow, brow, H, slice, kq, acc);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) red[slice][mb * NB + j][lane] = acc[mb][j];
+    }
     MID_MARK(2);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int j = 0; j < NB; ++j) red[wave][mb * NB + j][lane] = acc[mb][j];
     __syncthreads();
     MID_MARK(3);
   }
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64 * MidShape<BU>::NW) void gru_step_mid_kernel(con
         const int fc = g * BU + eu;
         const int sl = (rr >> 2) * 16 + (fc & 15);
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
+        for (int w = 0; w < kMidSlices; ++w)
           hg[g] += reinterpret_cast<const float*>(&red[w][mb * NB + (fc >> 4)][sl])[reg];
       }
     }
@@ -1396,11 +1397,18 @@ static int mid_units(int H, int m_blocks) {
 }
 
 // `mid_blocks`: 16/32-sequence blocks of ALL requests of the call that run a mid-size step at this
-// time step (they share the chip, and a launch when their shapes agree).
-int step_kind(const FwdJob& j, int S_t, int mid_blocks) {
+// time step (they share the chip, and a launch when their shapes agree).  `alone`: nothing else of
+// the call competes for workgroup slots at this step (no LDS-tiled step, no chain moved to the
+// side stream, no attention pass started beside the steps) — the 8-wave shape is used (bit 512);
+// it and the 4-wave shape compute bit-identical results (kMidSlices).
+int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone) {
   if (j.p.t >= j.t_mid) {   // mid-size kernel (vec shapes only)
+    const char* we = getenv("CMHSE_MID_WAVES");   // experiments: force 4 or 8
+    if (we && atoi(we) == 4) alone = false;
+    if (we && atoi(we) == 8) alone = true;
     const int bu = mid_units(j.b->H, mid_blocks);
-    return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0);
+    return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0) |
+           (alone ? 512 : 0);
   }
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
@@ -1440,8 +1448,13 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   switch (kind & 3) {
     case 3: {
       const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
-#define CMHSE_MID_LAUNCH(MB, BU) \
-  hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU>), dim3(grid), dim3(64 * MidShape<BU>::NW), 0, stream, g)
+#define CMHSE_MID_LAUNCH(MB, BU)                                                                      \
+  do {                                                                                                \
+    if ((kind & 512) != 0)                                                                            \
+      hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU, 8>), dim3(grid), dim3(512), 0, stream, g);      \
+    else                                                                                              \
+      hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU, 4>), dim3(grid), dim3(256), 0, stream, g);      \
+  } while (0)
       if ((kind & 32) != 0) {
         if (bu == 4) CMHSE_MID_LAUNCH(1, 4);
         else if (bu == 8) CMHSE_MID_LAUNCH(1, 8);
@@ -1553,12 +1566,15 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     int mid_blocks = 0;
     for (int k = 0; k < n; ++k)
       if (t < jobs[k].b->Tmax && t >= jobs[k].t_mid) mid_blocks += mid_m_blocks(jobs[k].b->step_count_host[t]);
+    bool alone = !forked;
+    for (int k = 0; k < n; ++k)
+      if (t < jobs[k].b->Tmax && t < jobs[k].t_mid) alone = false;   // a tiled / tiny step runs too
     for (int k = 0; k < n; ++k) {
       done[k] = t >= jobs[k].b->Tmax;
       if (done[k]) continue;
       FwdJob& j = jobs[k];
       j.p.t = t;
-      kind[k] = step_kind(j, j.b->step_count_host[t], mid_blocks);
+      kind[k] = step_kind(j, j.b->step_count_host[t], mid_blocks, alone);
       any_tiled = any_tiled || (kind[k] & 3) == 1 || (kind[k] & 3) == 2;
     }
     for (int k = 0; k < n; ++k) {

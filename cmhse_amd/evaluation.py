@@ -114,6 +114,18 @@ def _copy_stream(device):
   return _SIDE_STREAMS[key]
 
 
+# Pinned float32 blocks for the deferred 'Letest' values, recycled by flush(): page-locking a fresh
+# block while the GPU is busy costs milliseconds (see ops.upload).
+_HOST_SCALARS = []
+
+
+def _host_scalars(n):
+  for i, h in enumerate(_HOST_SCALARS):
+    if h.numel() >= n:
+      return _HOST_SCALARS.pop(i)[:n]
+  return torch.empty(max(n, 1024), dtype=torch.float32).pin_memory()[:n]
+
+
 def _pinned_f32(t):
   return (isinstance(t, (torch.Tensor, ops.Ragged)) and not t.is_cuda and t.dtype == torch.float32
           and t.is_contiguous() and t.is_pinned())
@@ -314,7 +326,10 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
       group, sizes, host, ev, _keep = pending.pop(0)
       if ev is not None:
         ev.synchronize()
-      for b, bs, lv in zip(group, sizes, host.tolist()):
+      values = host.tolist()
+      if ev is not None:
+        _HOST_SCALARS.append(host)     # read: the pinned block may carry the next group's values
+      for b, bs, lv in zip(group, sizes, values):
         val_logger.update('Letest', lv, bs)
         batch_time.update(time.time() - state['end'])
         state['end'] = time.time()
@@ -337,8 +352,8 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
         num_clips_total.extend(b[8])
         cur_vid_total.extend(b[11])
       if defer_logging:
-        host = torch.empty(loss_dev.shape, dtype=loss_dev.dtype, pin_memory=True)
-        host.copy_(loss_dev, non_blocking=True)
+        host = _host_scalars(loss_dev.numel())
+        host.copy_(loss_dev.reshape(-1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         pending.append((group, enc['batch_sizes'], host, ev, loss_dev))

@@ -19,14 +19,44 @@ def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Pinned staging blocks of upload(), recycled by this module: [capacity-sorted] entries of
+# (uint8 pinned tensor, event of its last copy).  Page-locking memory (hipHostMalloc) while the GPU
+# is busy was measured at 5-100 ms per call on the GPU box (torch's own pinned cache hands a block
+# back only after the copy's event has completed, and a copy queued behind a pass's kernels
+# completes late, so it kept allocating mid-pass); after warm-up this pool allocates nothing.
+_STAGING = []
+
+
+def _staging_block(nbytes):
+  for i, (buf, ev) in enumerate(_STAGING):
+    if buf.numel() >= nbytes and ev.query():
+      return _STAGING.pop(i)
+  cap = 1 << max(16, int(nbytes - 1).bit_length())
+  return torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.cuda.Event()
+
+
 def upload(arr, device):
   """Small host array -> device without blocking the host: pinned staging + async copy (a pageable
-  copy would make the host wait for everything already queued on the stream).  The pinned block
-  is recycled by torch only after the copy has completed."""
+  copy would make the host wait for everything already queued on the stream).  The staging block
+  is reused only after its copy has completed (event on the copying stream)."""
   t = torch.from_numpy(arr)
   if torch.device(device).type != 'cuda':
     return t.to(device)
-  return t.pin_memory().to(device, non_blocking=True)
+  arr = np.ascontiguousarray(arr)
+  n = arr.nbytes
+  if n == 0:
+    return torch.from_numpy(arr).to(device)
+  buf, ev = _staging_block(n)
+  view = buf[:n].view(torch.from_numpy(arr).dtype).view(arr.shape)
+  view.copy_(torch.from_numpy(arr))
+  dev = view.to(device, non_blocking=True)
+  ev.record(torch.cuda.current_stream(dev.device))
+  # keep the list sorted by capacity so the smallest fitting block is taken first
+  k = 0
+  while k < len(_STAGING) and _STAGING[k][0].numel() < buf.numel():
+    k += 1
+  _STAGING.insert(k, (buf, ev))
+  return dev
 
 
 def _require_cuda(t, name):

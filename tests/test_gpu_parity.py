@@ -1471,7 +1471,7 @@ def test_pad_rows_kernel_rebuilds_collate_fn_tensors(dev, img_dim):
   from cmhse_amd import collate, ops, synthetic
   samples = synthetic.dataset_samples(5, img_dim, 7)
   ref = collate.collate_fn(samples)
-  pk = collate.upload_packed(collate.collate_packed(samples), dev)
+  pk = collate.upload_packed(collate.collate_packed(samples, pin=True), dev)
   for k in range(4):
     assert isinstance(pk[k], ops.Ragged) and pk[k].is_cuda
     got = pk[k].padded()
@@ -1539,7 +1539,7 @@ def test_packed_loader_encodes_bit_identically(dev, monkeypatch):
   batches = synthetic.make_batches(spec, 6, opt.img_dim, opt.vocab_size, seed=4)
   on_dev = [tuple(t.to(dev) if isinstance(t, torch.Tensor) and t.dim() > 1 else t for t in b)
             for b in batches]
-  packed_host = [collate.collate_packed(collate.split_samples(b)) for b in batches]
+  packed_host = [collate.collate_packed(collate.split_samples(b), pin=True) for b in batches]
   packed_dev = [collate.upload_packed(b, dev) for b in packed_host]
   quiet = lambda *a, **k: None
   want, nc_w, _ = evaluation.encode_data_device(opt, model, on_dev, logging=quiet)
@@ -1549,3 +1549,37 @@ def test_packed_loader_encodes_bit_identically(dev, monkeypatch):
     assert nc_g == nc_w
     for k in want:
       assert torch.equal(got[k], want[k]), (pipe, k)
+
+
+@pytest.mark.gpu
+def test_dataloader_with_collate_packed_feeds_train_emb(dev):
+  """The reference's loader construction (activity_net/data.py:157-162: DataLoader(collate_fn=...,
+  pin_memory=True)) with collate_packed in place of collate_fn: the pin thread pins the Ragged
+  members, and train_emb on such a batch logs the same losses as on collate_fn's batch."""
+  import copy
+  from cmhse_amd import collate, ops, synthetic
+  from cmhse_amd.model import VSE
+  opt = golden_opt('maxout', low_level_loss=True, norm=True)
+  torch.manual_seed(3)
+  model_a = VSE(opt)
+  model_b = VSE(opt)
+  model_b.load_state_dict(copy.deepcopy(model_a.state_dict(opt)), opt)
+  samples = synthetic.dataset_samples(11, opt.img_dim, 12)
+  for s in samples:   # token ids inside the model's vocabulary
+    assert max(float(c.max()) for c in s[1]) < opt.vocab_size
+  logs = []
+  for model, fn in [(model_a, collate.collate_fn), (model_b, collate.collate_packed)]:
+    loader = torch.utils.data.DataLoader(samples, batch_size=6, shuffle=False, pin_memory=True,
+                                         collate_fn=fn, num_workers=0)
+    model.logger = MeterLog()
+    model.train_start(opt)
+    for batch in loader:
+      if fn is collate.collate_packed:
+        assert isinstance(batch[0], ops.Ragged) and batch[0].is_pinned() and batch[1].is_pinned()
+      model.train_emb(opt, *batch)
+    logs.append([c for c in model.logger.calls if c[0].startswith('Le')])
+  assert len(logs[0]) == 2 * 7
+  for a, b in zip(logs[0], logs[1]):
+    assert a[0] == b[0] and a[2] == b[2]
+    assert loss_close(a[1], b[1]), (a, b)     # second step: after an Adam update with atomics upstream
+  assert logs[0][:7] == logs[1][:7]           # first step: bit-identical forward
