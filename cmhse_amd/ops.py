@@ -19,43 +19,49 @@ def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# Pinned staging blocks of upload(), recycled by this module: [capacity-sorted] entries of
-# (uint8 pinned tensor, event of its last copy).  Page-locking memory (hipHostMalloc) while the GPU
-# is busy was measured at 5-100 ms per call on the GPU box (torch's own pinned cache hands a block
-# back only after the copy's event has completed, and a copy queued behind a pass's kernels
-# completes late, so it kept allocating mid-pass); after warm-up this pool allocates nothing.
-_STAGING = []
+# Pinned staging of upload(): ONE page-locked arena cut into fixed slots, taken round-robin; a
+# slot is reused only after the copy that last read it has completed (its event).  Page-locking
+# memory (hipHostMalloc) while the GPU is busy was measured at 5-100 ms per call on the GPU box,
+# and torch's own pinned cache hands a block back only after the copy's event has completed — late,
+# when the copy is queued behind a pass's kernels — so it kept allocating in the middle of passes.
+# The arena is allocated once, at the first upload (model set-up / warm-up).
+_SLOT_BYTES = 2 << 20
+_N_SLOTS = 64
+_ARENA = {'buf': None, 'events': None, 'next': 0}
 
 
-def _staging_block(nbytes):
-  for i, (buf, ev) in enumerate(_STAGING):
-    if buf.numel() >= nbytes and ev.query():
-      return _STAGING.pop(i)
-  cap = 1 << max(16, int(nbytes - 1).bit_length())
-  return torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.cuda.Event()
+def _staging_slot(nbytes):
+  """(pinned uint8 view of >= nbytes, event to record after the copy)."""
+  if nbytes > _SLOT_BYTES:    # larger than any schedule array of this path: a block of its own
+    return torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.cuda.Event()
+  if _ARENA['buf'] is None:
+    _ARENA['buf'] = torch.empty(_SLOT_BYTES * _N_SLOTS, dtype=torch.uint8).pin_memory()
+    _ARENA['events'] = [None] * _N_SLOTS
+  i = _ARENA['next']
+  _ARENA['next'] = (i + 1) % _N_SLOTS
+  ev = _ARENA['events'][i]
+  if ev is None:
+    ev = _ARENA['events'][i] = torch.cuda.Event()
+  else:
+    ev.synchronize()          # 63 uploads ago: complete unless the host is far ahead of the GPU
+  return _ARENA['buf'][i * _SLOT_BYTES:(i + 1) * _SLOT_BYTES], ev
 
 
 def upload(arr, device):
   """Small host array -> device without blocking the host: pinned staging + async copy (a pageable
-  copy would make the host wait for everything already queued on the stream).  The staging block
-  is reused only after its copy has completed (event on the copying stream)."""
-  t = torch.from_numpy(arr)
+  copy would make the host wait for everything already queued on the stream)."""
   if torch.device(device).type != 'cuda':
-    return t.to(device)
+    return torch.from_numpy(arr).to(device)
   arr = np.ascontiguousarray(arr)
   n = arr.nbytes
   if n == 0:
     return torch.from_numpy(arr).to(device)
-  buf, ev = _staging_block(n)
-  view = buf[:n].view(torch.from_numpy(arr).dtype).view(arr.shape)
-  view.copy_(torch.from_numpy(arr))
+  buf, ev = _staging_slot(n)
+  src = torch.from_numpy(arr)
+  view = buf[:n].view(src.dtype).view(arr.shape)
+  view.copy_(src)
   dev = view.to(device, non_blocking=True)
   ev.record(torch.cuda.current_stream(dev.device))
-  # keep the list sorted by capacity so the smallest fitting block is taken first
-  k = 0
-  while k < len(_STAGING) and _STAGING[k][0].numel() < buf.numel():
-    k += 1
-  _STAGING.insert(k, (buf, ev))
   return dev
 
 
