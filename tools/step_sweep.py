@@ -37,6 +37,8 @@ def main():
       outs = []
       for rnd in range(4):
         for i, a in enumerate(arms):
+          for k in {k for arm in arms for k in arm}:
+            os.environ.pop(k, None)
           os.environ.update(a)
           with torch.no_grad():
             layer(x, lens)
