@@ -538,7 +538,10 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 // pass — uses 4 waves: a 512-thread workgroup needs two free wave slots on every SIMD of one CU at
 // once and starves among 256-thread workgroups that refill slots one by one (615-video share of
 // the split: 50.2 ms per pass with 8 waves, 42.5 with 4).
-constexpr int kMidRing = 2;
+#ifndef CMHSE_MID_RING
+#define CMHSE_MID_RING 2   // 16-k blocks in flight per wave (tools/mid_shape_sweep.sh builds 2, 4, 8)
+#endif
+constexpr int kMidRing = CMHSE_MID_RING;
 
 // K is always cut into kMidSlices = 8 slices with one accumulator each, combined in slice order:
 // with 8 waves every wave owns one slice, with 4 waves wave w runs slices w and w + 4 one after
