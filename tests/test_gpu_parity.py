@@ -1583,3 +1583,32 @@ def test_dataloader_with_collate_packed_feeds_train_emb(dev):
     assert a[0] == b[0] and a[2] == b[2]
     assert loss_close(a[1], b[1]), (a, b)     # second step: after an Adam update with atomics upstream
   assert logs[0][:7] == logs[1][:7]           # first step: bit-identical forward
+
+
+@pytest.mark.gpu
+def test_fused_adam_is_the_same_update(dev, monkeypatch):
+  """VSE's optimizer is torch.optim.Adam(params, lr) as upstream (model.py:160); the fused
+  implementation it selects on the GPU applies the same update as torch's default one."""
+  import copy
+  from cmhse_amd import synthetic
+  from cmhse_amd.model import VSE
+  opt = golden_opt('attention', low_level_loss=True, norm=True)
+  torch.manual_seed(9)
+  model_a = VSE(opt)
+  monkeypatch.setenv('CMHSE_FUSED_ADAM', '0')
+  model_b = VSE(opt)
+  model_b.load_state_dict(copy.deepcopy(model_a.state_dict(opt)), opt)
+  assert model_a.optimizer.defaults.get('fused') and not model_b.optimizer.defaults.get('fused')
+  assert model_a.optimizer.param_groups[0]['lr'] == model_b.optimizer.param_groups[0]['lr'] == 0.001
+  spec = synthetic.ragged_spec(8, seed=4, max_frames=9, max_video=11)
+  batch = synthetic.make_batches(spec, 8, opt.img_dim, opt.vocab_size, seed=6)[0]
+  for model in (model_a, model_b):
+    model.logger = MeterLog()
+    model.train_start(opt)
+    for _ in range(3):
+      model.train_emb(opt, *batch)
+  for ma, mb in zip(model_a._modules(), model_b._modules()):
+    for (na, pa), (nb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+      if na == 'embed.weight':   # its gradient is scattered with float atomics
+        continue
+      assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-6, na
