@@ -24,6 +24,7 @@ namespace cmhse {
 
 constexpr int kSimBM = 128;
 constexpr int kSimBN = 128;
+constexpr int kSimSmallMax = 512;   // stored-score matrices up to this size use 64 x 64 tiles
 
 enum { kSimDiag = 0, kSimRank = 1, kSimStore = 2 };
 
@@ -52,9 +53,13 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int MODE, bool VEC>
+// TS = 32 x 32 blocks per wave in each direction: 2 = the 128 x 128 tile; 1 = a 64 x 64 tile for the
+// small matrices of the training losses (n = 32 ... ~130: ONE 128 x 128 workgroup there is a
+// 62 us MFMA chain per wave, four to nine 64 x 64 workgroups run it in a quarter of that).  Same k
+// order per output: bit-identical.
+template <int MODE, bool VEC, int TS = 2>
 __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
-  constexpr int BM = kSimBM, BN = kSimBN;
+  constexpr int BM = 64 * TS, BN = 64 * TS;
   SimParams p = p_;
   if (p.blk_off != nullptr) {
     const int off = p.blk_off[blockIdx.y];
@@ -111,30 +116,32 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
     bv[i] = j < p.M;
     br[i] = row_addr(p.B + static_cast<int64_t>(bv[i] ? j : 0) * p.D);
   }
-  f32x16 acc[2][2];
+  f32x16 acc[TS][TS];
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms)
+  for (int ms = 0; ms < TS; ++ms)
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) acc[ms][ns] = zero16();
-  const int b_row0[2] = {wn * 64, wn * 64 + 32};
-  nt_phase<BM, BN, 2, 2, 2, 1, VEC>(smem, ar, av, br, bv, p.D, wm * 64, b_row0, acc);
+    for (int ns = 0; ns < TS; ++ns) acc[ms][ns] = zero16();
+  int b_row0[TS];
+#pragma unroll
+  for (int ns = 0; ns < TS; ++ns) b_row0[ns] = wn * 32 * TS + 32 * ns;
+  nt_phase<BM, BN, TS, TS, TS, TS - 1, VEC>(smem, ar, av, br, bv, p.D, wm * 32 * TS, b_row0, acc);
 
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms) {
+  for (int ms = 0; ms < TS; ++ms) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int li = i0 + wm * 64 + ms * 32 + acc_row(r, lane);  // local stripe row
+      const int li = i0 + wm * 32 * TS + ms * 32 + acc_row(r, lane);  // local stripe row
       const int gi = p.row0 + li;                                  // its diagonal column
       const bool rok = li < p.nrows;
       if (MODE == kSimDiag) {
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns) {
+        for (int ns = 0; ns < TS; ++ns) {
           const int j = j0 + b_row0[ns] + acc_col(lane);
           if (rok && j == gi) p.diag[li] = acc[ms][ns][r];
         }
       } else if (MODE == kSimStore) {
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns) {
+        for (int ns = 0; ns < TS; ++ns) {
           const int j = j0 + b_row0[ns] + acc_col(lane);
           if (rok && j < p.M) p.scores[static_cast<int64_t>(li) * p.M + j] = acc[ms][ns][r];
         }
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
         int cnt = 0;
         unsigned long long best = 0ull;
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns) {
+        for (int ns = 0; ns < TS; ++ns) {
           const int j = j0 + b_row0[ns] + acc_col(lane);
           const float v = acc[ms][ns][r];
           if (rok && j < p.M) {
@@ -292,7 +299,9 @@ static int launch_sim_store(const float* A, const float* B, int n, int m, int D,
   p.D = D;
   p.row0 = 0;
   p.nrows = n;
-  p.n_tiles = (m + kSimBN - 1) / kSimBN;
+  const bool small = n <= kSimSmallMax && m <= kSimSmallMax;   // training-loss sizes: 64 x 64 tiles
+  const int bt = small ? 64 : kSimBN;
+  p.n_tiles = (m + bt - 1) / bt;
   p.m_tiles8 = 0;
   p.diag = nullptr;
   p.rank = nullptr;
@@ -300,15 +309,18 @@ static int launch_sim_store(const float* A, const float* B, int n, int m, int D,
   p.scores = scores;
   p.blk_off = nullptr;
   p.blk_stride = 0;
-  const int64_t blocks = static_cast<int64_t>(p.n_tiles) * ((n + kSimBM - 1) / kSimBM);
+  const int64_t blocks = static_cast<int64_t>(p.n_tiles) * ((n + bt - 1) / bt);
   if (blocks > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
-  const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
-  if (D % 4 == 0)
-    hipLaunchKernelGGL((sim_kernel<kSimStore, true>), dim3(static_cast<unsigned>(blocks)),
-                       dim3(kThreads), smem, stream, p);
+  const size_t smem = small ? TileSmem<64, 64>::kBytes : TileSmem<kSimBM, kSimBN>::kBytes;
+  const dim3 grid(static_cast<unsigned>(blocks));
+  if (small && D % 4 == 0)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, true, 1>), grid, dim3(kThreads), smem, stream, p);
+  else if (small)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, false, 1>), grid, dim3(kThreads), smem, stream, p);
+  else if (D % 4 == 0)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, true>), grid, dim3(kThreads), smem, stream, p);
   else
-    hipLaunchKernelGGL((sim_kernel<kSimStore, false>), dim3(static_cast<unsigned>(blocks)),
-                       dim3(kThreads), smem, stream, p);
+    hipLaunchKernelGGL((sim_kernel<kSimStore, false>), grid, dim3(kThreads), smem, stream, p);
   return CMHSE_OK;
 }
 
@@ -466,7 +478,9 @@ extern "C" int cmhse_contrastive_blocks_fwd(const float* im, const float* s,
   p.N = p.M = p.nrows = max_n;
   p.D = D;
   p.row0 = 0;
-  p.n_tiles = (max_n + kSimBN - 1) / kSimBN;
+  const bool small = max_n <= kSimSmallMax;
+  const int bt = small ? 64 : kSimBN;
+  p.n_tiles = (max_n + bt - 1) / bt;
   p.m_tiles8 = 0;
   p.diag = nullptr;
   p.rank = nullptr;
@@ -474,9 +488,15 @@ extern "C" int cmhse_contrastive_blocks_fwd(const float* im, const float* s,
   p.scores = static_cast<float*>(workspace);
   p.blk_off = blk_off;
   p.blk_stride = static_cast<int64_t>(max_n) * max_n;
-  const unsigned tiles = static_cast<unsigned>(p.n_tiles) * ((max_n + kSimBM - 1) / kSimBM);
-  const size_t smem = TileSmem<kSimBM, kSimBN>::kBytes;
-  if (D % 4 == 0)
+  const unsigned tiles = static_cast<unsigned>(p.n_tiles) * ((max_n + bt - 1) / bt);
+  const size_t smem = small ? TileSmem<64, 64>::kBytes : TileSmem<kSimBM, kSimBN>::kBytes;
+  if (small && D % 4 == 0)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, true, 1>), dim3(tiles, n_blocks), dim3(kThreads), smem,
+                       stream, p);
+  else if (small)
+    hipLaunchKernelGGL((sim_kernel<kSimStore, false, 1>), dim3(tiles, n_blocks), dim3(kThreads), smem,
+                       stream, p);
+  else if (D % 4 == 0)
     hipLaunchKernelGGL((sim_kernel<kSimStore, true>), dim3(tiles, n_blocks), dim3(kThreads), smem,
                        stream, p);
   else
