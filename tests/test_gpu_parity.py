@@ -1612,3 +1612,34 @@ def test_fused_adam_is_the_same_update(dev, monkeypatch):
       if na == 'embed.weight':   # its gradient is scattered with float atomics
         continue
       assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-6, na
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,H', [(5, 1024), (29, 1024), (70, 256), (200, 64)])
+def test_small_batch_step_shapes_are_bit_identical(dev, S, H, monkeypatch):
+  """The mid-size step's launch shapes — 16 / 8 / 4 hidden units per workgroup, 8 waves x 1 K slice
+  or 4 waves x 2 — are scheduling choices: every combination gives the same bits, forward and
+  (through the saved gates) backward."""
+  from cmhse_amd import layers
+  torch.manual_seed(S)
+  I = 40
+  layer = layers.Attention(I, H).to(dev)
+  lens = torch.randint(1, 9, (S,), dtype=torch.int64)
+  lens[0] = 8
+  x = torch.randn(S, 8, I, device=dev)
+  h0 = torch.randn(S, H, device=dev)
+  outs = []
+  for units, waves in [('16', '8'), ('16', '4'), ('8', '8'), ('8', '4'), ('4', '8'), ('4', '4'), ('0', '')]:
+    monkeypatch.setenv('CMHSE_MID_UNITS', units)
+    if waves:
+      monkeypatch.setenv('CMHSE_MID_WAVES', waves)
+    else:
+      monkeypatch.delenv('CMHSE_MID_WAVES', raising=False)
+    xr = x.clone().requires_grad_(True)
+    layer.zero_grad()
+    y = layer(xr, lens, h0)
+    y.square().sum().backward()
+    outs.append((y.detach().clone(), xr.grad.clone(), layer.rnn.weight_hh_l0.grad.clone()))
+  for o in outs[1:]:
+    for a, b in zip(outs[0], o):
+      assert torch.equal(a, b)
