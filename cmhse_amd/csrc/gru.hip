@@ -1218,9 +1218,28 @@ struct FwdJob {
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
 };
 
-int gru_msub() {
-  static const int msub = [] { const char* e = getenv("CMHSE_GRU_MSUB"); return (e && atoi(e) == 2) ? 2 : 1; }();
-  return msub;
+// Rows per tile of the fp32 LDS-tiled kernels in units of 64: CMHSE_GRU_MSUB = 1 | 2 forces one
+// (read per call: A/B runs switch it inside one process); unset = 0 = chosen per launch.
+int gru_msub_forced() {
+  const char* e = getenv("CMHSE_GRU_MSUB");
+  const int v = e ? atoi(e) : 0;
+  return (v == 1 || v == 2) ? v : 0;
+}
+
+// 128-row tiles (2 workgroups per CU, 230 registers per lane) halve the weight bytes and cut the
+// LDS fragment reads per MFMA by a third; 64-row tiles (3 per CU) have half the work per wave, so
+// a launch of only a round or two of workgroups ends sooner.  Measured on boxes that hold
+// 1.75-2.0 GHz under this load: full split 287-290 ms per pass with 128 rows against 297-303 with
+// 64 (C3D 185 / 190.7); a 615-video share of the split 48.4 against 42.9; 1230 videos equal.
+// Launches of at least kTallTileMinWGs 64-row workgroups (all fp32 tiled requests of the time
+// step together) therefore use the 128-row tile.
+constexpr int kTallTileMinWGs = 2048;
+int gru_msub_for(int wgs64) {
+  const int f = gru_msub_forced();
+  if (f) return f;
+  const char* e = getenv("CMHSE_TALL_TILE_MIN_WGS");
+  const int thr = e ? atoi(e) : kTallTileMinWGs;
+  return (thr > 0 && wgs64 >= thr) ? 2 : 1;
 }
 
 // CMHSE_GRU_RASTER=<R> (read per call: A/B runs switch it inside one process): N tiles per XCD
@@ -1404,7 +1423,9 @@ static int mid_units(int H, int m_blocks) {
 // the call competes for workgroup slots at this step (no LDS-tiled step, no chain moved to the
 // side stream, no attention pass started beside the steps) — the 8-wave shape is used (bit 512);
 // it and the 4-wave shape compute bit-identical results (kMidSlices).
-int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone) {
+// `tiled_wgs`: 64-row workgroups of all requests that run an fp32 LDS-tiled step at this time step
+// (bit 2048 = 128-row tiles, gru_msub_for()).
+int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wgs) {
   if (j.p.t >= j.t_mid) {   // mid-size kernel (vec shapes only)
     const char* we = getenv("CMHSE_MID_WAVES");   // experiments: force 4 or 8
     if (we && atoi(we) == 4) alone = false;
@@ -1416,6 +1437,7 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone) {
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
   if (k == 1 && j.hoist_all) k |= 64;   // tiled step on the hoisted projection (K = H only)
+  if (k == 1 && !j.hoist_all && gru_msub_for(tiled_wgs) == 2) k |= 2048;
   return k | (j.vec ? 0 : 4);
 }
 
@@ -1447,7 +1469,7 @@ void launch_xproj(const FwdJob& j, hipStream_t stream) {
 
 void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t stream) {
   const bool vec = (kind & 4) == 0;
-  const int msub = gru_msub();
+  const int msub = (kind & 2048) != 0 ? 2 : 1;
   switch (kind & 3) {
     case 3: {
       const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
@@ -1516,7 +1538,7 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   }
   if ((kind & 3) == 0)
     return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
-  const int bm = ((kind & 3) == 2 || gru_msub() == 2) ? 128 : 64;
+  const int bm = ((kind & 3) == 2 || (kind & 2048) != 0) ? 128 : 64;
   int m_tiles = (S_t + bm - 1) / bm;
   if (j.p.raster > 1) {
     const int C = 8 / (j.p.n_tiles / j.p.raster);
@@ -1570,14 +1592,20 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     for (int k = 0; k < n; ++k)
       if (t < jobs[k].b->Tmax && t >= jobs[k].t_mid) mid_blocks += mid_m_blocks(jobs[k].b->step_count_host[t]);
     bool alone = !forked;
+    int tiled_wgs = 0;
     for (int k = 0; k < n; ++k)
-      if (t < jobs[k].b->Tmax && t < jobs[k].t_mid) alone = false;   // a tiled / tiny step runs too
+      if (t < jobs[k].b->Tmax && t < jobs[k].t_mid) {
+        alone = false;   // a tiled / tiny step runs too
+        const int S_k = jobs[k].b->step_count_host[t];
+        if (S_k > tiny_max_seqs() && !jobs[k].bf3 && !jobs[k].hoist_all)
+          tiled_wgs += jobs[k].p.n_tiles * ((S_k + 63) / 64);
+      }
     for (int k = 0; k < n; ++k) {
       done[k] = t >= jobs[k].b->Tmax;
       if (done[k]) continue;
       FwdJob& j = jobs[k];
       j.p.t = t;
-      kind[k] = step_kind(j, j.b->step_count_host[t], mid_blocks, alone);
+      kind[k] = step_kind(j, j.b->step_count_host[t], mid_blocks, alone, tiled_wgs);
       any_tiled = any_tiled || (kind[k] & 3) == 1 || (kind[k] & 3) == 2;
     }
     for (int k = 0; k < n; ++k) {
@@ -1680,8 +1708,12 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   const GruWs& L = job.L;
   char* wsb = job.wsb;
   const int64_t sum_T = job.sum_T;
-  const int msub = gru_msub();
   const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
+  // tile height of the projection: 64 rows; CMHSE_ATT_MSUB (or CMHSE_GRU_MSUB) = 2 forces 128
+  // (measured equal on the full split: 285.0 against 285.8 ms per pass)
+  const char* ae = getenv("CMHSE_ATT_MSUB");
+  const int att_forced = ae ? atoi(ae) : gru_msub_forced();
+  const int msub = (att_forced == 2) ? 2 : 1;
   float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
   AttnEnergyParams ep;
   ep.hs_s = nullptr;

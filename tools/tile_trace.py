@@ -71,7 +71,9 @@ def main():
   tr = trace.cpu().numpy().reshape(n_wg, 8)
   tr = tr[tr[:, 4] != 0]          # CMHSE_GRU_MSUB=2 launches half as many workgroups
   n_wg = len(tr)
-  rows_per_tile = 128 if os.environ.get('CMHSE_GRU_MSUB') == '2' else 64
+  # unset: the launcher picks 128-row tiles for launches of >= 2048 64-row workgroups (gru_msub_for)
+  msub_env = os.environ.get('CMHSE_GRU_MSUB')
+  rows_per_tile = 128 if (msub_env == '2' or (msub_env is None and n_wg >= 2048)) else 64
   t = tr[:, :5].astype(np.float64) * 0.01   # us (100 MHz)
   t0 = t[:, 0].min()
   t -= t0
