@@ -261,15 +261,18 @@ void gru_step_kernel(const GruStepGroup grp) {
   const float b_z = p.b_ih[H + uc] + p.b_hh[H + uc];
   const float b_in = p.b_ih[2 * H + uc];
   const float b_hn = p.b_hh[2 * H + uc];
+  // previous states of BOTH 32-row sub-tiles first: the stores of sub-tile 0
+  // may alias the loads of sub-tile 1 as far as the compiler knows, so left inside the loop below
+  // the second round trip starts only after the first sub-tile's gate math and stores
+  float hp_all[MSUB][16];
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms) {
     const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
-    float hp[16], hn[16];
     if (t > 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mrow0 + acc_row(r, lane);
-        hp[r] = hs[(off_prev + (m < S_t ? m : (S_t - 1))) * H + uc];
+        hp_all[ms][r] = hs[(off_prev + (m < S_t ? m : (S_t - 1))) * H + uc];
       }
     } else if (h0_rows != nullptr) {
       rowaddr_t hrow[16];
@@ -279,11 +282,17 @@ void gru_step_kernel(const GruStepGroup grp) {
         hrow[r] = h0_rows[m < S_t ? m : (S_t - 1)];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hp[r] = reinterpret_cast<const float*>(hrow[r])[uc];
+      for (int r = 0; r < 16; ++r) hp_all[ms][r] = reinterpret_cast<const float*>(hrow[r])[uc];
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hp[r] = 0.f;
+      for (int r = 0; r < 16; ++r) hp_all[ms][r] = 0.f;
     }
+  }
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms) {
+    const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
+    float hn[16];
+    const float (&hp)[16] = hp_all[ms];
     if (HOIST) {
       // the hoisted input terms of this lane's 16 (sequence, unit) elements: one round trip
       // (four rows at a time: all sixteen at once cost the third wave per SIMD)
