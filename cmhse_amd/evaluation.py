@@ -140,6 +140,8 @@ def _empty_like_on(t, device):
 
 def _dev_seq(t, device, dtype):
   """Loader tensor (padded or Ragged; host or device) -> contiguous `dtype` storage on `device`."""
+  if type(t) is torch.Tensor and t.is_cuda and t.dtype == dtype and t.is_contiguous():
+    return t          # already in place (616 of these per pass of the full split: keep it cheap)
   if isinstance(t, ops.Ragged):
     return ops.seq_keep(t if t.is_cuda else t.to(device, non_blocking=True), dtype)
   return ops.seq_keep(_to_dev(t, device), dtype)
