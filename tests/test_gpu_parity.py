@@ -1594,6 +1594,7 @@ def test_fused_adam_is_the_same_update(dev, monkeypatch):
   from cmhse_amd.model import VSE
   opt = golden_opt('attention', low_level_loss=True, norm=True)
   torch.manual_seed(9)
+  monkeypatch.setenv('CMHSE_FUSED_ADAM', '1')
   model_a = VSE(opt)
   monkeypatch.setenv('CMHSE_FUSED_ADAM', '0')
   model_b = VSE(opt)
