@@ -81,6 +81,11 @@ SIGNATURES = {
     'cmhse_contrastive_blocks_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_float, c_int32, c_int32, c_void_p,
                                                     c_void_p, c_size_t, c_void_p]),
+    'cmhse_contrastive_blocks_bwd_workspace': (c_size_t, [c_int32, c_int32]),
+    'cmhse_contrastive_blocks_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                                    c_int32, c_int32, c_float, c_int32, c_int32,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                    c_void_p]),
     'cmhse_gru_pool_bwd_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32,
                                                 c_int32]),
     'cmhse_gru_pool_bwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),

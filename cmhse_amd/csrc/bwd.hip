@@ -270,10 +270,26 @@ struct TnParams {
   int32_t M, N, n_tiles;
   int64_t K;
   const float* scale;  // optional device scalar multiplied into C
+  // several products in one launch (blockIdx.y = block b, rows blk_off[b] .. blk_off[b+1] of the
+  // caller's row-blocked operands): A is the block's [n_b, n_b] matrix at a + b * blk_stride
+  // (lda = n_b), B / C are rows blk_off[b].. of b / c; M = K = n_b
+  const int32_t* blk_off;
+  int64_t blk_stride;
 };
 
 template <bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const TnParams q) {
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const TnParams q_) {
+  TnParams q = q_;
+  if (q.blk_off != nullptr) {
+    const int b = blockIdx.y, off = q.blk_off[b], nb = q.blk_off[b + 1] - off;
+    q.a += b * q.blk_stride;
+    q.lda = nb;
+    q.b += static_cast<int64_t>(off) * q.ldb;
+    q.c += static_cast<int64_t>(off) * q.ldc;
+    q.M = nb;
+    q.K = nb;
+    if ((blockIdx.x / q.n_tiles) * 128 >= nb) return;   // M tile outside this (smaller) block
+  }
   constexpr int BM = 128, BN = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -633,10 +649,37 @@ struct LossBwdParams {
   float* col_cnt;    // [n] sum_i g_im(i,j)
   float* G;          // [n, n]
   float* GT;         // [n, n]
+  // several independent losses in one launch set (cmhse_contrastive_blocks_bwd): block
+  // b = blockIdx.y has n = blk_off[b+1] - blk_off[b]; its scores / G / GT start b * blk_stride
+  // floats into their buffers (leading dimension = its own n), its vectors b * vec_stride, its
+  // upstream gradient is gout[b]
+  const int32_t* blk_off;
+  int64_t blk_stride;     // floats between the blocks of G / GT
+  int64_t score_stride;   // floats between the blocks of the stored scores (the forward's layout)
+  int32_t vec_stride;
 };
 
+// the parameters of block blockIdx.y (or the struct itself for a single loss)
+__device__ __forceinline__ LossBwdParams loss_bwd_block(const LossBwdParams& q_) {
+  LossBwdParams q = q_;
+  if (q.blk_off != nullptr) {
+    const int b = blockIdx.y;
+    q.n = q.blk_off[b + 1] - q.blk_off[b];
+    q.scores += b * q.score_stride;
+    q.G += b * q.blk_stride;
+    q.GT += b * q.blk_stride;
+    q.row_arg += b * q.vec_stride;
+    q.col_arg += b * q.vec_stride;
+    q.row_cnt += b * q.vec_stride;
+    q.col_cnt += b * q.vec_stride;
+    q.gout += b;
+  }
+  return q;
+}
+
 // one wave per row (rows pass) or per column (columns pass): counts / argmax of violating entries
-__global__ __launch_bounds__(kThreads) void loss_bwd_stats_kernel(const LossBwdParams q) {
+__global__ __launch_bounds__(kThreads) void loss_bwd_stats_kernel(const LossBwdParams q_) {
+  const LossBwdParams q = loss_bwd_block(q_);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = q.n;
   const int idx = blockIdx.x * 4 + wave;  // [0, 2n): rows then columns
@@ -680,7 +723,8 @@ __global__ __launch_bounds__(kThreads) void loss_bwd_stats_kernel(const LossBwdP
   }
 }
 
-__global__ __launch_bounds__(kThreads) void loss_bwd_build_kernel(const LossBwdParams q) {
+__global__ __launch_bounds__(kThreads) void loss_bwd_build_kernel(const LossBwdParams q_) {
+  const LossBwdParams q = loss_bwd_block(q_);
   const int n = q.n;
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (e >= static_cast<int64_t>(n) * n) return;
@@ -821,6 +865,7 @@ static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
   TnParams q;
   q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.b_addr = b_addr; q.c = c; q.ldc = ldc;
   q.M = M; q.N = N; q.K = K; q.n_tiles = (N + 127) / 128; q.scale = scale;
+  q.blk_off = nullptr; q.blk_stride = 0;
   const unsigned grid = static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
   const size_t smem = TnSmem<128, 128>::kBytes;
   if (vec)
@@ -1257,6 +1302,7 @@ extern "C" int cmhse_contrastive_bwd(const float* im, const float* s, const floa
   q.col_arg = reinterpret_cast<int32_t*>(ws + 2 * mat + vecb);
   q.row_cnt = reinterpret_cast<float*>(ws + 2 * mat + 2 * vecb);
   q.col_cnt = reinterpret_cast<float*>(ws + 2 * mat + 3 * vecb);
+  q.blk_off = nullptr; q.blk_stride = 0; q.score_stride = 0; q.vec_stride = 0;
   hipLaunchKernelGGL(loss_bwd_stats_kernel, dim3((2 * n + 3) / 4), dim3(kThreads), 0, st, q);
   const int64_t elems = static_cast<int64_t>(n) * n;
   hipLaunchKernelGGL(loss_bwd_build_kernel, dim3(static_cast<unsigned>((elems + kThreads - 1) / kThreads)),
@@ -1265,6 +1311,63 @@ extern "C" int cmhse_contrastive_bwd(const float* im, const float* s, const floa
   // d im[i][d] = sum_j G[i][j] s[j][d]  = TN(A = G^T, B = s);  d s[j][d] = sum_i G[i][j] im[i][d]
   launch_tn(q.GT, n, s, D, nullptr, d_im, D, n, D, n, nullptr, vec, st);
   launch_tn(q.G, n, im, D, nullptr, d_s, D, n, D, n, nullptr, vec, st);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" size_t cmhse_contrastive_blocks_bwd_workspace(int32_t n_blocks, int32_t max_n) {
+  if (n_blocks <= 0 || max_n <= 0) return 0;
+  return static_cast<size_t>(n_blocks) *
+         (2 * ws_align(static_cast<size_t>(max_n) * max_n * 4) + 4 * ws_align(static_cast<size_t>(max_n) * 4));
+}
+
+extern "C" int cmhse_contrastive_blocks_bwd(const float* im, const float* s, const float* scores,
+                                            const int32_t* blk_off, int32_t n_blocks, int32_t max_n,
+                                            int32_t D, float margin, int32_t max_violation,
+                                            int32_t norm, const float* grad_out, float* d_im,
+                                            float* d_s, void* workspace, size_t workspace_bytes,
+                                            void* stream_) {
+  if (!im || !s || !scores || !blk_off || !grad_out || !d_im || !d_s || !workspace || n_blocks <= 0 ||
+      max_n <= 0 || D <= 0)
+    return CMHSE_ERR_ARG;
+  if (n_blocks > 65535) return CMHSE_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
+      workspace_bytes < cmhse_contrastive_blocks_bwd_workspace(n_blocks, max_n))
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  char* ws = static_cast<char*>(workspace);
+  const size_t mat = ws_align(static_cast<size_t>(max_n) * max_n * 4);
+  const size_t vecb = ws_align(static_cast<size_t>(max_n) * 4);
+  LossBwdParams q;
+  q.scores = scores; q.gout = grad_out; q.n = max_n; q.max_violation = max_violation; q.norm = norm;
+  q.margin = margin;
+  q.G = reinterpret_cast<float*>(ws);
+  q.GT = reinterpret_cast<float*>(ws + n_blocks * mat);
+  char* vecs = ws + 2 * n_blocks * mat;
+  q.row_arg = reinterpret_cast<int32_t*>(vecs);
+  q.col_arg = reinterpret_cast<int32_t*>(vecs + n_blocks * vecb);
+  q.row_cnt = reinterpret_cast<float*>(vecs + 2 * n_blocks * vecb);
+  q.col_cnt = reinterpret_cast<float*>(vecs + 3 * n_blocks * vecb);
+  q.blk_off = blk_off;
+  q.blk_stride = static_cast<int64_t>(mat / 4);           // floats between blocks of G / GT
+  q.vec_stride = static_cast<int32_t>(vecb / 4);
+  // the stored scores of the forward pass: block b at scores + b * max_n * max_n
+  // (cmhse_contrastive_blocks_fwd's workspace), leading dimension = the block's own n
+  q.score_stride = static_cast<int64_t>(max_n) * max_n;
+  hipLaunchKernelGGL(loss_bwd_stats_kernel, dim3((2 * max_n + 3) / 4, n_blocks), dim3(kThreads), 0, st, q);
+  const int64_t elems = static_cast<int64_t>(max_n) * max_n;
+  hipLaunchKernelGGL(loss_bwd_build_kernel,
+                     dim3(static_cast<unsigned>((elems + kThreads - 1) / kThreads), n_blocks),
+                     dim3(kThreads), 0, st, q);
+  // d im[i][d] = sum_j G[i][j] s[j][d] = TN(A = G^T, B = s);  d s[j][d] = sum_i G[i][j] im[i][d]
+  TnParams t;
+  t.lda = max_n; t.ldb = D; t.b_addr = nullptr; t.ldc = D; t.M = max_n; t.N = D; t.K = max_n;
+  t.n_tiles = (D + 127) / 128; t.scale = nullptr; t.blk_off = blk_off; t.blk_stride = q.blk_stride;
+  const unsigned grid = static_cast<unsigned>(t.n_tiles) * ((max_n + 127) / 128);
+  const size_t smem = TnSmem<128, 128>::kBytes;
+  t.a = q.GT; t.b = s; t.c = d_im;
+  hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid, n_blocks), dim3(kThreads), smem, st, t);
+  t.a = q.G; t.b = im; t.c = d_s;
+  hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid, n_blocks), dim3(kThreads), smem, st, t);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
@@ -1326,6 +1429,7 @@ extern "C" int cmhse_groupwise_bwd(const float* im, const float* s, int32_t n, i
   q.col_arg = reinterpret_cast<int32_t*>(lws + 2 * mat + vecb);
   q.row_cnt = reinterpret_cast<float*>(lws + 2 * mat + 2 * vecb);
   q.col_cnt = reinterpret_cast<float*>(lws + 2 * mat + 3 * vecb);
+  q.blk_off = nullptr; q.blk_stride = 0; q.score_stride = 0; q.vec_stride = 0;
   hipLaunchKernelGGL(loss_bwd_stats_kernel, dim3((2 * B + 3) / 4), dim3(kThreads), 0, st, q);
   const int64_t elems = static_cast<int64_t>(B) * B;
   hipLaunchKernelGGL(loss_bwd_build_kernel, dim3(static_cast<unsigned>((elems + kThreads - 1) / kThreads)),

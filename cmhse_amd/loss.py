@@ -38,6 +38,43 @@ class _ContrastiveFn(torch.autograd.Function):
     return d_im, d_s, None, None, None, None
 
 
+class _ContrastiveBlocksFn(torch.autograd.Function):
+  """Several ContrastiveLoss evaluations in one launch set: block b = rows of two row-blocked
+  matrices (cmhse_contrastive_blocks_fwd / _bwd).  Returns the vector of per-block losses."""
+
+  @staticmethod
+  def forward(ctx, im, s, sizes, margin, max_violation, norm, need):
+    imd, sd = im.detach(), s.detach()
+    if not need:
+      return ops.contrastive_blocks_fwd(imd, sd, sizes, margin, max_violation, norm)
+    losses, state = ops.contrastive_blocks_fwd(imd, sd, sizes, margin, max_violation, norm,
+                                               keep=True)
+    ctx.save_for_backward(imd, sd)
+    ctx.state, ctx.cfg = state, (margin, max_violation, norm)
+    return losses
+
+  @staticmethod
+  def backward(ctx, grad):
+    im, s = ctx.saved_tensors
+    margin, max_violation, norm = ctx.cfg
+    d_im, d_s = ops.contrastive_blocks_bwd(im, s, ctx.state, margin, max_violation, norm,
+                                           grad.contiguous())
+    return d_im, d_s, None, None, None, None, None
+
+
+def contrastive_losses(criterion, pairs):
+  """criterion(a_k, b_k) for every pair of a list, as ONE launch set forward and one backward:
+  the 4-7 ContrastiveLoss calls of a training step (model.py:333-343) are tiny (n = 32 ... ~130)
+  and launch-bound one by one.  Returns the float32 vector of the losses, differentiable wrt every
+  a_k / b_k.  Values are those of criterion(a_k, b_k) bit for bit."""
+  im = torch.cat([a for a, _ in pairs], 0)
+  s = torch.cat([b for _, b in pairs], 0)
+  sizes = [int(a.shape[0]) for a, _ in pairs]
+  need = torch.is_grad_enabled() and (im.requires_grad or s.requires_grad)
+  return _ContrastiveBlocksFn.apply(im, s, sizes, criterion.margin, criterion.max_violation,
+                                    criterion.norm, need)
+
+
 class _L2NormFn(torch.autograd.Function):
   """F.normalize (model.py:333-343) with its backward on the HIP path."""
 

@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import ops
 from .decoder import DecoderSequence, EuclideanLoss
 from .layers import Attention, Maxout, Seq2Seq
-from .loss import ContrastiveLoss, GroupWiseContrastiveLoss, normalize
+from .loss import ContrastiveLoss, GroupWiseContrastiveLoss, contrastive_losses, normalize
 
 
 def _make_rnn(rnn_type, in_dim, embed_size, bidirectional):
@@ -103,6 +103,8 @@ def _word_rows(table, tokens):
 # twice the workgroups takes twice as long.  Bit-identical either way (tested).
 TRAIN_GROUPED = [os.environ.get('CMHSE_TRAIN_GROUPED', '0') == '1']
 TRAIN_TWO_STREAMS = [os.environ.get('CMHSE_TRAIN_STREAMS', '1') == '1']
+# the 4-7 contrastive losses of a step as one launch set (loss.contrastive_losses); 0 = one by one
+BATCHED_LOSSES = [os.environ.get('CMHSE_BATCHED_LOSSES', '1') == '1']
 _TOWER_STREAMS = {}
 
 
@@ -182,6 +184,7 @@ class VSE(object):
     self.Eiters = 0
     self.logger = None
     self._pending_log = None
+    self._loss_weights = {}     # weight vectors of the batched losses, by number of terms
 
   # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
   def _modules(self):
@@ -389,20 +392,46 @@ class VSE(object):
     _tick('towers:joined')
     n = normalize
     nv, npar = n(vid_emb), n(para_emb)
-    loss_1 = self.forward_loss(nv, npar, '_vid')
-    loss_3 = self.forward_loss(n(vid_context), n(para_context), '_ctx_low_lvel')
-    loss_5 = (self.forward_loss(nv, nv, '_vid_inloss') +
-              self.forward_loss(npar, npar, '_para_inloss')) / 2
-    loss = loss_1 + loss_3 + loss_5
-    if opts.low_level_loss:
-      nc, ns = n(clip_emb), n(cap_emb)
-      if getattr(opts, 'weak_low_level_loss', False):      # model.py:338-340
-        loss_2 = self.forward_weak_loss(nc, ns, num_clips, num_caps, '_wlow_lvel')
-      else:
-        loss_2 = self.forward_loss(nc, ns, '_low_lvel')
-      loss_6 = (self.forward_loss(nc, nc, '_clip_inloss') +
-                self.forward_loss(ns, ns, '_cap_inloss')) / 2
-      loss = loss + loss_2 + loss_6
+    weak = opts.low_level_loss and getattr(opts, 'weak_low_level_loss', False)
+    if BATCHED_LOSSES[0]:
+      # model.py:333-343 — the same 4-7 ContrastiveLoss evaluations with the same weights, as ONE
+      # launch set forward and one backward (loss.contrastive_losses); logged in the reference's
+      # order.  (name, a, b, weight in the total)
+      terms = [('_vid', nv, npar, 1.0), ('_ctx_low_lvel', n(vid_context), n(para_context), 1.0),
+               ('_vid_inloss', nv, nv, 0.5), ('_para_inloss', npar, npar, 0.5)]
+      loss_2 = None
+      if opts.low_level_loss:
+        nc, ns = n(clip_emb), n(cap_emb)
+        if not weak:
+          terms.append(('_low_lvel', nc, ns, 1.0))
+        terms += [('_clip_inloss', nc, nc, 0.5), ('_cap_inloss', ns, ns, 0.5)]
+      values = contrastive_losses(self.criterion, [(a, b) for _, a, b, _ in terms])
+      for k, (name, a, _, _) in enumerate(terms):
+        if weak and name == '_clip_inloss':      # model.py:338-340: its place in the log
+          loss_2 = self.forward_weak_loss(nc, ns, num_clips, num_caps, '_wlow_lvel')
+        self._log('Le' + name, values[k], a.size(0))
+      w = self._loss_weights.get(len(terms))
+      if w is None or w.device != values.device:
+        w = torch.tensor([t[3] for t in terms], dtype=torch.float32, device=values.device)
+        self._loss_weights[len(terms)] = w
+      loss = torch.dot(values, w)
+      if loss_2 is not None:
+        loss = loss + loss_2
+    else:
+      loss_1 = self.forward_loss(nv, npar, '_vid')
+      loss_3 = self.forward_loss(n(vid_context), n(para_context), '_ctx_low_lvel')
+      loss_5 = (self.forward_loss(nv, nv, '_vid_inloss') +
+                self.forward_loss(npar, npar, '_para_inloss')) / 2
+      loss = loss_1 + loss_3 + loss_5
+      if opts.low_level_loss:
+        nc, ns = n(clip_emb), n(cap_emb)
+        if weak:      # model.py:338-340
+          loss_2 = self.forward_weak_loss(nc, ns, num_clips, num_caps, '_wlow_lvel')
+        else:
+          loss_2 = self.forward_loss(nc, ns, '_low_lvel')
+        loss_6 = (self.forward_loss(nc, nc, '_clip_inloss') +
+                  self.forward_loss(ns, ns, '_cap_inloss')) / 2
+        loss = loss + loss_2 + loss_6
     if self.reconstruct_loss:        # model.py:346-348
       loss_recon = (self.forward_reconstruct_loss(clip_recon, clip_emb.detach(), '_clip_recon') +
                     self.forward_reconstruct_loss(cap_recon, cap_emb.detach(), '_cap_recon'))

@@ -555,9 +555,10 @@ def contrastive_fwd(im, s, margin, max_violation, norm, want_scores=False):
   return (loss, scores) if want_scores else loss
 
 
-def contrastive_blocks_fwd(im, s, block_sizes, margin, max_violation, norm):
+def contrastive_blocks_fwd(im, s, block_sizes, margin, max_violation, norm, keep=False):
   """Per-block ContrastiveLoss over consecutive row blocks of im / s (cmhse_contrastive_blocks_fwd):
-  returns a float32 device tensor [len(block_sizes)]."""
+  returns a float32 device tensor [len(block_sizes)]; with `keep` also the state
+  contrastive_blocks_bwd needs (the stored score blocks live in the call's workspace)."""
   lib = _lib.load()
   im = _f32c(im, 'im')
   s = _f32c(s, 's')
@@ -576,7 +577,32 @@ def contrastive_blocks_fwd(im, s, block_sizes, margin, max_violation, norm):
                                         int(bool(norm)), losses.data_ptr(), ws.data_ptr(),
                                         ws_bytes, _stream())
   _lib.check(rc, 'cmhse_contrastive_blocks_fwd')
+  if keep:
+    return losses, dict(scores=ws, off=off_d, nb=nb, max_n=max_n)
   return losses
+
+
+def contrastive_blocks_bwd(im, s, state, margin, max_violation, norm, grad_losses):
+  """d(sum_b grad_losses[b] * loss_b) / d im, d s (cmhse_contrastive_blocks_bwd); `state` from
+  contrastive_blocks_fwd(keep=True)."""
+  lib = _lib.load()
+  im = _f32c(im, 'im')
+  s = _f32c(s, 's')
+  g = _f32c(grad_losses, 'grad_losses').reshape(-1)
+  nb, max_n = state['nb'], state['max_n']
+  if g.numel() != nb:
+    raise ValueError('one upstream gradient per block')
+  d_im = torch.empty_like(im)
+  d_s = torch.empty_like(s)
+  ws_bytes = lib.cmhse_contrastive_blocks_bwd_workspace(nb, max_n)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=im.device)
+  rc = lib.cmhse_contrastive_blocks_bwd(im.data_ptr(), s.data_ptr(), state['scores'].data_ptr(),
+                                        state['off'].data_ptr(), nb, max_n, im.shape[1],
+                                        float(margin), int(bool(max_violation)), int(bool(norm)),
+                                        g.data_ptr(), d_im.data_ptr(), d_s.data_ptr(),
+                                        ws.data_ptr(), ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_contrastive_blocks_bwd')
+  return d_im, d_s
 
 
 def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):

@@ -227,6 +227,19 @@ int cmhse_contrastive_blocks_fwd(const float* im, const float* s, const int32_t*
                                  int32_t max_violation, int32_t norm, float* losses,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of cmhse_contrastive_blocks_fwd — what loss.backward() (model.py:367) computes through
+ * the 4-7 ContrastiveLoss calls of a training step (model.py:333-343) when they are evaluated as
+ * blocks of two row-blocked matrices: `scores` is the forward call's workspace (block b's stored
+ * n_b x n_b scores at scores + b * max_n * max_n floats), grad_out[b] (device) the upstream gradient
+ * of losses[b]; d_im / d_s ([rows, D], same row blocking as im / s) receive the gradients.  One
+ * launch set (statistics, coefficient matrices, two batched TN products) for all blocks. */
+size_t cmhse_contrastive_blocks_bwd_workspace(int32_t n_blocks, int32_t max_n);
+int cmhse_contrastive_blocks_bwd(const float* im, const float* s, const float* scores,
+                                 const int32_t* blk_off, int32_t n_blocks, int32_t max_n, int32_t D,
+                                 float margin, int32_t max_violation, int32_t norm,
+                                 const float* grad_out, float* d_im, float* d_s, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* ---- backward pass (what loss.backward(), model.py:367, computes through the operators above) ---- */
 
 /* Parameter gradients of one encoder layer, same shapes as cmhse_gru_weights; overwritten. */

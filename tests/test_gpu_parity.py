@@ -1644,3 +1644,37 @@ def test_small_batch_step_shapes_are_bit_identical(dev, S, H, monkeypatch):
   for o in outs[1:]:
     for a, b in zip(outs[0], o):
       assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('max_violation', [False, True])
+def test_batched_losses_equal_the_separate_calls(dev, max_violation):
+  """loss.contrastive_losses (cmhse_contrastive_blocks_fwd / _bwd: one launch set for several
+  ContrastiveLoss evaluations) against the separate criterion(a, b) calls: values bit for bit,
+  gradients bit for bit per operand."""
+  from cmhse_amd.loss import ContrastiveLoss, contrastive_losses
+  torch.manual_seed(3)
+  crit = ContrastiveLoss(margin=0.2, max_violation=max_violation, norm=True)
+  sizes = [32, 120, 32, 7, 129]
+  D = 96
+  a = [torch.nn.functional.normalize(torch.randn(n, D, device=dev), dim=1) for n in sizes]
+  b = [torch.nn.functional.normalize(x + 0.7 * torch.randn_like(x), dim=1) for x in a]
+  w = torch.tensor([1.0, 0.5, 2.0, 1.0, 0.25], device=dev)
+  sep_a = [x.clone().requires_grad_(True) for x in a]
+  sep_b = [x.clone().requires_grad_(True) for x in b]
+  sep = torch.stack([crit(x, y) for x, y in zip(sep_a, sep_b)])
+  torch.dot(sep, w).backward()
+  bat_a = [x.clone().requires_grad_(True) for x in a]
+  bat_b = [x.clone().requires_grad_(True) for x in b]
+  bat = contrastive_losses(crit, list(zip(bat_a, bat_b)))
+  assert torch.equal(bat, sep)
+  torch.dot(bat, w).backward()
+  for k in range(len(sizes)):
+    assert torch.equal(bat_a[k].grad, sep_a[k].grad), k
+    assert torch.equal(bat_b[k].grad, sep_b[k].grad), k
+  # the self-similarity form CL(x, x) of model.py:335-336: both operands are the same tensor
+  x1 = a[1].clone().requires_grad_(True)
+  x2 = a[1].clone().requires_grad_(True)
+  crit(x1, x1).backward()
+  contrastive_losses(crit, [(x2, x2)])[0].backward()
+  assert torch.equal(x1.grad, x2.grad)

@@ -55,6 +55,7 @@ def main():
     os.environ.update(arm)
     # host-side switches of cmhse_amd.model (module-level lists), by the same names as their env
     model_mod.TRAIN_GROUPED[0] = arm.get('CMHSE_TRAIN_GROUPED', '0') == '1'
+    model_mod.BATCHED_LOSSES[0] = arm.get('CMHSE_BATCHED_LOSSES', '1') == '1'
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
