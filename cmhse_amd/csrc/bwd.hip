@@ -1081,7 +1081,8 @@ static int bwd_mid_units(int H, int m_blocks) {
   if (forced == 16 || forced == 8 || forced == 4) return forced;
   // Unlike the forward step (K = H), narrower tiles LOSE here: the 32 dgh rows of K = 3H floats
   // (384 KB) every workgroup pulls dominate, and 128-256 workgroups of them cost more L2 bandwidth
-  // than the spread gains (train_emb step, C3D: 16 units 12.8 ms, 8 units 16.0, 4 units 15.9).
+  // than the spread gains (train_emb step, C3D: 16 units 12.8 ms, 8 units 16.0, 4 units 15.9; later,
+  // at 11.3 ms, 32 units — two column blocks per wave — 11.9).
   (void)H;
   (void)m_blocks;
   return 16;
