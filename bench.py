@@ -394,8 +394,14 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  # warm-up passes run under the same timers as the timed ones: their HIP events come from (and go
+  # back to) the library's free list, so the timed region creates none
   for _ in range(args.warmup):
-    step()
+    with ops.StepTimers() as wt, ops.SimTimers() as wst:
+      step()
+      sync()
+    wt.collect()
+    wst.collect()
   sync()
   if os.environ.get('CMHSE_BENCH_GC_FREEZE', '1') == '1':
     # the loader batches, schedules and modules built so far are ~10^6 long-lived Python objects;

@@ -25,6 +25,7 @@
 //                     weighted sum over time; HBM-bound, one pass over hs.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 #include <math.h>
 #include <stdint.h>
@@ -1186,6 +1187,32 @@ __global__ __launch_bounds__(kThreads) void pad_rows_kernel(const PadRowsParams 
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+namespace {
+std::mutex g_event_mutex;
+std::vector<hipEvent_t> g_event_free[2];   // [0] hipEventDisableTiming, [1] timing
+}  // namespace
+
+hipEvent_t event_get(bool timing) {
+  {
+    std::lock_guard<std::mutex> lock(g_event_mutex);
+    std::vector<hipEvent_t>& fl = g_event_free[timing ? 1 : 0];
+    if (!fl.empty()) {
+      hipEvent_t ev = fl.back();
+      fl.pop_back();
+      return ev;
+    }
+  }
+  hipEvent_t ev = nullptr;
+  const hipError_t rc = timing ? hipEventCreate(&ev) : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  return rc == hipSuccess ? ev : nullptr;
+}
+
+void event_put(hipEvent_t ev, bool timing) {
+  if (ev == nullptr) return;
+  std::lock_guard<std::mutex> lock(g_event_mutex);
+  g_event_free[timing ? 1 : 0].push_back(ev);
+}
+
 int hoist_max_seqs() {   // read per call.  Off by default: measured +2 % at 615 videos, -3 % at 1230
   const char* e = getenv("CMHSE_HOIST_MAX_SEQS");
   return e ? atoi(e) : 0;
@@ -1561,11 +1588,11 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
 
 // Orders `waiter` behind everything queued on `signal` so far.
 static void stream_after(hipStream_t waiter, hipStream_t signal) {
-  hipEvent_t ev;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+  hipEvent_t ev = event_get(false);
+  if (ev != nullptr) {
     (void)hipEventRecord(ev, signal);
-    (void)hipStreamWaitEvent(waiter, ev, 0);
-    (void)hipEventDestroy(ev);   // released by the runtime once the wait has consumed it
+    (void)hipStreamWaitEvent(waiter, ev, 0);   // captures the record above: the event may be re-recorded
+    event_put(ev, false);
   } else {
     (void)hipStreamSynchronize(signal);
   }
@@ -1657,10 +1684,11 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       const bool stamp = timer != nullptr && ((kind[k] & 3) == 1 || (kind[k] & 3) == 2);
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (stamp) {
-        if (hipEventCreate(&e0) != hipSuccess) e0 = nullptr;
-        if (e0 && hipEventCreate(&e1) != hipSuccess) {   // no pair: release the first, time nothing
-          (void)hipEventDestroy(e0);
-          e0 = e1 = nullptr;
+        e0 = event_get(true);
+        e1 = e0 ? event_get(true) : nullptr;
+        if (e0 && !e1) {   // no pair: release the first, time nothing
+          event_put(e0, true);
+          e0 = nullptr;
         }
         if (e0 && e1) (void)hipEventRecord(e0, stream);
       }
@@ -1920,12 +1948,10 @@ extern "C" void* cmhse_timer_create(void) {
   t->launches = 0;
   t->tiled_flops = 0.0;
   t->tiled_bytes = 0.0;
-  if (hipEventCreate(&t->start) != hipSuccess) {
-    delete t;
-    return nullptr;
-  }
-  if (hipEventCreate(&t->stop) != hipSuccess) {
-    (void)hipEventDestroy(t->start);
+  t->start = event_get(true);
+  t->stop = t->start ? event_get(true) : nullptr;
+  if (!t->start || !t->stop) {
+    event_put(t->start, true);
     delete t;
     return nullptr;
   }
@@ -1935,9 +1961,9 @@ extern "C" void* cmhse_timer_create(void) {
 extern "C" void cmhse_timer_destroy(void* timer) {
   Timer* t = static_cast<Timer*>(timer);
   if (!t) return;
-  (void)hipEventDestroy(t->start);
-  (void)hipEventDestroy(t->stop);
-  for (hipEvent_t e : t->tiled_events) (void)hipEventDestroy(e);
+  event_put(t->start, true);
+  event_put(t->stop, true);
+  for (hipEvent_t e : t->tiled_events) event_put(e, true);
   delete t;
 }
 

@@ -94,6 +94,16 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   return L;
 }
 
+// HIP events are recycled through a process-wide free list (gru.hip): creating one can stall the
+// host for tens of milliseconds when the runtime grows its pools while the GPU is busy (measured:
+// 65 ms inside a validation pass), and the step launcher needs one per stream hand-over, a timer
+// two per tiled launch.  event_get() pops a recycled event of the wanted kind or creates one;
+// event_put() returns it (an event may be re-recorded as soon as nothing waits for its old use:
+// the launcher's wait-events are consumed by hipStreamWaitEvent at enqueue time, the timers'
+// events are read before their handle is destroyed).
+hipEvent_t event_get(bool timing);
+void event_put(hipEvent_t ev, bool timing);
+
 // cmhse_timer handle (measurement aid, include/cmhse_hip.h): HIP events owned by the handle.
 struct Timer {
   hipEvent_t start, stop;

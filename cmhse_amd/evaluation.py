@@ -117,6 +117,7 @@ def _copy_stream(device):
 # Pinned float32 blocks for the deferred 'Letest' values, recycled by flush(): page-locking a fresh
 # block while the GPU is busy costs milliseconds (see ops.upload).
 _HOST_SCALARS = []
+_HOST_EVENTS = []
 
 
 def _host_scalars(n):
@@ -176,9 +177,8 @@ def encode_group(model, group, contextual_model=True, device=None):
       v_sched = ops.SeqSchedule(
           np.concatenate([np.asarray(b[4], dtype=np.int64) for b in group] +
                          [np.asarray(b[6], dtype=np.int64) for b in group]), device,
-          x_ptrs=np.concatenate([ops.seq_row_ptrs(t) for t in clips_l + vids_l]),
-          src_ptrs=np.concatenate([ops.seq_row_ptrs(b[0]) for b in group] +
-                                  [ops.seq_row_ptrs(b[2]) for b in group]))
+          x_ptrs=ops.seq_row_ptrs_many(clips_l + vids_l),
+          src_ptrs=ops.seq_row_ptrs_many([b[0] for b in group] + [b[2] for b in group]))
       v_events = ops.pull_steps(v_sched, int(group[0][0].shape[2]), copy, UPLOAD_CHUNK[0])
     for t in clips_l + vids_l:
       t.record_stream(copy)        # allocated on the caller's stream, written on the copy stream
@@ -193,8 +193,8 @@ def encode_group(model, group, contextual_model=True, device=None):
     len_cap.append(np.asarray(b[5], dtype=np.int64))
     len_vid.append(np.asarray(b[6], dtype=np.int64))
     len_par.append(np.asarray(b[7], dtype=np.int64))
-    num_clips.extend(int(c) for c in b[8])
-    num_caps.extend(int(c) for c in b[9])
+    num_clips.extend(b[8])
+    num_caps.extend(b[9])
   n_clip = int(sum(len(l) for l in len_clip))
   n_cap = int(sum(len(l) for l in len_cap))
   n_vid = len(num_clips)
@@ -218,7 +218,7 @@ def encode_group(model, group, contextual_model=True, device=None):
 
   def visual_tower():
     # level 1: clips of all batches, then whole-video streams of all batches (same weights)
-    ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in clips_l + vids_l])
+    ptrs = ops.seq_row_ptrs_many(clips_l + vids_l)
     lens = np.concatenate(len_clip + len_vid)
     vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
@@ -228,7 +228,7 @@ def encode_group(model, group, contextual_model=True, device=None):
 
   def text_tower():
     # level 1: sentences, then paragraphs (embedding lookup fused into the operand load)
-    ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in caps_l + pars_l])
+    ptrs = ops.seq_row_ptrs_many(caps_l + pars_l)
     lens = np.concatenate(len_cap + len_par)
     txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
@@ -254,8 +254,8 @@ def encode_group(model, group, contextual_model=True, device=None):
   elif GROUP_TOWERS[0]:
     # The two towers are independent: step t of both level-1 encoders shares one launch
     # (cmhse_gru_pool_fwd_multi), then step t of both level-2 encoders.
-    v_ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in clips_l + vids_l])
-    t_ptrs = np.concatenate([ops.seq_row_ptrs(t) for t in caps_l + pars_l])
+    v_ptrs = ops.seq_row_ptrs_many(clips_l + vids_l)
+    t_ptrs = ops.seq_row_ptrs_many(caps_l + pars_l)
     # The visual chain (<= 80 frames) ends long before the text chain (paragraphs of hundreds of
     # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
     # side stream while the visual attention pass runs on this one, instead of after it.
@@ -331,6 +331,7 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
       values = host.tolist()
       if ev is not None:
         _HOST_SCALARS.append(host)     # read: the pinned block may carry the next group's values
+        _HOST_EVENTS.append(ev)        # ... and its event the next group's copy
       for b, bs, lv in zip(group, sizes, values):
         val_logger.update('Letest', lv, bs)
         batch_time.update(time.time() - state['end'])
@@ -356,7 +357,7 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
       if defer_logging:
         host = _host_scalars(loss_dev.numel())
         host.copy_(loss_dev.reshape(-1), non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = _HOST_EVENTS.pop() if _HOST_EVENTS else torch.cuda.Event()
         ev.record()
         pending.append((group, enc['batch_sizes'], host, ev, loss_dev))
       else:

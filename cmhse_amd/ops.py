@@ -35,15 +35,18 @@ def _staging_slot(nbytes):
   if nbytes > _SLOT_BYTES:    # larger than any schedule array of this path: a block of its own
     return torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.cuda.Event()
   if _ARENA['buf'] is None:
+    # everything that can stall later is paid here, once: page-locking, the first touch of every
+    # page (a fresh slot's first copy ran at 0.1 GB/s), and the creation of the slots' events
+    # (torch creates an event at its first record; one such creation was seen to take 65 ms)
     _ARENA['buf'] = torch.empty(_SLOT_BYTES * _N_SLOTS, dtype=torch.uint8).pin_memory()
-    _ARENA['events'] = [None] * _N_SLOTS
+    _ARENA['buf'].zero_()
+    _ARENA['events'] = [torch.cuda.Event() for _ in range(_N_SLOTS)]
+    for ev in _ARENA['events']:
+      ev.record()
   i = _ARENA['next']
   _ARENA['next'] = (i + 1) % _N_SLOTS
   ev = _ARENA['events'][i]
-  if ev is None:
-    ev = _ARENA['events'][i] = torch.cuda.Event()
-  else:
-    ev.synchronize()          # 63 uploads ago: complete unless the host is far ahead of the GPU
+  ev.synchronize()            # 63 uploads ago: complete unless the host is far ahead of the GPU
   return _ARENA['buf'][i * _SLOT_BYTES:(i + 1) * _SLOT_BYTES], ev
 
 
@@ -246,6 +249,22 @@ class Ragged(object):
 def seq_row_ptrs(t):
   """Per-sequence base addresses of a loader tensor: padded [S, T, ...] or Ragged."""
   return t.row_ptrs() if isinstance(t, Ragged) else padded_row_ptrs(t)
+
+
+def seq_row_ptrs_many(tensors):
+  """np.concatenate([seq_row_ptrs(t) for t in tensors]) without one small NumPy array per tensor
+  (a validation split hands over hundreds of loader batches per encoder)."""
+  if not tensors:
+    return np.zeros(0, dtype=np.uint64)
+  if any(isinstance(t, Ragged) for t in tensors):
+    return np.concatenate([seq_row_ptrs(t) for t in tensors])
+  n = len(tensors)
+  bases = np.fromiter((t.data_ptr() for t in tensors), dtype=np.uint64, count=n)
+  counts = np.fromiter((t.shape[0] for t in tensors), dtype=np.int64, count=n)
+  strides = np.fromiter((t.stride(0) * t.element_size() for t in tensors), dtype=np.uint64, count=n)
+  starts = np.cumsum(counts) - counts
+  within = (np.arange(int(counts.sum()), dtype=np.int64) - np.repeat(starts, counts)).astype(np.uint64)
+  return np.repeat(bases, counts) + within * np.repeat(strides, counts)
 
 
 def seq_keep(t, dtype):
