@@ -315,6 +315,7 @@ class StepTimers(object):
 
 PULL_EVENT_TIMING = [False]     # tools/ab_host.py: timed events to see when each chunk landed
 LAST_PULL_EVENTS = [None]
+_LAST_PULL_TIMED = [False]
 
 
 def pull_steps(sched, row_floats, copy_stream, chunk=8):
@@ -326,6 +327,11 @@ def pull_steps(sched, row_floats, copy_stream, chunk=8):
   if sched.p_src is None:
     raise ValueError('schedule was built without src_ptrs')
   events = {}
+  # the previous call's events are recycled (creating one while the GPU is busy can stall the host
+  # for tens of ms): the step launcher's waits on them were captured when they were queued
+  pool = []
+  if not PULL_EVENT_TIMING[0] and LAST_PULL_EVENTS[0] and not _LAST_PULL_TIMED[0]:
+    pool = list(LAST_PULL_EVENTS[0].values())
   sched.meta.record_stream(copy_stream)
   bounds, t = [], 0
   while t < sched.Tmax:
@@ -339,10 +345,11 @@ def pull_steps(sched, row_floats, copy_stream, chunk=8):
                               int(sched.step_count_host[t0]), row_floats, t0, t1,
                               ctypes.c_void_p(copy_stream.cuda_stream))
     _lib.check(rc, 'cmhse_pull_steps')
-    ev = torch.cuda.Event(enable_timing=PULL_EVENT_TIMING[0])
+    ev = pool.pop() if pool else torch.cuda.Event(enable_timing=PULL_EVENT_TIMING[0])
     ev.record(copy_stream)
     events[t0] = ev
   LAST_PULL_EVENTS[0] = events
+  _LAST_PULL_TIMED[0] = PULL_EVENT_TIMING[0]
   return events
 
 
