@@ -35,10 +35,12 @@ python bench.py > $D/bench_default.json 2> $D/bench_default.err
 python bench.py --workload anet_c3d_val --host_steps 0 --cpu_batches 0 > $D/bench_c3d.json 2>/dev/null
 python bench.py --workload didemo_icep_val --host_steps 0 --cpu_batches 0 --fast_steps 0 --train_steps 0 > $D/bench_didemo.json 2>/dev/null
 python tools/ab_pass.py --modes "CMHSE_GRU_RASTER=0;CMHSE_GRU_RASTER=4;CMHSE_GRU_RASTER=8;CMHSE_GRU_RASTER=16" --rounds 3 > $D/raster_ab_icep.txt 2>&1
+python tools/ab_pass.py --modes "CMHSE_GRU_MSUB=1;CMHSE_GRU_MSUB=2;CMHSE_X=1" --rounds 3 > $D/tile_height_ab.txt 2>&1
+for m in 1 2 1 2; do CMHSE_GRU_MSUB=$m bash tools/power_probe.sh "tile rows $((64*m))" python tools/ab_pass.py --modes "CMHSE_X=1" --rounds 6 --passes 3; done > $D/power_probe.txt 2>&1
 python tools/ab_host.py --rounds 2 --modes "PIPE=0;PIPE=1;PIPE=1,CMHSE_PULL_GRID=16,CMHSE_PULL_THREADS=256;PIPE=1,CMHSE_PULL_GRID=128" > $D/upload_pipeline.txt 2>&1
-python tools/step_sweep.py --sizes 1,8,16,32,64,152,320,512,1024 --dims 500,300,1024 --arms "CMHSE_MID_MAX_SEQS=0;CMHSE_MID_UNITS=16;CMHSE_MID_UNITS=0" > $D/step_sweep.txt 2>&1
-python tools/ab_train.py --config c3d --modes "CMHSE_BWD_MID_MAX_SEQS=0,CMHSE_MID_UNITS=16;CMHSE_BWD_MID_MAX_SEQS=0;CMHSE_MID_UNITS=16;CMHSE_X=1" > $D/train_ab.txt 2>&1
-python tools/ab_train.py --config icep_recon --modes "CMHSE_BWD_MID_MAX_SEQS=0,CMHSE_MID_UNITS=16;CMHSE_X=1" >> $D/train_ab.txt 2>&1
+bash tools/mid_shape_sweep.sh > $D/step_sweep.txt 2>&1
+python tools/ab_train.py --config c3d --modes "CMHSE_BWD_MID_MAX_SEQS=0,CMHSE_MID_UNITS=16,CMHSE_MID_WAVES=4,CMHSE_BATCHED_LOSSES=0,CMHSE_FUSED_ADAM=0;CMHSE_BATCHED_LOSSES=0;CMHSE_X=1" > $D/train_ab.txt 2>&1
+python tools/ab_train.py --config icep_recon --modes "CMHSE_BWD_MID_MAX_SEQS=0,CMHSE_MID_UNITS=16,CMHSE_MID_WAVES=4,CMHSE_BATCHED_LOSSES=0;CMHSE_X=1" >> $D/train_ab.txt 2>&1
 timeout 60 tools/microbench/weights_reread.bin > $D/weights_reread.txt 2>&1
 python tools/mid_trace.py 152 12 > $D/mid_trace_S152.txt 2>&1
 python tools/mid_trace.py 8 12 > $D/mid_trace_S8.txt 2>&1
