@@ -77,11 +77,18 @@ def costs_of(batches, img_dim=None):
   return out
 
 
+_PENDING_LOG = []
+
+
 def _default_encode(opt, model, batches):
   if not batches:
     return None
-  cat, _, _ = evaluation.encode_data_device(opt, model, batches, logging=lambda *a: None)
-  return cat['vid_emb'], cat['para_emb']   # (logging flushed inside: the exchange step follows)
+  # the per-batch 'Letest' meters (evaluation.py:129) are replayed at the end of validate_sharded,
+  # after the exchange and the ranking kernels are queued: no host sync in front of them
+  cat, _, _, finish = evaluation.encode_data_device(opt, model, batches, logging=lambda *a: None,
+                                                    defer_logging=True)
+  _PENDING_LOG.append(finish)
+  return cat['vid_emb'], cat['para_emb']
 
 
 def _default_rank(queries, gallery, row0, nrows):
@@ -156,6 +163,8 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   packed = torch.stack([r_i, t_i, r_t, t_t], 1).to(torch.int32)
   t3 = sync()
   full = all_gather_rows(packed, counts, group).cpu().numpy()
+  while _PENDING_LOG:
+    _PENDING_LOG.pop()()
   if timings is not None:
     timings.update(encode_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3,
                    score_ms=(t3 - t2) * 1e3, videos=nrows)
