@@ -187,6 +187,11 @@ struct AttnBwdParams {
   int32_t H, n_tiles;
 };
 
+// One workgroup per sequence; its four waves take the time steps round-robin and need no barrier
+// per step (a wave reduces its own dot products with shuffles, and pass 2 revisits exactly the
+// steps the same wave handled in pass 1, so it reads back its own da_t).  The previous form walked
+// the steps one by one with two workgroup barriers each: 0.22-0.34 ms per call at T <= 80, at the
+// head of each tower's backward pass.
 __global__ __launch_bounds__(kThreads) void attn_pool_bwd_kernel(const AttnBwdParams q) {
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = q.lens[s], H = q.H;
@@ -211,34 +216,31 @@ __global__ __launch_bounds__(kThreads) void attn_pool_bwd_kernel(const AttnBwdPa
   }
   __syncthreads();
   const float den = s_den;
-  // pass 1: da_t (block dot product) -> de scratch holds da_t; c = sum_t a_t da_t
+  // pass 1: da_t = g . h_t (one wave per step) -> de scratch holds da_t; c = sum_t a_t da_t
   float c_acc = 0.f;
-  for (int t = 0; t < len; ++t) {
+  for (int t = wave; t < len; t += 4) {
     const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
+    const float* hr = q.hs + row * H;
     float d = 0.f;
-    for (int u = tid; u < H; u += kThreads) d += g[u] * q.hs[row * H + u];
+    for (int u = lane; u < H; u += 64) d += g[u] * hr[u];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
-    if (lane == 0) wpart[wave] = d;
-    __syncthreads();
-    if (tid == 0) {
-      const float da = wpart[0] + wpart[1] + wpart[2] + wpart[3];
-      const float a = expf(energy(t)) / den;
-      q.de[row] = da;  // temporarily da_t
-      c_acc += a * da;
-    }
-    __syncthreads();
+    const float a = expf(energy(t)) / den;
+    if (lane == 0) q.de[row] = d;  // temporarily da_t
+    c_acc += a * d;
   }
-  if (tid == 0) s_c = c_acc;
+  if (lane == 0) wpart[wave] = c_acc;
+  __syncthreads();
+  if (tid == 0) s_c = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
   __syncthreads();
   const float c = s_c;
-  // pass 2: de_t and dpool rows
-  for (int t = 0; t < len; ++t) {
+  // pass 2: de_t and dpool rows (same wave -> same steps as in pass 1)
+  for (int t = wave; t < len; t += 4) {
     const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
     const float a = expf(energy(t)) / den;
-    for (int u = tid; u < H; u += kThreads) q.dpool[row * H + u] = a * g[u];
-    __syncthreads();
-    if (tid == 0) q.de[row] = a * (q.de[row] - c);
+    float* dp = q.dpool + row * H;
+    for (int u = lane; u < H; u += 64) dp[u] = a * g[u];
+    if (lane == 0) q.de[row] = a * (q.de[row] - c);
   }
 }
 
