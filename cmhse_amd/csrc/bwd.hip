@@ -192,13 +192,15 @@ struct AttnBwdParams {
 // steps the same wave handled in pass 1, so it reads back its own da_t).  The previous form walked
 // the steps one by one with two workgroup barriers each: 0.22-0.34 ms per call at T <= 80, at the
 // head of each tower's backward pass.
-__global__ __launch_bounds__(kThreads) void attn_pool_bwd_kernel(const AttnBwdParams q) {
+constexpr int kPoolBwdThreads = 1024;   // 16 waves: a sequence of 80 steps is 5 steps per wave
+__global__ __launch_bounds__(kPoolBwdThreads) void attn_pool_bwd_kernel(const AttnBwdParams q) {
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = q.lens[s], H = q.H;
   const float* g = q.dout + static_cast<int64_t>(q.out_row[s]) * H;
-  __shared__ float red[kThreads];
+  constexpr int NT = kPoolBwdThreads, NW = NT / 64;
+  __shared__ float red[NT];
   __shared__ float s_den, s_c;
-  __shared__ float wpart[4];
+  __shared__ float wpart[NW];
   auto energy = [&](int t) {
     const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
     float e = 0.f;
@@ -206,19 +208,20 @@ __global__ __launch_bounds__(kThreads) void attn_pool_bwd_kernel(const AttnBwdPa
     return e;
   };
   float part = 0.f;
-  for (int t = tid; t < len; t += kThreads) part += expf(energy(t));
+  for (int t = tid; t < len; t += NT) part += expf(energy(t));
   red[tid] = part;
   __syncthreads();
   if (tid == 0) {
     float d = 0.f;
-    for (int i = 0; i < kThreads; ++i) d += red[i];
+    const int used = len < NT ? len : NT;      // threads past `len` hold 0
+    for (int i = 0; i < used; ++i) d += red[i];
     s_den = d + 0.0001f;
   }
   __syncthreads();
   const float den = s_den;
   // pass 1: da_t = g . h_t (one wave per step) -> de scratch holds da_t; c = sum_t a_t da_t
   float c_acc = 0.f;
-  for (int t = wave; t < len; t += 4) {
+  for (int t = wave; t < len; t += NW) {
     const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
     const float* hr = q.hs + row * H;
     float d = 0.f;
@@ -231,11 +234,15 @@ __global__ __launch_bounds__(kThreads) void attn_pool_bwd_kernel(const AttnBwdPa
   }
   if (lane == 0) wpart[wave] = c_acc;
   __syncthreads();
-  if (tid == 0) s_c = (wpart[0] + wpart[1]) + (wpart[2] + wpart[3]);
+  if (tid == 0) {
+    float cs = 0.f;
+    for (int w = 0; w < NW; ++w) cs += wpart[w];
+    s_c = cs;
+  }
   __syncthreads();
   const float c = s_c;
   // pass 2: de_t and dpool rows (same wave -> same steps as in pass 1)
-  for (int t = wave; t < len; t += 4) {
+  for (int t = wave; t < len; t += NW) {
     const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
     const float a = expf(energy(t)) / den;
     float* dp = q.dpool + row * H;
@@ -1037,7 +1044,7 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
     ap.dout = dout; ap.hs = hs; ap.e_part = reinterpret_cast<const float*>(fws + F.e_part);
     ap.lens = b->lens; ap.out_row = b->out_row; ap.step_off = b->step_off;
     ap.dpool = dpool; ap.de = de; ap.rows = sum_T; ap.H = H; ap.n_tiles = (H + kAttBN - 1) / kAttBN;
-    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(S), dim3(kThreads), 0, st, ap);
+    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(S), dim3(kPoolBwdThreads), 0, st, ap);
     hipLaunchKernelGGL(attn_du_kernel, dim3(static_cast<unsigned>(sum_T)), dim3(kThreads), 0, st,
                        de, v, w->w_att, du, sum_T, H);
     launch_colsum(v, de, g->dw_att, cs_scratch, sum_T, H, H, st);      // d att_w = sum_p de_p v_p
