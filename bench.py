@@ -15,9 +15,13 @@ Workloads (config.workload):
   didemo_icep_val configs[3] (img_dim=2048, all-80-frame clips, vocab 7205, N=1004)
   plumbing       configs[0]: 64 videos x 4 clips x 10 frames, batch 16
 
-N>1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL): the SAME split is
-sharded over ranks (strong scaling): each rank encodes its slice, embeddings are all-gathered,
-each rank scores its row stripe (cmhse_amd/parallel_eval.py).
+N>1, one rank per GPU, backend nccl = RCCL: the SAME split is sharded over ranks (strong scaling):
+each rank encodes its share, embeddings are all-gathered, each rank scores its row stripe
+(cmhse_amd/parallel_eval.py).  Launched either by torch.distributed.run (RANK / WORLD_SIZE /
+MASTER_* in the environment) or bare — `python bench.py --gpus N` with no WORLD_SIZE set starts
+its own N ranks as fresh child processes (the parent never touches the GPU, nothing is re-exec'd)
+and exits with the worst child's return code.  On a box with fewer GPUs than ranks the children
+share the GPUs over a gloo group (a functional run of the N-rank path, flagged in the JSON).
 
 The JSON line also carries
   roofline      for the dominant kernel (gru_step_kernel): algorithmic FLOPs of the timed launches
@@ -40,6 +44,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 import torch
@@ -138,8 +143,10 @@ def gru_flops_per_step(I, H):
   return 2 * 3 * H * I + 2 * 3 * H * H + 14 * H
 
 
-def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full):
-  """NumPy oracle on the host cores over the first `n_sample_batches` loader batches."""
+def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
+  """NumPy oracle on the host cores over the first `n_sample_batches` loader batches (BASELINE.md
+  §3: a 512-video subset, one warm-up pass, median of >= 3 timed passes, scaled encode ~ N and
+  scoring ~ N^2)."""
   sys.path.insert(0, os.path.join(REPO, 'oracle'))
   import cmhse_oracle as oracle
   sub = synthetic.SplitSpec(spec.num_clips, spec.frames_per_clip, spec.frames_per_video,
@@ -166,31 +173,51 @@ def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full):
       dt = time.time() - t0
     if best_t is None or dt < best_t:
       best_n, best_t = n_thr, dt
+  enc_s, score_s = [], []
   with threadpool_limits(limits=best_n):
-    t0 = time.time()
-    res = oracle.encode_data(opt.rnn_type, sds, np_batches, margin=opt.margin)
-    t_enc = time.time() - t0
-    t0 = time.time()
-    oracle.i2t(res[0], res[1])
-    oracle.t2i(res[0], res[1])
-    t_score = time.time() - t0
+    for rep in range(repeats + 1):        # pass 0 is the warm-up
+      t0 = time.time()
+      res = oracle.encode_data(opt.rnn_type, sds, np_batches, margin=opt.margin)
+      t1 = time.time()
+      oracle.i2t(res[0], res[1])
+      oracle.t2i(res[0], res[1])
+      t2 = time.time()
+      if rep > 0:
+        enc_s.append(t1 - t0)
+        score_s.append(t2 - t1)
+  t_enc, t_score = float(np.median(enc_s)), float(np.median(score_s))
   scale = n_full / float(nv)
   t_full = t_enc * scale + t_score * scale * scale
+  cpu_model = ''
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('model name'):
+        cpu_model = line.split(':', 1)[1].strip()
+        break
+  except OSError:
+    pass
   return {
       'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': best_n,
-      'kind': 'port',
+      'kind': 'port', 'host_cpu': cpu_model, 'host_logical_cpus': ncpu,
+      'videos_per_s': nv / t_enc, 'passes': repeats,
       'sample': ('NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS limited to %d threads = fastest of '
                  'a calibration over {8,16,32,64,%d} on this %d-core host) on the first %d videos '
-                 '(%d loader batches) of the same split: encode %.2f s, i2t+t2i %.3f s; '
-                 'extrapolated to N=%d with encode ~ N and scoring ~ N^2'
-                 % (best_n, ncpu, ncpu, nv, len(batches), t_enc, t_score, n_full)),
+                 '(%d loader batches) of the same split: 1 warm-up pass, median of %d timed passes: '
+                 'encode %.2f s, i2t+t2i %.3f s; extrapolated to N=%d with encode ~ N and '
+                 'scoring ~ N^2' % (best_n, ncpu, ncpu, nv, len(batches), repeats, t_enc, t_score,
+                                    n_full)),
   }
+
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 
 
 def fast_mode_bench(opt, model, batches, N, n_steps):
   """Supplementary: the same validation pass with CMHSE_MATH_BF16X3 (3-term bf16 hi/lo split on
   the bf16 matrix pipe, fp32 accumulate, for the large encoder GEMMs; ranking stays exact fp32),
-  with its measured deviation from the exact-fp32 embeddings.  Never the headline `value`."""
+  with its measured deviation from the exact-fp32 embeddings and ranks, and its own roofline: the
+  tiled step kernel's algorithmic FLOPs over its HIP-event time against the bf16 MFMA peak / 3
+  (three MFMAs per product).  Never the headline `value`."""
   quiet = lambda *a, **k: None
 
   def one_pass():
@@ -199,25 +226,56 @@ def fast_mode_bench(opt, model, batches, N, n_steps):
     r_t, _ = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
     return cat, r_i, r_t
 
-  ref_cat, _, _ = one_pass()          # exact fp32
+  ref_cat, ref_i, ref_t = one_pass()          # exact fp32
   try:
     ops.set_math_mode('bf16x3')
-    one_pass()
-    torch.cuda.synchronize()
+    with ops.StepTimers() as wt:
+      one_pass()
+      torch.cuda.synchronize()
+    wt.collect()
     t0 = time.perf_counter()
-    for _ in range(n_steps):
-      cat, _, _ = one_pass()
-    torch.cuda.synchronize()
+    with ops.StepTimers() as timers:
+      for _ in range(n_steps):
+        cat, r_i, r_t = one_pass()
+      torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_steps
+    spans = timers.collect()
   finally:
     ops.set_math_mode('fp32')
+  ms = sum(s[3][0] for s in spans)
+  flops = sum(s[3][1] for s in spans)
+  launches = sum(s[3][3] for s in spans)
+  achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+  peak = BF16_MFMA_PEAK_TFLOPS / 3.0
   diff = max(float((cat[k] - ref_cat[k]).abs().max()) for k in ['vid_emb', 'para_emb', 'clip_emb',
                                                                  'cap_emb', 'vid_ctx', 'para_ctx'])
+  moved = int((r_i != ref_i).sum()) + int((r_t != ref_t).sum())
+  # ranks of a trained model's embeddings: the same perturbation applied to SURVEY S5's correlated
+  # embeddings (R@1 ~ 33 %): re-rank normalize(a + (bf16x3 - fp32 deviation of the video rows)),
+  # which shows whether a 1e-6 deviation moves any rank where the scores are spread like a real
+  # model's (with random-init encoders on random inputs all scores sit within ~1e-3 of each other)
+  a, b = synthetic.correlated_embeddings(N, cat['vid_emb'].shape[1], 3.0, seed=0)
+  ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+  dev_v = cat['vid_emb'] - ref_cat['vid_emb']
+  dev_p = cat['para_emb'] - ref_cat['para_emb']
+  base_i, _ = ops.sim_rank(ad, bd)
+  base_t, _ = ops.sim_rank(bd, ad)
+  pert_i, _ = ops.sim_rank(ops.l2norm_rows(ad + dev_v), ops.l2norm_rows(bd + dev_p))
+  pert_t, _ = ops.sim_rank(ops.l2norm_rows(bd + dev_p), ops.l2norm_rows(ad + dev_v))
+  moved_corr = int((pert_i != base_i).sum()) + int((pert_t != base_t).sum())
   return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
                   'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
                   'attention projection); ranking kernel exact fp32',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
-          'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff}
+          'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
+          'rank_rows_moved_vs_fp32_random_init': moved, 'rank_rows_total': 2 * N,
+          'rank_rows_moved_on_correlated_embeddings': moved_corr,
+          'roofline': {'kernel': 'gru_step_kernel<bf16x3>', 'bound': 'mfma', 'achieved': achieved,
+                       'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent products)',
+                       'frac': achieved / peak, 'launches': launches,
+                       'avg_launch_us': (ms * 1e3 / launches) if launches else None,
+                       'kernel_time_share': (ms * 1e-3) / (dt * n_steps) if dt > 0 else None,
+                       'note': 'peak = dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product'}}
 
 
 def rank_check(N, D, n_sample=256, seed=0):
@@ -243,32 +301,150 @@ def rank_check(N, D, n_sample=256, seed=0):
                     'top-1 vs fp64 NumPy' % (N, D)}
 
 
-def train_bench(wl, opt, model, batches, n_steps):
-  """Supplementary: BASELINE configs[1] as a TRAINING step (VSE.train_emb, model.py:309-369:
-  6 encoder passes, 7 contrastive losses with --low_level_loss --norm, backward, Adam) on loader
-  batches of the same split — forward and backward on the HIP path, torch.optim.Adam update."""
-  import copy
+TRAIN_CONFIGS = {
+    # BASELINE configs[1]: README "HSE tau=0 on ActivityNet with C3D": --low_level_loss --norm
+    'anet_c3d_tau0': dict(img_dim=500, feat='normal', vocab=13058, dataset='anet',
+                          flags=dict(low_level_loss=True, norm=True),
+                          baseline='configs[1]: ActivityNet C3D (img_dim=500, embed=1024) HSE tau=0, batch 32'),
+    # the metric's model (ICEP dims) with configs[1]'s losses: round 2's train_step leg, kept for continuity
+    'anet_icep_tau0': dict(img_dim=2048, feat='relu', vocab=13058, dataset='anet',
+                           flags=dict(low_level_loss=True, norm=True),
+                           baseline='ICEP dims with configs[1] losses (no reconstruction)'),
+    # BASELINE configs[2]
+    'anet_icep_recon': dict(img_dim=2048, feat='relu', vocab=13058, dataset='anet',
+                            flags=dict(low_level_loss=True, norm=True, reconstruct_loss=True,
+                                       weight_recon=5e-4),
+                            baseline='configs[2]: ActivityNet ICEP HSE tau=5e-4 --low_level_loss '
+                                     '--reconstruct_loss --norm, batch 32'),
+    # BASELINE configs[3]: DiDeMo ICEP, tau = 5e-4 (same flags as configs[2]; all-80-frame clips,
+    # short sentences, vocab 7205)
+    'didemo_icep_recon': dict(img_dim=2048, feat='relu', vocab=7205, dataset='didemo',
+                              flags=dict(low_level_loss=True, norm=True, reconstruct_loss=True,
+                                         weight_recon=5e-4),
+                              baseline='configs[3]: DiDeMo ICEP HSE tau=5e-4, batch 32'),
+}
+
+
+def train_step_work(batch, img_dim, H, flags, attention, word_dim=300):
+  """Algorithmic FLOPs of one VSE.train_emb step on `batch` (model.py:309-369) and the number of
+  DEPENDENT GRU steps on its longest tower (each a kernel launch that cannot start before the
+  previous one has finished: the latency floor of a small-batch step).
+
+  Per packed (sequence, step) row of an encoder with input width I:
+    forward   2*3H*(I+H) + 14H            (+ 2H^2 + 6H for the attention projection)
+    backward  2*3H*H   dh_{t-1} = dGh . W_hh               (the BPTT chain)
+              2*3H*I   dW_ih += dGx^T x,   2*3H*H  dW_hh += dGh^T h_{t-1}
+              2*3H*I   dx = dGx . W_ih     (only where the input needs a gradient: level 2, the
+                                            word-embedding table, the decoders)
+              4H^2     attention: dW_lin += du^T h and dpool += du . W_lin
+  A decoder's input is constant over its steps (model.py:261-265): its input projection and dx are
+  counted once per SEQUENCE."""
+  lc, lw, lv, lp = (np.asarray(batch[i]) for i in (4, 5, 6, 7))
+  n_clips, B = len(lc), len(lv)
+  att = (2.0 * H * H + 6.0 * H) if attention else 0.0
+  att_b = 4.0 * H * H if attention else 0.0
+
+  def enc(rows, I, need_dx, seqs=None):
+    if seqs is None:    # ordinary input
+      fwd = rows * (6.0 * H * (I + H) + 14.0 * H + att)
+      bwd = rows * (6.0 * H * H + 6.0 * H * I + 6.0 * H * H + (6.0 * H * I if need_dx else 0.0) + att_b)
+    else:               # time-constant input: projection / dW_ih / dx once per sequence
+      fwd = rows * (6.0 * H * H + 14.0 * H) + seqs * 6.0 * H * I
+      bwd = rows * (12.0 * H * H) + seqs * 12.0 * H * I
+    return fwd, bwd
+  parts = [enc(float(lc.sum() + lv.sum()), img_dim, False),        # clip_enc on clips + whole videos
+           enc(float(lw.sum() + lp.sum()), word_dim, True),        # txt_enc (+ d embedding table)
+           enc(float(n_clips), H, True), enc(float(n_clips), H, True)]   # level 2, h0 = context
+  vis_chain = int(max(lc.max(), lv.max())) + int(max(batch[8]))
+  txt_chain = int(max(lw.max(), lp.max())) + int(max(batch[9]))
+  if flags.get('reconstruct_loss'):
+    attention_saved, att, att_b = att, 0.0, 0.0                      # decoders pool nothing
+    parts += [enc(float(n_clips), H, True, seqs=B), enc(float(n_clips), H, True, seqs=B)]
+    att = attention_saved
+    vis_chain += int(max(batch[8]))
+    txt_chain += int(max(batch[9]))
+  fwd = sum(p[0] for p in parts)
+  bwd = sum(p[1] for p in parts)
+  return fwd, bwd, 2 * max(vis_chain, txt_chain)      # forward + backward launches of that tower
+
+
+def train_bench(name, embed, rnn_type, n_steps, device):
+  """One BASELINE training configuration as driver-timed VSE.train_emb steps (model.py:309-369:
+  forward, 4-7 contrastive (+2 reconstruction) losses, backward, Adam) on batch-32 loader batches
+  of an ActivityNet- / DiDeMo-shaped split — forward and backward on the HIP path.  Priced with
+  the step's algorithmic FLOPs against the exact-fp32 MFMA peak and with its dependent-step count."""
   from cmhse_amd.evaluation import LogCollector
-  topt = copy.copy(opt)
-  topt.low_level_loss, topt.norm = True, True
-  model.criterion.norm = True
+  cfg = TRAIN_CONFIGS[name]
+  wl = dict(batch=32, img_dim=cfg['img_dim'], vocab=cfg['vocab'], feat=cfg['feat'])
+  opt = make_opt(wl, rnn_type, embed)
+  for k, v in cfg['flags'].items():
+    setattr(opt, k, v)
+  torch.manual_seed(1)
+  model = VSE(opt)
   model.logger = LogCollector()
-  model.train_start(topt)
+  model.train_start(opt)
+  spec = synthetic.anet_like_spec(wl['batch'] * max(1, min(n_steps, 10)), seed=0,
+                                  dataset=cfg['dataset'])
+  gen = torch.Generator(device=device)
+  batches, clip_pos = [], 0
+  for bi, b0 in enumerate(range(0, spec.n_videos, wl['batch'])):
+    gen.manual_seed(7919 + bi)
+    b1 = min(spec.n_videos, b0 + wl['batch'])
+    batches.append(device_batch(spec, b0, b1, clip_pos, wl['img_dim'], wl['vocab'], wl['feat'], gen,
+                                device))
+    clip_pos += sum(spec.num_clips[b0:b1])
   # steady state: every batch shape of the timed steps has been seen once (the caching allocator
   # and the event pools grow on first sight of a shape — tens of ms that belong to start-up)
   use = [batches[i % len(batches)] for i in range(n_steps)]
   for b in use:
-    model.train_emb(topt, *b)
+    model.train_emb(opt, *b)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for b in use:
-    model.train_emb(topt, *b)
+    model.train_emb(opt, *b)
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / n_steps
-  model.criterion.norm = opt.norm
-  return {'config': 'train_emb, batch %d, img_dim %d, %s pooling, --low_level_loss --norm'
-                    % (wl['batch'], wl['img_dim'], opt.rnn_type),
-          'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt}
+  work = [train_step_work(b, wl['img_dim'], embed, cfg['flags'], rnn_type == 'attention') for b in use]
+  fwd = float(np.mean([w[0] for w in work]))
+  bwd = float(np.mean([w[1] for w in work]))
+  chain = float(np.mean([w[2] for w in work]))
+  mfma_floor_ms = (fwd + bwd) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+  step_us = measured_step_latency_us()       # (forward, backward) us per dependent launch
+  chain_floor_ms = chain * 0.5 * (step_us[0] + step_us[1]) * 1e-3 if step_us else None
+  floor = max(mfma_floor_ms, chain_floor_ms or 0.0)
+  losses = {k: float(m.val) for k, m in model.logger.meters.items() if k.startswith('Le')}
+  del model
+  torch.cuda.empty_cache()
+  return {'config': cfg['baseline'],
+          'flags': ' '.join('--%s' % k if v is True else '--%s %g' % (k, v)
+                            for k, v in sorted(cfg['flags'].items())),
+          'rnn_type': rnn_type, 'batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': embed,
+          'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt,
+          'tflop_per_step': (fwd + bwd) / 1e12, 'tflop_forward': fwd / 1e12,
+          'tflop_backward': bwd / 1e12, 'achieved_tflops': (fwd + bwd) / dt / 1e12,
+          'dependent_steps': chain,
+          'mfma_floor_ms': mfma_floor_ms, 'chain_floor_ms': chain_floor_ms,
+          'chain_step_us': step_us,
+          'frac_of_floor': (floor / (dt * 1e3)) if floor > 0 else None,
+          'bound': 'max(FLOPs / 157.3 TFLOP/s fp32 MFMA, dependent steps x the measured latency '
+                   'of one small-batch step launch on an idle chip)',
+          'last_losses': losses}
+
+
+def measured_step_latency_us():
+  """Latency of ONE dependent small-batch GRU step launch, forward and BPTT (the mid-size step
+  kernels at a handful of sequences on an idle chip, launch gap included), from the committed
+  sweep of the newest round (profiles/r*_step_latency.json: {"forward_us": x, "backward_us": y}).
+  None if absent."""
+  import glob
+  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_step_latency.json')))
+  if not paths:
+    return None
+  try:
+    d = json.load(open(paths[-1]))
+    return float(d['forward_us']), float(d['backward_us'])
+  except (ValueError, KeyError, OSError):
+    return None
 
 
 def measured_traffic(kernel='gru_step'):
@@ -305,6 +481,49 @@ def measured_clock_ghz():
   return None
 
 
+def launch_ranks(n):
+  """`python bench.py --gpus N` from a bare shell: start N rank processes of this same command
+  (fresh children; this parent has not initialised the GPU — torch.cuda.device_count() does not —
+  and nothing is exec'd over it), wait for them, return the worst return code.  Rank 0's stdout
+  is this process's stdout, so exactly one JSON line comes out."""
+  import socket
+  import subprocess
+  n_gpus = torch.cuda.device_count()
+  if n_gpus < 1:
+    sys.stderr.write('bench.py: no GPU visible\n')
+    return 2
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ)
+  env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(n),
+             HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  if n_gpus < n:
+    # fewer GPUs than ranks: the ranks share them and talk over gloo (RCCL needs one device per
+    # rank) — a functional run of the N-rank path, reported as such ("backend" in the JSON)
+    env['CMHSE_BENCH_BACKEND'] = 'gloo'
+    sys.stderr.write('bench.py: %d GPU(s) for %d ranks: sharing GPUs over a gloo group\n'
+                     % (n_gpus, n))
+  procs = []
+  for r in range(n):
+    e = dict(env, RANK=str(r), LOCAL_RANK=str(r % n_gpus))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                  stdout=None if r == 0 else subprocess.DEVNULL))
+  worst, live = 0, set(range(n))
+  while live:
+    for r in sorted(live):
+      rc = procs[r].poll()
+      if rc is None:
+        continue
+      live.discard(r)
+      if rc != 0:
+        worst = worst or rc
+        for q in live:          # a dead rank leaves the others waiting in a collective
+          procs[q].terminate()
+    time.sleep(0.05)
+  return worst
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -314,30 +533,34 @@ def main():
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
-  ap.add_argument('--fast_steps', type=int, default=2,
+  ap.add_argument('--fast_steps', type=int, default=10,
                   help='also time this many passes in the bf16x3 math mode (0 = skip)')
   ap.add_argument('--train_steps', type=int, default=10,
-                  help='also time this many VSE.train_emb steps on loader batches (0 = skip)')
+                  help='also time this many VSE.train_emb steps per BASELINE training config (0 = skip)')
+  ap.add_argument('--train_configs', default='anet_c3d_tau0,anet_icep_tau0,anet_icep_recon,didemo_icep_recon',
+                  help='comma-separated subset of %s' % ', '.join(sorted(TRAIN_CONFIGS)))
   ap.add_argument('--host_steps', type=int, default=2,
                   help='also time this many passes with the loader batches in pinned HOST memory '
                        '(PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--rank_check', type=int, default=1,
                   help='check HIP ranks on correlated embeddings against fp64 NumPy (0 = skip)')
-  ap.add_argument('--cpu_batches', type=int, default=8,
-                  help='loader batches in the CPU-baseline sample (0 = skip)')
+  ap.add_argument('--cpu_batches', type=int, default=16,
+                  help='loader batches in the CPU-baseline sample (16 x 32 = the 512-video subset '
+                       'of BASELINE.md section 3; 0 = skip)')
   args = ap.parse_args()
 
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(launch_ranks(args.gpus))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
-    raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with '
-                     'torch.distributed.run)' % (args.gpus, world))
-  # CMHSE_BENCH_BACKEND=gloo: debugging aid — exercises the N-rank path (deal, gathers, merge,
-  # per-rank report) with every rank on GPU 0 of a box that has fewer GPUs than ranks
+    raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+  # CMHSE_BENCH_BACKEND=gloo: the N-rank path (deal, gathers, merge, per-rank report) with ranks
+  # sharing GPUs on a box that has fewer of them than ranks (set by launch_ranks)
   backend = os.environ.get('CMHSE_BENCH_BACKEND', 'nccl')
   if backend == 'gloo':
-    local_rank = 0
+    local_rank = local_rank % max(1, torch.cuda.device_count())
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
@@ -366,11 +589,16 @@ def main():
   N = spec.n_videos
   quiet = lambda *a, **k: None
 
+  from cmhse_amd.evaluation import report_from_ranks
   phase_ms, phase_sum = {}, {}
+  last = {}
 
   debug = os.environ.get('CMHSE_BENCH_DEBUG', '0') == '1'   # host-side marks of every pass on stderr
 
   def step():
+    """One validation pass, scored: the embeddings are encoded, both directions ranked, the
+    per-batch meters replayed, and the ranks brought to the host and turned into the Recall@K /
+    median-rank report (evaluation.py:173-184) — all inside the timed region."""
     if world == 1:
       h0 = time.perf_counter()
       cat, _, _, finish_log = encode_data_device(opt, model, batches, logging=quiet,
@@ -378,14 +606,18 @@ def main():
       h1 = time.perf_counter()
       r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
+      packed = torch.stack([r_i, t_i, r_t, t_t])
       h2 = time.perf_counter()
       finish_log()     # the per-batch 'Letest' meters (evaluation.py:129), after the ranking is queued
+      host = packed.cpu().numpy().astype(np.float64)     # ONE device-to-host copy for both directions
+      last['rep_i'], last['rep_t'] = report_from_ranks(host[0]), report_from_ranks(host[2])
       if debug:
-        sys.stderr.write('pass host ms: encode queued %.1f, ranking queued %.1f, log flushed %.1f\n'
+        sys.stderr.write('pass host ms: encode queued %.1f, ranking queued %.1f, scored %.1f\n'
                          % ((h1 - h0) * 1e3, (h2 - h1) * 1e3, (time.perf_counter() - h2) * 1e3))
-      return r_i, r_t
+      return host[0], host[2]
     res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed,
                                          assignment=assignment, timings=phase_ms)
+    last['rep_i'], last['rep_t'] = res[0], res[1]
     for k, v in phase_ms.items():
       phase_sum[k] = phase_sum.get(k, 0.0) + v
     return res[2], res[3]
@@ -405,6 +637,7 @@ def main():
     wt.collect()
     wst.collect()
   sync()
+  phase_sum.clear()      # the per-rank phase times below are those of the timed passes only
   if os.environ.get('CMHSE_BENCH_GC_FREEZE', '1') == '1':
     # the loader batches, schedules and modules built so far are ~10^6 long-lived Python objects;
     # an unlucky full collection walks them all in the middle of a pass (tens of ms of host stall
@@ -435,8 +668,9 @@ def main():
   sim_achieved = sim_flops / (sim_ms * 1e-3) / 1e12 if sim_ms > 0 else 0.0
   per_rank = [{'ms_per_step': my_elapsed / args.steps * 1e3}]
   if world > 1:
-    # per-rank phase times of the TIMED passes (warm-up passes are subtracted out by resetting)
-    mine = [my_elapsed / args.steps * 1e3] + [phase_sum.get(k, 0.0) / max(1, args.steps + args.warmup)
+    # per-rank phase times of the TIMED passes: device time between HIP events on the rank's
+    # stream (parallel_eval._Phases) — the passes are not synchronised for them
+    mine = [my_elapsed / args.steps * 1e3] + [phase_sum.get(k, 0.0) / max(1, args.steps)
                                                for k in ('encode_ms', 'exchange_ms', 'score_ms')] + \
         [float(phase_ms.get('videos', 0)), costs_sum(costs, assignment[rank])]
     t = torch.tensor(mine, dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
@@ -460,8 +694,6 @@ def main():
   clk = measured_clock_ghz()
   traffic = measured_traffic('gru_step_kernel<')
   if rank == 0:
-    if isinstance(ranks_i, torch.Tensor):
-      ranks_i = ranks_i.cpu().numpy()
     r1 = 100.0 * float((np.asarray(ranks_i) < 1).mean())
     out = {
         'metric': 'video-paragraph pairs encoded+scored per second (full hot path: hierarchical '
@@ -472,9 +704,21 @@ def main():
         'data': 'synthetic',
         'config': {'workload': args.workload, 'n_videos': N, 'n_clips': len(spec.frames_per_clip),
                    'loader_batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': args.embed,
-                   'rnn_type': args.rnn_type, 'step': 'encode_data + i2t + t2i over the split',
-                   'sharding': 'loader batches dealt to ranks by GRU work (longest paragraph first), one all-gather of the embeddings, row-stripe scoring'},
+                   'rnn_type': args.rnn_type,
+                   'step': 'encode_data + i2t + t2i over the split, ranks on the host and the '
+                           'Recall@K / median-rank report computed (evaluation.py:173-184)',
+                   'sharding': 'loader batches dealt to ranks by GRU work (longest paragraph first), one all-gather of the embeddings, row-stripe scoring',
+                   'backend': ('single process' if world == 1 else
+                               ('RCCL (nccl), one rank per GPU' if backend != 'gloo' else
+                                'gloo, %d ranks sharing %d GPU(s): functional run of the N-rank '
+                                'path, not a scaling measurement' % (world, torch.cuda.device_count())))},
         'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
+        'report_i2t_random_init': {k: float(v) for k, v in last['rep_i'].items()},
+        'report_t2i_random_init': {k: float(v) for k, v in last['rep_t'].items()},
+        # identity of the integer ranks of both directions (partition-independent by construction:
+        # the same value for every n_gpus)
+        'ranks_crc32': zlib.crc32(np.asarray(ranks_i, dtype=np.int64).tobytes() +
+                                  np.asarray(ranks_t, dtype=np.int64).tobytes()),
         'per_rank': per_rank,
         'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -516,8 +760,6 @@ def main():
       out['rank_check'] = rank_check(N, args.embed)
     if world == 1 and args.fast_steps > 0:
       out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)
-    if world == 1 and args.train_steps > 0:
-      out['train_step'] = train_bench(wl, opt, model, batches, args.train_steps)
     if world == 1 and args.host_steps > 0:
       # the reference's loader contract hands over host tensors (activity_net/data.py:114-150):
       # same pass, inputs uploaded inside the timed region (one H2D per loader tensor, no overlap)
@@ -540,9 +782,19 @@ def main():
                                'host_bytes_per_pass': nbytes,
                                'note': 'loader batches in pinned host memory, uploaded inside the '
                                        'timed pass; not the headline value'}
+      del host
     if world == 1 and args.cpu_batches > 0:
       out['cpu_baseline'] = cpu_baseline(wl, opt, model, spec, args.cpu_batches, N)
+    if world == 1 and args.train_steps > 0:
+      # the three BASELINE training configurations (configs[1..3]) as driver-timed train_emb steps
+      del batches, model
+      torch.cuda.empty_cache()
+      out['train_steps'] = {name: train_bench(name, args.embed, args.rnn_type, args.train_steps, device)
+                            for name in args.train_configs.split(',') if name}
+      if 'anet_icep_tau0' in out['train_steps']:      # round 2's key, same configuration
+        out['train_step'] = out['train_steps']['anet_icep_tau0']
     print(json.dumps(out))
+    sys.stdout.flush()
   if world > 1:
     dist.destroy_process_group()
 

@@ -121,10 +121,12 @@ _HOST_EVENTS = []
 
 
 def _host_scalars(n):
+  """A pinned float32 BLOCK of at least n elements (callers slice it for use and hand the whole
+  block back to the pool, so its capacity never shrinks)."""
   for i, h in enumerate(_HOST_SCALARS):
     if h.numel() >= n:
-      return _HOST_SCALARS.pop(i)[:n]
-  return torch.empty(max(n, 1024), dtype=torch.float32).pin_memory()[:n]
+      return _HOST_SCALARS.pop(i)
+  return torch.empty(max(n, 1024), dtype=torch.float32).pin_memory()
 
 
 def _pinned_f32(t):
@@ -325,12 +327,12 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
     """Replay model.logger.update('Letest', value, batch size) (model.py:291) for the groups whose
     loss values have reached the host, batch by batch in loader order."""
     while pending:
-      group, sizes, host, ev, _keep = pending.pop(0)
+      group, sizes, host, ev, block = pending.pop(0)
       if ev is not None:
         ev.synchronize()
       values = host.tolist()
       if ev is not None:
-        _HOST_SCALARS.append(host)     # read: the pinned block may carry the next group's values
+        _HOST_SCALARS.append(block)    # read: the pinned block may carry the next group's values
         _HOST_EVENTS.append(ev)        # ... and its event the next group's copy
       for b, bs, lv in zip(group, sizes, values):
         val_logger.update('Letest', lv, bs)
@@ -355,11 +357,12 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
         num_clips_total.extend(b[8])
         cur_vid_total.extend(b[11])
       if defer_logging:
-        host = _host_scalars(loss_dev.numel())
-        host.copy_(loss_dev.reshape(-1), non_blocking=True)
+        block = _host_scalars(loss_dev.numel())
+        host = block[:loss_dev.numel()]
+        host.copy_(loss_dev.reshape(-1), non_blocking=True)   # (stream-ordered after the loss kernels)
         ev = _HOST_EVENTS.pop() if _HOST_EVENTS else torch.cuda.Event()
         ev.record()
-        pending.append((group, enc['batch_sizes'], host, ev, loss_dev))
+        pending.append((group, enc['batch_sizes'], host, ev, block))
       else:
         pending.append((group, enc['batch_sizes'], loss_dev.cpu(), None, None))
         flush()
@@ -410,6 +413,19 @@ def _rank_report(queries, gallery):
   ranks = rank.cpu().numpy().astype(numpy.float64)      # the reference stores ranks in float64
   top1 = top1.cpu().numpy().astype(numpy.float64)
   return report_from_ranks(ranks), top1, ranks
+
+
+def i2t_t2i(images, captions):
+  """Both directions of train.validate's scoring (train.py:234-236: i2t then t2i on the same two
+  matrices) with ONE device-to-host copy: the two ranking launches are queued back to back and
+  their four int32 vectors come down together.  Returns ((report, top1, ranks) of i2t, same of
+  t2i), each exactly what i2t / t2i return."""
+  v, p = _as_device(images), _as_device(captions)
+  r_i, t_i = ops.sim_rank(v, p)
+  r_t, t_t = ops.sim_rank(p, v)
+  host = torch.stack([r_i, t_i, r_t, t_t]).cpu().numpy().astype(numpy.float64)
+  return ((report_from_ranks(host[0]), host[1], host[0]),
+          (report_from_ranks(host[2]), host[3], host[2]))
 
 
 def i2t(images, captions, npts=None, measure='cosine'):

@@ -175,9 +175,11 @@ class VSE(object):
       params += list(self.sent_seq_dec.parameters())
     self.params = params
     # model.py:160 — torch.optim.Adam(params, lr).  Same optimizer, same state and param_groups
-    # (train.py:269-270 mutates the LR through them); `fused=True` only selects torch's
-    # single-launch implementation of the identical update (15 small launches less at the end of
-    # every step: 12.4 -> 12.2 ms).  CMHSE_FUSED_ADAM=0 keeps torch's default.
+    # (train.py:269-270 mutates the LR through them); `fused=True` selects torch's single-launch
+    # implementation of the same update rule (15 small launches less at the end of every step:
+    # 12.4 -> 12.2 ms).  It is equal to the default implementation within rounding, not guaranteed
+    # bit for bit, and keeps state['step'] as a device tensor; CMHSE_FUSED_ADAM=0 selects torch's
+    # default (what the parity tests against the reference's optimiser trajectory use).
     fused = os.environ.get('CMHSE_FUSED_ADAM', '1') == '1' and all(p.is_cuda for p in params)
     self.optimizer = (torch.optim.Adam(params, lr=opt.learning_rate, fused=True) if fused
                       else torch.optim.Adam(params, lr=opt.learning_rate))
@@ -480,5 +482,9 @@ class VSE(object):
         torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
       self.optimizer.step()
       _tick('adam:done')
-    finally:
-      self._flush_log()
+    except BaseException:
+      # a failed step logs nothing: copying the queued loss values down here could raise a second
+      # error (an asynchronous HIP fault) that hides the first, and would record a partial step
+      self._pending_log = None
+      raise
+    self._flush_log()

@@ -65,30 +65,28 @@ def assign_batches(costs, world):
 
 
 def costs_of(batches, img_dim=None):
-  """Per-batch (work, chain) from the loader's own length tensors (slots 4-7 of the 12-tuple); a
-  batch that carries none (a stub that only says how many videos it has) counts its videos."""
+  """Per-batch (work, chain) from the loader's own length tensors (slots 4-7 of the 12-tuple).
+  If ANY batch carries none (a stub that only says how many videos it has — a loader that
+  materialises only the rank's own batches), EVERY batch is priced by its video count: the deal
+  must be a function of what all ranks see alike, and a stub is all some ranks know of a batch."""
+  if any(b[4] is None or b[7] is None for b in batches):
+    return [(float(len(b[8])), 0) for b in batches]
   out = []
   for b in batches:
-    if b[4] is None or b[7] is None:
-      out.append((float(len(b[8])), 0))
-      continue
     I = img_dim if img_dim is not None else (int(b[0].shape[2]) if hasattr(b[0], 'shape') else 1024)
     out.append(batch_cost(np.asarray(b[4]), np.asarray(b[6]), np.asarray(b[5]), np.asarray(b[7]), I))
   return out
 
 
-_PENDING_LOG = []
-
-
 def _default_encode(opt, model, batches):
+  """(video embeddings, paragraph embeddings, finish): `finish()` replays the per-batch 'Letest'
+  meters (evaluation.py:129); validate_sharded calls it after the exchange and the ranking kernels
+  are queued, so no host sync stands in front of them."""
   if not batches:
     return None
-  # the per-batch 'Letest' meters (evaluation.py:129) are replayed at the end of validate_sharded,
-  # after the exchange and the ranking kernels are queued: no host sync in front of them
   cat, _, _, finish = evaluation.encode_data_device(opt, model, batches, logging=lambda *a: None,
                                                     defer_logging=True)
-  _PENDING_LOG.append(finish)
-  return cat['vid_emb'], cat['para_emb']
+  return cat['vid_emb'], cat['para_emb'], finish
 
 
 def _default_rank(queries, gallery, row0, nrows):
@@ -116,13 +114,89 @@ def all_gather_rows(local, counts, group=None):
   return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)], 0)
 
 
+def all_gather_pair(a, b, counts, group=None):
+  """The exchange step: rows of `a` and `b` (same shape [n_r, D]) of every rank in ONE collective —
+  each rank contributes [max(counts), 2, D] (its a rows and b rows side by side, zero padded) —
+  returned as two contiguous [sum(counts), D] matrices, rank after rank."""
+  world = dist.get_world_size(group)
+  D = int(a.shape[1])
+  mx = max(max(counts), 1)
+  via_host = a.is_cuda and dist.get_backend(group) == 'gloo'
+  dev = torch.device('cpu') if via_host else a.device
+  n = int(a.shape[0])
+  padded = torch.empty((mx, 2, D), dtype=a.dtype, device=dev)
+  padded[:n, 0] = a
+  padded[:n, 1] = b
+  if n < mx:
+    padded[n:].zero_()
+  out = torch.empty((world * mx, 2, D), dtype=a.dtype, device=dev)
+  dist.all_gather_into_tensor(out, padded, group=group)
+  if via_host:
+    out = out.to(a.device)
+  keep = [out[r * mx:r * mx + c] for r, c in enumerate(counts) if c > 0]
+  if not keep:
+    z = torch.zeros(0, D, dtype=a.dtype, device=a.device)
+    return z, z.clone()
+  # the split into two row-major matrices is the one copy (it also drops the padding)
+  A = torch.cat([k[:, 0] for k in keep], 0)
+  B = torch.cat([k[:, 1] for k in keep], 0)
+  return A, B
+
+
+def _same_on_all_ranks(assignment, group, device):
+  """Raise on every rank if the ranks derived different deals (a collective entered with
+  mismatched shapes would hang instead)."""
+  import zlib
+  h = zlib.crc32(repr(assignment).encode()) & 0x7fffffff
+  on_gpu = dist.get_backend(group) != 'gloo' and device is not None and \
+      torch.device(device).type == 'cuda'
+  t = torch.tensor([h, -h], dtype=torch.int64, device=device if on_gpu else 'cpu')
+  dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+  if int(t[0]) != h or int(t[1]) != -h:
+    raise RuntimeError('validate_sharded: the ranks derived different batch-to-rank deals from '
+                       'their loaders; pass the same `assignment` on every rank')
+
+
+_PHASE_EVENTS = {}    # device index -> timing events ready for reuse (creating one while the GPU
+                      # is busy can stall the host for tens of ms, see ops.upload)
+
+
+class _Phases(object):
+  """Phase marks of one sharded pass.  On a GPU they are HIP events on the current stream, read
+  after the pass's own final device-to-host copy — the timed pass is never drained for them."""
+
+  def __init__(self, use_events):
+    self.use_events, self.marks = use_events, []
+    self.pool = _PHASE_EVENTS.setdefault(torch.cuda.current_device(), []) if use_events else None
+
+  def mark(self):
+    if self.use_events:
+      ev = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+      ev.record()
+      self.marks.append(ev)
+    else:
+      self.marks.append(time.perf_counter())
+
+  def spans_ms(self):
+    m = self.marks
+    if self.use_events:
+      m[-1].synchronize()
+      out = [m[i].elapsed_time(m[i + 1]) for i in range(len(m) - 1)]
+      self.pool.extend(m)
+      return out
+    return [(m[i + 1] - m[i]) * 1e3 for i in range(len(m) - 1)]
+
+
 def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_fn=None,
                      device=None, dim=None, assignment=None, timings=None):
   """Sharded counterpart of train.validate's encode_data + i2t + t2i (train.py:223-236).
   Returns (report_i2t, report_t2i, ranks_i2t, ranks_t2i, top1_i2t, top1_t2i) on every rank, rows in
   loader order.  `assignment`: per-rank batch-index lists (default: assign_batches on the loader's
-  lengths).  `timings`: a dict that receives this rank's encode_ms / exchange_ms / score_ms (host
-  clock around device syncs) — measurement only."""
+  lengths, checked to agree across ranks).  `encode_fn(opt, model, batches)` returns None (no
+  batches), (V, P) or (V, P, finish) — `finish()` is called once the ranking is queued.
+  `timings`: a dict that receives this rank's encode_ms / exchange_ms / score_ms — on a GPU from
+  HIP events on the current stream (device time between the marks; the pass is not synchronised
+  for them) — measurement only."""
   encode_fn = encode_fn or _default_encode
   rank_fn = rank_fn or _default_rank
   world = dist.get_world_size(group)
@@ -130,44 +204,53 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   batches = list(data_loader)
   if assignment is None:
     assignment = assign_batches(costs_of(batches), world)
+    _same_on_all_ranks(assignment, group, device)
   sizes = [len(b[8]) for b in batches]
   starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
   # global (loader-order) video index of every row of the gathered matrices, rank after rank
   perm = np.concatenate([np.arange(starts[i], starts[i + 1]) for r in range(world)
                          for i in assignment[r]] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
   counts = [int(sum(sizes[i] for i in assignment[r])) for r in range(world)]
+  on_gpu = torch.cuda.is_available() and device is not None and torch.device(device).type == 'cuda'
+  ph = _Phases(on_gpu) if timings is not None else None
 
-  def sync():
-    if timings is not None and torch.cuda.is_available() and device is not None and \
-        torch.device(device).type == 'cuda':
-      torch.cuda.synchronize()
-    return time.perf_counter()
-
-  t0 = sync()
-  enc = encode_fn(opt, model, [batches[i] for i in assignment[me]])
-  if enc is None:
-    if device is None or dim is None:
-      raise ValueError('a rank with an empty shard needs `device` and `dim`')
-    v_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
-    p_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
-  else:
-    v_loc, p_loc = enc
-  t1 = sync()
-  V = all_gather_rows(v_loc, counts, group)
-  P = all_gather_rows(p_loc, counts, group)
-  t2 = sync()
-  row0 = sum(counts[:me])
-  nrows = counts[me]
-  r_i, t_i = rank_fn(V, P, row0, nrows)
-  r_t, t_t = rank_fn(P, V, row0, nrows)
-  packed = torch.stack([r_i, t_i, r_t, t_t], 1).to(torch.int32)
-  t3 = sync()
-  full = all_gather_rows(packed, counts, group).cpu().numpy()
-  while _PENDING_LOG:
-    _PENDING_LOG.pop()()
-  if timings is not None:
-    timings.update(encode_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3,
-                   score_ms=(t3 - t2) * 1e3, videos=nrows)
+  finish, ok = None, False
+  try:
+    if ph:
+      ph.mark()
+    enc = encode_fn(opt, model, [batches[i] for i in assignment[me]])
+    if enc is None:
+      if device is None or dim is None:
+        raise ValueError('a rank with an empty shard needs `device` and `dim`')
+      v_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
+      p_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
+    else:
+      v_loc, p_loc = enc[0], enc[1]
+      finish = enc[2] if len(enc) > 2 else None
+    if ph:
+      ph.mark()
+    V, P = all_gather_pair(v_loc, p_loc, counts, group)
+    if ph:
+      ph.mark()
+    row0 = sum(counts[:me])
+    nrows = counts[me]
+    r_i, t_i = rank_fn(V, P, row0, nrows)
+    r_t, t_t = rank_fn(P, V, row0, nrows)
+    packed = torch.stack([r_i, t_i, r_t, t_t], 1).to(torch.int32)
+    if ph:
+      ph.mark()
+    full = all_gather_rows(packed, counts, group).cpu().numpy()
+    ok = True
+  finally:
+    # the deferred 'Letest' replay belongs to THIS call: run it, or drop it on an error path (a
+    # failed pass must not leave a closure behind that pins its loader batches and would be
+    # replayed into the next call)
+    fin, finish = finish, None
+    if fin is not None and ok:
+      fin()
+  if ph:
+    enc_ms, exch_ms, score_ms = ph.spans_ms()
+    timings.update(encode_ms=enc_ms, exchange_ms=exch_ms, score_ms=score_ms, videos=nrows)
   # rows are in rank-major (permuted) order: put them back in loader order; a top-1 is an index
   # into the permuted gallery and maps through the same permutation
   n = len(perm)
@@ -177,3 +260,4 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   top1_i[perm], top1_t[perm] = perm[full[:, 1]], perm[full[:, 3]]
   return (evaluation.report_from_ranks(ranks_i), evaluation.report_from_ranks(ranks_t),
           ranks_i, ranks_t, top1_i, top1_t)
+

@@ -1678,3 +1678,4 @@ def test_batched_losses_equal_the_separate_calls(dev, max_violation):
   crit(x1, x1).backward()
   contrastive_losses(crit, [(x2, x2)])[0].backward()
   assert torch.equal(x1.grad, x2.grad)
+

@@ -84,6 +84,87 @@ def test_sharded_validation_matches_single_process(tmp_path, oracle, world, n_vi
     np.testing.assert_array_equal(got['top1_t'], top1_t)
 
 
+def _stub_worker(rank, world, port, out_dir, lie):
+  """Each rank materialises only the batches a count-based deal gives it (the others are stubs
+  that carry only num_clips) and calls validate_sharded WITHOUT an assignment."""
+  sys.path.insert(0, REPO)
+  from cmhse_amd import parallel_eval, synthetic
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  n_videos, batch = 23, 4
+  a, b = synthetic.correlated_embeddings(n_videos, 16, 2.0, seed=5)
+  sizes = [min(n_videos, k0 + batch) - k0 for k0 in range(0, n_videos, batch)]
+  own = parallel_eval.assign_batches([(float(s), 0) for s in sizes], world)[rank]
+  batches = []
+  for i, k0 in enumerate(range(0, n_videos, batch)):
+    k1 = min(n_videos, k0 + batch)
+    bt = [None] * 12
+    bt[8] = tuple([1] * (k1 - k0))
+    if i in own:   # materialised: it carries length arrays, the stubs do not
+      for slot in (4, 5, 6, 7):
+        bt[slot] = np.full(k1 - k0, 3 + i + (rank if lie else 0), dtype=np.int64)
+      bt[0] = (a[k0:k1], b[k0:k1])
+    batches.append(tuple(bt))
+  if lie:          # every rank has "all lengths" but sees different ones: the deals differ
+    batches = [tuple(np.full(len(bt[8]), 5 + 7 * ((i + rank) % 3), dtype=np.int64)
+                     if slot in (4, 5, 6, 7) else bt[slot] for slot in range(12))
+               for i, bt in enumerate(batches)]
+
+  def encode_fn(opt, model, mine):
+    if not mine:
+      return None
+    return (torch.from_numpy(np.concatenate([m[0][0] for m in mine])),
+            torch.from_numpy(np.concatenate([m[0][1] for m in mine])))
+
+  def rank_fn(q, g, row0, nrows):
+    d = q[row0:row0 + nrows].numpy().astype(np.float64) @ g.numpy().astype(np.float64).T
+    diag = d[np.arange(nrows), row0 + np.arange(nrows)][:, None]
+    return (torch.from_numpy((d > diag).sum(1).astype(np.int32)),
+            torch.from_numpy(d.argmax(1).astype(np.int32)))
+
+  try:
+    res = parallel_eval.validate_sharded(None, None, batches, encode_fn=encode_fn,
+                                         rank_fn=rank_fn, device='cpu', dim=16)
+    np.savez(os.path.join(out_dir, 's%d.npz' % rank), ranks_i=res[2], ranks_t=res[3])
+  except RuntimeError as e:
+    open(os.path.join(out_dir, 'err%d.txt' % rank), 'w').write(str(e))
+  dist.destroy_process_group()
+
+
+def test_default_deal_with_per_rank_materialised_loaders(tmp_path, oracle):
+  """a loader that materialises only the rank's own batches hands every rank a
+  different mix of stubs; the default deal must still be the same on all ranks."""
+  from cmhse_amd import synthetic
+  mp.spawn(_stub_worker, args=(2, _free_port(), str(tmp_path), False), nprocs=2, join=True)
+  a, b = synthetic.correlated_embeddings(23, 16, 2.0, seed=5)
+  _, _, ranks_i = oracle.i2t(a, b, np.float64)
+  _, _, ranks_t = oracle.t2i(a, b, np.float64)
+  for r in range(2):
+    got = np.load(os.path.join(str(tmp_path), 's%d.npz' % r))
+    np.testing.assert_array_equal(got['ranks_i'], ranks_i)
+    np.testing.assert_array_equal(got['ranks_t'], ranks_t)
+
+
+def test_diverging_default_deals_raise_instead_of_hanging(tmp_path):
+  mp.spawn(_stub_worker, args=(2, _free_port(), str(tmp_path), True), nprocs=2, join=True)
+  for r in range(2):
+    assert 'different batch-to-rank deals' in open(os.path.join(str(tmp_path), 'err%d.txt' % r)).read()
+
+
+def test_costs_of_prices_by_count_when_any_batch_is_a_stub():
+  from cmhse_amd import parallel_eval
+  full = [None] * 12
+  full[0] = np.zeros((2, 3, 8), np.float32)
+  full[8] = (1, 1)
+  for slot in (4, 5, 6, 7):
+    full[slot] = np.array([3, 2])
+  stub = [None] * 12
+  stub[8] = (1, 1, 1)
+  assert parallel_eval.costs_of([tuple(full), tuple(stub)]) == [(2.0, 0), (3.0, 0)]
+  assert parallel_eval.costs_of([tuple(full)])[0][0] > 1e3
+
+
 def test_shard_range_is_a_partition():
   from cmhse_amd.parallel_eval import shard_range
   for n in [0, 1, 7, 154]:
