@@ -395,9 +395,12 @@ def train_bench(name, embed, rnn_type, n_steps, device):
     clip_pos += sum(spec.num_clips[b0:b1])
   # steady state: every batch shape of the timed steps has been seen once (the caching allocator
   # and the event pools grow on first sight of a shape — tens of ms that belong to start-up)
+  # (two warm-up rounds: building the model left the GPU idle for a second, and a round of ten
+  # steps is too short to bring it back to its working clocks)
   use = [batches[i % len(batches)] for i in range(n_steps)]
-  for b in use:
-    model.train_emb(opt, *b)
+  for _ in range(2):
+    for b in use:
+      model.train_emb(opt, *b)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for b in use:
@@ -760,6 +763,15 @@ def main():
       out['rank_check'] = rank_check(N, args.embed)
     if world == 1 and args.fast_steps > 0:
       out['fast_mode'] = fast_mode_bench(opt, model, batches, N, args.fast_steps)
+    if world == 1 and args.train_steps > 0:
+      # the BASELINE training configurations (configs[1..3]) as driver-timed train_emb steps —
+      # timed while the GPU is still at its working clocks (right behind the validation passes:
+      # after the tens of idle seconds of the CPU baseline the first hundred milliseconds of GPU
+      # work run at idle clocks, and a training leg is only a few hundred milliseconds long)
+      out['train_steps'] = {name: train_bench(name, args.embed, args.rnn_type, args.train_steps, device)
+                            for name in args.train_configs.split(',') if name}
+      if 'anet_icep_tau0' in out['train_steps']:      # round 2's key, same configuration
+        out['train_step'] = out['train_steps']['anet_icep_tau0']
     if world == 1 and args.host_steps > 0:
       # the reference's loader contract hands over host tensors (activity_net/data.py:114-150):
       # same pass, inputs uploaded inside the timed region (one H2D per loader tensor, no overlap)
@@ -785,14 +797,6 @@ def main():
       del host
     if world == 1 and args.cpu_batches > 0:
       out['cpu_baseline'] = cpu_baseline(wl, opt, model, spec, args.cpu_batches, N)
-    if world == 1 and args.train_steps > 0:
-      # the three BASELINE training configurations (configs[1..3]) as driver-timed train_emb steps
-      del batches, model
-      torch.cuda.empty_cache()
-      out['train_steps'] = {name: train_bench(name, args.embed, args.rnn_type, args.train_steps, device)
-                            for name in args.train_configs.split(',') if name}
-      if 'anet_icep_tau0' in out['train_steps']:      # round 2's key, same configuration
-        out['train_step'] = out['train_steps']['anet_icep_tau0']
     print(json.dumps(out))
     sys.stdout.flush()
   if world > 1:

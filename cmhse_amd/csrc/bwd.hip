@@ -19,6 +19,7 @@
 #include "gru_ws.hpp"
 #include "nt_core.hpp"
 #include "tn_core.hpp"
+#include "tn_rows.hpp"
 
 namespace cmhse {
 
@@ -110,6 +111,7 @@ struct RowAddrParams {
   const float* zero_row;
   uint64_t* xaddr;
   uint64_t* hpaddr;
+  uint64_t* hsaddr;   // address of h_{t,s} itself (the B rows of dW_lin), or NULL
   int32_t* p_t;
   int32_t Tmax, I, H, vocab, x_step;
   int64_t sum_T;
@@ -124,7 +126,7 @@ __global__ void row_addr_kernel(const RowAddrParams q) {
     if (q.step_off[mid] <= p) lo = mid; else hi = mid;
   }
   const int t = lo, s = static_cast<int>(p - q.step_off[t]);
-  q.p_t[p] = t;
+  if (q.p_t != nullptr) q.p_t[p] = t;
   if (q.tok_rows != nullptr) {
     long long tok = reinterpret_cast<const long long*>(q.tok_rows[s])[t];
     tok = tok < 0 ? 0 : (tok >= q.vocab ? q.vocab - 1 : tok);
@@ -132,6 +134,8 @@ __global__ void row_addr_kernel(const RowAddrParams q) {
   } else {
     q.xaddr[p] = q.x_rows[s] + static_cast<uint64_t>(t) * q.x_step * 4u;
   }
+  if (q.hsaddr != nullptr) q.hsaddr[p] = reinterpret_cast<uint64_t>(q.hs + p * q.H);
+  if (q.hpaddr == nullptr) return;
   if (t > 0)
     q.hpaddr[p] = reinterpret_cast<uint64_t>(q.hs + (static_cast<int64_t>(q.step_off[t - 1]) + s) * q.H);
   else if (q.h0_rows != nullptr)
@@ -324,7 +328,9 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const TnParams q_) {
 }
 
 // C[m][n] = sum_k A[m][k] B[n][k]; output row m goes to c_addr[m] (or c + m*ldc);
-// mode 0 store, 1 accumulate (+=), 2 atomic add (rows may repeat: embedding-table scatter).
+// mode 0 store, 1 accumulate (+=), 2 atomic add (rows may repeat: embedding-table scatter),
+// 3 store the partial product of K segment blockIdx.y at c + blockIdx.y * M * ldc (dense scratch;
+// splitk_reduce_kernel adds the segments in a fixed order).
 struct NtOutParams {
   const float* a;  // [M, lda]
   int64_t lda;
@@ -377,18 +383,32 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_out_kernel(const NtOutParams
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
       if (m >= q.M) continue;
-      float* crow = q.c_addr ? reinterpret_cast<float*>(q.c_addr[m])
-                             : q.c + static_cast<int64_t>(m) * q.ldc;
+      float* crow = (q.c_addr && q.mode != 3) ? reinterpret_cast<float*>(q.c_addr[m])
+                                              : q.c + static_cast<int64_t>(m) * q.ldc;
+      if (q.mode == 3) crow += static_cast<int64_t>(blockIdx.y) * q.M * q.ldc;
 #pragma unroll
       for (int ns = 0; ns < 2; ++ns) {
         const int n = n0 + b_row0[ns] + acc_col(lane);
         if (n >= q.N) continue;
         const float v = acc[ms][ns][r];
-        if (q.mode == 0) crow[n] = v;
+        if (q.mode == 0 || q.mode == 3) crow[n] = v;
         else if (q.mode == 1) crow[n] += v;
         else atomicAdd(crow + n, v);
       }
     }
+}
+
+// out row m (at c_addr[m]) = part[0][m] + part[1][m] + ... in segment order (bitwise reproducible)
+__global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(const float* __restrict__ part,
+                                                                 const uint64_t* __restrict__ c_addr,
+                                                                 int splits, int M, int N) {
+  const int m = blockIdx.x;
+  float* dst = reinterpret_cast<float*>(c_addr[m]);
+  for (int n = threadIdx.x; n < N; n += kThreads) {
+    float s = 0.f;
+    for (int y = 0; y < splits; ++y) s += part[(static_cast<int64_t>(y) * M + m) * N + n];
+    dst[n] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -883,27 +903,29 @@ static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid), dim3(kThreads), smem, st, q);
 }
 
-// `split_ok`: the caller's C is a dense [M, ldc] matrix this call may zero and fill with atomic
-// adds — the weight-gradient GEMMs have few output tiles (24 x 4 for dW_ih at H = 1024, I = 500)
-// and a long K (all packed rows), so K is split until about three workgroups per CU exist.
+// Split-K for products with few output tiles and a long K: the workgroups of one tile accumulate
+// with float atomics.  `split` = 1: C is a dense [M, ldc = N] matrix this call may zero itself;
+// `split` = 2: the caller's output rows are already zero (rows through c_addr, or mode 2 targets).
 static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
                           int64_t ldc, const uint64_t* c_addr, int M, int N, int K, int mode,
-                          hipStream_t st, bool split_ok = false) {
+                          hipStream_t st, int split = 0) {
   NtOutParams q;
   q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.c = c; q.ldc = ldc; q.c_addr = c_addr;
   q.M = M; q.N = N; q.K = K; q.mode = mode; q.n_tiles = (N + 127) / 128;
   q.k_seg = 0;
   const unsigned grid = static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
   unsigned splits = 1;
-  if (split_ok && mode == 0 && c_addr == nullptr && ldc == N && grid < 512 && K >= 2048) {
+  const bool own_zero = split == 1 && mode == 0 && c_addr == nullptr && ldc == N;
+  const bool pre_zero = split == 2 && (mode == 0 || mode == 2);
+  if ((own_zero || pre_zero) && grid < 512 && K >= 512) {
     splits = (768 + grid - 1) / grid;
-    const unsigned max_splits = static_cast<unsigned>(K / 1024);   // >= 64 chunks per segment
+    const unsigned max_splits = static_cast<unsigned>(K / 256);   // >= 16 chunks per segment
     if (splits > max_splits) splits = max_splits;
     if (splits > 1) {
       q.k_seg = ((K + static_cast<int>(splits) - 1) / static_cast<int>(splits) + 15) / 16 * 16;
       splits = static_cast<unsigned>((K + q.k_seg - 1) / q.k_seg);
       q.mode = 2;
-      (void)hipMemsetAsync(c, 0, static_cast<size_t>(M) * N * sizeof(float), st);
+      if (own_zero) (void)hipMemsetAsync(c, 0, static_cast<size_t>(M) * N * sizeof(float), st);
     }
   }
   const size_t smem = TileSmem<128, 128>::kBytes;
@@ -914,9 +936,74 @@ static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t l
     hipLaunchKernelGGL(gemm_nt_out_kernel<false>, dim3(grid, splits), dim3(kThreads), smem, st, q);
 }
 
+// A product with few output rows and a long K whose rows are written exactly once (d(input) of the
+// level-2 encoders: ~120 rows x K = 3H): one 128-row tile per 128 columns would walk all of K on a
+// handful of CUs (200 us for 0.75 GFLOP).  K is cut into segments, every segment's partial goes
+// to scratch, and a second small launch adds the segments in order — no atomics, reproducible.
+constexpr int kDetSplitRows = 256, kDetSplitMax = 12;
+static size_t det_split_scratch_bytes(int64_t sum_T, int I) {
+  const int64_t rows = sum_T < kDetSplitRows ? sum_T : kDetSplitRows;
+  return static_cast<size_t>(kDetSplitMax) * rows * I * sizeof(float);
+}
+static void launch_nt_rows_once(const float* a, int64_t lda, const float* b, int64_t ldb,
+                                const uint64_t* c_addr, int M, int N, int K, float* scratch,
+                                hipStream_t st) {
+  int splits = K / 256;
+  if (splits > kDetSplitMax) splits = kDetSplitMax;
+  if (M > kDetSplitRows || splits < 2) {
+    launch_nt_out(a, lda, b, ldb, nullptr, 0, c_addr, M, N, K, 0, st);
+    return;
+  }
+  NtOutParams q;
+  q.a = a; q.lda = lda; q.b = b; q.ldb = ldb; q.c = scratch; q.ldc = N; q.c_addr = nullptr;
+  q.M = M; q.N = N; q.K = K; q.mode = 3; q.n_tiles = (N + 127) / 128;
+  q.k_seg = ((K + splits - 1) / splits + 15) / 16 * 16;
+  splits = (K + q.k_seg - 1) / q.k_seg;
+  const unsigned grid = static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
+  const size_t smem = TileSmem<128, 128>::kBytes;
+  const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
+  if (vec)
+    hipLaunchKernelGGL(gemm_nt_out_kernel<true>, dim3(grid, splits), dim3(kThreads), smem, st, q);
+  else
+    hipLaunchKernelGGL(gemm_nt_out_kernel<false>, dim3(grid, splits), dim3(kThreads), smem, st, q);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(kThreads), 0, st, scratch, c_addr, splits, M, N);
+}
+
+// One launch of gemm_tn_rows_kernel: up to kTnRowsMaxProblems products over the packed rows
+// [p0, p1), each C (and bias) stored (accumulate = 0) or added to (1).
+struct TnRowsLaunch {
+  TnRowsGroup g;
+  unsigned grid;
+  TnRowsLaunch() : grid(0) { g.n = 0; }
+  void add(const float* a, int64_t lda, const uint64_t* b_addr, float* c, int64_t ldc, float* bias,
+           int M, int N) {
+    TnRowsProblem& q = g.q[g.n];
+    q.a = a; q.lda = lda; q.b_addr = b_addr; q.c = c; q.ldc = ldc;
+    q.bias = bias; q.M = M; q.N = N; q.n_tiles = (N + 127) / 128;
+    g.start[g.n] = grid;
+    grid += static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
+    ++g.n;
+  }
+  void launch(int64_t p0, int64_t p1, bool accumulate, hipStream_t st) {
+    if (g.n == 0 || p1 <= p0) return;
+    for (int k = g.n; k < kTnRowsMaxProblems; ++k) g.start[k] = 0xffffffffu;
+    // the kernel addresses A rows with 32-bit byte offsets from the first row of the range
+    int64_t max_lda = 1;
+    for (int k = 0; k < g.n; ++k) max_lda = g.q[k].lda > max_lda ? g.q[k].lda : max_lda;
+    const int64_t max_rows = (0x7fffffffLL / (max_lda * 4)) / kBK * kBK;
+    const size_t smem = TileSmem<128, 128>::kBytes;
+    for (int64_t a = p0; a < p1; a += max_rows) {
+      g.p0 = a;
+      g.p1 = (a + max_rows < p1) ? a + max_rows : p1;
+      g.accumulate = (accumulate || a > p0) ? 1 : 0;
+      hipLaunchKernelGGL(gemm_tn_rows_kernel, dim3(grid), dim3(kThreads), smem, st, g);
+    }
+  }
+};
+
 struct BwdWs {
-  size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, p_t, zero_row,
-      colsum, t_a, t_b, total;
+  size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, dxaddr, hsaddr, p_t, zero_row,
+      colsum, dx_part, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -934,12 +1021,12 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.de = take(mode == CMHSE_POOL_ATTN ? static_cast<size_t>(sum_T) * 4 : 0);
   L.xaddr = take(static_cast<size_t>(sum_T) * 8);
   L.hpaddr = take(static_cast<size_t>(sum_T) * 8);
+  L.dxaddr = take(static_cast<size_t>(sum_T) * 8);
+  L.hsaddr = take(mode == CMHSE_POOL_ATTN ? static_cast<size_t>(sum_T) * 8 : 0);
   L.p_t = take(static_cast<size_t>(sum_T) * 4);
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
-  const size_t kp = static_cast<size_t>((sum_T + 3) / 4 * 4);
-  L.t_a = take(static_cast<size_t>(3) * H * kp * 4);
-  L.t_b = take(static_cast<size_t>(H > I ? H : I) * kp * 4);
+  L.dx_part = take(det_split_scratch_bytes(sum_T, I));
   L.total = off;
   return L;
 }
@@ -973,6 +1060,12 @@ struct BwdJob {
   int64_t sum_T, off;     // off: running step offset of the BPTT walk (starts at sum_T)
   int32_t pool_mode;
   BwdStepParams sp;
+  // weight gradients beside the chain: the packed rows [off, chunk_hi) have been produced by the
+  // BPTT steps launched so far and not yet been contracted; `side` is the stream the products of
+  // a closed chunk are launched on (== the main stream when the caller gave none)
+  hipStream_t side;
+  int64_t chunk_hi;
+  bool chunk_first;
 };
 
 int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode,
@@ -1009,7 +1102,9 @@ int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   return CMHSE_OK;
 }
 
-// Phase 1 (pooling backward -> dpool) and the W_hh transpose the BPTT steps read.
+// Phase 1 (pooling backward -> dpool) and the W_hh transpose the BPTT steps read, on `st`; what
+// the chain does not wait for (the row-address tables of the weight-gradient products, dW_lin,
+// db_lin, d att_w) goes to the job's side stream.
 void bwd_begin(BwdJob& j, hipStream_t st) {
   const cmhse_seq_batch* b = j.b;
   const cmhse_gru_weights* w = j.w;
@@ -1026,14 +1121,25 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   float* whh_t = reinterpret_cast<float*>(ws + L.whh_t);
   float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
   float* cs_scratch = reinterpret_cast<float*>(ws + L.colsum);
-  float* t_a = reinterpret_cast<float*>(ws + L.t_a);
-  float* t_b = reinterpret_cast<float*>(ws + L.t_b);
-  const int64_t kp = (sum_T + 3) / 4 * 4;  // packed-row count padded for dwordx4 rows
   const float* dout = j.dout;
   const int pool_mode = j.pool_mode;
+  const bool beside = j.side != st;
 
   (void)hipMemsetAsync(zero_row, 0, static_cast<size_t>(H > I ? H : I) * 4, st);
   (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
+  if (beside) stream_after(j.side, st);     // fork: the caller's inputs (and zero_row) are ready
+  // per packed row: address of x_{t,s} and of h_{t-1,s} — the B operands of dW_ih / dW_hh
+  RowAddrParams rp;
+  rp.x_rows = b->x_rows; rp.tok_rows = b->tok_rows; rp.emb = b->emb_table; rp.h0_rows = b->h0_rows;
+  rp.step_off = b->step_off; rp.hs = hs; rp.zero_row = zero_row;
+  rp.xaddr = reinterpret_cast<uint64_t*>(ws + L.xaddr);
+  rp.hpaddr = reinterpret_cast<uint64_t*>(ws + L.hpaddr);
+  rp.p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
+  rp.hsaddr = (pool_mode == CMHSE_POOL_ATTN) ? reinterpret_cast<uint64_t*>(ws + L.hsaddr) : nullptr;
+  rp.Tmax = b->Tmax; rp.I = I; rp.H = H; rp.vocab = b->vocab; rp.x_step = b->x_step_floats;
+  rp.sum_T = sum_T;
+  hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)), dim3(256),
+                     0, j.side, rp);
   // ---- 1. pooling backward -> dpool ----
   if (pool_mode == CMHSE_POOL_ATTN) {
     float* du = reinterpret_cast<float*>(ws + L.du);
@@ -1047,15 +1153,15 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
     hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(S), dim3(kPoolBwdThreads), 0, st, ap);
     hipLaunchKernelGGL(attn_du_kernel, dim3(static_cast<unsigned>(sum_T)), dim3(kThreads), 0, st,
                        de, v, w->w_att, du, sum_T, H);
-    launch_colsum(v, de, g->dw_att, cs_scratch, sum_T, H, H, st);      // d att_w = sum_p de_p v_p
-    launch_colsum(du, nullptr, g->db_lin, cs_scratch, sum_T, H, H, st);
-    // d W_lin[n][k] = sum_p du[p][n] hs[p][k]
-    launch_gather_t(du, H, nullptr, t_a, sum_T, H, kp, st);
-    launch_gather_t(hs, H, nullptr, t_b, sum_T, H, kp, st);
-    launch_nt_out(t_a, kp, t_b, kp, g->dw_lin, H, nullptr, H, H, static_cast<int>(kp), 0, st, true);
-    // dpool += du . W_lin  (NT on W_lin^T)
+    // the chain needs dpool += du . W_lin  (NT on W_lin^T) ...
     launch_transpose(w->w_lin, wlin_t, H, H, st);
     launch_nt_out(du, H, wlin_t, H, dpool, H, nullptr, static_cast<int>(sum_T), H, H, 1, st);
+    // ... but not d W_lin[n][k] = sum_p du[p][n] hs[p][k], d b_lin = sum_p du[p], d att_w = sum_p de_p v_p
+    if (beside) stream_after(j.side, st);
+    TnRowsLaunch tl;
+    tl.add(du, H, reinterpret_cast<const uint64_t*>(ws + L.hsaddr), g->dw_lin, H, g->db_lin, H, H);
+    tl.launch(0, sum_T, false, j.side);
+    launch_colsum(v, de, g->dw_att, cs_scratch, sum_T, H, H, j.side);
   } else {
     if (pool_mode != CMHSE_POOL_ALL)
       (void)hipMemsetAsync(dpool, 0, static_cast<size_t>(sum_T) * H * 4, st);
@@ -1067,6 +1173,21 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   }
 
   launch_transpose(w->w_hh, whh_t, 3 * H, H, st);
+  if (j.dx_rows || j.d_emb_table)   // d(input) = dGx . W_ih runs on W_ih^T (NT)
+    launch_transpose(w->w_ih, reinterpret_cast<float*>(ws + L.wih_t), 3 * H, I, j.side);
+  if (j.dx_rows || j.d_emb_table) {
+    // the output row of every packed row: d x_{t,s} at dx_rows[s] + t * x_step floats, or the
+    // row of token (t, s) inside d_emb_table (same offset as inside the table)
+    RowAddrParams rq = rp;
+    rq.xaddr = reinterpret_cast<uint64_t*>(ws + L.dxaddr);
+    rq.hpaddr = nullptr;
+    rq.hsaddr = nullptr;
+    rq.p_t = nullptr;
+    if (j.dx_rows) { rq.x_rows = j.dx_rows; rq.tok_rows = nullptr; }
+    else rq.emb = j.d_emb_table;
+    hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)), dim3(256),
+                       0, j.side, rq);
+  }
   BwdStepParams& sp = j.sp;
   sp.whh_t = whh_t; sp.dpool = dpool;
   sp.gates = reinterpret_cast<const float*>(fws + F.gates);
@@ -1075,6 +1196,50 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   sp.dgx = reinterpret_cast<float*>(ws + L.dgx);
   sp.dgh = reinterpret_cast<float*>(ws + L.dgh);
   sp.dh0 = j.dh0; sp.H = H;
+  j.chunk_hi = sum_T;
+  j.chunk_first = true;
+}
+
+// Packed rows a weight-gradient chunk should at least span (K of its products): long enough that
+// a tile's fill / drain and the read-modify-write of its C tile are amortised, short enough that
+// the products of the LAST chunk — the only ones the chain cannot hide — are brief.
+constexpr int64_t kChunkRows = 1024;
+
+// The rows [j.off, j.chunk_hi) are final (the BPTT step that wrote j.off .. has been launched on
+// `st`): contract them into dW_ih / db_ih, dW_hh / db_hh and scatter their d(input), on the side
+// stream, ordered behind that step by an event.
+void bwd_chunk(BwdJob& j, hipStream_t st) {
+  const int64_t p0 = j.off, p1 = j.chunk_hi;
+  if (p1 <= p0) return;
+  const cmhse_seq_batch* b = j.b;
+  const cmhse_gru_grads* g = j.g;
+  const int I = b->I, H = b->H;
+  char* ws = j.ws;
+  const BwdWs& L = j.L;
+  float* dgx = reinterpret_cast<float*>(ws + L.dgx);
+  float* dgh = reinterpret_cast<float*>(ws + L.dgh);
+  if (j.side != st) stream_after(j.side, st);
+  TnRowsLaunch tl;
+  tl.add(dgx, 3 * H, reinterpret_cast<const uint64_t*>(ws + L.xaddr), g->dw_ih, I, g->db_ih, 3 * H, I);
+  tl.add(dgh, 3 * H, reinterpret_cast<const uint64_t*>(ws + L.hpaddr), g->dw_hh, H, g->db_hh, 3 * H, H);
+  tl.launch(p0, p1, !j.chunk_first, j.side);
+  if (j.dx_rows || j.d_emb_table) {
+    // d(input): dx_p = dGx_p . W_ih, rows scattered through the output-row table.  A
+    // time-constant input and the embedding table receive SUMS over packed rows (rows repeat:
+    // float atomics into the caller's zeroed storage, K split when the tiles are few); ordinary
+    // rows are written exactly once, reproducibly.
+    const uint64_t* dxaddr = reinterpret_cast<const uint64_t*>(ws + L.dxaddr) + p0;
+    const float* wih_t = reinterpret_cast<const float*>(ws + L.wih_t);
+    const bool sums = j.d_emb_table != nullptr || b->x_step_floats == 0;
+    if (sums)
+      launch_nt_out(dgx + p0 * 3 * H, 3 * H, wih_t, 3 * H, nullptr, 0, dxaddr,
+                    static_cast<int>(p1 - p0), I, 3 * H, 2, j.side, 2);
+    else
+      launch_nt_rows_once(dgx + p0 * 3 * H, 3 * H, wih_t, 3 * H, dxaddr, static_cast<int>(p1 - p0), I,
+                          3 * H, reinterpret_cast<float*>(ws + L.dx_part), j.side);
+  }
+  j.chunk_hi = p0;
+  j.chunk_first = false;
 }
 
 // Active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel
@@ -1173,76 +1338,24 @@ void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
         hipLaunchKernelGGL((gru_bwd_step_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, st, g);
       }
     }
+    // weight gradients of the rows this launch completed, beside the rest of the chain: a chunk
+    // closes when it spans kChunkRows rows, and at step 0
+    for (int k = 0; k < n; ++k) {
+      BwdJob& j = jobs[k];
+      const int t = j.b->Tmax - 1 - i;
+      if (t < 0) continue;
+      if (t == 0 || j.chunk_hi - j.off >= kChunkRows) bwd_chunk(j, st);
+    }
   }
 }
 
-// Phases 3 and 4: weight gradients over all packed rows, d(input).
+// Join: everything the side stream did for job j is ordered in front of what follows on `st`.
 void bwd_finish(BwdJob& j, hipStream_t st) {
-  const cmhse_seq_batch* b = j.b;
-  const cmhse_gru_weights* w = j.w;
-  const cmhse_gru_grads* g = j.g;
-  const int Tmax = b->Tmax, I = b->I, H = b->H;
-  const int64_t sum_T = j.sum_T;
-  const BwdWs& L = j.L;
-  char* ws = j.ws;
-  const float* hs = reinterpret_cast<const float*>(j.fws + j.F.hs);
-  float* dgx = reinterpret_cast<float*>(ws + L.dgx);
-  float* dgh = reinterpret_cast<float*>(ws + L.dgh);
-  float* wih_t = reinterpret_cast<float*>(ws + L.wih_t);
-  uint64_t* xaddr = reinterpret_cast<uint64_t*>(ws + L.xaddr);
-  uint64_t* hpaddr = reinterpret_cast<uint64_t*>(ws + L.hpaddr);
-  int32_t* p_t = reinterpret_cast<int32_t*>(ws + L.p_t);
-  float* zero_row = reinterpret_cast<float*>(ws + L.zero_row);
-  float* cs_scratch = reinterpret_cast<float*>(ws + L.colsum);
-  float* t_a = reinterpret_cast<float*>(ws + L.t_a);
-  float* t_b = reinterpret_cast<float*>(ws + L.t_b);
-  const int64_t kp = (sum_T + 3) / 4 * 4;
-  const uint64_t* dx_rows = j.dx_rows;
-  float* d_emb_table = j.d_emb_table;
-
-  // ---- 3. weight gradients over all packed rows ----
-  RowAddrParams rp;
-  rp.x_rows = b->x_rows; rp.tok_rows = b->tok_rows; rp.emb = b->emb_table; rp.h0_rows = b->h0_rows;
-  rp.step_off = b->step_off; rp.hs = hs; rp.zero_row = zero_row; rp.xaddr = xaddr;
-  rp.hpaddr = hpaddr; rp.p_t = p_t; rp.Tmax = Tmax; rp.I = I; rp.H = H; rp.vocab = b->vocab;
-  rp.x_step = b->x_step_floats;
-  rp.sum_T = sum_T;
-  hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)), dim3(256),
-                     0, st, rp);
-  // dW_ih[g][i] = sum_p dGx[p][g] x_p[i]: transpose both operands so the packed-row index is
-  // K-contiguous, then the NT tile loop (twice the rate of the [k][m]-staged TN loop)
-  launch_gather_t(dgx, 3 * H, nullptr, t_a, sum_T, 3 * H, kp, st);
-  launch_gather_t(nullptr, 0, xaddr, t_b, sum_T, I, kp, st);
-  launch_nt_out(t_a, kp, t_b, kp, g->dw_ih, I, nullptr, 3 * H, I, static_cast<int>(kp), 0, st, true);
-  launch_gather_t(dgh, 3 * H, nullptr, t_a, sum_T, 3 * H, kp, st);
-  launch_gather_t(nullptr, 0, hpaddr, t_b, sum_T, H, kp, st);
-  launch_nt_out(t_a, kp, t_b, kp, g->dw_hh, H, nullptr, 3 * H, H, static_cast<int>(kp), 0, st, true);
-  launch_colsum(dgx, nullptr, g->db_ih, cs_scratch, sum_T, 3 * H, 3 * H, st);
-  launch_colsum(dgh, nullptr, g->db_hh, cs_scratch, sum_T, 3 * H, 3 * H, st);
-
-  // ---- 4. d(input): dx_p = dgx_p . W_ih, scattered to the caller's rows / the embedding table ----
-  if (dx_rows || d_emb_table) {
-    launch_transpose(w->w_ih, wih_t, 3 * H, I, st);
-    if (dx_rows) {
-      // reuse xaddr as the output row table: d x_{t,s} lives at dx_rows[s] + t*I floats
-      RowAddrParams rq = rp;
-      rq.x_rows = dx_rows; rq.tok_rows = nullptr;
-      hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)),
-                         dim3(256), 0, st, rq);
-      // a time-constant input receives the SUM over its steps: rows repeat -> atomic accumulate
-      // into the caller's (zeroed) rows; ordinary inputs are written exactly once
-      launch_nt_out(dgx, 3 * H, wih_t, 3 * H, nullptr, 0, xaddr, static_cast<int>(sum_T), I, 3 * H,
-                    b->x_step_floats == 0 ? 2 : 0, st);
-    } else {
-      // xaddr[p] = table row of token (t,s); same row offset inside d_emb_table
-      RowAddrParams rq = rp;
-      rq.emb = d_emb_table;
-      hipLaunchKernelGGL(row_addr_kernel, dim3(static_cast<unsigned>((sum_T + 255) / 256)),
-                         dim3(256), 0, st, rq);
-      launch_nt_out(dgx, 3 * H, wih_t, 3 * H, nullptr, 0, xaddr, static_cast<int>(sum_T), I, 3 * H,
-                    2, st);
-    }
+  if (j.off != 0 || j.chunk_hi != 0) {   // (defensive: the t = 0 step always closes the last chunk)
+    j.off = 0;
+    bwd_chunk(j, st);
   }
+  if (j.side != st) stream_after(st, j.side);
 }
 
 }  // namespace
@@ -1258,6 +1371,7 @@ extern "C" int cmhse_gru_pool_bwd_multi(const cmhse_gru_bwd_job* reqs, int32_t n
                                r.dx_rows, r.d_emb_table, r.dh0, r.workspace, r.workspace_bytes,
                                &jobs[k]);
     if (rc != CMHSE_OK) return rc;
+    jobs[k].side = r.side_stream ? static_cast<hipStream_t>(r.side_stream) : st;
   }
   for (int k = 0; k < n_jobs; ++k) bwd_begin(jobs[k], st);
   bwd_steps(jobs, n_jobs, st);
@@ -1274,6 +1388,7 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   r.seqs = b; r.weights = w; r.pool_mode = pool_mode; r.dout = dout;
   r.fwd_workspace = fwd_workspace; r.grads = g; r.dx_rows = dx_rows; r.d_emb_table = d_emb_table;
   r.dh0 = dh0; r.workspace = workspace; r.workspace_bytes = workspace_bytes;
+  r.side_stream = nullptr;
   return cmhse_gru_pool_bwd_multi(&r, 1, stream_);
 }
 

@@ -1188,14 +1188,24 @@ __global__ __launch_bounds__(kThreads) void pad_rows_kernel(const PadRowsParams 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 namespace {
+constexpr int kMaxDevices = 64;
 std::mutex g_event_mutex;
-std::vector<hipEvent_t> g_event_free[2];   // [0] hipEventDisableTiming, [1] timing
+std::vector<hipEvent_t> g_event_free[kMaxDevices][2];   // [device][0 = hipEventDisableTiming, 1 = timing]
+int event_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+  return dev;
+}
 }  // namespace
 
+// An event belongs to the device that was current when it was created; recording it on another
+// device's stream fails.  The free lists are therefore per device, and both calls use the device
+// that is current in the calling thread (the one whose streams the caller passes).
 hipEvent_t event_get(bool timing) {
-  {
+  const int dev = event_device();
+  if (dev >= 0) {
     std::lock_guard<std::mutex> lock(g_event_mutex);
-    std::vector<hipEvent_t>& fl = g_event_free[timing ? 1 : 0];
+    std::vector<hipEvent_t>& fl = g_event_free[dev][timing ? 1 : 0];
     if (!fl.empty()) {
       hipEvent_t ev = fl.back();
       fl.pop_back();
@@ -1209,8 +1219,27 @@ hipEvent_t event_get(bool timing) {
 
 void event_put(hipEvent_t ev, bool timing) {
   if (ev == nullptr) return;
+  const int dev = event_device();
+  if (dev < 0) {
+    (void)hipEventDestroy(ev);
+    return;
+  }
   std::lock_guard<std::mutex> lock(g_event_mutex);
-  g_event_free[timing ? 1 : 0].push_back(ev);
+  g_event_free[dev][timing ? 1 : 0].push_back(ev);
+}
+
+void stream_after(hipStream_t waiter, hipStream_t signal) {
+  hipEvent_t ev = event_get(false);
+  bool ordered = false;
+  if (ev != nullptr) {
+    // (the wait captures the record: the event may be re-recorded right after)
+    ordered = hipEventRecord(ev, signal) == hipSuccess && hipStreamWaitEvent(waiter, ev, 0) == hipSuccess;
+    event_put(ev, false);
+  }
+  if (!ordered) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(signal);     // host-side ordering: slower, never wrong
+  }
 }
 
 int hoist_max_seqs() {   // read per call.  Off by default: measured +2 % at 615 videos, -3 % at 1230
@@ -1585,18 +1614,6 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
 int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool);
-
-// Orders `waiter` behind everything queued on `signal` so far.
-static void stream_after(hipStream_t waiter, hipStream_t signal) {
-  hipEvent_t ev = event_get(false);
-  if (ev != nullptr) {
-    (void)hipEventRecord(ev, signal);
-    (void)hipStreamWaitEvent(waiter, ev, 0);   // captures the record above: the event may be re-recorded
-    event_put(ev, false);
-  } else {
-    (void)hipStreamSynchronize(signal);
-  }
-}
 
 int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;

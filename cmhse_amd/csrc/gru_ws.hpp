@@ -94,15 +94,20 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   return L;
 }
 
-// HIP events are recycled through a process-wide free list (gru.hip): creating one can stall the
-// host for tens of milliseconds when the runtime grows its pools while the GPU is busy (measured:
-// 65 ms inside a validation pass), and the step launcher needs one per stream hand-over, a timer
-// two per tiled launch.  event_get() pops a recycled event of the wanted kind or creates one;
-// event_put() returns it (an event may be re-recorded as soon as nothing waits for its old use:
-// the launcher's wait-events are consumed by hipStreamWaitEvent at enqueue time, the timers'
-// events are read before their handle is destroyed).
+// HIP events are recycled through per-device free lists (gru.hip; the library's one piece of
+// process-wide state, mutex-guarded): creating an event can stall the host for tens of
+// milliseconds when the runtime grows its pools while the GPU is busy (measured: 65 ms inside a
+// validation pass), and the step launcher needs one per stream hand-over, a timer two per tiled
+// launch.  event_get() pops a recycled event of the wanted kind for the CURRENT device or creates
+// one; event_put() returns it to that device's list (an event may be re-recorded as soon as
+// nothing waits for its old use: the launcher's wait-events are consumed by hipStreamWaitEvent at
+// enqueue time, the timers' events are read before their handle is destroyed).
 hipEvent_t event_get(bool timing);
 void event_put(hipEvent_t ev, bool timing);
+
+// Orders `waiter` behind everything queued on `signal` so far (one pooled event; falls back to a
+// host-side hipStreamSynchronize(signal) if the event cannot be recorded or waited for).
+void stream_after(hipStream_t waiter, hipStream_t signal);
 
 // cmhse_timer handle (measurement aid, include/cmhse_hip.h): HIP events owned by the handle.
 struct Timer {

@@ -1,0 +1,258 @@
+// tn_rows.hpp — weight-gradient products straight from the packed rows (exact fp32 MFMA).
+//
+//   C[m][n] (+)= sum_{p = p0}^{p1 - 1} A[p][m] * B_p[n]          bias[m] (+)= sum_p A[p][m]
+//
+// is the shape of every weight gradient of the path: dW_ih = dGx^T X, dW_hh = dGh^T H_prev,
+// dW_lin = dU^T Hs (and db_ih, db_hh, db_lin, the column sums of the same A).  The contraction
+// index is the PACKED ROW p = (time step, sequence): both operands lie row-major with p as the
+// row index, so neither is K-contiguous.  Round 2 copied both through HBM into K-major form
+// (gather_transpose) and ran the NT loop over all rows once the BPTT chain had finished.  Here the
+// transposition happens on the way into LDS:
+//   * global -> registers: thread (c = tid & 127, kg = tid >> 7) loads column c of the 8 packed
+//     rows kg*8 .. kg*8+7 of a 16-row chunk — one dword per row, a wave reading 256 contiguous
+//     bytes of a row; the row base is wave-uniform (a buffer descriptor in scalar registers), the
+//     lane offset constant over the loop, so a load costs no vector-ALU instruction
+//     (nt_core.hpp: vector-ALU work in the K loop costs matrix time);
+//   * registers -> LDS: two ds_write_b128 put those 8 k of column c into the [row = c][16 k] tile
+//     layout of nt_core.hpp (row stride 20 floats: conflict-free for these writes too);
+//   * the MFMA side is nt_phase's: one ds_read_b128 per operand feeds four v_mfma_f32_32x32x2_f32,
+//     the same rotated software pipeline, one barrier per 16 rows.
+// Because a row RANGE is an argument, the product can be taken chunk by chunk while the BPTT chain
+// is still producing earlier time steps (rows of steps >= t are final once the chain has passed t):
+// the launches ride on a side stream beside the latency-bound chain (bwd.hip), accumulate in launch
+// order (no atomics: the gradients are bitwise reproducible), and several products over the same
+// row range share one launch (TnRowsGroup).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "nt_core.hpp"
+
+namespace cmhse {
+
+struct TnRowsProblem {
+  const float* a;          // column m of packed row p at a + p * lda + m
+  int64_t lda;
+  const uint64_t* b_addr;  // [rows] address of the B row of packed row p (N floats)
+  float* c;                // [M, ldc]
+  int64_t ldc;
+  float* bias;             // [M] column sums of A over the row range, or NULL
+  int32_t M, N, n_tiles;   // n_tiles = ceil(N / 128)
+};
+
+constexpr int kTnRowsMaxProblems = 4;
+
+struct TnRowsGroup {
+  TnRowsProblem q[kTnRowsMaxProblems];
+  uint32_t start[kTnRowsMaxProblems];   // first workgroup of problem k
+  int32_t n;
+  int32_t accumulate;   // 0: C (and bias) = the product over the range; 1: += (a later chunk)
+  int64_t p0, p1;       // the packed rows contracted over
+};
+
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2)))
+void gemm_tn_rows_kernel(const TnRowsGroup g) {
+  constexpr int BM = 128, BN = 128, MSUB = 2, NSUB = 2;
+  using SM = TileSmem<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int qi = 0;
+#pragma unroll
+  for (int k = 1; k < kTnRowsMaxProblems; ++k)
+    if (k < g.n && blockIdx.x >= g.start[k]) qi = k;
+  const TnRowsProblem& q = g.q[qi];
+  const unsigned wg = blockIdx.x - g.start[qi];
+  const int n0 = static_cast<int>(wg % q.n_tiles) * BN, m0 = static_cast<int>(wg / q.n_tiles) * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = tid & 127;
+  const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);   // waves 0,1: rows 0..7; waves 2,3: rows 8..15
+  // this thread's column of the A tile / B tile, clamped into the matrix (columns past the edge
+  // compute on a valid column's data and are never stored)
+  const unsigned am = static_cast<unsigned>((m0 + c < q.M) ? (m0 + c) : (q.M - 1));
+  const unsigned bn = static_cast<unsigned>((n0 + c < q.N) ? (n0 + c) : (q.N - 1));
+  const int64_t p0 = g.p0, p1 = g.p1;
+  const int nchunks = static_cast<int>((p1 - p0 + kBK - 1) / kBK);
+  if (nchunks <= 0) return;
+  const bool want_bias = (q.bias != nullptr) && (n0 == 0);   // workgroup-uniform
+  // Row bases are wave-uniform and live in scalar registers.  Loads are BUFFER loads: resource
+  // descriptor (SGPRs: the row's base address) + this lane's constant 32-bit byte offset + a scalar
+  // offset — no vector-ALU instruction per load.  A rows: one descriptor at the first row of the
+  // range, the row selected by the scalar offset; B rows: a descriptor per row, its base read from
+  // the address table through SCALAR loads (constant address space), one chunk ahead of the vector
+  // loads that use it.  Row indices are relative to p0 and 32-bit (the launcher bounds the range
+  // so that row * lda * 4 stays below 2^31).
+  typedef const __attribute__((address_space(4))) uint64_t* cptr_u64;
+  constexpr int kRsrcFlags = 0x00020000;     // raw buffer, 32-bit data format (gfx9 / CDNA)
+  const int nrows = static_cast<int>(p1 - p0);
+  const int lda_b = static_cast<int>(q.lda) * 4;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(q.a + p0 * q.lda), 0, 0x7fffffff, kRsrcFlags);
+  cptr_u64 const b_tab = (cptr_u64)(reinterpret_cast<uintptr_t>(q.b_addr + p0));
+  const unsigned a_off = am * 4u, b_off = bn * 4u;
+
+  float ra[8], rb[8];
+  rowaddr_t nb[8];          // B row bases of the next chunk to load (scalar)
+  float bsum = 0.f;
+  f32x16 acc[MSUB][NSUB];
+#pragma unroll
+  for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) acc[i][j] = zero16();
+
+  // row j of this wave's half of chunk ch, relative to p0, clamped into the range (the tail chunk
+  // re-reads the last row; write_lds masks it)
+  auto row_of = [&](int ch, int j) {
+    const int r = ch * kBK + kg * 8 + j;
+    return (r < nrows) ? r : (nrows - 1);
+  };
+  auto fetch_rows = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nb[j] = b_tab[row_of(ch, j)];
+  };
+  // loads of chunk ch: 8 packed rows, one dword of each operand per row (B bases from `nb`)
+  auto issue_global = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, a_off, row_of(ch, j) * lda_b, 0));
+      const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(nb[j]), 0, 0x7fffffff, kRsrcFlags);
+      rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off, 0, 0));
+    }
+  };
+  auto write_lds = [&](int buf, int ch, auto maskedc) {
+    constexpr bool MASKED = decltype(maskedc)::value;
+    if (MASKED) {
+      const int rk = ch * kBK + kg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (rk + j >= nrows) ra[j] = 0.f;    // A = 0 removes the row from C and from the bias
+    }
+    if (want_bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += ra[j];
+    }
+    float* ap = SM::a(smem, buf) + c * kLdsLd + kg * 8;
+    float* bp = SM::b(smem, buf) + c * kLdsLd + kg * 8;
+    *reinterpret_cast<float4*>(ap) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+    *reinterpret_cast<float4*>(ap + 4) = make_float4(ra[4], ra[5], ra[6], ra[7]);
+    *reinterpret_cast<float4*>(bp) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    *reinterpret_cast<float4*>(bp + 4) = make_float4(rb[4], rb[5], rb[6], rb[7]);
+  };
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const int a_row0 = wm * 64;
+  const int b_row0[NSUB] = {wn * 64, wn * 64 + 32};
+  float4 f0a[MSUB], f0b[NSUB], f1a[MSUB], f1b[NSUB];
+  auto read_frags = [&](int buf, int kb, float4(&fa)[MSUB], float4(&fb)[NSUB]) {
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms)
+      fa[ms] = *reinterpret_cast<const float4*>(SM::a(smem, buf) +
+                                                (a_row0 + ms * 32 + frow) * kLdsLd + kb * 8 + fk);
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+      fb[ns] = *reinterpret_cast<const float4*>(SM::b(smem, buf) +
+                                                (b_row0[ns] + frow) * kLdsLd + kb * 8 + fk);
+  };
+  auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB], auto j0c, auto j1c) {
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+#pragma unroll
+      for (int ms = 0; ms < MSUB; ++ms) {
+        const float av = (j == 0) ? fa[ms].x : (j == 1) ? fa[ms].y : (j == 2) ? fa[ms].z : fa[ms].w;
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          const float bv = (j == 0) ? fb[ns].x : (j == 1) ? fb[ns].y : (j == 2) ? fb[ns].z : fb[ns].w;
+          acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ms][ns], 0, 0, 0);
+        }
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  using Plain = std::integral_constant<bool, false>;
+  using Masked = std::integral_constant<bool, true>;
+  // chunk ch lies wholly inside the range?
+  auto full = [&](int ch) { return (ch + 1) * kBK <= nrows; };
+
+  // the rotated software pipeline of nt_phase (see there): only the barrier is exposed
+  fetch_rows(0);
+  issue_global(0);
+  if (nchunks > 1) fetch_rows(1);
+  if (full(0)) write_lds(0, 0, Plain{}); else write_lds(0, 0, Masked{});
+  __syncthreads();
+  read_frags(0, 0, f0a, f0b);
+  if (nchunks > 1) {
+    issue_global(1);
+    if (nchunks > 2) fetch_rows(2);
+  }
+  read_frags(0, 1, f1a, f1b);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_block(f0a, f0b, I0{}, I3{});
+  __builtin_amdgcn_sched_barrier(0);
+  if (nchunks > 1) {
+    if (full(1)) write_lds(1, 1, Plain{}); else write_lds(1, 1, Masked{});
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_block(f0a, f0b, I3{}, I4{});
+  for (int ch = 1; ch < nchunks; ++ch) {
+    const int cur = ch & 1;
+    const bool more = ch + 1 < nchunks;      // uniform
+    __syncthreads();
+    read_frags(cur, 0, f0a, f0b);
+    if (more) {
+      issue_global(ch + 1);
+      if (ch + 2 < nchunks) fetch_rows(ch + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f1a, f1b, I0{}, I4{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(cur, 1, f1a, f1b);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f0a, f0b, I0{}, I3{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if (full(ch + 1)) write_lds(cur ^ 1, ch + 1, Plain{}); else write_lds(cur ^ 1, ch + 1, Masked{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f0a, f0b, I3{}, I4{});
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_block(f1a, f1b, I0{}, I4{});
+  __syncthreads();
+
+  // ---- epilogue ----
+  const bool accum = g.accumulate != 0;
+  if (want_bias) {
+    // column sums: the two row halves (kg) of every column meet in LDS, fixed order
+    float* red = smem;
+    if (kg == 1) red[c] = bsum;
+    __syncthreads();
+    if (kg == 0 && m0 + c < q.M) {
+      const float s = bsum + red[c];
+      float* dst = q.bias + m0 + c;
+      *dst = accum ? (*dst + s) : s;
+    }
+  }
+  float* const cbase = q.c;
+  const int64_t ldc = q.ldc;
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
+      if (m >= q.M) continue;
+      float* crow = cbase + static_cast<int64_t>(m) * ldc;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        const int n = n0 + b_row0[ns] + acc_col(lane);
+        if (n >= q.N) continue;
+        const float v = acc[ms][ns][r];
+        crow[n] = accum ? (crow[n] + v) : v;
+      }
+    }
+}
+
+}  // namespace cmhse

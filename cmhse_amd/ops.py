@@ -639,6 +639,26 @@ def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
                                   want_dh0=want_dh0)])[0]
 
 
+# Throughput work beside a latency chain (cmhse_gru_bwd_job.side_stream): every stream that runs
+# backward passes gets ONE companion stream, created on first use and kept.  The library forks to
+# it and joins it back inside the call, so the caller's stream semantics do not change and no
+# record_stream bookkeeping is needed (nothing the side stream touches is freed before the join).
+SIDE_STREAMS = [os.environ.get('CMHSE_SIDE_STREAMS', '1') == '1']
+_SIDE_OF = {}
+
+
+def side_stream():
+  """The companion stream of the current stream (None when disabled)."""
+  if not SIDE_STREAMS[0]:
+    return None
+  cur = torch.cuda.current_stream()
+  key = (cur.device.index, cur.cuda_stream)
+  st = _SIDE_OF.get(key)
+  if st is None:
+    st = _SIDE_OF[key] = torch.cuda.Stream(cur.device)
+  return st
+
+
 def gru_pool_bwd_multi(requests):
   """cmhse_gru_pool_bwd_multi: `requests` = keyword dicts of gru_pool_bwd for INDEPENDENT encoders
   (the two towers of a training step); their BPTT steps share launches.  Returns [(grads, dh0)]."""
@@ -647,6 +667,7 @@ def gru_pool_bwd_multi(requests):
     raise ValueError('gru_pool_bwd_multi takes 1..%d requests' % MAX_JOBS)
   jobs = (_lib.GruBwdJob * len(requests))()
   keep, out = [], []
+  side = side_stream()
   for k, r in enumerate(requests):
     grads, dh0, g, dx_dev, ws, ws_bytes, dout = _prepare_bwd(**r)
     fctx = r['fctx']
@@ -662,6 +683,7 @@ def gru_pool_bwd_multi(requests):
     jobs[k].dh0 = dh0.data_ptr() if dh0 is not None else None
     jobs[k].workspace = ws.data_ptr()
     jobs[k].workspace_bytes = ws_bytes
+    jobs[k].side_stream = ctypes.c_void_p(side.cuda_stream) if side is not None else None
     keep.append((g, dx_dev, ws, dout))
     out.append((grads, dh0))
   rc = lib.cmhse_gru_pool_bwd_multi(jobs, len(requests), _stream())

@@ -258,7 +258,9 @@ typedef struct cmhse_gru_grads {
  * pool_mode | CMHSE_SAVE_FOR_BACKWARD).  Writes the parameter gradients to `grads` and, optionally,
  *   dx_rows      [S] device addresses: d loss / d x of step 0 of (sorted) sequence s goes there, rows
  *                of stride I floats (used for the level-2 encoders, whose inputs are level-1
- *                embeddings, model.py:252-253);
+ *                embeddings, model.py:252-253).  Ordinary rows are written exactly once; the
+ *                row of a time-constant input (x_step_floats = 0) receives the SUM over its steps,
+ *                accumulated with float atomics: zero it first;
  *   d_emb_table  [vocab, I]: gradient of embed.weight, ACCUMULATED with float atomics (zero it
  *                first); token batches only (model.py:94);
  *   dh0          [S, H] (row indexing of `out`): d loss / d hidden (layers.py:98-100).
@@ -287,6 +289,16 @@ typedef struct cmhse_gru_bwd_job {
   float* dh0;
   void* workspace;
   size_t workspace_bytes;
+  void* side_stream;   /* optional second hipStream_t (or NULL).  The BPTT chain of a training batch
+                          is a sequence of short dependent launches that leaves most of the chip
+                          idle; the weight-gradient products (dW_ih, dW_hh, the bias sums, dW_lin)
+                          and d(input) are throughput work whose operands — the gate-derivative
+                          rows of steps >= t — are final as soon as the chain has passed t.  With a
+                          side stream they are launched there chunk of time steps by chunk, each
+                          ordered behind the step that completed its rows by an event, and run
+                          beside the rest of the chain; the call joins the side stream back into
+                          `stream` before it returns.  Results are bit-identical with and without
+                          it (the chunks accumulate in the same order either way). */
 } cmhse_gru_bwd_job;
 int cmhse_gru_pool_bwd_multi(const cmhse_gru_bwd_job* jobs, int32_t n_jobs, void* stream);
 
