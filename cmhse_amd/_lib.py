@@ -42,7 +42,7 @@ class SeqBatch(ctypes.Structure):
 class GruJob(ctypes.Structure):
   _fields_ = [('seqs', ctypes.POINTER(SeqBatch)), ('weights', ctypes.POINTER(GruWeights)),
               ('pool_mode', c_int32), ('out', c_void_p), ('workspace', c_void_p),
-              ('workspace_bytes', c_size_t), ('tail_stream', c_void_p)]
+              ('workspace_bytes', c_size_t), ('tail_stream', c_void_p), ('stream', c_void_p)]
 
 
 class GruBwdJob(ctypes.Structure):
@@ -50,7 +50,7 @@ class GruBwdJob(ctypes.Structure):
               ('pool_mode', c_int32), ('dout', c_void_p), ('fwd_workspace', c_void_p),
               ('grads', ctypes.POINTER(GruGrads)), ('dx_rows', c_void_p), ('d_emb_table', c_void_p),
               ('dh0', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_size_t),
-              ('side_stream', c_void_p)]
+              ('stream', c_void_p), ('side_stream', c_void_p)]
 
 
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)

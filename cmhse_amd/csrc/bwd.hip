@@ -1066,6 +1066,7 @@ struct BwdJob {
   hipStream_t side;
   int64_t chunk_hi;
   bool chunk_first;
+  hipStream_t st;         // the stream of this request's chain (its own, or the call's)
 };
 
 int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode,
@@ -1265,7 +1266,7 @@ static int bwd_mid_units(int H, int m_blocks) {
 // Phase 2: BPTT of all jobs, last step first.  Launch i serves step Tmax_k - 1 - i of every job k
 // that still has one (and the extra t = -1 launch of a job that wants d h0); jobs of equal block
 // size share the launch.
-void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
+void bwd_steps(BwdJob* jobs, int n) {
   static const int nw8_max = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
   int longest = 0;
   for (int k = 0; k < n; ++k) longest = jobs[k].b->Tmax > longest ? jobs[k].b->Tmax : longest;
@@ -1303,8 +1304,9 @@ void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
       g.n = 0;
       unsigned grid = 0;
       const int kd = kind[k];
+      hipStream_t st = jobs[k].st;
       for (int m = k; m < n; ++m) {
-        if (kind[m] != kd) continue;
+        if (kind[m] != kd || jobs[m].st != st) continue;   // same kernel, same stream: one launch
         g.j[g.n] = jobs[m].sp;
         g.start[g.n] = grid;
         grid += grid_k[m];
@@ -1344,7 +1346,7 @@ void bwd_steps(BwdJob* jobs, int n, hipStream_t st) {
       BwdJob& j = jobs[k];
       const int t = j.b->Tmax - 1 - i;
       if (t < 0) continue;
-      if (t == 0 || j.chunk_hi - j.off >= kChunkRows) bwd_chunk(j, st);
+      if (t == 0 || j.chunk_hi - j.off >= kChunkRows) bwd_chunk(j, j.st);
     }
   }
 }
@@ -1371,11 +1373,22 @@ extern "C" int cmhse_gru_pool_bwd_multi(const cmhse_gru_bwd_job* reqs, int32_t n
                                r.dx_rows, r.d_emb_table, r.dh0, r.workspace, r.workspace_bytes,
                                &jobs[k]);
     if (rc != CMHSE_OK) return rc;
-    jobs[k].side = r.side_stream ? static_cast<hipStream_t>(r.side_stream) : st;
+    jobs[k].st = r.stream ? static_cast<hipStream_t>(r.stream) : st;
+    jobs[k].side = r.side_stream ? static_cast<hipStream_t>(r.side_stream) : jobs[k].st;
   }
-  for (int k = 0; k < n_jobs; ++k) bwd_begin(jobs[k], st);
-  bwd_steps(jobs, n_jobs, st);
-  for (int k = 0; k < n_jobs; ++k) bwd_finish(jobs[k], st);
+  auto first_use = [&](int k) {   // fork / join every own stream once
+    if (jobs[k].st == st) return false;
+    for (int m = 0; m < k; ++m)
+      if (jobs[m].st == jobs[k].st) return false;
+    return true;
+  };
+  for (int k = 0; k < n_jobs; ++k)
+    if (first_use(k)) stream_after(jobs[k].st, st);
+  for (int k = 0; k < n_jobs; ++k) bwd_begin(jobs[k], jobs[k].st);
+  bwd_steps(jobs, n_jobs);
+  for (int k = 0; k < n_jobs; ++k) bwd_finish(jobs[k], jobs[k].st);
+  for (int k = 0; k < n_jobs; ++k)
+    if (first_use(k)) stream_after(st, jobs[k].st);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
@@ -1388,6 +1401,7 @@ extern "C" int cmhse_gru_pool_bwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   r.seqs = b; r.weights = w; r.pool_mode = pool_mode; r.dout = dout;
   r.fwd_workspace = fwd_workspace; r.grads = g; r.dx_rows = dx_rows; r.d_emb_table = d_emb_table;
   r.dh0 = dh0; r.workspace = workspace; r.workspace_bytes = workspace_bytes;
+  r.stream = nullptr;
   r.side_stream = nullptr;
   return cmhse_gru_pool_bwd_multi(&r, 1, stream_);
 }

@@ -1279,6 +1279,7 @@ struct FwdJob {
   bool hoist_all;            // the input projection of EVERY step is hoisted (xproj at t = 0)
   int64_t rows_split;        // bf16x3: packed rows of the steps the tiled bf16x3 kernel serves
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
+  hipStream_t own_stream;    // optional stream ALL launches of this request go to (forked from / joined into the call's)
   bool pooled;               // attention already launched (early, beside the others' tail)
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
 };
@@ -1629,6 +1630,17 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     if (jobs[k].tail_stream != nullptr && jobs[k].tail_stream != main_stream) side = jobs[k].tail_stream;
   hipStream_t js[kMaxJobs];
   for (int k = 0; k < kMaxJobs; ++k) js[k] = main_stream;
+  // A request with a stream of its own (the towers of a training step: independent latency chains
+  // that should advance side by side from their first step) runs there from start to end; the
+  // host interleaves the launches of all requests step by step, so no chain waits for another
+  // one's launches to be queued.
+  for (int k = 0; k < n; ++k)
+    if (jobs[k].own_stream != nullptr && jobs[k].own_stream != main_stream) {
+      bool seen = false;
+      for (int m = 0; m < k; ++m) seen = seen || js[m] == jobs[k].own_stream;
+      if (!seen) stream_after(jobs[k].own_stream, main_stream);
+      js[k] = jobs[k].own_stream;
+    }
   bool forked = false;
   auto fork = [&](int k) {
     if (side == nullptr || js[k] != main_stream) return;
@@ -1726,6 +1738,12 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     // (b) A request whose chain ends here while others go on: the others continue on the side
     // stream and its attention pass starts now on the caller's stream, so the two overlap (the
     // tail is a few sequences per step: latency-bound launches on an otherwise idle chip).
+    for (int k = 0; k < n; ++k) {   // a chain on its own stream pools as soon as it ends
+      FwdJob& j = jobs[k];
+      if (!j.pooled && js[k] != main_stream && js[k] == j.own_stream && j.pool_mode == CMHSE_POOL_ATTN &&
+          t == j.b->Tmax - 1 && launch_attention(j, js[k], j.sum_T, true) == CMHSE_OK)
+        j.pooled = true;
+    }
     for (int k = 0; k < n; ++k) {
       FwdJob& j = jobs[k];
       if (j.pooled || side == nullptr || js[k] != main_stream || j.pool_mode != CMHSE_POOL_ATTN ||
@@ -1743,7 +1761,8 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       // produced so far: only the rows of their remaining tail steps are left for after the tail
       for (int m = 0; m < n; ++m) {
         FwdJob& o = jobs[m];
-        if (m == k || o.pool_mode != CMHSE_POOL_ATTN || o.pooled || t >= o.b->Tmax - 1 || o.off <= 0)
+        if (m == k || o.pool_mode != CMHSE_POOL_ATTN || o.pooled || t >= o.b->Tmax - 1 || o.off <= 0 ||
+            o.own_stream != nullptr)
           continue;
         if (js[m] != main_stream) stream_after(main_stream, js[m]);   // its steps <= t
         (void)launch_attention(o, main_stream, o.off, false);
@@ -1852,6 +1871,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
                                reqs[k].workspace, reqs[k].workspace_bytes, stream, &jobs[k]);
     if (rc != CMHSE_OK) return rc;
     jobs[k].tail_stream = static_cast<hipStream_t>(reqs[k].tail_stream);
+    jobs[k].own_stream = static_cast<hipStream_t>(reqs[k].stream);
     jobs[k].pooled = false;
     jobs[k].att_rows_done = 0;
   }
@@ -1862,6 +1882,14 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
   if (timer) {
     (void)hipEventRecord(timer->stop, stream);
     timer->launches = launches;
+  }
+  // join the requests' own streams (each once) back into the caller's
+  for (int k = 0; k < n_jobs; ++k) {
+    hipStream_t own = jobs[k].own_stream;
+    if (own == nullptr || own == stream) continue;
+    bool seen = false;
+    for (int m = 0; m < k; ++m) seen = seen || jobs[m].own_stream == own;
+    if (!seen) stream_after(stream, own);
   }
   for (int k = 0; k < n_jobs; ++k) {
     if (jobs[k].pool_mode != CMHSE_POOL_ATTN || jobs[k].pooled) continue;
@@ -1882,6 +1910,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   req.workspace = workspace;
   req.workspace_bytes = workspace_bytes;
   req.tail_stream = nullptr;
+  req.stream = nullptr;
   return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
 }
 

@@ -161,21 +161,21 @@ class _GroupedGRUPoolFn(torch.autograd.Function):
   tensors of _PackedGRUPoolFn per spec, flattened; outputs: one tensor per spec."""
 
   @staticmethod
-  def forward(ctx, specs, *flat):
+  def forward(ctx, specs, streams, *flat):
     reqs, svs = [], []
     for i, spec in enumerate(specs):
       req, sv = _fwd_request(spec, *flat[10 * i:10 * i + 10])
       reqs.append(req)
       svs.append(sv)
-    results = ops.gru_pool_fwd_multi(reqs)
+    results = ops.gru_pool_fwd_multi(reqs, job_streams=streams)
     for sv, (_, fctx) in zip(svs, results):
       sv.fctx = fctx
-    ctx.svs = svs
+    ctx.svs, ctx.streams = svs, streams
     return tuple(out for out, _ in results)
 
   @staticmethod
   def backward(ctx, *grad_outs):
-    need = ctx.needs_input_grad
+    need = ctx.needs_input_grad[1:]      # (after `streams`)
     reqs, extra = [], []
     for i, (sv, g) in enumerate(zip(ctx.svs, grad_outs)):
       if g is None:      # this encoder's output did not reach the loss
@@ -185,15 +185,18 @@ class _GroupedGRUPoolFn(torch.autograd.Function):
       req, dx, dtable = _bwd_request(sv, g, need[1 + 10 * i:1 + 10 * i + 10])
       reqs.append(req)
       extra.append((dx, dtable))
-    out = [None]
-    for (grads, dh0), (dx, dtable) in zip(ops.gru_pool_bwd_multi(reqs), extra):
+    out = [None, None]
+    for (grads, dh0), (dx, dtable) in zip(ops.gru_pool_bwd_multi(reqs, job_streams=ctx.streams), extra):
       out.extend(_grads_tuple(grads, dx, dh0, dtable))
     return tuple(out)
 
 
-def run_grouped(calls):
+def run_grouped(calls, streams=None):
   """`calls`: list of (layer, SeqInput, x, hidden, table) for independent encoders; runs them as
-  ONE autograd node with shared per-step launches and returns their outputs in order."""
+  ONE autograd node and returns their outputs in order.  Without `streams` their time steps share
+  launches on the current stream; with `streams` (one torch stream per call) every encoder is a
+  chain of its own on its stream, forward and backward, and the host queues the launches of all
+  of them step by step — side by side from the first step."""
   flat, specs = [], []
   for layer, spec, x, hidden, table in calls:
     w_lin, b_lin, w_att = layer._extra_weights()
@@ -205,7 +208,7 @@ def run_grouped(calls):
     flat.extend(tensors)
   if len({s.need_grad for s in specs}) > 1:    # mixed: keep them apart (not a training-step case)
     return [_PackedGRUPoolFn.apply(spec, *flat[10 * i:10 * i + 10]) for i, spec in enumerate(specs)]
-  return list(_GroupedGRUPoolFn.apply(specs, *flat))
+  return list(_GroupedGRUPoolFn.apply(specs, None if streams is None else list(streams), *flat))
 
 
 def _lens_numpy(q_len):

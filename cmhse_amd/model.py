@@ -94,17 +94,23 @@ def _word_rows(table, tokens):
   return ops.gather_rows(table, tokens)
 
 
-# A training step's two towers are independent until the losses.  Default: the two towers on two
-# HIP streams (23.4 -> 18.8 ms per step in round 1).  CMHSE_TRAIN_GROUPED=1 instead groups step t
-# of the visual and the text encoder into one launch, forward (cmhse_gru_pool_fwd_multi) and
-# backward (cmhse_gru_pool_bwd_multi), one autograd node per level: half the dependent launches,
-# twice the workgroups in each — measured 15.4 against 14.9 ms per step: at a training batch the
-# step kernels are bound by operand bandwidth per CU, not by launch latency, so a launch with
-# twice the workgroups takes twice as long.  Bit-identical either way (tested).
-TRAIN_GROUPED = [os.environ.get('CMHSE_TRAIN_GROUPED', '0') == '1']
-TRAIN_TWO_STREAMS = [os.environ.get('CMHSE_TRAIN_STREAMS', '1') == '1']
-# the 4-7 contrastive losses of a step as one launch set (loss.contrastive_losses); 0 = one by one
-BATCHED_LOSSES = [os.environ.get('CMHSE_BATCHED_LOSSES', '1') == '1']
+# A training step's two towers (encoders and decoders alike) are independent until the losses, and
+# at training batch sizes every GRU time step is a short, latency-bound launch.  How the two
+# chains are scheduled (TRAIN_SCHEDULE[0], CMHSE_TRAIN_SCHEDULE; all four give the same values, and
+# bit-identical ones wherever the backward pass has no float atomics — tested):
+#   'interleaved'  (default) each level of the two towers is ONE call and ONE autograd node in which
+#                  every tower is a chain on a stream of its own, and the host queues step t of both
+#                  before step t + 1 of either: side by side from the first step, both directions;
+#   'towers'       one call per tower and level, each tower on its own stream (round 2): the second
+#                  tower starts only when the host has queued the whole first one (~100 launches
+#                  forward, ~250 backward);
+#   'grouped'      step t of both towers in one shared launch on one stream (half the dependent
+#                  launches, twice the workgroups each: 15.4 against 14.9 ms per step in round 2 —
+#                  a step kernel at a training batch is bound by operand bandwidth per CU);
+#   'serial'       one stream, one tower after the other.
+TRAIN_SCHEDULE = [os.environ.get('CMHSE_TRAIN_SCHEDULE', 'interleaved')]
+# the 4-7 contrastive losses of a step as one launch set (loss.contrastive_losses); False = one by one
+BATCHED_LOSSES = [True]
 _TOWER_STREAMS = {}
 
 
@@ -333,8 +339,9 @@ class VSE(object):
         sent_recon = self.sent_seq_dec.forward_repeat(cap_recon, lw)
       return cap_emb, para_context, para_emb, cap_recon, sent_recon, word
 
-    def grouped_towers():
-      from .layers import run_grouped
+    def grouped_towers(streams=None):
+      from .layers import run_grouped as _run_grouped
+      run_grouped = lambda calls: _run_grouped(calls, streams)
       _tick('vis:start')
       vis, txt = run_grouped([
           self.clip_enc.rnn.call_multi([clips, videos], [lengths_clip, lengths_video]),
@@ -362,13 +369,16 @@ class VSE(object):
       return ((clip_emb, vid_context, vid_emb, clip_recon, frame_recon),
               (cap_emb, para_context, para_emb, cap_recon, sent_recon, word))
 
-    if TRAIN_GROUPED[0]:
+    schedule = TRAIN_SCHEDULE[0]
+    if schedule not in ('interleaved', 'towers', 'grouped', 'serial'):
+      raise ValueError('unknown training schedule %r' % (schedule,))
+    if schedule == 'interleaved':
+      out_v, out_t = grouped_towers(_tower_streams(clips.device))
+    elif schedule == 'grouped':
       out_v, out_t = grouped_towers()
-    elif TRAIN_TWO_STREAMS[0]:
-      # The two towers (encoders and decoders alike) meet only in the losses.  At training batch
-      # sizes every GRU time step is a short launch; on two HIP streams the launches of one tower
-      # fill the ramps and tails of the other's.  autograd runs each backward node on its forward's
-      # stream, so the two BPTT chains overlap the same way.
+    elif schedule == 'towers':
+      # autograd runs each backward node on its forward's stream, so the two BPTT chains sit on
+      # the towers' streams as well
       main = torch.cuda.current_stream()
       s_vis, s_txt = _tower_streams(clips.device)
       s_vis.wait_stream(main)

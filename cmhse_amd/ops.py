@@ -421,13 +421,15 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, **kw):
                                   device=device, **kw)])[0]
 
 
-def gru_pool_fwd_multi(requests, tail_stream=None):
+def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
   """cmhse_gru_pool_fwd_multi: `requests` is a list of keyword dicts (the arguments of
   gru_pool_fwd) for INDEPENDENT encoders; their time steps share launches.  Returns a list of
   (out, ctx), bit-identical to separate gru_pool_fwd calls.  With `tail_stream` (a torch stream,
   ideally high priority) the steps left over when an attention-pooled request's shorter chain
   has ended continue there while that request's pooling pass runs on the current stream; the
-  call rejoins the current stream before it returns."""
+  call rejoins the current stream before it returns.  With `job_streams` (one torch stream per
+  request) every request runs on its own stream, the launches of all requests interleaved step by
+  step (cmhse_gru_job.stream); forked from and joined into the current stream inside the call."""
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_fwd_multi takes 1..%d requests' % MAX_JOBS)
@@ -440,6 +442,8 @@ def gru_pool_fwd_multi(requests, tail_stream=None):
     jobs[k].out = job['out'].data_ptr()
     jobs[k].workspace = job['ws'].data_ptr()
     jobs[k].workspace_bytes = job['ws_bytes']
+    if job_streams is not None:
+      jobs[k].stream = ctypes.c_void_p(job_streams[k].cuda_stream)
     if tail_stream is not None and len(prepared) > 1:
       jobs[k].tail_stream = ctypes.c_void_p(tail_stream.cuda_stream)
       for t in [job['out'], job['ws'], job['ctx']['sched'].meta] + job['ctx']['keep']:
@@ -449,7 +453,7 @@ def gru_pool_fwd_multi(requests, tail_stream=None):
     handle = lib.cmhse_timer_create()
     prepared[0][0]['b'].step_timer = handle
     StepTimers.active.items.append((handle, [m for _, m in prepared]))
-  if len(prepared) == 1:
+  if len(prepared) == 1 and job_streams is None:
     job = prepared[0][0]
     rc = lib.cmhse_gru_pool_fwd(ctypes.byref(job['b']), ctypes.byref(job['w']), job['mode_flags'],
                                 job['out'].data_ptr(), job['ws'].data_ptr(), job['ws_bytes'],
@@ -647,11 +651,11 @@ SIDE_STREAMS = [os.environ.get('CMHSE_SIDE_STREAMS', '1') == '1']
 _SIDE_OF = {}
 
 
-def side_stream():
-  """The companion stream of the current stream (None when disabled)."""
+def side_stream(cur=None):
+  """The companion stream of `cur` (default: the current stream); None when disabled."""
   if not SIDE_STREAMS[0]:
     return None
-  cur = torch.cuda.current_stream()
+  cur = cur or torch.cuda.current_stream()
   key = (cur.device.index, cur.cuda_stream)
   st = _SIDE_OF.get(key)
   if st is None:
@@ -659,15 +663,16 @@ def side_stream():
   return st
 
 
-def gru_pool_bwd_multi(requests):
+def gru_pool_bwd_multi(requests, job_streams=None):
   """cmhse_gru_pool_bwd_multi: `requests` = keyword dicts of gru_pool_bwd for INDEPENDENT encoders
-  (the two towers of a training step); their BPTT steps share launches.  Returns [(grads, dh0)]."""
+  (the two towers of a training step); their BPTT steps share launches — or, with `job_streams`
+  (one torch stream per request), run as separate chains on those streams with their launches
+  interleaved step by step.  Returns [(grads, dh0)]."""
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_bwd_multi takes 1..%d requests' % MAX_JOBS)
   jobs = (_lib.GruBwdJob * len(requests))()
   keep, out = [], []
-  side = side_stream()
   for k, r in enumerate(requests):
     grads, dh0, g, dx_dev, ws, ws_bytes, dout = _prepare_bwd(**r)
     fctx = r['fctx']
@@ -683,6 +688,9 @@ def gru_pool_bwd_multi(requests):
     jobs[k].dh0 = dh0.data_ptr() if dh0 is not None else None
     jobs[k].workspace = ws.data_ptr()
     jobs[k].workspace_bytes = ws_bytes
+    if job_streams is not None:
+      jobs[k].stream = ctypes.c_void_p(job_streams[k].cuda_stream)
+    side = side_stream(job_streams[k] if job_streams is not None else None)
     jobs[k].side_stream = ctypes.c_void_p(side.cuda_stream) if side is not None else None
     keep.append((g, dx_dev, ws, dout))
     out.append((grads, dh0))

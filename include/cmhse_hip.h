@@ -150,6 +150,13 @@ typedef struct cmhse_gru_job {
                           request whose chain has dropped to small-batch steps while another
                           request still launches LDS-tiled steps that do not fill the chip, so
                           that its short launches run beside those instead of between them. */
+  void* stream;        /* optional hipStream_t of this request's OWN launches (or NULL = the call's
+                          stream).  The towers of a training step are independent latency chains of
+                          short dependent launches: given a stream each, they advance side by side
+                          from their first step — the host queues step t of every request before
+                          step t + 1 of any, so no chain waits for another chain's launches to be
+                          queued.  The call forks the stream from, and joins it back into, the
+                          call's stream.  Results do not depend on it. */
 } cmhse_gru_job;
 int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
 
@@ -289,6 +296,7 @@ typedef struct cmhse_gru_bwd_job {
   float* dh0;
   void* workspace;
   size_t workspace_bytes;
+  void* stream;        /* optional hipStream_t of this request's own launches (see cmhse_gru_job.stream) */
   void* side_stream;   /* optional second hipStream_t (or NULL).  The BPTT chain of a training batch
                           is a sequence of short dependent launches that leaves most of the chip
                           idle; the weight-gradient products (dW_ih, dW_hh, the bias sums, dW_lin)

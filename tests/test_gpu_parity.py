@@ -496,16 +496,15 @@ def test_loss_backward_vs_golden(dev, n):
       grad_close(a2.grad.cpu().numpy(), g[tag + '.da_self'], tag + '.da_self')
 
 
-@pytest.mark.parametrize('schedule', ['grouped', 'two_streams', 'one_stream'])
+@pytest.mark.parametrize('schedule', ['interleaved', 'towers', 'grouped', 'serial'])
 @pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
 def test_train_emb_gradients_vs_golden(dev, rnn_type, schedule, monkeypatch):  # noqa: C901
   """One full VSE.train_emb step (forward, 7 losses, backward, Adam): the parameter gradients
   left in .grad equal the reference's for every encoder, and the parameters moved — with the two
-  towers grouped into shared per-step launches in both directions (default), on two HIP streams,
-  and on one."""
+  towers as interleaved chains on their own streams inside one call per level (default), as one
+  call per tower on two HIP streams, grouped into shared per-step launches, and on one stream."""
   from cmhse_amd import model as model_mod
-  monkeypatch.setattr(model_mod, 'TRAIN_GROUPED', [schedule == 'grouped'])
-  monkeypatch.setattr(model_mod, 'TRAIN_TWO_STREAMS', [schedule == 'two_streams'])
+  monkeypatch.setattr(model_mod, 'TRAIN_SCHEDULE', [schedule])
   g = load_golden('model_%s.npz' % rnn_type)
   batch = torch_batches(golden_batches(g))[1]
   for mv in (0, 1):

@@ -54,8 +54,10 @@ def main():
       os.environ.pop(k, None)
     os.environ.update(arm)
     # host-side switches of cmhse_amd.model (module-level lists), by the same names as their env
-    model_mod.TRAIN_GROUPED[0] = arm.get('CMHSE_TRAIN_GROUPED', '0') == '1'
     model_mod.BATCHED_LOSSES[0] = arm.get('CMHSE_BATCHED_LOSSES', '1') == '1'
+    model_mod.TRAIN_SCHEDULE[0] = arm.get('CMHSE_TRAIN_SCHEDULE', 'interleaved')
+    from cmhse_amd import ops as ops_mod
+    ops_mod.SIDE_STREAMS[0] = arm.get('CMHSE_SIDE_STREAMS', '1') == '1'
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
