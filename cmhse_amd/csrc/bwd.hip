@@ -984,26 +984,80 @@ struct TnRowsLaunch {
     grid += static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
     ++g.n;
   }
-  void launch(int64_t p0, int64_t p1, bool accumulate, hipStream_t st) {
+  // `part`: scratch of `part_floats` floats for the row split's parts (nullptr = never split)
+  void launch(int64_t p0, int64_t p1, bool accumulate, hipStream_t st, float* part = nullptr,
+              int64_t part_floats = 0) {
     if (g.n == 0 || p1 <= p0) return;
     for (int k = g.n; k < kTnRowsMaxProblems; ++k) g.start[k] = 0xffffffffu;
     // the kernel addresses A rows with 32-bit byte offsets from the first row of the range
-    int64_t max_lda = 1;
-    for (int k = 0; k < g.n; ++k) max_lda = g.q[k].lda > max_lda ? g.q[k].lda : max_lda;
+    int64_t max_lda = 1, per_split = 0;
+    for (int k = 0; k < g.n; ++k) {
+      max_lda = g.q[k].lda > max_lda ? g.q[k].lda : max_lda;
+      g.part_off[k] = per_split;
+      per_split += static_cast<int64_t>(g.q[k].M) * g.q[k].N + g.q[k].M;
+    }
     const int64_t max_rows = (0x7fffffffLL / (max_lda * 4)) / kBK * kBK;
     const size_t smem = TileSmem<128, 128>::kBytes;
     for (int64_t a = p0; a < p1; a += max_rows) {
       g.p0 = a;
       g.p1 = (a + max_rows < p1) ? a + max_rows : p1;
       g.accumulate = (accumulate || a > p0) ? 1 : 0;
-      hipLaunchKernelGGL(gemm_tn_rows_kernel, dim3(grid), dim3(kThreads), smem, st, g);
+      // Row split: the number of splits (<= 8, >= 256 rows each, parts fitting the scratch) that
+      // leaves the busiest CU the least above the average, three workgroups per CU being
+      // resident at once; a launch that already fills the chip is not split (its parts would
+      // cost more traffic than the evening-out returns).
+      const int64_t rows = g.p1 - g.p0;
+      int best = 1;
+      if (part != nullptr && grid < 1024) {
+        double best_cost = 1e30;
+        for (int sp = 1; sp <= 8 && (sp == 1 || (rows / sp >= 256 && per_split * sp <= part_floats)); ++sp) {
+          const double wgs = static_cast<double>(grid) * sp;
+          const double per_cu = wgs / 256.0;
+          const double busiest = static_cast<double>((static_cast<int64_t>(wgs) + 255) / 256);
+          // time ~ the busiest CU's share of the work; co-residents below three leave latency exposed
+          const double fill = per_cu >= 3.0 ? 1.0 : (per_cu >= 2.0 ? 1.15 : 1.6);
+          const double cost = busiest / sp * fill * (1.0 + 0.03 * (sp - 1));
+          if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+        }
+      }
+      g.seg = 0;
+      g.part = nullptr;
+      g.part_stride = 0;
+      unsigned splits = 1;
+      if (best > 1) {
+        g.seg = static_cast<int32_t>(((rows + best - 1) / best + kBK - 1) / kBK * kBK);
+        splits = static_cast<unsigned>((rows + g.seg - 1) / g.seg);
+        g.part = part;
+        g.part_stride = per_split;
+      }
+      hipLaunchKernelGGL(gemm_tn_rows_kernel, dim3(grid, splits), dim3(kThreads), smem, st, g);
+      if (splits > 1)
+        for (int k = 0; k < g.n; ++k) {
+          TnRowsReduce r;
+          r.part = part; r.part_stride = per_split; r.part_off = g.part_off[k];
+          r.c = g.q[k].c; r.ldc = g.q[k].ldc; r.bias = g.q[k].bias; r.M = g.q[k].M; r.N = g.q[k].N;
+          r.splits = static_cast<int32_t>(splits); r.accumulate = g.accumulate;
+          const int64_t total = static_cast<int64_t>(r.M) * r.N + r.M;
+          const unsigned blocks = static_cast<unsigned>((total + kThreads * 4 - 1) / (kThreads * 4));
+          hipLaunchKernelGGL(tn_rows_reduce_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(kThreads),
+                             0, st, r);
+        }
     }
   }
 };
 
+// Scratch of the weight-gradient row split (TnRowsLaunch): up to 4 parts of [dW_ih | db_ih | dW_hh |
+// db_hh] (or 8 of the smaller dW_lin); none for a batch too short to be split at all.
+static size_t wg_part_floats(int64_t sum_T, int I, int H) {
+  if (sum_T < 512) return 0;
+  const size_t per_split = static_cast<size_t>(3) * H * (I + H + 2);
+  const size_t want = sum_T / 256 < 4 ? static_cast<size_t>(sum_T / 256) : 4;
+  return per_split * want;
+}
+
 struct BwdWs {
   size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, dxaddr, hsaddr, p_t, zero_row,
-      colsum, dx_part, total;
+      colsum, dx_part, wg_part, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -1027,6 +1081,7 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
   L.dx_part = take(det_split_scratch_bytes(sum_T, I));
+  L.wg_part = take(wg_part_floats(sum_T, I, H) * sizeof(float));
   L.total = off;
   return L;
 }
@@ -1161,7 +1216,8 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
     if (beside) stream_after(j.side, st);
     TnRowsLaunch tl;
     tl.add(du, H, reinterpret_cast<const uint64_t*>(ws + L.hsaddr), g->dw_lin, H, g->db_lin, H, H);
-    tl.launch(0, sum_T, false, j.side);
+    tl.launch(0, sum_T, false, j.side, reinterpret_cast<float*>(ws + L.wg_part),
+              static_cast<int64_t>(wg_part_floats(sum_T, I, H)));
     launch_colsum(v, de, g->dw_att, cs_scratch, sum_T, H, H, j.side);
   } else {
     if (pool_mode != CMHSE_POOL_ALL)
@@ -1223,7 +1279,8 @@ void bwd_chunk(BwdJob& j, hipStream_t st) {
   TnRowsLaunch tl;
   tl.add(dgx, 3 * H, reinterpret_cast<const uint64_t*>(ws + L.xaddr), g->dw_ih, I, g->db_ih, 3 * H, I);
   tl.add(dgh, 3 * H, reinterpret_cast<const uint64_t*>(ws + L.hpaddr), g->dw_hh, H, g->db_hh, 3 * H, H);
-  tl.launch(p0, p1, !j.chunk_first, j.side);
+  tl.launch(p0, p1, !j.chunk_first, j.side, reinterpret_cast<float*>(ws + L.wg_part),
+            static_cast<int64_t>(wg_part_floats(j.sum_T, I, H)));
   if (j.dx_rows || j.d_emb_table) {
     // d(input): dx_p = dGx_p . W_ih, rows scattered through the output-row table.  A
     // time-constant input and the embedding table receive SUMS over packed rows (rows repeat:

@@ -50,9 +50,22 @@ struct TnRowsGroup {
   int32_t n;
   int32_t accumulate;   // 0: C (and bias) = the product over the range; 1: += (a later chunk)
   int64_t p0, p1;       // the packed rows contracted over
+  // Row split (gridDim.y = splits > 1): workgroup (x, y) contracts rows [p0 + y * seg, ...) of tile
+  // x and stores its part of C (dense, leading dimension N) and of the bias into the scratch block
+  // of split y: part + y * part_stride + part_off[problem] (C, then M floats of bias);
+  // tn_rows_reduce_kernel then adds the parts to C in the order of y.  More workgroups per tile —
+  // a launch with few tiles fills the chip, several share a CU and hide each other's latencies —
+  // and the sum is still taken in a fixed order: bitwise reproducible, no atomics.
+  int32_t seg;          // rows per split (multiple of 16); 0 = no split
+  float* part;
+  int64_t part_stride;
+  int64_t part_off[kTnRowsMaxProblems];
 };
 
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2)))
+#ifndef CMHSE_TNROWS_WAVES
+#define CMHSE_TNROWS_WAVES 3
+#endif
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CMHSE_TNROWS_WAVES)))
 void gemm_tn_rows_kernel(const TnRowsGroup g) {
   constexpr int BM = 128, BN = 128, MSUB = 2, NSUB = 2;
   using SM = TileSmem<BM, BN>;
@@ -72,9 +85,12 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
   // compute on a valid column's data and are never stored)
   const unsigned am = static_cast<unsigned>((m0 + c < q.M) ? (m0 + c) : (q.M - 1));
   const unsigned bn = static_cast<unsigned>((n0 + c < q.N) ? (n0 + c) : (q.N - 1));
-  const int64_t p0 = g.p0, p1 = g.p1;
-  const int nchunks = static_cast<int>((p1 - p0 + kBK - 1) / kBK);
-  if (nchunks <= 0) return;
+  int64_t p0 = g.p0, p1 = g.p1;
+  if (g.seg > 0) {
+    p0 += static_cast<int64_t>(blockIdx.y) * g.seg;
+    p1 = (p0 + g.seg < p1) ? (p0 + g.seg) : p1;
+  }
+  const int nchunks = static_cast<int>((p1 - p0 + kBK - 1) / kBK);   // (>= 1: the launcher sizes seg so)
   const bool want_bias = (q.bias != nullptr) && (n0 == 0);   // workgroup-uniform
   // Row bases are wave-uniform and live in scalar registers.  Loads are BUFFER loads: resource
   // descriptor (SGPRs: the row's base address) + this lane's constant 32-bit byte offset + a scalar
@@ -224,7 +240,15 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
   __syncthreads();
 
   // ---- epilogue ----
-  const bool accum = g.accumulate != 0;
+  const bool accum = g.accumulate != 0 && g.seg == 0;    // (a split's part is always stored)
+  float* cbase = q.c;
+  float* bias = q.bias;
+  int64_t ldc = q.ldc;
+  if (g.seg > 0) {
+    cbase = g.part + static_cast<int64_t>(blockIdx.y) * g.part_stride + g.part_off[qi];
+    bias = cbase + static_cast<int64_t>(q.M) * q.N;
+    ldc = q.N;
+  }
   if (want_bias) {
     // column sums: the two row halves (kg) of every column meet in LDS, fixed order
     float* red = smem;
@@ -232,12 +256,10 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
     __syncthreads();
     if (kg == 0 && m0 + c < q.M) {
       const float s = bsum + red[c];
-      float* dst = q.bias + m0 + c;
+      float* dst = bias + m0 + c;
       *dst = accum ? (*dst + s) : s;
     }
   }
-  float* const cbase = q.c;
-  const int64_t ldc = q.ldc;
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
@@ -253,6 +275,29 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
         crow[n] = accum ? (crow[n] + v) : v;
       }
     }
+}
+
+// C[m][n] (+)= part_0[m][n] + part_1[m][n] + ... and bias[m] likewise, in split order.
+struct TnRowsReduce {
+  const float* part;
+  int64_t part_stride, part_off;
+  float* c;
+  int64_t ldc;
+  float* bias;
+  int32_t M, N, splits, accumulate;
+};
+
+__global__ __launch_bounds__(kThreads) void tn_rows_reduce_kernel(const TnRowsReduce q) {
+  const int64_t total = static_cast<int64_t>(q.M) * q.N + (q.bias ? q.M : 0);
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; e < total;
+       e += static_cast<int64_t>(gridDim.x) * kThreads) {
+    float s = 0.f;
+    for (int y = 0; y < q.splits; ++y) s += q.part[y * q.part_stride + q.part_off + e];
+    float* dst;
+    if (e < static_cast<int64_t>(q.M) * q.N) dst = q.c + (e / q.N) * q.ldc + (e % q.N);
+    else dst = q.bias + (e - static_cast<int64_t>(q.M) * q.N);
+    *dst = q.accumulate ? (*dst + s) : s;
+  }
 }
 
 }  // namespace cmhse
