@@ -42,7 +42,8 @@ class SeqBatch(ctypes.Structure):
 class GruJob(ctypes.Structure):
   _fields_ = [('seqs', ctypes.POINTER(SeqBatch)), ('weights', ctypes.POINTER(GruWeights)),
               ('pool_mode', c_int32), ('out', c_void_p), ('workspace', c_void_p),
-              ('workspace_bytes', c_size_t), ('tail_stream', c_void_p), ('stream', c_void_p)]
+              ('workspace_bytes', c_size_t), ('tail_stream', c_void_p), ('stream', c_void_p),
+              ('side_stream', c_void_p)]
 
 
 class GruBwdJob(ctypes.Structure):

@@ -986,7 +986,7 @@ struct TnRowsLaunch {
   }
   // `part`: scratch of `part_floats` floats for the row split's parts (nullptr = never split)
   void launch(int64_t p0, int64_t p1, bool accumulate, hipStream_t st, float* part = nullptr,
-              int64_t part_floats = 0) {
+              int64_t part_floats = 0, bool beside = false) {
     if (g.n == 0 || p1 <= p0) return;
     for (int k = g.n; k < kTnRowsMaxProblems; ++k) g.start[k] = 0xffffffffu;
     // the kernel addresses A rows with 32-bit byte offsets from the first row of the range
@@ -1004,11 +1004,14 @@ struct TnRowsLaunch {
       g.accumulate = (accumulate || a > p0) ? 1 : 0;
       // Row split: the number of splits (<= 8, >= 256 rows each, parts fitting the scratch) that
       // leaves the busiest CU the least above the average, three workgroups per CU being
-      // resident at once; a launch that already fills the chip is not split (its parts would
-      // cost more traffic than the evening-out returns).
+      // resident at once.  A chunk that is not the last one (`beside`: the chain is still running
+      // when it is launched) is split only if its tiles leave CUs empty: there the parts' extra
+      // traffic competes with the chain for the cache fabric both are bound by, and evening out
+      // the last round buys nothing.  (The rule depends on the shapes only, never on whether a
+      // side stream is used: results are bit-identical with and without one.)
       const int64_t rows = g.p1 - g.p0;
       int best = 1;
-      if (part != nullptr && grid < 1024) {
+      if (part != nullptr && grid < (beside ? 256u : 1024u)) {
         double best_cost = 1e30;
         for (int sp = 1; sp <= 8 && (sp == 1 || (rows / sp >= 256 && per_split * sp <= part_floats)); ++sp) {
           const double wgs = static_cast<double>(grid) * sp;
@@ -1280,7 +1283,7 @@ void bwd_chunk(BwdJob& j, hipStream_t st) {
   tl.add(dgx, 3 * H, reinterpret_cast<const uint64_t*>(ws + L.xaddr), g->dw_ih, I, g->db_ih, 3 * H, I);
   tl.add(dgh, 3 * H, reinterpret_cast<const uint64_t*>(ws + L.hpaddr), g->dw_hh, H, g->db_hh, 3 * H, H);
   tl.launch(p0, p1, !j.chunk_first, j.side, reinterpret_cast<float*>(ws + L.wg_part),
-            static_cast<int64_t>(wg_part_floats(j.sum_T, I, H)));
+            static_cast<int64_t>(wg_part_floats(j.sum_T, I, H)), p0 > 0);
   if (j.dx_rows || j.d_emb_table) {
     // d(input): dx_p = dGx_p . W_ih, rows scattered through the output-row table.  A
     // time-constant input and the embedding table receive SUMS over packed rows (rows repeat:

@@ -708,7 +708,8 @@ struct XprojParams {
   const int32_t* step_off;
   const float* w_ih;
   float* gx;
-  int64_t p0, rows;
+  int64_t p0, rows;      // gx row m is packed row p0 + m; this launch computes gx rows [m_begin, rows)
+  int64_t m_begin;
   int32_t I, N, vocab, x_step, Tmax, t_first, n_tiles, per_seq;
 };
 
@@ -719,7 +720,7 @@ void xproj_kernel(const XprojParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int n0 = (blockIdx.x % p.n_tiles) * BN;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
+  const int64_t m0 = p.m_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
   const int srow = tid >> 2;
   rowaddr_t ar[1], br[BN / 64];
   bool av[1], bv[BN / 64];
@@ -1280,6 +1281,7 @@ struct FwdJob {
   int64_t rows_split;        // bf16x3: packed rows of the steps the tiled bf16x3 kernel serves
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
   hipStream_t own_stream;    // optional stream ALL launches of this request go to (forked from / joined into the call's)
+  hipStream_t side_stream;   // optional stream for throughput work beside a small-batch chain (projection chunks, attention)
   bool pooled;               // attention already launched (early, beside the others' tail)
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
 };
@@ -1507,8 +1509,9 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
   return k | (j.vec ? 0 : 4);
 }
 
-// The input projection of every step >= t_mid of a job, launched once before the first of them.
-void launch_xproj(const FwdJob& j, hipStream_t stream) {
+// The input projection of the steps >= t_mid of a job: gx rows [m_begin, m_end) (relative to the
+// first hoisted row; m_end < 0 = all of them).
+void launch_xproj(const FwdJob& j, hipStream_t stream, int64_t m_begin = 0, int64_t m_end = -1) {
   const cmhse_seq_batch* b = j.b;
   const int t_first = j.hoist_all ? 0 : j.t_mid;
   XprojParams q;
@@ -1521,6 +1524,8 @@ void launch_xproj(const FwdJob& j, hipStream_t stream) {
   q.p0 = j.p.gx_p0;
   q.per_seq = j.p.gx_per_seq;
   q.rows = q.per_seq ? b->step_count_host[t_first] : (j.sum_T - j.p.gx_p0);
+  if (m_end >= 0 && m_end < q.rows) q.rows = m_end;
+  q.m_begin = m_begin;
   q.I = b->I;
   q.N = 3 * b->H;
   q.vocab = b->vocab;
@@ -1528,7 +1533,8 @@ void launch_xproj(const FwdJob& j, hipStream_t stream) {
   q.Tmax = b->Tmax;
   q.t_first = t_first;
   q.n_tiles = (q.N + 191) / 192;
-  const int64_t grid = static_cast<int64_t>(q.n_tiles) * ((q.rows + 63) / 64);
+  const int64_t grid = static_cast<int64_t>(q.n_tiles) * ((q.rows - q.m_begin + 63) / 64);
+  if (grid <= 0) return;
   const size_t smem = TileSmem<64, 192>::kBytes;
   hipLaunchKernelGGL(xproj_kernel, dim3(static_cast<unsigned>(grid)), dim3(kThreads), smem, stream, q);
 }
@@ -1616,8 +1622,16 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 // Time steps of all jobs, step t of every still-running job in as few launches as kinds allow.
 int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool);
 
+// Rows of the input projection in front of a chunked chain / per later chunk (launch_steps)
+constexpr int64_t kXprojFirstRows = 512, kXprojChunkRows = 1536;
+struct XprojPlan {
+  std::vector<int> step;        // first step of chunk c (c >= 1)
+  std::vector<hipEvent_t> ev;   // recorded behind chunk c's launch on the side stream
+};
+
 int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;
+  XprojPlan plan[kMaxJobs];
   // Every chain starts on the caller's stream; a chain moves to the call's side stream (at most
   // once, ordered by an event) when it should run BESIDE the others instead of between them:
   //   (a) it has dropped to small-batch steps while another chain still launches LDS-tiled steps
@@ -1688,8 +1702,50 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
           for (int q = t + 1; q < j.b->Tmax; ++q)
             if (j.b->step_events_host[q] != nullptr)
               (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[q])), 0);
-        launch_xproj(j, stream);
+        // A chain that is small-batch from its first step (a training batch) with a side stream:
+        // only the projection of the first steps stands in front of the chain; the rest is cut
+        // into chunks of time steps that run on the side stream BESIDE the chain, step t waiting
+        // (event) for the chunk that holds its rows.  A GEMM of img_dim = 2048 rows is as long as
+        // the whole 80-step chain it used to precede.
+        const bool chunked = j.side_stream != nullptr && j.side_stream != stream && t == 0 &&
+                             j.t_mid == 0 && !j.p.gx_per_seq && j.sum_T >= 4 * kXprojChunkRows;
+        if (!chunked) {
+          launch_xproj(j, stream);
+        } else {
+          XprojPlan& xp = plan[k];
+          int64_t row = 0, chunk_begin = 0;
+          int t0 = 0;
+          for (int q = 0; q < j.b->Tmax; ++q) {
+            row += j.b->step_count_host[q];
+            const int64_t want = (t0 == 0) ? kXprojFirstRows : kXprojChunkRows;
+            if (row - chunk_begin >= want || q == j.b->Tmax - 1) {
+              if (t0 == 0) {
+                launch_xproj(j, stream, 0, row);
+                stream_after(j.side_stream, stream);     // fork: the inputs are ready
+              } else {
+                launch_xproj(j, j.side_stream, chunk_begin, row);
+                hipEvent_t ev = event_get(false);
+                if (ev != nullptr && hipEventRecord(ev, j.side_stream) == hipSuccess) {
+                  xp.step.push_back(t0);
+                  xp.ev.push_back(ev);
+                } else {                                  // no event: order the whole stream instead
+                  event_put(ev, false);
+                  (void)hipGetLastError();
+                  (void)hipStreamSynchronize(j.side_stream);
+                }
+              }
+              chunk_begin = row;
+              t0 = q + 1;
+            }
+          }
+        }
       }
+      for (size_t c = 0; c < plan[k].step.size(); ++c)
+        if (plan[k].step[c] == t) {     // the chunk that holds step t's rows
+          (void)hipStreamWaitEvent(stream, plan[k].ev[c], 0);
+          event_put(plan[k].ev[c], false);
+          plan[k].ev[c] = nullptr;
+        }
       j.p.S_t = S_t;
       j.p.off_prev = j.off - (t > 0 ? j.b->step_count_host[t - 1] : 0);
       j.p.off_cur = j.off;
@@ -1872,6 +1928,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     if (rc != CMHSE_OK) return rc;
     jobs[k].tail_stream = static_cast<hipStream_t>(reqs[k].tail_stream);
     jobs[k].own_stream = static_cast<hipStream_t>(reqs[k].stream);
+    jobs[k].side_stream = static_cast<hipStream_t>(reqs[k].side_stream);
     jobs[k].pooled = false;
     jobs[k].att_rows_done = 0;
   }
@@ -1911,6 +1968,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   req.workspace_bytes = workspace_bytes;
   req.tail_stream = nullptr;
   req.stream = nullptr;
+  req.side_stream = nullptr;
   return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
 }
 

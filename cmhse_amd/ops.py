@@ -444,6 +444,10 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
     jobs[k].workspace_bytes = job['ws_bytes']
     if job_streams is not None:
       jobs[k].stream = ctypes.c_void_p(job_streams[k].cuda_stream)
+    if job['mode_flags'] & SAVE_FOR_BACKWARD:      # a training call: throughput work beside the chain
+      side = side_stream(job_streams[k] if job_streams is not None else None)
+      if side is not None:
+        jobs[k].side_stream = ctypes.c_void_p(side.cuda_stream)
     if tail_stream is not None and len(prepared) > 1:
       jobs[k].tail_stream = ctypes.c_void_p(tail_stream.cuda_stream)
       for t in [job['out'], job['ws'], job['ctx']['sched'].meta] + job['ctx']['keep']:
@@ -453,7 +457,7 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
     handle = lib.cmhse_timer_create()
     prepared[0][0]['b'].step_timer = handle
     StepTimers.active.items.append((handle, [m for _, m in prepared]))
-  if len(prepared) == 1 and job_streams is None:
+  if len(prepared) == 1 and job_streams is None and not jobs[0].side_stream:
     job = prepared[0][0]
     rc = lib.cmhse_gru_pool_fwd(ctypes.byref(job['b']), ctypes.byref(job['w']), job['mode_flags'],
                                 job['out'].data_ptr(), job['ws'].data_ptr(), job['ws_bytes'],
@@ -659,6 +663,8 @@ def side_stream(cur=None):
   key = (cur.device.index, cur.cuda_stream)
   st = _SIDE_OF.get(key)
   if st is None:
+    # (default priority, like the chain's stream: with either of the two raised the step is
+    # 8-17 % slower — measured, profiles/r03_train_ab.txt)
     st = _SIDE_OF[key] = torch.cuda.Stream(cur.device)
   return st
 

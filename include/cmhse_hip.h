@@ -157,6 +157,12 @@ typedef struct cmhse_gru_job {
                           step t + 1 of any, so no chain waits for another chain's launches to be
                           queued.  The call forks the stream from, and joins it back into, the
                           call's stream.  Results do not depend on it. */
+  void* side_stream;   /* optional hipStream_t (or NULL) for throughput work beside a chain that is
+                          small-batch from its first step (a training batch): the hoisted input
+                          projection x W_ih^T is then cut into chunks of time steps — only the first
+                          stands in front of the chain, the others run on side_stream beside it, step
+                          t waiting (event) for the chunk that holds its rows.  Results do not
+                          depend on it. */
 } cmhse_gru_job;
 int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
 

@@ -32,6 +32,7 @@ def main():
   ap.add_argument('--rounds', type=int, default=5)
   ap.add_argument('--steps', type=int, default=8)
   ap.add_argument('--rnn_type', default='attention')
+  ap.add_argument('--resident', type=int, default=1, help='1: batches resident in HBM (what bench.py times); 0: pinned host batches')
   args = ap.parse_args()
   arms = [dict(kv.split('=') for kv in m.split(',') if kv) for m in args.modes.split(';')]
   keys = sorted({k for a in arms for k in a})
@@ -45,7 +46,10 @@ def main():
   model = VSE(opt)
   spec = synthetic.anet_like_spec(32 * 4, seed=0, dataset=wl['dataset'])
   batches = synthetic.make_batches(spec, 32, wl['img_dim'], wl['vocab'], seed=0, feat=wl['feat'])
-  batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
+  if args.resident:
+    batches = [tuple(t.cuda() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)) for b in batches]
+  else:
+    batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
   model.logger = LogCollector()
   model.train_start(opt)
 

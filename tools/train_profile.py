@@ -36,6 +36,7 @@ def main():
   ap.add_argument('--config', default='icep_recon', choices=sorted(CONFIGS))
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--rnn_type', default='attention')
+  ap.add_argument('--resident', type=int, default=1, help='1: batches resident in HBM (what bench.py times); 0: pinned host batches')
   ap.add_argument('--timeline', type=int, default=0, help='host (h) / GPU (g) ms at phase marks')
   args = ap.parse_args()
   cfg = dict(CONFIGS[args.config])
@@ -48,7 +49,10 @@ def main():
   model = VSE(opt)
   spec = synthetic.anet_like_spec(32 * 4, seed=0, dataset=wl['dataset'])
   batches = synthetic.make_batches(spec, 32, wl['img_dim'], wl['vocab'], seed=0, feat=wl['feat'])
-  batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
+  if args.resident:
+    batches = [tuple(t.cuda() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)) for b in batches]
+  else:
+    batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
   model.logger = LogCollector()
   model.train_start(opt)
   use = [batches[i % len(batches)] for i in range(args.steps + 3)]
