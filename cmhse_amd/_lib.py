@@ -122,6 +122,7 @@ SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(c_int32)]),
+    'cmhse_tune': (ctypes.c_int, [ctypes.c_char_p, c_int32, ctypes.POINTER(c_int32)]),
     'cmhse_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'cmhse_version': (ctypes.c_char_p, []),
 }

@@ -33,12 +33,15 @@ def is_stale():
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-  if not force and not is_stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+  """Build the product library (default) or, with `out` / `extra_flags`, another build of the same
+  sources at another path (tools/: instrumented builds; load it through CMHSE_HIP_LIB)."""
+  global LIB
+  if out is None and not extra_flags and not force and not is_stale():
     return LIB
+  target = out or LIB
   cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-o', LIB + '.tmp'] + [os.path.join(CSRC, s) for s in SOURCES]
-  cmd[1:1] = os.environ.get('CMHSE_HIPCC_FLAGS', '').split()   # experiments: extra -D switches
+         '-o', target + '.tmp'] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
   if verbose:
     cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
   res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -46,8 +49,8 @@ def build(force=False, verbose=False):
     raise RuntimeError('hipcc failed:\n' + res.stdout)
   if verbose:
     print(res.stdout)
-  os.replace(LIB + '.tmp', LIB)
-  return LIB
+  os.replace(target + '.tmp', target)
+  return target
 
 
 if __name__ == '__main__':

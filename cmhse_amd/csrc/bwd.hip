@@ -1304,30 +1304,22 @@ void bwd_chunk(BwdJob& j, hipStream_t st) {
 }
 
 // Active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel
-// (CMHSE_BWD_MID_MAX_SEQS, read per call; 0 = never), and its hidden units per workgroup
-// (CMHSE_BWD_MID_UNITS = 16 | 8 | 4 forces one).
-static int bwd_mid_max_seqs() {
-  const char* e = getenv("CMHSE_BWD_MID_MAX_SEQS");
-  return e ? atoi(e) : 512;
-}
-static int bwd_mid_units(int H, int m_blocks) {
-  const char* e = getenv("CMHSE_BWD_MID_UNITS");
-  const int forced = e ? atoi(e) : 0;
-  if (forced == 16 || forced == 8 || forced == 4) return forced;
-  // Unlike the forward step (K = H), narrower tiles LOSE here: the 32 dgh rows of K = 3H floats
-  // (384 KB) every workgroup pulls dominate, and 128-256 workgroups of them cost more L2 bandwidth
-  // than the spread gains (train_emb step, C3D: 16 units 12.8 ms, 8 units 16.0, 4 units 15.9; later,
-  // at 11.3 ms, 32 units — two column blocks per wave — 11.9).
-  (void)H;
-  (void)m_blocks;
-  return 16;
-}
+// (Tunables::bwd_mid_max_seqs; 0 = never).  Its unit tile is 16: unlike the forward step (K = H),
+// narrower tiles LOSE here — the 32 dgh rows of K = 3H floats (384 KB) every workgroup pulls
+// dominate, and 128-256 workgroups of them cost more L2 bandwidth than the spread gains (train_emb
+// step, C3D: 16 units 12.8 ms, 8 units 16.0, 4 units 15.9; later, at 11.3 ms, 32 units — two column
+// blocks per wave — 11.9).
+static int bwd_mid_max_seqs() { return tunables().bwd_mid_max_seqs.load(std::memory_order_relaxed); }
+constexpr int kBwdMidUnits = 16;
+// active sequences at or below which the 32 x 32-tile BPTT step (unaligned shapes, large batches)
+// splits K over 8 waves instead of 4: a pure latency chain on an under-filled chip
+constexpr int kBwdNw8Max = 256;
 
 // Phase 2: BPTT of all jobs, last step first.  Launch i serves step Tmax_k - 1 - i of every job k
 // that still has one (and the extra t = -1 launch of a job that wants d h0); jobs of equal block
 // size share the launch.
 void bwd_steps(BwdJob* jobs, int n) {
-  static const int nw8_max = [] { const char* e = getenv("CMHSE_TINY_NW8_MAX"); return e ? atoi(e) : 256; }();
+  constexpr int nw8_max = kBwdNw8Max;
   int longest = 0;
   for (int k = 0; k < n; ++k) longest = jobs[k].b->Tmax > longest ? jobs[k].b->Tmax : longest;
   for (int i = 0; i <= longest; ++i) {
@@ -1353,7 +1345,7 @@ void bwd_steps(BwdJob* jobs, int n) {
       kind[k] = ((S_t <= nw8_max) ? 2 : 1) | ((b->H % 4 == 0) ? 0 : 4);
       if (b->H % 4 == 0 && S_t <= bwd_mid_max_seqs()) {   // the 16 x 16 x 4 tile shapes
         const int bm = (S_t <= 16) ? 16 : 32;
-        const int bu = bwd_mid_units(b->H, (S_t + bm - 1) / bm);
+        const int bu = kBwdMidUnits;
         kind[k] = 8 | (bm == 16 ? 16 : 0) | (bu == 8 ? 32 : 0) | (bu == 4 ? 64 : 0);
         grid_k[k] = static_cast<unsigned>((b->H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
       }
@@ -1377,18 +1369,18 @@ void bwd_steps(BwdJob* jobs, int n) {
       const bool vec = (kd & 4) == 0;
       if ((kd & 8) != 0) {
         const int bu = (kd & 64) != 0 ? 4 : ((kd & 32) != 0 ? 8 : 16);
-#define CMHSE_BWD_MID_LAUNCH(MB, BU) \
+#define BWD_MID_LAUNCH_(MB, BU) \
   hipLaunchKernelGGL((gru_bwd_step_mid_kernel<MB, BU>), dim3(grid), dim3(64 * kBwdMidNW), 0, st, g)
         if ((kd & 16) != 0) {
-          if (bu == 4) CMHSE_BWD_MID_LAUNCH(1, 4);
-          else if (bu == 8) CMHSE_BWD_MID_LAUNCH(1, 8);
-          else CMHSE_BWD_MID_LAUNCH(1, 16);
+          if (bu == 4) BWD_MID_LAUNCH_(1, 4);
+          else if (bu == 8) BWD_MID_LAUNCH_(1, 8);
+          else BWD_MID_LAUNCH_(1, 16);
         } else {
-          if (bu == 4) CMHSE_BWD_MID_LAUNCH(2, 4);
-          else if (bu == 8) CMHSE_BWD_MID_LAUNCH(2, 8);
-          else CMHSE_BWD_MID_LAUNCH(2, 16);
+          if (bu == 4) BWD_MID_LAUNCH_(2, 4);
+          else if (bu == 8) BWD_MID_LAUNCH_(2, 8);
+          else BWD_MID_LAUNCH_(2, 16);
         }
-#undef CMHSE_BWD_MID_LAUNCH
+#undef BWD_MID_LAUNCH_
       } else if ((kd & 3) == 2) {
         if (vec)
           hipLaunchKernelGGL((gru_bwd_step_kernel<true, 8>), dim3(grid), dim3(512), 0, st, g);

@@ -30,6 +30,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <new>
 
@@ -60,7 +61,6 @@ struct GruStepParams {
   float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
   int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
   int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
-  int32_t raster;   // N tiles per XCD group of the tiled step's workgroup rasterisation (0 = default)
   // mid-size step (gru_step_mid_kernel): hoisted input projection x W_ih^T of the small-batch steps,
   // row (off_cur + m - gx_p0) for an ordinary input, row m (the sorted sequence) for a
   // time-constant one
@@ -80,7 +80,7 @@ struct GruStepGroup {
   int32_t n;
 };
 
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
 // Timing-only debug build (tools/tile_trace.py): per-workgroup stamps of the tiled step —
 // [0] first instruction, [1] K loops start, [2] after the kernarg reads, [3] K loops end,
 // [4] state stores drained (s_memrealtime, 10 ns); [5]/[7] s_memtime at [1]/[3]; [6] HW_ID | XCC_ID << 32.
@@ -119,18 +119,11 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
-// HOIST (experiment, CMHSE_HOIST_MAX_SEQS, off by default): the input projection of this job was
-// hoisted into xproj_kernel (gx[row, 3H]): the tile loop keeps only K = H and the epilogue adds the
-// three input terms.  Meant for steps whose grids do not fill the chip for several rounds (a
-// rank's share of the split): two thirds of the work then run as ONE filled GEMM instead of in 80
-// under-filled launches.  Measured: the under-filled steps were not that inefficient (workgroups
-// with fewer co-runners run faster) and the big projection runs at 94 TFLOP/s, so the pass moves
-// by +2 % (615 videos) ... -3 % (1230 videos): not enabled.
-template <bool VEC, int MSUB, bool BF3, bool HOIST = false>
+template <bool VEC, int MSUB, bool BF3>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_kernel(const GruStepGroup grp) {
   constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
   const uint64_t t_first = wall_clock64();
 #endif
   unsigned wg;
@@ -139,7 +132,7 @@ void gru_step_kernel(const GruStepGroup grp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   TRACE_MARK(2);
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
   if (threadIdx.x == 0 && g_trace) {
     g_trace[static_cast<size_t>(blockIdx.x) * 8 + 6] =
         static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
@@ -149,19 +142,8 @@ void gru_step_kernel(const GruStepGroup grp) {
 #endif
   // 1-D grid, N tile fastest: blocks b and b+8 land on the same XCD (round-robin dispatch), so
   // with H/BU a multiple of 8 every XCD's L2 keeps re-serving the same two weight-row slices.
-  int nt_ = wg % p.n_tiles, mt_ = wg / p.n_tiles;
-  if (p.raster > 1) {
-    // experiment (tools/ab_pass.py, CMHSE_GRU_RASTER): XCD label x = wg % 8 owns R consecutive N
-    // tiles (a weight slice of R x 3 x 64 rows) for every C-th M tile instead of 2 N tiles for all
-    // M tiles: the A rows are then pulled through 8 / C = n_tiles / R L2s instead of all 8.
-    const int R = p.raster, G = p.n_tiles / R, C = 8 / G;
-    const int x = wg & 7, q = wg >> 3;
-    nt_ = R * (x % G) + q % R;
-    mt_ = C * (q / R) + x / G;
-  }
-  const int u0 = nt_ * BU;
-  const int m0 = mt_ * BM;
-  if (m0 >= p.S_t) return;   // padding workgroups of a rasterisation with C > 1
+  const int u0 = static_cast<int>(wg % p.n_tiles) * BU;
+  const int m0 = static_cast<int>(wg / p.n_tiles) * BM;
   const int srow = tid >> 2;
   const int I = p.I, H = p.H;
 
@@ -175,9 +157,7 @@ void gru_step_kernel(const GruStepGroup grp) {
     const int m = m0 + srow + 64 * i;
     av[i] = m < p.S_t;
     const int mc = av[i] ? m : (p.S_t - 1);
-    if (HOIST) {
-      ax[i] = 0;   // no x phase
-    } else if (BF3) {
+    if (BF3) {
       ax[i] = row_addr(p.xs + (p.off_cur + mc) * split_ld(I));   // (token lookups included)
     } else if (p.tok_rows != nullptr) {
       long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
@@ -233,7 +213,7 @@ void gru_step_kernel(const GruStepGroup grp) {
   const int32_t* const out_row = p.out_row;
   const int32_t* const lens = p.lens;
   TRACE_MARK(1);
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
   if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime();
 #endif
   if (BF3) {
@@ -241,11 +221,11 @@ void gru_step_kernel(const GruStepGroup grp) {
     nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2, true>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   } else {
-    if (!HOIST) nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   }
   TRACE_MARK(3);
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
   if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -294,30 +274,6 @@ void gru_step_kernel(const GruStepGroup grp) {
     const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
     float hn[16];
     const float (&hp)[16] = hp_all[ms];
-    if (HOIST) {
-      // the hoisted input terms of this lane's 16 (sequence, unit) elements: one round trip
-      // (four rows at a time: all sixteen at once cost the third wave per SIMD)
-#pragma unroll
-      for (int r4 = 0; r4 < 16; r4 += 4) {
-        float gr[4], gz[4], gn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = mrow0 + acc_row(r4 + i, lane);
-          const int mc = m < S_t ? m : (S_t - 1);
-          const float* gxr = p.gx + (p.gx_per_seq ? static_cast<int64_t>(mc) : (off_cur + mc - p.gx_p0)) * 3 * H + uc;
-          gr[i] = gxr[0];
-          gz[i] = gxr[H];
-          gn[i] = gxr[2 * H];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          acc[ms][0][r4 + i] += gr[i];
-          acc[ms][1][r4 + i] += gz[i];
-          acc[ms][2][r4 + i] = gn[i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mrow0 + acc_row(r, lane);
@@ -352,7 +308,7 @@ void gru_step_kernel(const GruStepGroup grp) {
         }
       }
     }
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
     if (ms == MSUB - 1) {   // stores of the state drained: what the slot's successor waits for
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
@@ -412,7 +368,6 @@ void gru_step_kernel(const GruStepGroup grp) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kTinyBM = 32;
 constexpr int kTinyBU = 8;
-constexpr int kTinyMaxSeqs = 1024;  // above this the LDS-tiled kernel is faster (measured sweep)
 
 // NW = waves per workgroup splitting K: 4, or 8 when so few sequences are active that the launch
 // is a pure latency chain (half the MFMA chain per wave, twice the waves on an under-filled chip).
@@ -548,10 +503,7 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 // pass — uses 4 waves: a 512-thread workgroup needs two free wave slots on every SIMD of one CU at
 // once and starves among 256-thread workgroups that refill slots one by one (615-video share of
 // the split: 50.2 ms per pass with 8 waves, 42.5 with 4).
-#ifndef CMHSE_MID_RING
-#define CMHSE_MID_RING 2   // 16-k blocks in flight per wave (tools/mid_shape_sweep.sh builds 2, 4, 8)
-#endif
-constexpr int kMidRing = CMHSE_MID_RING;
+constexpr int kMidRing = 2;   // 16-k blocks in flight per wave (4 and 8 measured slower, see above)
 
 // K is always cut into kMidSlices = 8 slices with one accumulator each, combined in slice order:
 // with 8 waves every wave owns one slice, with 4 waves wave w runs slices w and w + 4 one after
@@ -574,7 +526,7 @@ __global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGrou
   const int m0 = (wg / u_tiles) * BM;
   const int r16 = lane & 15, kq = lane >> 4;
   const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
   // tools/mid_trace.py: stamps of step t, workgroup wg at g_trace[(t * gridDim.x + blockIdx.x) * 8 + i]
 #define MID_MARK(i)                                                                       \
   do {                                                                                    \
@@ -692,7 +644,7 @@ __global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGrou
       p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
     }
   }
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
   __builtin_amdgcn_s_waitcnt(0);
   MID_MARK(5);
 #endif
@@ -1150,12 +1102,8 @@ __global__ __launch_bounds__(kThreads) void split_rows_kernel(const SplitRowsPar
   }
 }
 
-// Tuning override (benchmarks / tests): CMHSE_TINY_MAX_SEQS=<n> moves the small-batch / tiled
-// crossover (read per call, so tests can force the tiled kernels onto small fixtures).
-static int tiny_max_seqs() {
-  const char* e = getenv("CMHSE_TINY_MAX_SEQS");
-  return e ? atoi(e) : kTinyMaxSeqs;
-}
+// small-batch / tiled crossover of the forward steps (Tunables::tiny_max_seqs)
+static int tiny_max_seqs() { return tunables().tiny_max_seqs.load(std::memory_order_relaxed); }
 
 // ---------------------------------------------------------------------------------------------
 // collate_fn's padding (activity_net/data.py:114-150) as an index kernel: S ragged sequences stored
@@ -1243,14 +1191,9 @@ void stream_after(hipStream_t waiter, hipStream_t signal) {
   }
 }
 
-int hoist_max_seqs() {   // read per call.  Off by default: measured +2 % at 615 videos, -3 % at 1230
-  const char* e = getenv("CMHSE_HOIST_MAX_SEQS");
-  return e ? atoi(e) : 0;
-}
-
-int mid_max_seqs() {   // read per call, so one process can A/B it (tools/step_sweep.py)
-  const char* e = getenv("CMHSE_MID_MAX_SEQS");
-  return e ? atoi(e) : 1024;
+Tunables& tunables() {
+  static Tunables t;
+  return t;
 }
 
 }  // namespace cmhse
@@ -1277,7 +1220,6 @@ struct FwdJob {
   int32_t pool_mode;
   bool vec, bf3, save;
   int32_t t_mid;             // first step served by the mid-size kernel (Tmax: none)
-  bool hoist_all;            // the input projection of EVERY step is hoisted (xproj at t = 0)
   int64_t rows_split;        // bf16x3: packed rows of the steps the tiled bf16x3 kernel serves
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
   hipStream_t own_stream;    // optional stream ALL launches of this request go to (forked from / joined into the call's)
@@ -1286,38 +1228,16 @@ struct FwdJob {
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
 };
 
-// Rows per tile of the fp32 LDS-tiled kernels in units of 64: CMHSE_GRU_MSUB = 1 | 2 forces one
-// (read per call: A/B runs switch it inside one process); unset = 0 = chosen per launch.
-int gru_msub_forced() {
-  const char* e = getenv("CMHSE_GRU_MSUB");
-  const int v = e ? atoi(e) : 0;
-  return (v == 1 || v == 2) ? v : 0;
-}
-
 // 128-row tiles (2 workgroups per CU, 230 registers per lane) halve the weight bytes and cut the
 // LDS fragment reads per MFMA by a third; 64-row tiles (3 per CU) have half the work per wave, so
 // a launch of only a round or two of workgroups ends sooner.  Measured on boxes that hold
 // 1.75-2.0 GHz under this load: full split 287-290 ms per pass with 128 rows against 297-303 with
 // 64 (C3D 185 / 190.7); a 615-video share of the split 48.4 against 42.9; 1230 videos equal.
-// Launches of at least kTallTileMinWGs 64-row workgroups (all fp32 tiled requests of the time
-// step together) therefore use the 128-row tile.
-constexpr int kTallTileMinWGs = 2048;
+// Launches of at least Tunables::tall_tile_min_wgs (2048) 64-row workgroups (all fp32 tiled
+// requests of the time step together) therefore use the 128-row tile.
 int gru_msub_for(int wgs64) {
-  const int f = gru_msub_forced();
-  if (f) return f;
-  const char* e = getenv("CMHSE_TALL_TILE_MIN_WGS");
-  const int thr = e ? atoi(e) : kTallTileMinWGs;
+  const int thr = tunables().tall_tile_min_wgs.load(std::memory_order_relaxed);
   return (thr > 0 && wgs64 >= thr) ? 2 : 1;
-}
-
-// CMHSE_GRU_RASTER=<R> (read per call: A/B runs switch it inside one process): N tiles per XCD
-// group, valid when it divides the N-tile count and leaves 1, 2, 4 or 8 groups.
-int gru_raster(int n_tiles) {
-  const char* e = getenv("CMHSE_GRU_RASTER");
-  const int R = e ? atoi(e) : 0;
-  if (R <= 1 || n_tiles % R != 0) return 0;
-  const int G = n_tiles / R;
-  return (G == 1 || G == 2 || G == 4 || G == 8) ? R : 0;
 }
 
 int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode, float* out,
@@ -1381,7 +1301,6 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   p.pool_mode = pool_mode;
   p.x_step = b->x_step_floats;
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
-  p.raster = gru_raster(p.n_tiles);
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
   job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
@@ -1402,15 +1321,6 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
     }
     p.gx = reinterpret_cast<float*>(wsb + L.gx);
     p.gx_p0 = p0;
-    p.gx_per_seq = (b->x_rows != nullptr && b->x_step_floats == 0) ? 1 : 0;
-  }
-  // a batch too small to fill the chip with its tiled steps: hoist the projection of all steps
-  // (not while the inputs are still arriving chunk by chunk: the GEMM would wait for all of them)
-  job->hoist_all = job->vec && !bf3 && job->t_mid > 0 && b->S <= hoist_max_seqs() &&
-                   b->step_events_host == nullptr;
-  if (job->hoist_all) {
-    p.gx = reinterpret_cast<float*>(wsb + L.gx);
-    p.gx_p0 = 0;
     p.gx_per_seq = (b->x_rows != nullptr && b->x_step_floats == 0) ? 1 : 0;
   }
   p.w_ih_s = nullptr;
@@ -1463,23 +1373,13 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
 
 // Which step kernel serves job `j` at its current step: 0 = tiny, 1 = tiled fp32, 2 = tiled bf16x3;
 // bit 2 = scalar-load variant.  Jobs of equal kind share a launch.
-// Active sequences at or below which the small-batch FORWARD step splits K over 8 waves instead of
-// 4.  Off by default: the forward step gains nothing from it (its chain is not what bounds it), and
-// its 64 KB of LDS keeps the launch from slipping in beside an attention pass (tail_stream); the
-// BPTT step, whose K = 3H chain is twice as long, does use the 8-wave form (bwd.hip).
-static int tiny_nw8_max() {
-  static const int v = [] { const char* e = getenv("CMHSE_TINY_FWD_NW8_MAX"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 // Hidden units per workgroup of the mid-size step: the narrowest of 16, 8, 4 whose grid still
 // fits the chip in one round (more, smaller tiles = more CUs pulling operands; past one round the
-// replicated h rows cost more than the spread gains).  CMHSE_MID_UNITS = 16 | 8 | 4 forces one.
+// replicated h rows cost more than the spread gains).  Tunables::mid_units = 16 | 8 | 4 forces one.
 constexpr int kChipCUs = 256;
 static int mid_m_blocks(int S_t) { return (S_t <= 16) ? 1 : (S_t + 31) / 32; }
 static int mid_units(int H, int m_blocks) {
-  const char* e = getenv("CMHSE_MID_UNITS");
-  const int forced = e ? atoi(e) : 0;
+  const int forced = tunables().mid_units.load(std::memory_order_relaxed);
   if (forced == 16 || forced == 8 || forced == 4) return forced;
   for (int bu = 4; bu < 16; bu *= 2)
     if (((H + bu - 1) / bu) * m_blocks <= kChipCUs) return bu;
@@ -1495,17 +1395,15 @@ static int mid_units(int H, int m_blocks) {
 // (bit 2048 = 128-row tiles, gru_msub_for()).
 int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wgs) {
   if (j.p.t >= j.t_mid) {   // mid-size kernel (vec shapes only)
-    const char* we = getenv("CMHSE_MID_WAVES");   // experiments: force 4 or 8
-    if (we && atoi(we) == 4) alone = false;
-    if (we && atoi(we) == 8) alone = true;
+    const int waves = tunables().mid_waves.load(std::memory_order_relaxed);   // 4 | 8 forces a shape
+    if (waves == 4) alone = false;
+    if (waves == 8) alone = true;
     const int bu = mid_units(j.b->H, mid_blocks);
     return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0) |
            (alone ? 512 : 0);
   }
   int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
-  if (k == 0 && S_t <= tiny_nw8_max()) k |= 16;
-  if (k == 1 && j.hoist_all) k |= 64;   // tiled step on the hoisted projection (K = H only)
-  if (k == 1 && !j.hoist_all && gru_msub_for(tiled_wgs) == 2) k |= 2048;
+  if (k == 1 && gru_msub_for(tiled_wgs) == 2) k |= 2048;
   return k | (j.vec ? 0 : 4);
 }
 
@@ -1513,7 +1411,7 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
 // first hoisted row; m_end < 0 = all of them).
 void launch_xproj(const FwdJob& j, hipStream_t stream, int64_t m_begin = 0, int64_t m_end = -1) {
   const cmhse_seq_batch* b = j.b;
-  const int t_first = j.hoist_all ? 0 : j.t_mid;
+  const int t_first = j.t_mid;
   XprojParams q;
   q.x_rows = b->x_rows;
   q.tok_rows = b->tok_rows;
@@ -1545,7 +1443,7 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   switch (kind & 3) {
     case 3: {
       const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
-#define CMHSE_MID_LAUNCH(MB, BU)                                                                      \
+#define MID_LAUNCH_(MB, BU)                                                                      \
   do {                                                                                                \
     if ((kind & 512) != 0)                                                                            \
       hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU, 8>), dim3(grid), dim3(512), 0, stream, g);      \
@@ -1553,24 +1451,19 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
       hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU, 4>), dim3(grid), dim3(256), 0, stream, g);      \
   } while (0)
       if ((kind & 32) != 0) {
-        if (bu == 4) CMHSE_MID_LAUNCH(1, 4);
-        else if (bu == 8) CMHSE_MID_LAUNCH(1, 8);
-        else CMHSE_MID_LAUNCH(1, 16);
+        if (bu == 4) MID_LAUNCH_(1, 4);
+        else if (bu == 8) MID_LAUNCH_(1, 8);
+        else MID_LAUNCH_(1, 16);
       } else {
-        if (bu == 4) CMHSE_MID_LAUNCH(2, 4);
-        else if (bu == 8) CMHSE_MID_LAUNCH(2, 8);
-        else CMHSE_MID_LAUNCH(2, 16);
+        if (bu == 4) MID_LAUNCH_(2, 4);
+        else if (bu == 8) MID_LAUNCH_(2, 8);
+        else MID_LAUNCH_(2, 16);
       }
-#undef CMHSE_MID_LAUNCH
+#undef MID_LAUNCH_
       break;
     }
     case 0:
-      if ((kind & 16) != 0) {
-        if (vec)
-          hipLaunchKernelGGL((gru_step_tiny_kernel<true, 8>), dim3(grid), dim3(512), 0, stream, g);
-        else
-          hipLaunchKernelGGL((gru_step_tiny_kernel<false, 8>), dim3(grid), dim3(512), 0, stream, g);
-      } else if (vec) {
+      if (vec) {
         hipLaunchKernelGGL((gru_step_tiny_kernel<true, 4>), dim3(grid), dim3(kThreads), 0, stream, g);
       } else {
         hipLaunchKernelGGL((gru_step_tiny_kernel<false, 4>), dim3(grid), dim3(kThreads), 0, stream, g);
@@ -1591,9 +1484,7 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
           hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads), smem, stream, g);
       } else {
         const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
-        if ((kind & 64) != 0)
-          hipLaunchKernelGGL((gru_step_kernel<true, 1, false, true>), dim3(grid), dim3(kThreads), smem, stream, g);
-        else if (vec)
+        if (vec)
           hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
         else
           hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
@@ -1611,11 +1502,7 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   if ((kind & 3) == 0)
     return static_cast<unsigned>((H + kTinyBU - 1) / kTinyBU) * ((S_t + kTinyBM - 1) / kTinyBM);
   const int bm = ((kind & 3) == 2 || (kind & 2048) != 0) ? 128 : 64;
-  int m_tiles = (S_t + bm - 1) / bm;
-  if (j.p.raster > 1) {
-    const int C = 8 / (j.p.n_tiles / j.p.raster);
-    m_tiles = (m_tiles + C - 1) / C * C;
-  }
+  const int m_tiles = (S_t + bm - 1) / bm;
   return static_cast<unsigned>(j.p.n_tiles) * m_tiles;
 }
 
@@ -1676,7 +1563,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (t < jobs[k].b->Tmax && t < jobs[k].t_mid) {
         alone = false;   // a tiled / tiny step runs too
         const int S_k = jobs[k].b->step_count_host[t];
-        if (S_k > tiny_max_seqs() && !jobs[k].bf3 && !jobs[k].hoist_all)
+        if (S_k > tiny_max_seqs() && !jobs[k].bf3)
           tiled_wgs += jobs[k].p.n_tiles * ((S_k + 63) / 64);
       }
     for (int k = 0; k < n; ++k) {
@@ -1696,7 +1583,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       hipStream_t stream = js[k];
       if (j.b->step_events_host != nullptr && j.b->step_events_host[t] != nullptr)
         (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[t])), 0);
-      if (t == (j.hoist_all ? 0 : j.t_mid)) {
+      if (t == j.t_mid) {
         // the hoisted projection reads the inputs of ALL remaining steps: wait for their uploads
         if (j.b->step_events_host != nullptr)
           for (int q = t + 1; q < j.b->Tmax; ++q)
@@ -1783,7 +1670,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         timer->tiled_events.push_back(e0);
         timer->tiled_events.push_back(e1);
         for (int q = 0; q < g.n; ++q) {
-          const double I = (kind[k] & 64) != 0 ? 0.0 : g.j[q].I, H = g.j[q].H;   // hoisted: K = H only
+          const double I = g.j[q].I, H = g.j[q].H;
           timer->tiled_flops += g.j[q].S_t * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
           // x_t in, h_{t-1} in, h_t out per sequence; the weights once per launch
           timer->tiled_bytes += g.j[q].S_t * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
@@ -1838,11 +1725,9 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   char* wsb = job.wsb;
   const int64_t sum_T = job.sum_T;
   const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
-  // tile height of the projection: 64 rows; CMHSE_ATT_MSUB (or CMHSE_GRU_MSUB) = 2 forces 128
-  // (measured equal on the full split: 285.0 against 285.8 ms per pass)
-  const char* ae = getenv("CMHSE_ATT_MSUB");
-  const int att_forced = ae ? atoi(ae) : gru_msub_forced();
-  const int msub = (att_forced == 2) ? 2 : 1;
+  // tile height of the projection: 64 rows (128 measured equal on the full split: 285.0 against
+  // 285.8 ms per pass)
+  constexpr int msub = 1;
   float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
   AttnEnergyParams ep;
   ep.hs_s = nullptr;
@@ -1888,12 +1773,6 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
       const unsigned g2 = static_cast<unsigned>(((hi - cut + 127) / 128) * att_tiles);
       hipLaunchKernelGGL((attn_energy_kernel<true, 2, true, false>), dim3(g2), dim3(kThreads), att_smem, stream, ep);
     }
-  } else if (msub == 2) {
-    const size_t att_smem = TileSmem<128, kAttBN>::kBytes;
-    if (job.vec)
-      hipLaunchKernelGGL((attn_energy_kernel<true, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
-    else
-      hipLaunchKernelGGL((attn_energy_kernel<false, 2, false>), dim3(att_grid), dim3(kThreads), att_smem, stream, ep);
   } else {
     const size_t att_smem = TileSmem<64, kAttBN>::kBytes;
     if (job.vec)
@@ -1986,14 +1865,11 @@ extern "C" int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t*
   p.row_floats = row_floats;
   p.t0 = t0;
   p.t1 = t1;
-  const char* ge = getenv("CMHSE_PULL_GRID");   // experiments (tools/ab_host.py)
-  const char* te = getenv("CMHSE_PULL_THREADS");
   // 32 single-wave workgroups, 8 x 16 B in flight per lane: 57 GB/s alone (the PCIe Gen5 x16 rate),
   // and the smallest footprint that does it — beside the step kernel every resident pull wave
   // takes a SIMD's free registers, i.e. one of that CU's three step-workgroup slots (sweep in
   // profiles/r02_upload_pipeline.txt: 16 x 256 threads 358 ms / pass, 128 x 64 422, 32 x 64 330)
-  const int cap = (ge && atoi(ge) > 0) ? atoi(ge) : 32;
-  const int thr = (te && (atoi(te) == 128 || atoi(te) == 256)) ? atoi(te) : 64;
+  constexpr int cap = 32, thr = 64;
   const unsigned grid = static_cast<unsigned>(n_active < cap ? n_active : cap);
   hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(thr), 0,
                      static_cast<hipStream_t>(stream_), p);
@@ -2046,6 +1922,22 @@ extern "C" int cmhse_gather_rows(const float* table, const int64_t* ids, int64_t
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
+extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
+  if (!name) return CMHSE_ERR_ARG;
+  Tunables& t = tunables();
+  struct { const char* name; std::atomic<int>* v; } table[] = {
+      {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
+      {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
+      {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs}};
+  for (auto& e : table)
+    if (strcmp(name, e.name) == 0) {
+      const int old = (value >= 0) ? e.v->exchange(value) : e.v->load();
+      if (old_value) *old_value = old;
+      return CMHSE_OK;
+    }
+  return CMHSE_ERR_ARG;
+}
+
 extern "C" void* cmhse_timer_create(void) {
   Timer* t = new (std::nothrow) Timer;
   if (!t) return nullptr;
@@ -2079,7 +1971,7 @@ extern "C" int cmhse_timer_elapsed_ms(void* timer, float* ms_host) {
   return CMHSE_OK;
 }
 
-#ifdef CMHSE_TRACE
+#ifdef TILE_TRACE_BUILD
 extern "C" int cmhse_debug_set_trace(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(cmhse::g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }

@@ -14,35 +14,41 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 #include "../../include/cmhse_hip.h"
 
 namespace cmhse {
 
-#ifndef CMHSE_ATT_BN
-#define CMHSE_ATT_BN 256
-#endif
-constexpr int kAttBN = CMHSE_ATT_BN;  // columns of W_lin per attention-energy workgroup (128 or 256)
+constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
 
 struct GruWs {
   size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, total;
 };
 
-// Active sequences at or below which a step runs on the mid-size kernel (gru_step_mid_kernel: the
-// input projection of those steps hoisted into one GEMM, split-K 16x16x4 MFMA tiles for the
-// recurrent part).  CMHSE_MID_MAX_SEQS overrides (0 disables the kernel).
-int mid_max_seqs();
-
-// Experiment (default 0 = off): batches of at most CMHSE_HOIST_MAX_SEQS sequences hoist the input
-// projection of ALL their steps, so that their under-filled tiled steps keep only K = H.
-int hoist_max_seqs();
+// Kernel-shape crossovers a caller may move (cmhse_tune, include/cmhse_hip.h): values, never
+// results.  Read with relaxed atomics at every call.
+struct Tunables {
+  // active sequences at or below which a forward step runs on the small-batch kernels instead of
+  // the LDS-tiled one (tests set 0 to force the tiled kernels onto small fixtures)
+  std::atomic<int> tiny_max_seqs{1024};
+  // active sequences at or below which a step runs on the mid-size kernel (gru_step_mid_kernel:
+  // the input projection of those steps hoisted into one GEMM, split-K 16x16x4 MFMA tiles for
+  // the recurrent part); 0 disables it
+  std::atomic<int> mid_max_seqs{1024};
+  std::atomic<int> mid_units{0};          // 16 | 8 | 4 forces the mid-size step's unit tile (0 = by grid size)
+  std::atomic<int> mid_waves{0};          // 4 | 8 forces its waves per workgroup (0 = by schedule)
+  std::atomic<int> tall_tile_min_wgs{2048};  // 64-row workgroups from which a tiled launch uses 128-row tiles (0 = never)
+  std::atomic<int> bwd_mid_max_seqs{512};    // active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel
+};
+Tunables& tunables();
+static inline int mid_max_seqs() { return tunables().mid_max_seqs.load(std::memory_order_relaxed); }
 
 // Upper bound of the packed rows whose input projection is hoisted (the rows of the steps with at
 // most mid_max_seqs() active sequences; all rows when the whole batch is small enough).
 static inline int64_t gx_rows_bound(int32_t S, int32_t Tmax, int64_t sum_T) {
   const int64_t mm = mid_max_seqs();
-  if (S <= hoist_max_seqs()) return sum_T;
   if (mm <= 0) return 0;
   if (S <= mm || Tmax <= 0) return sum_T;
   const int64_t b = mm * static_cast<int64_t>(Tmax);

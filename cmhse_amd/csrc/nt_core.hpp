@@ -48,21 +48,17 @@ typedef const __attribute__((address_space(1))) f32x4* gptr_f32x4;
 // global_load, a generic-pointer cast would still be emitted as flat_load (which also counts on
 // lgkmcnt and would be waited for together with the LDS fragment reads).
 typedef uint64_t rowaddr_t;
-#ifndef CMHSE_STREAM_A
-#define CMHSE_STREAM_A 0
-#endif
-constexpr bool kStreamA = CMHSE_STREAM_A != 0;
 __device__ __forceinline__ rowaddr_t row_addr(const float* p) {
   return reinterpret_cast<rowaddr_t>(p);
 }
 
-template <bool VEC, bool STREAM = false>
+template <bool VEC>
 __device__ __forceinline__ float4 issue_row4(rowaddr_t p, int k, int klim) {
   float4 v;
   if (VEC) {
     const int kk = (k < klim) ? k : (klim - 4);
     gptr_f32x4 src = (gptr_f32x4)(p + static_cast<rowaddr_t>(kk) * 4u);
-    const f32x4 g = STREAM ? __builtin_nontemporal_load(src) : *src;
+    const f32x4 g = *src;
     v = make_float4(g.x, g.y, g.z, g.w);
   } else {
     const int last = klim - 1;
@@ -160,7 +156,7 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC, kStreamA>(arow[i], kn, K);
+      for (int i = 0; i < AP; ++i) ra[i] = issue_row4<VEC>(arow[i], kn, K);
 #pragma unroll
       for (int i = 0; i < BP; ++i) rb[i] = issue_row4<VEC>(brow[i], kn, K);
     }
@@ -188,9 +184,6 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   // MFMAs of one 8-k block for k sub-steps j in [J0, J1)
   auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB], auto j0c, auto j1c) {
     constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
-#if defined(CMHSE_MFMA_SETPRIO)   // raised wave priority around the MFMA blocks: +3 % before the lean
-    __builtin_amdgcn_s_setprio(1);  // loop existed, -0.9 % with it (measured), so off by default
-#endif
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
 #pragma unroll
@@ -207,9 +200,6 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
         }
       }
     }
-#if defined(CMHSE_MFMA_SETPRIO)
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
   using I0 = std::integral_constant<int, 0>;
   using I3 = std::integral_constant<int, 3>;
@@ -239,7 +229,6 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
   __builtin_amdgcn_sched_barrier(0);
   mfma_block(f0a, f0b, I3{}, I4{});
   int c = 1;
-#if !defined(CMHSE_NO_LEAN_LOOP)
   if (VEC) {
     // Lean steady state, two chunks per trip.  Every vector-ALU instruction in this loop costs
     // matrix-pipe time (tools/microbench/mfma_lds_feed_f32.hip: 32 of them per 24 MFMAs take 19 %
@@ -297,33 +286,20 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
       kp += 2 * kBK;
     }
   }
-#endif
   for (; c < nchunks; ++c) {
     const int cur = c & 1;
     const int kn = (c + 1) * kBK + sk;  // past the end: clamped address, zeroed by finish_row4
-    // CMHSE_ABL_*: timing-only ablations for tools/tile_trace.py (wrong results by design): which
-    // part of the loop's data movement costs wall time and shader clock.
-#if !defined(CMHSE_ABL_NOBAR)
     __syncthreads();
-#endif
-#if !defined(CMHSE_ABL_NOLDSR)
     read_frags(cur, 0, f0a, f0b);
-#endif
-#if !defined(CMHSE_ABL_NOGLOBAL)
     issue_global(kn);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f1a, f1b, I0{}, I4{});
     __builtin_amdgcn_sched_barrier(0);
-#if !defined(CMHSE_ABL_NOLDSR)
     read_frags(cur, 1, f1a, f1b);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f0a, f0b, I0{}, I3{});
     __builtin_amdgcn_sched_barrier(0);
-#if !defined(CMHSE_ABL_NOLDSW)
     write_lds(cur ^ 1, kn);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f0a, f0b, I3{}, I4{});
   }
@@ -515,7 +491,6 @@ __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool 
     rb[d] = issue_row4<VEC>(brow, k, K);
   }
   int it = 0;
-#if !defined(CMHSE_NO_LEAN_LOOP)
   if (VEC) {
     // Lean steady state (see nt_phase): while every k this trip consumes or prefetches lies inside
     // K — for all NW waves, so the bound is uniform — no tail masks, no clamps, and the loads go
@@ -542,7 +517,6 @@ __device__ __forceinline__ void tiny_phase(rowaddr_t arow, rowaddr_t brow, bool 
       pb += kSlot * kTinyRing;
     }
   }
-#endif
   for (; it < nmine; it += kTinyRing) {
 #pragma unroll
     for (int d = 0; d < kTinyRing; ++d) {

@@ -96,7 +96,7 @@ def _word_rows(table, tokens):
 
 # A training step's two towers (encoders and decoders alike) are independent until the losses, and
 # at training batch sizes every GRU time step is a short, latency-bound launch.  How the two
-# chains are scheduled (TRAIN_SCHEDULE[0], CMHSE_TRAIN_SCHEDULE; all four give the same values, and
+# chains are scheduled (TRAIN_SCHEDULE[0]; all four give the same values, and
 # bit-identical ones wherever the backward pass has no float atomics — tested):
 #   'interleaved'  (default) each level of the two towers is ONE call and ONE autograd node in which
 #                  every tower is a chain on a stream of its own, and the host queues step t of both
@@ -108,9 +108,11 @@ def _word_rows(table, tokens):
 #                  launches, twice the workgroups each: 15.4 against 14.9 ms per step in round 2 —
 #                  a step kernel at a training batch is bound by operand bandwidth per CU);
 #   'serial'       one stream, one tower after the other.
-TRAIN_SCHEDULE = [os.environ.get('CMHSE_TRAIN_SCHEDULE', 'interleaved')]
+TRAIN_SCHEDULE = ['interleaved']
 # the 4-7 contrastive losses of a step as one launch set (loss.contrastive_losses); False = one by one
 BATCHED_LOSSES = [True]
+# torch.optim.Adam(fused=True): one launch for the whole update (VSE.__init__)
+FUSED_ADAM = [True]
 _TOWER_STREAMS = {}
 
 
@@ -184,9 +186,9 @@ class VSE(object):
     # (train.py:269-270 mutates the LR through them); `fused=True` selects torch's single-launch
     # implementation of the same update rule (15 small launches less at the end of every step:
     # 12.4 -> 12.2 ms).  It is equal to the default implementation within rounding, not guaranteed
-    # bit for bit, and keeps state['step'] as a device tensor; CMHSE_FUSED_ADAM=0 selects torch's
+    # bit for bit, and keeps state['step'] as a device tensor; FUSED_ADAM[0] = False selects torch's
     # default (what the parity tests against the reference's optimiser trajectory use).
-    fused = os.environ.get('CMHSE_FUSED_ADAM', '1') == '1' and all(p.is_cuda for p in params)
+    fused = FUSED_ADAM[0] and all(p.is_cuda for p in params)
     self.optimizer = (torch.optim.Adam(params, lr=opt.learning_rate, fused=True) if fused
                       else torch.optim.Adam(params, lr=opt.learning_rate))
     self.Eiters = 0

@@ -81,6 +81,32 @@ def _f32c(t, name):
   return t.contiguous()
 
 
+def tune(name, value=-1):
+  """cmhse_tune: set (value >= 0) or read (value < 0) one kernel-shape crossover of the library;
+  returns its previous value.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
+  tall_tile_min_wgs, bwd_mid_max_seqs (include/cmhse_hip.h)."""
+  old = ctypes.c_int32(0)
+  _lib.check(_lib.load().cmhse_tune(name.encode(), int(value), ctypes.byref(old)), 'cmhse_tune(%s)' % name)
+  return int(old.value)
+
+
+class tuned(object):
+  """Context manager: `with ops.tuned(tiny_max_seqs=0, mid_max_seqs=0): ...` moves crossovers for
+  the block and puts the previous values back."""
+
+  def __init__(self, **kw):
+    self.kw, self.old = kw, {}
+
+  def __enter__(self):
+    for k, v in self.kw.items():
+      self.old[k] = tune(k, v)
+    return self
+
+  def __exit__(self, *a):
+    for k, v in self.old.items():
+      tune(k, v)
+
+
 _MATH_MODE = [os.environ.get('CMHSE_MATH', 'fp32')]
 
 
@@ -651,7 +677,7 @@ def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
 # backward passes gets ONE companion stream, created on first use and kept.  The library forks to
 # it and joins it back inside the call, so the caller's stream semantics do not change and no
 # record_stream bookkeeping is needed (nothing the side stream touches is freed before the join).
-SIDE_STREAMS = [os.environ.get('CMHSE_SIDE_STREAMS', '1') == '1']
+SIDE_STREAMS = [True]
 _SIDE_OF = {}
 
 

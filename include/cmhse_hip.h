@@ -14,15 +14,15 @@
  *     as torch.LongTensor);
  *   - calls are asynchronous on `stream` and re-entrant; they allocate NO device memory: scratch
  *     is an explicit caller-owned workspace whose size the matching `*_workspace` function
- *     returns.  Host-side objects a call may create and release before it returns: one HIP event
- *     per stream fork/join when a `tail_stream` is used (cmhse_gru_pool_fwd_multi), and event
+ *     returns.  Host-side objects a call may take and give back before it returns: HIP events for
+ *     stream fork / join (`tail_stream`, `stream`, `side_stream` of the job structs) and the event
  *     pairs owned by a cmhse_timer handle when the caller passes one (measurement only);
- *   - the library keeps no mutable process-wide state.  It READS optional tuning overrides from
- *     the environment — kernel-shape crossovers and launch footprints, never results:
- *     CMHSE_MID_MAX_SEQS, CMHSE_TINY_MAX_SEQS, CMHSE_HOIST_MAX_SEQS, CMHSE_GRU_RASTER,
- *     CMHSE_PULL_GRID, CMHSE_PULL_THREADS per call; CMHSE_GRU_MSUB, CMHSE_TINY_FWD_NW8_MAX, CMHSE_TINY_NW8_MAX once,
- *     at first use — so concurrent calls from several host threads are safe as long as nobody
- *     rewrites those variables between a `*_workspace` query and the call it sizes;
+ *   - process-wide state, all of it host-side and mutex- or atomic-guarded: (i) per-device free
+ *     lists of those HIP events (creating an event while the GPU is busy can stall the host for
+ *     tens of milliseconds, so events are recycled; an event returns to the list of the device
+ *     that is current in the calling thread — use one device per thread across a call); (ii) the
+ *     kernel-shape crossovers of cmhse_tune() below.  Nothing else: no cached device memory, no
+ *     cached streams, no environment variables;
  *   - return value: 0 = success, negative = error code (cmhse_strerror); no exceptions or aborts
  *     cross the ABI.
  */
@@ -367,6 +367,23 @@ int32_t cmhse_timer_launches(void* timer);   /* step kernels launched inside the
  * algorithmic HBM bytes (4I + 8H per sequence and step, the weights once per launch) and count. */
 int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* bytes_host,
                       int32_t* launches_host);
+
+/* The one configuration entry point: kernel-shape crossovers a caller (a test, a benchmark) may
+ * move.  They change WHICH kernel shape serves a step, never a result beyond fp32 summation order
+ * (and the shapes selected by mid_units / mid_waves are bit-identical to each other).  `value` >= 0
+ * sets the tunable, < 0 only reads it; *old_value (if not NULL) receives the previous value.
+ *   "tiny_max_seqs"     1024  active sequences at or below which a forward step runs on the
+ *                             small-batch kernels instead of the LDS-tiled one
+ *   "mid_max_seqs"      1024  ... at or below which it runs on the mid-size kernel (hoisted input
+ *                             projection + split-K 16x16x4 tiles); 0 disables that kernel
+ *   "mid_units"            0  16 | 8 | 4 forces the mid-size step's hidden units per workgroup
+ *   "mid_waves"            0  4 | 8 forces its waves per workgroup
+ *   "tall_tile_min_wgs" 2048  64-row workgroups from which an LDS-tiled launch uses 128-row tiles
+ *   "bwd_mid_max_seqs"   512  active sequences at or below which a BPTT step runs on the mid-size
+ *                             backward kernel
+ * Process-wide (atomics): set them between calls, not while calls that size workspaces with them
+ * (`*_workspace` reads mid_max_seqs) are in flight on other threads.  Unknown name: CMHSE_ERR_ARG. */
+int cmhse_tune(const char* name, int32_t value, int32_t* old_value);
 
 /* Text for an error code returned by the functions above (static storage). */
 const char* cmhse_strerror(int code);

@@ -31,6 +31,21 @@ def dev():
   return torch.device('cuda', 0)
 
 
+@pytest.fixture
+def tune(dev):
+  """Move kernel-shape crossovers of the library (cmhse_tune) for one test; restored afterwards."""
+  from cmhse_amd import ops
+  saved = {}
+
+  def _set(**kw):
+    for k, v in kw.items():
+      old = ops.tune(k, v)
+      saved.setdefault(k, old)
+  yield _set
+  for k, v in saved.items():
+    ops.tune(k, v)
+
+
 def make_layer(cls_name, I, H, sd, dev):
   from cmhse_amd import layers
   layer = getattr(layers, cls_name)(I, H)
@@ -1328,7 +1343,7 @@ def test_grouped_backward_equals_separate_calls(dev):
 
 
 @pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
-def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, monkeypatch):
+def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, tune):
   """The optional bf16x3 math mode where parity means something: the REFERENCE's own outputs.
   The golden fixtures are small, so the LDS-tiled kernels (the only ones the mode touches) are
   forced onto them; encode_data then has to reproduce the reference's embeddings within the 1e-4
@@ -1339,8 +1354,7 @@ def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, monkeypatch):
   g = load_golden('model_%s.npz' % rnn_type)
   opt, model = golden_model(rnn_type, g)
   batches = torch_batches(golden_batches(g))
-  monkeypatch.setenv('CMHSE_TINY_MAX_SEQS', '0')
-  monkeypatch.setenv('CMHSE_MID_MAX_SEQS', '0')
+  tune(tiny_max_seqs=0, mid_max_seqs=0)
   exact = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
   try:
     ops.set_math_mode('bf16x3')
@@ -1360,7 +1374,7 @@ def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, monkeypatch):
     np.testing.assert_array_equal(top1, g['enc.%s.top1' % nm])
 
 
-def test_small_batch_chain_beside_tiled_chain_is_bit_identical(dev, monkeypatch):
+def test_small_batch_chain_beside_tiled_chain_is_bit_identical(dev, monkeypatch, tune):
   """cmhse_gru_pool_fwd_multi moves a chain that has dropped to small-batch steps onto the side
   stream while the other chain still launches LDS-tiled steps (a rank's share of the split on 8
   GPUs), and projects the still-running chain's rows early when the other one ends.  With the
@@ -1372,8 +1386,7 @@ def test_small_batch_chain_beside_tiled_chain_is_bit_identical(dev, monkeypatch)
   opt, model = golden_model('attention', g)
   spec = synthetic.ragged_spec(41, seed=13, max_frames=14, max_words=5, max_video=16)
   batches = synthetic.make_batches(spec, 8, opt.img_dim, opt.vocab_size, seed=3)
-  monkeypatch.setenv('CMHSE_TINY_MAX_SEQS', '40')
-  monkeypatch.setenv('CMHSE_MID_MAX_SEQS', '40')
+  tune(tiny_max_seqs=40, mid_max_seqs=40)
   keys = ('vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx')
   outs = []
   for early in (False, True, True, True):
@@ -1430,36 +1443,6 @@ def test_pinned_host_batches_at_icep_width(dev):
     got, _, _ = evaluation.encode_data_device(opt, model, pinned, logging=quiet)
     for k in want:
       assert torch.equal(got[k], want[k]), k
-
-
-@pytest.mark.parametrize('pool', ['attention', 'seq2seq'])
-def test_hoisted_projection_variant_matches(dev, oracle, pool, monkeypatch):
-  """CMHSE_HOIST_MAX_SEQS (experiment, off by default): the tiled step kernel on a fully hoisted
-  input projection (K = H only, input terms added in the epilogue) against the oracle and against
-  the default path."""
-  from cmhse_amd import layers
-  rng = np.random.RandomState(31)
-  S, T, I, H = 2300, 4, 36, 128
-  cls = {'attention': 'Attention', 'seq2seq': 'Seq2Seq'}[pool]
-  torch.manual_seed(6)
-  layer = getattr(layers, cls)(I, H)
-  sd = {'rnn.' + k: v.detach().numpy() for k, v in layer.state_dict().items()}
-  layer = layer.to(dev)
-  lens = rng.randint(1, T + 1, size=S)
-  lens[:1200] = T
-  x = rng.standard_normal((S, T, I)).astype(np.float32)
-  for i, l in enumerate(lens):
-    x[i, l:] = 0
-  xd = torch.from_numpy(x).to(dev)
-  with torch.no_grad():
-    base = layer(xd, torch.from_numpy(lens)).cpu().numpy()
-    monkeypatch.setenv('CMHSE_HOIST_MAX_SEQS', '100000')
-    hoisted = layer(xd, torch.from_numpy(lens)).cpu().numpy()
-  sample = np.sort(rng.choice(S, 40, replace=False))
-  want = oracle.pooled_gru_forward(pool, x[sample], lens[sample], sd, None, np.float64)
-  np.testing.assert_allclose(hoisted[sample], want, atol=EMB_TOL, rtol=0)
-  np.testing.assert_allclose(hoisted, base, atol=2e-6, rtol=0)
-  assert not np.array_equal(hoisted, base), 'the hoisted variant did not engage'
 
 
 @pytest.mark.gpu
@@ -1592,10 +1575,11 @@ def test_fused_adam_is_the_same_update(dev, monkeypatch):
   from cmhse_amd import synthetic
   from cmhse_amd.model import VSE
   opt = golden_opt('attention', low_level_loss=True, norm=True)
+  from cmhse_amd import model as model_mod
   torch.manual_seed(9)
-  monkeypatch.setenv('CMHSE_FUSED_ADAM', '1')
+  monkeypatch.setattr(model_mod, 'FUSED_ADAM', [True])
   model_a = VSE(opt)
-  monkeypatch.setenv('CMHSE_FUSED_ADAM', '0')
+  monkeypatch.setattr(model_mod, 'FUSED_ADAM', [False])
   model_b = VSE(opt)
   model_b.load_state_dict(copy.deepcopy(model_a.state_dict(opt)), opt)
   assert model_a.optimizer.defaults.get('fused') and not model_b.optimizer.defaults.get('fused')
@@ -1616,7 +1600,7 @@ def test_fused_adam_is_the_same_update(dev, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('S,H', [(5, 1024), (29, 1024), (70, 256), (200, 64)])
-def test_small_batch_step_shapes_are_bit_identical(dev, S, H, monkeypatch):
+def test_small_batch_step_shapes_are_bit_identical(dev, S, H, tune):
   """The mid-size step's launch shapes — 16 / 8 / 4 hidden units per workgroup, 8 waves x 1 K slice
   or 4 waves x 2 — are scheduling choices: every combination gives the same bits, forward and
   (through the saved gates) backward."""
@@ -1629,12 +1613,8 @@ def test_small_batch_step_shapes_are_bit_identical(dev, S, H, monkeypatch):
   x = torch.randn(S, 8, I, device=dev)
   h0 = torch.randn(S, H, device=dev)
   outs = []
-  for units, waves in [('16', '8'), ('16', '4'), ('8', '8'), ('8', '4'), ('4', '8'), ('4', '4'), ('0', '')]:
-    monkeypatch.setenv('CMHSE_MID_UNITS', units)
-    if waves:
-      monkeypatch.setenv('CMHSE_MID_WAVES', waves)
-    else:
-      monkeypatch.delenv('CMHSE_MID_WAVES', raising=False)
+  for units, waves in [(16, 8), (16, 4), (8, 8), (8, 4), (4, 8), (4, 4), (0, 0)]:
+    tune(mid_units=units, mid_waves=waves)
     xr = x.clone().requires_grad_(True)
     layer.zero_grad()
     y = layer(xr, lens, h0)

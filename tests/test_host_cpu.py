@@ -260,3 +260,31 @@ def test_collate_packed_holds_the_same_batch_without_padding():
   ptrs = pk[0].row_ptrs()
   assert int(ptrs[0]) == pk[0].data.data_ptr()
   assert int(ptrs[1] - ptrs[0]) == int(pk[0].lens[0]) * 10 * 4
+
+
+def test_tune_is_the_one_configuration_entry_point():
+  """cmhse_tune (include/cmhse_hip.h): reads, sets and restores a kernel-shape crossover without a
+  GPU; unknown names are an argument error, not a silent no-op."""
+  from cmhse_amd import ops
+  default = ops.tune('tiny_max_seqs')                 # read only
+  assert default == 1024
+  assert ops.tune('tiny_max_seqs', 7) == default      # set: returns the previous value
+  assert ops.tune('tiny_max_seqs') == 7
+  with ops.tuned(tiny_max_seqs=0, mid_units=8):
+    assert ops.tune('tiny_max_seqs') == 0 and ops.tune('mid_units') == 8
+  assert ops.tune('tiny_max_seqs') == 7 and ops.tune('mid_units') == 0
+  ops.tune('tiny_max_seqs', default)
+  with pytest.raises(RuntimeError):
+    ops.tune('no_such_tunable', 1)
+
+
+def test_the_library_reads_no_environment_variable():
+  """Experiment switches were retired in round 3: the native sources contain no getenv, and the
+  package reads exactly two variables (the library path and the math mode)."""
+  import glob
+  import re
+  root = os.path.join(REPO, 'cmhse_amd')
+  native = ''.join(open(f).read() for f in glob.glob(os.path.join(root, 'csrc', '*')))
+  assert 'getenv' not in native
+  py = ''.join(open(f).read() for f in glob.glob(os.path.join(root, '*.py')))
+  assert sorted(set(re.findall(r"environ(?:\.get)?\(\s*'(CMHSE_[A-Z0-9_]+)'", py))) == ['CMHSE_HIP_LIB', 'CMHSE_MATH']

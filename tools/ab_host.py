@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive validation pass (loader batches in pinned host memory) under different settings,
-arms interleaved in one process.  Arms: "K=V,K=V;K=V" of environment variables read per call
-(CMHSE_PULL_GRID) or at first use (CMHSE_COPY_PRIO: use one arm per process for that one)."""
+arms interleaved in one process.  Arms: "PIPE=0|1,CHUNK=n;..." (evaluation.PIPELINE_UPLOAD /
+UPLOAD_CHUNK)."""
 import argparse
 import os
 import statistics
@@ -75,9 +75,6 @@ def main():
   res = [[] for _ in arms]
   for rnd in range(args.rounds + 1):
     for i, a in enumerate(arms):
-      for k in keys:
-        os.environ.pop(k, None)
-      os.environ.update(a)
       evaluation.PIPELINE_UPLOAD[0] = a.get('PIPE', '1') == '1'
       evaluation.UPLOAD_CHUNK[0] = int(a.get('CHUNK', '8'))
       if rnd == 0:

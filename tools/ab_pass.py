@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of environment-switched kernel variants on the validation pass, inside ONE process with the
-arms interleaved (cdna_hip_programming.md §5.4 rule 24).
+"""A/B of kernel-shape crossovers / schedules on the validation pass, inside ONE process with the
+arms interleaved (cdna_hip_programming.md §5.4 rule 24; arms: tools/_arms.py).
 
-  python tools/ab_pass.py --modes "CMHSE_GRU_RASTER=0;CMHSE_GRU_RASTER=4" --rounds 3
+  python tools/ab_pass.py --modes "tune.tall_tile_min_wgs=0;tune.tall_tile_min_wgs=2048" --rounds 3
 
 Each arm: `--passes` timed passes (encode_data_device + i2t + t2i) per round; prints per arm the
 median / min ms per pass and the LDS-tiled step kernel's event-timed TFLOP/s.
@@ -22,6 +22,8 @@ import bench  # noqa: E402
 from cmhse_amd import ops, synthetic  # noqa: E402
 from cmhse_amd.evaluation import encode_data_device  # noqa: E402
 from cmhse_amd.model import VSE  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, 'tools'))
+import _arms  # noqa: E402
 
 
 def main():
@@ -32,8 +34,7 @@ def main():
   ap.add_argument('--passes', type=int, default=2)
   ap.add_argument('--n_videos', type=int, default=0)
   args = ap.parse_args()
-  arms = [dict(kv.split('=') for kv in m.split(',') if kv) for m in args.modes.split(';')]
-  keys = sorted({k for a in arms for k in a})
+  arms = _arms.parse(args.modes)
   device = torch.device('cuda', 0)
   torch.cuda.set_device(0)
   wl = dict(bench.WORKLOADS[args.workload])
@@ -54,9 +55,7 @@ def main():
     return cat
 
   def set_arm(a):
-    for k in keys:
-      os.environ.pop(k, None)
-    os.environ.update(a)
+    _arms.apply(a)
 
   ref = None
   res = [dict(ms=[], tf=[]) for _ in arms]

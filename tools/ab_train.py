@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of environment-switched kernel variants on the TRAINING step (VSE.train_emb), inside one
-process with the arms interleaved (the per-call switches of gru.hip / bwd.hip are read at every
-launch).
+"""A/B of schedules and kernel-shape crossovers on the TRAINING step (VSE.train_emb), inside one
+process with the arms interleaved (tools/_arms.py: cmhse_tune crossovers and the host-side schedule
+attributes).
 
-  python tools/ab_train.py --config c3d --modes "CMHSE_BWD_MID_MAX_SEQS=0;CMHSE_BWD_MID_MAX_SEQS=512"
+  python tools/ab_train.py --config c3d --modes "schedule=towers;schedule=interleaved,side_streams=0;"
 """
 import argparse
 import os
@@ -23,6 +23,7 @@ from cmhse_amd.evaluation import LogCollector  # noqa: E402
 from cmhse_amd import model as model_mod  # noqa: E402
 from cmhse_amd.model import VSE  # noqa: E402
 from train_profile import CONFIGS  # noqa: E402
+import _arms  # noqa: E402
 
 
 def main():
@@ -34,8 +35,7 @@ def main():
   ap.add_argument('--rnn_type', default='attention')
   ap.add_argument('--resident', type=int, default=1, help='1: batches resident in HBM (what bench.py times); 0: pinned host batches')
   args = ap.parse_args()
-  arms = [dict(kv.split('=') for kv in m.split(',') if kv) for m in args.modes.split(';')]
-  keys = sorted({k for a in arms for k in a})
+  arms = _arms.parse(args.modes)
   cfg = dict(CONFIGS[args.config])
   wl = dict(bench.WORKLOADS[cfg.pop('workload')])
   opt = bench.make_opt(wl, args.rnn_type, 1024)
@@ -54,14 +54,7 @@ def main():
   model.train_start(opt)
 
   def run(arm, n):
-    for k in keys:
-      os.environ.pop(k, None)
-    os.environ.update(arm)
-    # host-side switches of cmhse_amd.model (module-level lists), by the same names as their env
-    model_mod.BATCHED_LOSSES[0] = arm.get('CMHSE_BATCHED_LOSSES', '1') == '1'
-    model_mod.TRAIN_SCHEDULE[0] = arm.get('CMHSE_TRAIN_SCHEDULE', 'interleaved')
-    from cmhse_amd import ops as ops_mod
-    ops_mod.SIDE_STREAMS[0] = arm.get('CMHSE_SIDE_STREAMS', '1') == '1'
+    _arms.apply(arm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
@@ -77,7 +70,7 @@ def main():
       res[i].append(run(a, args.steps))
   print('%-56s %10s %10s   (ms per train_emb step, %s)' % ('arm', 'median', 'min', args.config))
   for a, r in zip(arms, res):
-    print('%-56s %10.2f %10.2f' % (','.join('%s=%s' % kv for kv in a.items()) or '(default)',
+    print('%-56s %10.2f %10.2f' % (_arms.label(a),
                                    statistics.median(r), min(r)))
 
 

@@ -1,5 +1,5 @@
 """Timing-only experiment: where does one mid-size GRU step (gru_step_mid_kernel) spend its time,
-and how long is the gap between two dependent step launches?  Builds a separate -DCMHSE_TRACE
+and how long is the gap between two dependent step launches?  Builds a separate -DTILE_TRACE_BUILD
 library (never loaded by the product path) and stamps s_memrealtime (10 ns) per workgroup:
   0 entry   1 operand addresses ready   2 MFMA loop done   3 LDS combine + barrier done
   4 gate math done (epilogue loads returned)   5 stores drained
@@ -26,7 +26,7 @@ def main():
   csrc = os.path.join(ROOT, 'cmhse_amd', 'csrc')
   lib_path = os.path.join(ROOT, 'cmhse_amd', 'libcmhse_trace.so')
   cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-DCMHSE_TRACE', '-o', lib_path] + [os.path.join(csrc, f) for f in ('gru.hip', 'sim.hip', 'bwd.hip')]
+         '-DTILE_TRACE_BUILD', '-o', lib_path] + [os.path.join(csrc, f) for f in ('gru.hip', 'sim.hip', 'bwd.hip')]
   srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
   stale = not os.path.exists(lib_path) or \
       os.path.getmtime(lib_path) < max(os.path.getmtime(p) for p in srcs)
@@ -52,7 +52,7 @@ def main():
            b_ih=torch.zeros(3 * H, device=dev), b_hh=torch.zeros(3 * H, device=dev))
   bm = 16 if S <= 16 else 32
   m_blocks = (S + bm - 1) // bm
-  bu = int(os.environ.get('CMHSE_MID_UNITS', '0'))
+  bu = ops.tune('mid_units')
   if bu not in (4, 8, 16):   # mid_units() of gru.hip: narrowest unit tile whose grid fits 256 CUs
     bu = next((b for b in (4, 8) if ((H + b - 1) // b) * m_blocks <= 256), 16)
   n_wg = m_blocks * ((H + bu - 1) // bu)

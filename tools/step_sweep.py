@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step cost of the small-batch GRU step kernels: one encoder call (Seq2Seq pooling, all
 sequences of full length T) at S sequences, with the mid-size kernel on (default) and off
-(CMHSE_MID_MAX_SEQS=0 -> tiny / tiled kernels), arms interleaved."""
+(tune.mid_max_seqs=0 -> tiny / tiled kernels), arms interleaved (tools/_arms.py)."""
 import argparse
 import os
 import statistics
@@ -14,6 +14,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 from cmhse_amd import layers  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, 'tools'))
+import _arms  # noqa: E402
 
 
 def main():
@@ -22,10 +24,10 @@ def main():
   ap.add_argument('--H', type=int, default=1024)
   ap.add_argument('--sizes', default='1,8,32,64,152,320,512,1024,1536,2048')
   ap.add_argument('--dims', default='500,300,1024')
-  ap.add_argument('--arms', default='CMHSE_MID_MAX_SEQS=0;CMHSE_MID_MAX_SEQS=4096')
+  ap.add_argument('--arms', default='tune.mid_max_seqs=0;tune.mid_max_seqs=4096')
   args = ap.parse_args()
   dev = torch.device('cuda', 0)
-  arms = [dict(kv.split('=') for kv in a.split(',')) for a in args.arms.split(';')]
+  arms = _arms.parse(args.arms)
   print('%6s %6s ' % ('I', 'S') + ' '.join('%28s' % a for a in args.arms.split(';')) + '   (us per step)')
   for I in [int(x) for x in args.dims.split(',')]:
     torch.manual_seed(0)
@@ -37,9 +39,7 @@ def main():
       outs = []
       for rnd in range(4):
         for i, a in enumerate(arms):
-          for k in {k for arm in arms for k in arm}:
-            os.environ.pop(k, None)
-          os.environ.update(a)
+          _arms.apply(a)
           with torch.no_grad():
             layer(x, lens)
             torch.cuda.synchronize()

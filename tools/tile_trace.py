@@ -1,6 +1,6 @@
 """Timing-only experiment: per-workgroup phase timestamps of gru_step_kernel on the MI355X.
 
-Builds a SEPARATE library with -DCMHSE_TRACE (cmhse_amd/libcmhse_trace.so, never loaded by the
+Builds a SEPARATE library with -DTILE_TRACE_BUILD (cmhse_amd/libcmhse_trace.so, never loaded by the
 product path), runs two time steps of a level-1-sized batch, and summarises where a tile's wall
 time goes (s_memrealtime, 10 ns ticks) and how the workgroups co-resident on one CU overlap.
 
@@ -25,7 +25,7 @@ def main():
   csrc = os.path.join(ROOT, 'cmhse_amd', 'csrc')
   lib_path = os.path.join(ROOT, 'cmhse_amd', os.environ.get('TRACE_LIB', 'libcmhse_trace.so'))
   cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-         '-DCMHSE_TRACE'] + os.environ.get('TRACE_FLAGS', '').split() + ['-o', lib_path] + [os.path.join(csrc, f) for f in
+         '-DTILE_TRACE_BUILD'] + os.environ.get('TRACE_FLAGS', '').split() + ['-o', lib_path] + [os.path.join(csrc, f) for f in
                                               ('gru.hip', 'sim.hip', 'bwd.hip')]
   srcs = [os.path.join(csrc, f) for f in os.listdir(csrc)]
   stale = not os.path.exists(lib_path) or \
@@ -69,11 +69,11 @@ def main():
     torch.cuda.synchronize()
   lib.cmhse_debug_set_trace(None)
   tr = trace.cpu().numpy().reshape(n_wg, 8)
-  tr = tr[tr[:, 4] != 0]          # CMHSE_GRU_MSUB=2 launches half as many workgroups
+  tr = tr[tr[:, 4] != 0]          # 128-row tiles launch half as many workgroups
   n_wg = len(tr)
   # unset: the launcher picks 128-row tiles for launches of >= 2048 64-row workgroups (gru_msub_for)
-  msub_env = os.environ.get('CMHSE_GRU_MSUB')
-  rows_per_tile = 128 if (msub_env == '2' or (msub_env is None and n_wg >= 2048)) else 64
+  thr = ops.tune('tall_tile_min_wgs')
+  rows_per_tile = 128 if (thr > 0 and n_wg >= thr) else 64
   t = tr[:, :5].astype(np.float64) * 0.01   # us (100 MHz)
   t0 = t[:, 0].min()
   t -= t0
