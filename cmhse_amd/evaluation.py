@@ -86,21 +86,15 @@ def _to_dev(t, device):
 TWO_STREAMS = [False]
 GROUP_TOWERS = [True]
 EARLY_POOL = [True]
-_SIDE_STREAMS = {}
 
 
 def _tail_stream(device):
-  key = (device.type, device.index, 'tail')
-  if key not in _SIDE_STREAMS:
-    _SIDE_STREAMS[key] = torch.cuda.Stream(device, priority=-1)   # above the default priority
-  return _SIDE_STREAMS[key]
+  return ops.stream_set(device)[0]
 
 
 def _side_streams(device):
-  key = (device.type, device.index)
-  if key not in _SIDE_STREAMS:
-    _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-  return _SIDE_STREAMS[key]
+  st = ops.stream_set(device)
+  return st[0], st[1]
 
 
 PIPELINE_UPLOAD = [True]      # pinned host batches are pulled chunk by chunk under the step pipeline
@@ -108,13 +102,9 @@ UPLOAD_CHUNK = [8]             # time steps per pull chunk once the pipeline is 
 
 
 def _copy_stream(device):
-  key = (device.type, device.index, 'copy')
-  if key not in _SIDE_STREAMS:
-    # high priority: its few, short workgroups should be dispatched as soon as a slot frees, and
-    # priority streams live on hardware queues of their own (a copy stream that shares the compute
-    # stream's hardware queue runs in submission order with it: no overlap at all, measured)
-    _SIDE_STREAMS[key] = torch.cuda.Stream(device, priority=-1)
-  return _SIDE_STREAMS[key]
+  # a stream on a hardware queue of its own (ops.stream_set): a copy stream that shares the compute
+  # stream's hardware queue runs in submission order with it — no overlap at all, measured
+  return ops.stream_set(device)[1]
 
 
 # Pinned float32 blocks for the deferred 'Letest' values, recycled by flush(): page-locking a fresh

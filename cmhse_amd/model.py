@@ -113,26 +113,12 @@ TRAIN_SCHEDULE = ['interleaved']
 BATCHED_LOSSES = [True]
 # torch.optim.Adam(fused=True): one launch for the whole update (VSE.__init__)
 FUSED_ADAM = [True]
-_TOWER_STREAMS = {}
 
 
 def _tower_streams(device):
-  """The two towers' streams and their companion streams (ops.side_stream), created together and
-  each used once right away.  The HIP runtime binds a stream to one of its few hardware queues when
-  the stream is first used, and which queue it gets depends on what has run before: streams first
-  used AFTER a validation pass had run its text tail on the high-priority side stream all landed on
-  one hardware queue — the two towers and their weight-gradient products then ran strictly one after
-  the other (22.9 instead of 11.2 ms per step, measured).  VSE.__init__ calls this, so the binding
-  happens before any other stream of the package exists."""
-  key = (device.type, device.index)
-  if key not in _TOWER_STREAMS:
-    pair = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-    sides = [ops.side_stream(s) for s in pair]
-    for s in list(pair) + [x for x in sides if x is not None]:
-      with torch.cuda.stream(s):
-        torch.zeros(1, device=device)
-    _TOWER_STREAMS[key] = pair
-  return _TOWER_STREAMS[key]
+  """The two towers' streams: [0] and [1] of the package's stream set (ops.stream_set)."""
+  st = ops.stream_set(device)
+  return st[0], st[1]
 
 
 # tools/train_timeline.py sets this to a list: (name, host perf_counter, event on the current
@@ -203,7 +189,7 @@ class VSE(object):
     fused = FUSED_ADAM[0] and all(p.is_cuda for p in params)
     self.optimizer = (torch.optim.Adam(params, lr=opt.learning_rate, fused=True) if fused
                       else torch.optim.Adam(params, lr=opt.learning_rate))
-    _tower_streams(next(iter(params)).device)     # bind the training streams to hardware queues now
+    ops.stream_set(next(iter(params)).device)     # bind the package's streams to hardware queues now
     self.Eiters = 0
     self.logger = None
     self._pending_log = None

@@ -673,26 +673,54 @@ def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
                                   want_dh0=want_dh0)])[0]
 
 
-# Throughput work beside a latency chain (cmhse_gru_bwd_job.side_stream): every stream that runs
-# backward passes gets ONE companion stream, created on first use and kept.  The library forks to
-# it and joins it back inside the call, so the caller's stream semantics do not change and no
-# record_stream bookkeeping is needed (nothing the side stream touches is freed before the join).
+# The package's streams.  The HIP runtime serves a process with a handful of hardware queues
+# (four by default) and binds a stream to one of them when the stream is first used; which queue
+# it gets depends on what ran before.  Streams that must run SIDE BY SIDE — the two towers of a
+# training step, a chain and the throughput work beside it, the text tail / the host pull beside the
+# caller's stream in a validation pass — must not share a queue: streams first used after a
+# validation pass had used a high-priority stream all landed on ONE queue (training steps 2x
+# slower), and binding the training streams first cost the validation pass 3-10 % the same way.
+# So the package owns exactly FOUR streams per device, created together and each used once right
+# away (first call: VSE.__init__), and every role is one of them:
+#   [0] tower A (visual) of a training step | the text tail of a validation pass (tail_stream)
+#   [1] tower B (text)                      | the host-pull copy stream of a validation pass
+#   [2] companion of [0] (and of any other stream): weight-gradient products, projection chunks
+#   [3] companion of [1]
+# With the default (null) stream that is five streams on four queues: [3] shares the null stream's
+# queue, which is idle while a training step's towers run.  All four have the default priority:
+# what rounds 1-2 bought with high-priority side streams was a queue of their own, not the
+# priority (validation pass 286.7-290.0 ms with default priority against 286.2-293.1 with [0], [1]
+# raised, alternating runs on one box) — and raised tower streams cost a training step 1-2 ms
+# (profiles/r03_stream_binding.txt).
 SIDE_STREAMS = [True]
-_SIDE_OF = {}
+_STREAM_SET = {}
+
+
+def stream_set(device=None):
+  device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+  key = device.index if device.index is not None else torch.cuda.current_device()
+  st = _STREAM_SET.get(key)
+  if st is None:
+    dev = torch.device('cuda', key)
+    st = tuple(torch.cuda.Stream(dev) for _ in range(4))
+    for s in st:
+      with torch.cuda.stream(s):
+        torch.zeros(1, device=dev)
+    _STREAM_SET[key] = st
+  return st
 
 
 def side_stream(cur=None):
-  """The companion stream of `cur` (default: the current stream); None when disabled."""
+  """The companion stream of `cur` (default: the current stream) for throughput work beside a
+  latency chain (cmhse_gru_job.side_stream / cmhse_gru_bwd_job.side_stream); None when disabled.
+  The library forks to it and joins it back inside the call, so the caller's stream semantics do
+  not change and no record_stream bookkeeping is needed (nothing the side stream touches is freed
+  before the join)."""
   if not SIDE_STREAMS[0]:
     return None
   cur = cur or torch.cuda.current_stream()
-  key = (cur.device.index, cur.cuda_stream)
-  st = _SIDE_OF.get(key)
-  if st is None:
-    # (default priority, like the chain's stream: with either of the two raised the step is
-    # 8-17 % slower — measured, profiles/r03_train_ab.txt)
-    st = _SIDE_OF[key] = torch.cuda.Stream(cur.device)
-  return st
+  st = stream_set(cur.device)
+  return st[3] if cur.cuda_stream == st[1].cuda_stream else st[2]
 
 
 def gru_pool_bwd_multi(requests, job_streams=None):
