@@ -383,12 +383,15 @@ def train_bench(name, embed, rnn_type, n_steps, device):
   model = VSE(opt)
   model.logger = LogCollector()
   model.train_start(opt)
-  spec = synthetic.anet_like_spec(wl['batch'] * max(1, min(n_steps, 10)), seed=0,
+  # the first loader batches of the same val-shaped split the validation pass runs on (round 2's
+  # train_step leg used exactly these, so the figures compare across rounds)
+  spec = synthetic.anet_like_spec(1004 if cfg['dataset'] == 'didemo' else 4917, seed=0,
                                   dataset=cfg['dataset'])
   gen = torch.Generator(device=device)
   batches, clip_pos = [], 0
-  for bi, b0 in enumerate(range(0, spec.n_videos, wl['batch'])):
-    gen.manual_seed(7919 + bi)
+  n_batches = max(1, min(n_steps, 10))
+  for bi, b0 in enumerate(range(0, n_batches * wl['batch'], wl['batch'])):
+    gen.manual_seed(bi)       # (build_loader's seeding: the same batches as the validation split's)
     b1 = min(spec.n_videos, b0 + wl['batch'])
     batches.append(device_batch(spec, b0, b1, clip_pos, wl['img_dim'], wl['vocab'], wl['feat'], gen,
                                 device))

@@ -249,6 +249,15 @@ void gru_step_kernel(const GruStepGroup grp) {
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms) {
     const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
+#if defined(TILE_TRACE_BUILD) && defined(TILE_TRACE_NO_HP)
+    // timing-only bound (tools/tile_trace.py, TRACE_FLAGS=-DTILE_TRACE_NO_HP; wrong results): the
+    // epilogue WITHOUT its re-read of the previous states — what capturing them from the h
+    // phase's LDS tiles could save at most
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hp_all[ms][r] = 0.f;
+    } else
+#endif
     if (t > 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
