@@ -627,6 +627,161 @@ __global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// BPTT step of a training-size batch (32 < S_t <= bwd_mid_max_seqs) as TWO launches that move a
+// third of the bytes.  The product of a step,  rec[S, H] = dGh_{t+1}[S, 3H] . W_hh[3H, H],  is a
+// skinny GEMM: a handful of row tiles, K = 3H.  gru_bwd_step_mid_kernel covers it with 32 x 16
+// tiles that each walk ALL of K — 320 workgroups x 576 KB = 184 MB of operands through the cache
+// fabric per step at S_t = 152, which is what bounds it (8 TB/s for 1 GFLOP) and what makes two
+// chains and the weight-gradient products beside them slow each other down.  Here:
+//   bwd_rec_part_kernel   32 x 128 tiles, K cut into `splits` slices over the grid's second
+//                         dimension (240-256 workgroups in all): operands staged through LDS in
+//                         32-k chunks (whole 128-byte lines per row), one 32x32x2 accumulator per
+//                         wave; writes the slice's partial tile to scratch.  Operand bytes per step:
+//                         outputs x K x 4 x (1/128 + 1/32) = 76 MB at S_t = 152.
+//   bwd_gates_kernel      adds the partials in slice order (bitwise reproducible), then the gate
+//                         derivatives of step t exactly as the one-launch kernels' epilogue.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRecBM = 32, kRecBN = 128, kRecBK = 32, kRecLd = kRecBK + 4;
+
+struct RecPartParams {
+  const float* a;     // dGh_{t+1} rows [S_next, K]
+  const float* b;     // W_hh^T rows [H, K]
+  float* part;        // [splits][m_pad][H]
+  int32_t S_next, H, K, k_slice, m_pad, n_tiles;
+};
+
+__global__ __launch_bounds__(kThreads) void bwd_rec_part_kernel(const RecPartParams q) {
+  __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
+  const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
+  const int k0 = static_cast<int>(blockIdx.y) * q.k_slice;
+  const int k1 = (k0 + q.k_slice < q.K) ? (k0 + q.k_slice) : q.K;
+  const int nchunks = (k1 - k0 + kRecBK - 1) / kRecBK;
+  // staging: a row of a chunk is 32 floats = 8 x 16 B; thread (row = tid >> 3, piece = tid & 7)
+  const int srow = tid >> 3, sk = (tid & 7) * 4;
+  rowaddr_t arow, brow[4];
+  {
+    const int m = m0 + srow;                                  // 32 A rows: threads 0..255 cover 32 x 8
+    arow = row_addr(q.a + static_cast<int64_t>(m < q.S_next ? m : (q.S_next - 1)) * q.K);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + srow + 32 * i;
+      brow[i] = row_addr(q.b + static_cast<int64_t>(n < q.H ? n : (q.H - 1)) * q.K);
+    }
+  }
+  float4 ra, rb[4];
+  auto issue = [&](int c) {
+    const int k = k0 + c * kRecBK + sk;
+    ra = issue_row4<true>(arow, k, k1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = issue_row4<true>(brow[i], k, k1);
+  };
+  auto stage = [&](int buf, int c) {
+    const int k = k0 + c * kRecBK + sk;
+    float* A = lds[buf];
+    float* B = lds[buf] + kRecBM * kRecLd;
+    *reinterpret_cast<float4*>(A + srow * kRecLd + sk) = finish_row4<true>(ra, true, k, k1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(B + (srow + 32 * i) * kRecLd + sk) = finish_row4<true>(rb[i], true, k, k1);
+  };
+  f32x16 acc = zero16();
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  issue(0);
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunks) issue(c + 1);
+    const float* A = lds[cur] + frow * kRecLd + fk;
+    const float* B = lds[cur] + (kRecBM + wave * 32 + frow) * kRecLd + fk;
+#pragma unroll
+    for (int kb = 0; kb < kRecBK / 8; ++kb) {
+      const float4 fa = *reinterpret_cast<const float4*>(A + kb * 8);
+      const float4 fb = *reinterpret_cast<const float4*>(B + kb * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+    if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
+    __syncthreads();
+  }
+  // the slice's partial tile: rows past S_next hold garbage of a clamped row and are never read
+  float* P = q.part + (static_cast<int64_t>(blockIdx.y) * q.m_pad + m0) * q.H;
+  const int n = n0 + wave * 32 + acc_col(lane);
+  if (n < q.H) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[static_cast<int64_t>(acc_row(r, lane)) * q.H + n] = acc[r];
+  }
+}
+
+struct GatesBwdParams {
+  BwdStepParams s;
+  const float* part;   // [splits][m_pad][H] or NULL (no continuing gradient: the chain's first launch)
+  int32_t splits, m_pad;
+};
+
+// one thread per (sequence, 4 hidden units)
+__global__ __launch_bounds__(kThreads) void bwd_gates_kernel(const GatesBwdParams g) {
+  const BwdStepParams& q = g.s;
+  const int H = q.H, K = 3 * H, h4 = H / 4;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= static_cast<int64_t>(q.S_t) * h4) return;
+  const int m = static_cast<int>(e / h4), u = static_cast<int>(e % h4) * 4;
+  float4 rec = zero4();
+  if (m < q.S_next) {
+    rec = *reinterpret_cast<const float4*>(q.carry + static_cast<int64_t>(m) * H + u);
+    float4 sum = zero4();
+    for (int y = 0; y < g.splits; ++y) {
+      const float4 p = *reinterpret_cast<const float4*>(
+          g.part + (static_cast<int64_t>(y) * g.m_pad + m) * H + u);
+      sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+    }
+    rec.x += sum.x; rec.y += sum.y; rec.z += sum.z; rec.w += sum.w;
+  }
+  if (q.t < 0) {  // final launch: d loss / d h0
+    *reinterpret_cast<float4*>(q.dh0 + static_cast<int64_t>(q.out_row[m]) * H + u) = rec;
+    return;
+  }
+  const int64_t p = q.off_cur + m;
+  const float4 dp = *reinterpret_cast<const float4*>(q.dpool + p * H + u);
+  const float* gp = q.gates + p * 4 * H + u;
+  const float4 rg = *reinterpret_cast<const float4*>(gp);
+  const float4 zg = *reinterpret_cast<const float4*>(gp + H);
+  const float4 ng = *reinterpret_cast<const float4*>(gp + 2 * H);
+  const float4 ghn = *reinterpret_cast<const float4*>(gp + 3 * H);
+  float4 hp = zero4();
+  if (q.t > 0)
+    hp = *reinterpret_cast<const float4*>(q.hs + (q.off_prev + m) * H + u);
+  else if (q.h0_rows != nullptr)
+    hp = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(q.h0_rows[m]) + u);
+  float4 drp, dzp, dnp, dnr, car;
+#define GATE_LANE_(c)                                            \
+  {                                                                   \
+    const float dh = rec.c + dp.c;                                    \
+    const float dn_pre = dh * (1.0f - zg.c) * (1.0f - ng.c * ng.c);   \
+    dzp.c = dh * (hp.c - ng.c) * zg.c * (1.0f - zg.c);                \
+    drp.c = dn_pre * ghn.c * rg.c * (1.0f - rg.c);                    \
+    dnp.c = dn_pre;                                                   \
+    dnr.c = dn_pre * rg.c;                                            \
+    car.c = dh * zg.c;                                                \
+  }
+  GATE_LANE_(x) GATE_LANE_(y) GATE_LANE_(z) GATE_LANE_(w)
+#undef GATE_LANE_
+  float* gx = q.dgx + p * K + u;
+  float* gh = q.dgh + p * K + u;
+  *reinterpret_cast<float4*>(gx) = drp;
+  *reinterpret_cast<float4*>(gx + H) = dzp;
+  *reinterpret_cast<float4*>(gx + 2 * H) = dnp;
+  *reinterpret_cast<float4*>(gh) = drp;
+  *reinterpret_cast<float4*>(gh + H) = dzp;
+  *reinterpret_cast<float4*>(gh + 2 * H) = dnr;
+  *reinterpret_cast<float4*>(q.carry + static_cast<int64_t>(m) * H + u) = car;
+}
+
+// ---------------------------------------------------------------------------------------------
 // F.normalize backward: dx = (g - y (y.g)) / max(||x||, eps), y = x / max(||x||, eps)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(const float* __restrict__ x,
@@ -1049,6 +1204,15 @@ struct TnRowsLaunch {
   }
 };
 
+// Scratch of the two-launch BPTT step: `splits` partial [m_pad, H] tiles, splits x row tiles <= 256
+// workgroups per 128 columns (rec_plan), i.e. at most 256 / (H / 128) x 32 rows of H floats.
+static size_t rec_part_floats(int S, int H) {
+  if (H % 4 != 0) return 0;
+  const int n_tiles = (H + kRecBN - 1) / kRecBN;
+  const size_t rows = static_cast<size_t>(256 / n_tiles + 1 + (S + 31) / 32) * 32;
+  return rows * H;
+}
+
 // Scratch of the weight-gradient row split (TnRowsLaunch): up to 4 parts of [dW_ih | db_ih | dW_hh |
 // db_hh] (or 8 of the smaller dW_lin); none for a batch too short to be split at all.
 static size_t wg_part_floats(int64_t sum_T, int I, int H) {
@@ -1060,7 +1224,7 @@ static size_t wg_part_floats(int64_t sum_T, int I, int H) {
 
 struct BwdWs {
   size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, dxaddr, hsaddr, p_t, zero_row,
-      colsum, dx_part, wg_part, total;
+      colsum, dx_part, wg_part, rec_part, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -1085,6 +1249,7 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
   L.dx_part = take(det_split_scratch_bytes(sum_T, I));
   L.wg_part = take(wg_part_floats(sum_T, I, H) * sizeof(float));
+  L.rec_part = take(rec_part_floats(S, H) * sizeof(float));
   L.total = off;
   return L;
 }
@@ -1346,9 +1511,39 @@ void bwd_steps(BwdJob* jobs, int n) {
       if (b->H % 4 == 0 && S_t <= bwd_mid_max_seqs()) {   // the 16 x 16 x 4 tile shapes
         const int bm = (S_t <= 16) ? 16 : 32;
         const int bu = kBwdMidUnits;
-        kind[k] = 8 | (bm == 16 ? 16 : 0) | (bu == 8 ? 32 : 0) | (bu == 4 ? 64 : 0);
+        kind[k] = 8 | (bm == 16 ? 16 : 0);
         grid_k[k] = static_cast<unsigned>((b->H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
+        const int split_min = tunables().bwd_split_min_seqs.load(std::memory_order_relaxed);
+        if (split_min > 0 && S_t >= split_min) kind[k] = 32;   // two launches, a third of the bytes
       }
+    }
+    for (int k = 0; k < n; ++k) {
+      if (kind[k] != 32) continue;
+      BwdJob& j = jobs[k];
+      const BwdStepParams& sp = j.sp;
+      const int H = sp.H, K = 3 * H;
+      GatesBwdParams gp;
+      gp.s = sp; gp.part = nullptr; gp.splits = 0; gp.m_pad = 0;
+      if (sp.S_next > 0) {
+        RecPartParams rp;
+        rp.a = sp.dgh_next; rp.b = sp.whh_t;
+        rp.part = reinterpret_cast<float*>(j.ws + j.L.rec_part);
+        rp.S_next = sp.S_next; rp.H = H; rp.K = K;
+        rp.n_tiles = (H + kRecBN - 1) / kRecBN;
+        const int m_tiles = (sp.S_next + kRecBM - 1) / kRecBM, tiles = rp.n_tiles * m_tiles;
+        int splits = 256 / tiles;
+        if (splits > K / 64) splits = K / 64;
+        if (splits < 1) splits = 1;
+        rp.k_slice = ((K + splits - 1) / splits + kRecBK - 1) / kRecBK * kRecBK;
+        splits = (K + rp.k_slice - 1) / rp.k_slice;
+        rp.m_pad = m_tiles * kRecBM;
+        hipLaunchKernelGGL(bwd_rec_part_kernel, dim3(tiles, splits), dim3(kThreads), 0, j.st, rp);
+        gp.part = rp.part; gp.splits = splits; gp.m_pad = rp.m_pad;
+      }
+      const int64_t elems = static_cast<int64_t>(sp.S_t) * (H / 4);
+      hipLaunchKernelGGL(bwd_gates_kernel, dim3(static_cast<unsigned>((elems + kThreads - 1) / kThreads)),
+                         dim3(kThreads), 0, j.st, gp);
+      kind[k] = 0;
     }
     for (int k = 0; k < n; ++k) {
       if (kind[k] == 0) continue;
@@ -1368,19 +1563,10 @@ void bwd_steps(BwdJob* jobs, int n) {
       for (int m = g.n; m < CMHSE_MAX_JOBS; ++m) g.start[m] = 0xffffffffu;
       const bool vec = (kd & 4) == 0;
       if ((kd & 8) != 0) {
-        const int bu = (kd & 64) != 0 ? 4 : ((kd & 32) != 0 ? 8 : 16);
-#define BWD_MID_LAUNCH_(MB, BU) \
-  hipLaunchKernelGGL((gru_bwd_step_mid_kernel<MB, BU>), dim3(grid), dim3(64 * kBwdMidNW), 0, st, g)
-        if ((kd & 16) != 0) {
-          if (bu == 4) BWD_MID_LAUNCH_(1, 4);
-          else if (bu == 8) BWD_MID_LAUNCH_(1, 8);
-          else BWD_MID_LAUNCH_(1, 16);
-        } else {
-          if (bu == 4) BWD_MID_LAUNCH_(2, 4);
-          else if (bu == 8) BWD_MID_LAUNCH_(2, 8);
-          else BWD_MID_LAUNCH_(2, 16);
-        }
-#undef BWD_MID_LAUNCH_
+        if ((kd & 16) != 0)
+          hipLaunchKernelGGL((gru_bwd_step_mid_kernel<1, kBwdMidUnits>), dim3(grid), dim3(64 * kBwdMidNW), 0, st, g);
+        else
+          hipLaunchKernelGGL((gru_bwd_step_mid_kernel<2, kBwdMidUnits>), dim3(grid), dim3(64 * kBwdMidNW), 0, st, g);
       } else if ((kd & 3) == 2) {
         if (vec)
           hipLaunchKernelGGL((gru_bwd_step_kernel<true, 8>), dim3(grid), dim3(512), 0, st, g);

@@ -381,6 +381,8 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *   "tall_tile_min_wgs" 2048  64-row workgroups from which an LDS-tiled launch uses 128-row tiles
  *   "bwd_mid_max_seqs"   512  active sequences at or below which a BPTT step runs on the mid-size
  *                             backward kernel
+ *   "bwd_split_min_seqs"  33  active sequences from which (up to bwd_mid_max_seqs) a BPTT step runs
+ *                             as two launches with K split over the grid; 0 = never
  * Process-wide (atomics): set them between calls, not while calls that size workspaces with them
  * (`*_workspace` reads mid_max_seqs) are in flight on other threads.  Unknown name: CMHSE_ERR_ARG. */
 int cmhse_tune(const char* name, int32_t value, int32_t* old_value);

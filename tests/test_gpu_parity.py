@@ -574,6 +574,55 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
       grad_close(pp.grad.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
 
 
+@pytest.mark.parametrize('pool,cls', [('attention', 'Attention'), ('maxout', 'Maxout')])
+def test_weight_gradients_in_time_chunks_beside_the_chain(dev, oracle, pool, cls, monkeypatch):
+  """The weight-gradient products (gemm_tn_rows_kernel) of a batch long enough to be taken in
+  several chunks of time steps (sum T ~ 3.5 k packed rows: chunks close every >= 1024 rows, the
+  last one mid-tile), with widths that are not tile multiples (3H = 216 rows of C, I = 36) and so
+  few tiles that every launch is row-split (parts + ordered reduce): every gradient against the
+  float64 oracle; bit-identical with the products on the chain's own stream instead of the side
+  stream; and bitwise reproducible from run to run (no atomics on this path)."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(77)
+  S, T, I, H = 330, 14, 36, 72
+  torch.manual_seed(8)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[:200] = rng.randint(T - 2, T + 1, size=200)
+  lens[0] = T
+  assert lens.sum() > 3 * 1024
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  w = rng.standard_normal((S, H)).astype(np.float32)
+
+  def run(side):
+    monkeypatch.setattr(ops, 'SIDE_STREAMS', [side])
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return [xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  beside, again, inline = run(True), run(True), run(False)
+  for a, b, c in zip(beside, again, inline):
+    assert torch.equal(a, b), 'not reproducible from run to run'
+    assert torch.equal(a, c), 'side stream changed the result'
+  _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+  grads, dx, dh0 = oracle.pooled_gru_backward(cache, w.astype(np.float64))
+  grad_close(beside[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
+  grad_close(beside[1].cpu().numpy(), dh0, pool + ' dh0')
+  for (pn, _), got in zip(layer.named_parameters(), beside[2:]):
+    grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
 @pytest.mark.parametrize('seed', range(12))
 def test_gru_pool_fuzz_forward_backward_vs_oracle(dev, oracle, seed):
   """Seeded random shapes, deliberately awkward: single sequences and single steps, widths that
