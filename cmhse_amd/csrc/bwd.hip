@@ -1160,13 +1160,14 @@ struct TnRowsLaunch {
       // Row split: the number of splits (<= 8, >= 256 rows each, parts fitting the scratch) that
       // leaves the busiest CU the least above the average, three workgroups per CU being
       // resident at once.  A chunk that is not the last one (`beside`: the chain is still running
-      // when it is launched) is split only if its tiles leave CUs empty: there the parts' extra
-      // traffic competes with the chain for the cache fabric both are bound by, and evening out
-      // the last round buys nothing.  (The rule depends on the shapes only, never on whether a
-      // side stream is used: results are bit-identical with and without one.)
+      // when it is launched) is split only below two tiles per CU: there the parts' extra traffic
+      // competes with the chain for the cache fabric both are bound by (train_emb step, ms, same
+      // box, split below 256 / 512 / 1024 tiles: C3D 9.19 / 9.10 / 9.09, ICEP 10.40 / 10.31 / 10.74,
+      // ICEP + reconstruction 11.30 / 11.22 / 11.62).  (The rule depends on the shapes only, never
+      // on whether a side stream is used: results are bit-identical with and without one.)
       const int64_t rows = g.p1 - g.p0;
       int best = 1;
-      if (part != nullptr && grid < (beside ? 256u : 1024u)) {
+      if (part != nullptr && grid < (beside ? 512u : 1024u)) {
         double best_cost = 1e30;
         for (int sp = 1; sp <= 8 && (sp == 1 || (rows / sp >= 256 && per_split * sp <= part_floats)); ++sp) {
           const double wgs = static_cast<double>(grid) * sp;
