@@ -670,14 +670,19 @@ __global__ __launch_bounds__(kThreads) void bwd_rec_part_kernel(const RecPartPar
       brow[i] = row_addr(q.b + static_cast<int64_t>(n < q.H ? n : (q.H - 1)) * q.K);
     }
   }
-  float4 ra, rb[4];
-  auto issue = [&](int c) {
+  // Two chunks of operands in flight in registers (R0 / R1) ahead of the chunk being multiplied:
+  // with ~one workgroup per CU nothing else hides the load latency (the rows of dGh were written
+  // by the previous step's gate kernel, often through another XCD's L2).  (Measured equal to one
+  // chunk in flight, 16.8 against 16.0 us per launch at S_t = 152: the launch is not bound by that
+  // latency but by its ~4 us of ramp, first loads and partial stores around 16 x 0.5 us of MFMAs.)
+  float4 ra0, rb0[4], ra1, rb1[4];
+  auto issue = [&](int c, float4& ra, float4 (&rb)[4]) {
     const int k = k0 + c * kRecBK + sk;
     ra = issue_row4<true>(arow, k, k1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) rb[i] = issue_row4<true>(brow[i], k, k1);
   };
-  auto stage = [&](int buf, int c) {
+  auto stage = [&](int buf, int c, const float4& ra, const float4 (&rb)[4]) {
     const int k = k0 + c * kRecBK + sk;
     float* A = lds[buf];
     float* B = lds[buf] + kRecBM * kRecLd;
@@ -688,12 +693,7 @@ __global__ __launch_bounds__(kThreads) void bwd_rec_part_kernel(const RecPartPar
   };
   f32x16 acc = zero16();
   const int frow = lane & 31, fk = (lane >> 5) * 4;
-  issue(0);
-  stage(0, 0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    if (c + 1 < nchunks) issue(c + 1);
+  auto compute = [&](int cur) {
     const float* A = lds[cur] + frow * kRecLd + fk;
     const float* B = lds[cur] + (kRecBM + wave * 32 + frow) * kRecLd + fk;
 #pragma unroll
@@ -705,7 +705,24 @@ __global__ __launch_bounds__(kThreads) void bwd_rec_part_kernel(const RecPartPar
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
     }
-    if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
+  };
+  issue(0, ra0, rb0);
+  if (nchunks > 1) issue(1, ra1, rb1);
+  stage(0, 0, ra0, rb0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    // even chunk c (LDS 0): R0 is free (chunk c is staged), R1 holds chunk c + 1
+    if (c + 2 < nchunks) issue(c + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    if (c + 1 < nchunks) stage(1, c + 1, ra1, rb1);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    // odd chunk c + 1 (LDS 1): R1 is free, R0 holds chunk c + 2
+    if (c + 3 < nchunks) issue(c + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    if (c + 2 < nchunks) stage(0, c + 2, ra0, rb0);
     __syncthreads();
   }
   // the slice's partial tile: rows past S_next hold garbage of a clamped row and are never read
@@ -1532,7 +1549,7 @@ void bwd_steps(BwdJob* jobs, int n) {
         rp.S_next = sp.S_next; rp.H = H; rp.K = K;
         rp.n_tiles = (H + kRecBN - 1) / kRecBN;
         const int m_tiles = (sp.S_next + kRecBM - 1) / kRecBM, tiles = rp.n_tiles * m_tiles;
-        int splits = 256 / tiles;
+        int splits = 256 / tiles;       // (512 / 768 / 1024 workgroups measured 4 / 9 / 14 % slower: more partials)
         if (splits > K / 64) splits = K / 64;
         if (splits < 1) splits = 1;
         rp.k_slice = ((K + splits - 1) / splits + kRecBK - 1) / kRecBK * kRecBK;
