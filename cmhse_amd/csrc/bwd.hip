@@ -3,14 +3,16 @@
 // F.normalize and ContrastiveLoss.forward, as hand-written gfx950 kernels.
 //
 //   cmhse_gru_pool_bwd      pooling backward -> dpool[sumT,H]; BPTT over the packed steps in reverse
-//                           (one launch per step: dh_{t} = dgates_{t+1} . W_hh + carry, gate
-//                           derivatives in the epilogue); weight gradients as TN GEMMs over all
-//                           packed rows; optional d(input) / d(h0) / d(embedding table).
+//                           (dh_{t} = dgates_{t+1} . W_hh + carry and the gate derivatives: one
+//                           launch per step, or two with K split over the grid at training-batch
+//                           sizes); weight gradients straight from the packed rows in chunks of
+//                           time steps beside the chain (tn_rows.hpp); optional d(input) / d(h0) /
+//                           d(embedding table).
 //   cmhse_l2norm_rows_bwd   F.normalize backward.
 //   cmhse_contrastive_bwd   d loss / d im, d loss / d s from the stored score matrix.
 //
-// Determinism: every reduction runs in a fixed order except the embedding-table scatter
-// (float atomics, like torch's CUDA embedding backward).
+// Determinism: every reduction runs in a fixed order except the sums into the embedding table and
+// into a time-constant decoder input (float atomics, like torch's CUDA embedding backward).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -37,32 +39,6 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __rest
   __syncthreads();
   for (int i = ty; i < 32; i += 8)
     if (c0 + i < C && r0 + tx < R) out[static_cast<int64_t>(c0 + i) * R + r0 + tx] = tile[tx][i];
-}
-
-// Gather + transpose: out[c][p] = row(p)[c] for p < R (rows through `addr` when given, else
-// in + p*ld), c < C; out rows have ldo floats and are zero-filled for R <= p < ldo.  Turns the
-// "sum over packed rows" weight-gradient products into K-contiguous NT GEMMs (nt_core.hpp).
-__global__ __launch_bounds__(kThreads) void gather_transpose_kernel(const float* __restrict__ in,
-                                                                    int64_t ld,
-                                                                    const uint64_t* __restrict__ addr,
-                                                                    float* __restrict__ out,
-                                                                    int64_t R, int C, int64_t ldo) {
-  __shared__ float tile[32][33];
-  const int64_t p0 = static_cast<int64_t>(blockIdx.x) * 32;
-  const int c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
-    const int64_t p = p0 + i;
-    float v = 0.f;
-    if (p < R && c0 + tx < C) {
-      const float* row = addr ? reinterpret_cast<const float*>(addr[p]) : in + p * ld;
-      v = row[c0 + tx];
-    }
-    tile[i][tx] = v;
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8)
-    if (c0 + i < C && p0 + tx < ldo) out[static_cast<int64_t>(c0 + i) * ldo + p0 + tx] = tile[tx][i];
 }
 
 // Column sums over the packed rows: out[c] = sum_p w[p] * in[p][c] (w == NULL -> 1), two stages,
@@ -1052,12 +1028,6 @@ static void launch_colsum(const float* in, const float* w, float* out, float* sc
                      in, w, scratch, rows, cols, ld);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads),
                      0, st, scratch, out, slabs, cols);
-}
-
-static void launch_gather_t(const float* in, int64_t ld, const uint64_t* addr, float* out, int64_t R,
-                            int C, int64_t ldo, hipStream_t st) {
-  hipLaunchKernelGGL(gather_transpose_kernel, dim3(static_cast<unsigned>((ldo + 31) / 32), (C + 31) / 32),
-                     dim3(kThreads), 0, st, in, ld, addr, out, R, C, ldo);
 }
 
 static void launch_tn(const float* a, int64_t lda, const float* b, int64_t ldb,
