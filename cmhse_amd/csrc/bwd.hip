@@ -611,8 +611,8 @@ __global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const 
 // chains and the weight-gradient products beside them slow each other down.  Here:
 //   bwd_rec_part_kernel   32 x 128 tiles, K cut into `splits` slices over the grid's second
 //                         dimension (240-256 workgroups in all): operands staged through LDS in
-//                         32-k chunks (whole 128-byte lines per row), one 32x32x2 accumulator per
-//                         wave; writes the slice's partial tile to scratch.  Operand bytes per step:
+//                         32-k chunks (whole 128-byte lines per row), eight waves each owning 16
+//                         columns (two 16x16x4 accumulators); writes the slice's partial tile to scratch.  Operand bytes per step:
 //                         outputs x K x 4 x (1/128 + 1/32) = 76 MB at S_t = 152.
 //   bwd_gates_kernel      adds the partials in slice order (bitwise reproducible), then the gate
 //                         derivatives of step t exactly as the one-launch kernels' epilogue.
@@ -626,87 +626,93 @@ struct RecPartParams {
   int32_t S_next, H, K, k_slice, m_pad, n_tiles;
 };
 
-__global__ __launch_bounds__(kThreads) void bwd_rec_part_kernel(const RecPartParams q) {
+constexpr int kRecThreads = 512;   // 8 waves: two per SIMD, so one wave's chunk barrier and LDS round trip hide under the other's MFMAs
+
+__global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPartParams q) {
   __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
+  constexpr int ROWS = kRecBM + kRecBN, PIECES = ROWS * (kRecBK / 4), NP = (PIECES + kRecThreads - 1) / kRecThreads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
   const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
   const int k0 = static_cast<int>(blockIdx.y) * q.k_slice;
   const int k1 = (k0 + q.k_slice < q.K) ? (k0 + q.k_slice) : q.K;
   const int nchunks = (k1 - k0 + kRecBK - 1) / kRecBK;
-  // staging: a row of a chunk is 32 floats = 8 x 16 B; thread (row = tid >> 3, piece = tid & 7)
-  const int srow = tid >> 3, sk = (tid & 7) * 4;
-  rowaddr_t arow, brow[4];
-  {
-    const int m = m0 + srow;                                  // 32 A rows: threads 0..255 cover 32 x 8
-    arow = row_addr(q.a + static_cast<int64_t>(m < q.S_next ? m : (q.S_next - 1)) * q.K);
+  // staging: a row of a chunk is 32 floats = 8 x 16 B: piece p = tid + 512 i -> staged row p >> 3
+  // (0..31 rows of dGh, 32..159 rows of W_hh^T), slot p & 7 — eight lanes read one whole 128-byte line
+  rowaddr_t rbase[NP];
+  int lds_off[NP], slot_k[NP];
+  bool live[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + srow + 32 * i;
-      brow[i] = row_addr(q.b + static_cast<int64_t>(n < q.H ? n : (q.H - 1)) * q.K);
+  for (int i = 0; i < NP; ++i) {
+    const int pc = tid + kRecThreads * i;
+    live[i] = pc < PIECES;
+    const int row = live[i] ? (pc >> 3) : 0, slot = pc & 7;
+    if (row < kRecBM) {
+      const int m = m0 + row;
+      rbase[i] = row_addr(q.a + static_cast<int64_t>(m < q.S_next ? m : (q.S_next - 1)) * q.K);
+    } else {
+      const int n = n0 + row - kRecBM;
+      rbase[i] = row_addr(q.b + static_cast<int64_t>(n < q.H ? n : (q.H - 1)) * q.K);
     }
+    slot_k[i] = slot * 4;
+    lds_off[i] = row * kRecLd + slot * 4;
   }
-  // Two chunks of operands in flight in registers (R0 / R1) ahead of the chunk being multiplied:
-  // with ~one workgroup per CU nothing else hides the load latency (the rows of dGh were written
-  // by the previous step's gate kernel, often through another XCD's L2).  (Measured equal to one
-  // chunk in flight, 16.8 against 16.0 us per launch at S_t = 152: the launch is not bound by that
-  // latency but by its ~4 us of ramp, first loads and partial stores around 16 x 0.5 us of MFMAs.)
-  float4 ra0, rb0[4], ra1, rb1[4];
-  auto issue = [&](int c, float4& ra, float4 (&rb)[4]) {
-    const int k = k0 + c * kRecBK + sk;
-    ra = issue_row4<true>(arow, k, k1);
+  float4 r[NP];
+  auto issue = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = issue_row4<true>(brow[i], k, k1);
+    for (int i = 0; i < NP; ++i)
+      if (live[i]) r[i] = issue_row4<true>(rbase[i], k0 + c * kRecBK + slot_k[i], k1);
   };
-  auto stage = [&](int buf, int c, const float4& ra, const float4 (&rb)[4]) {
-    const int k = k0 + c * kRecBK + sk;
-    float* A = lds[buf];
-    float* B = lds[buf] + kRecBM * kRecLd;
-    *reinterpret_cast<float4*>(A + srow * kRecLd + sk) = finish_row4<true>(ra, true, k, k1);
+  auto stage = [&](int buf, int c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(B + (srow + 32 * i) * kRecLd + sk) = finish_row4<true>(rb[i], true, k, k1);
+    for (int i = 0; i < NP; ++i)
+      if (live[i])
+        *reinterpret_cast<float4*>(&lds[buf][lds_off[i]]) =
+            finish_row4<true>(r[i], true, k0 + c * kRecBK + slot_k[i], k1);
   };
-  f32x16 acc = zero16();
-  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  // wave w owns the 16 columns 16 w .. 16 w + 15 of the 32 x 128 tile, both 16-row blocks:
+  // v_mfma_f32_16x16x4_f32, lane (r16 = lane & 15, kq = lane >> 4) feeds k = 4 kq + j of a 16-k block
+  f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+  const int r16 = lane & 15, kq = lane >> 4;
   auto compute = [&](int cur) {
-    const float* A = lds[cur] + frow * kRecLd + fk;
-    const float* B = lds[cur] + (kRecBM + wave * 32 + frow) * kRecLd + fk;
+    const float* A = &lds[cur][0] + r16 * kRecLd + 4 * kq;
+    const float* B = &lds[cur][0] + (kRecBM + 16 * wave + r16) * kRecLd + 4 * kq;
 #pragma unroll
-    for (int kb = 0; kb < kRecBK / 8; ++kb) {
-      const float4 fa = *reinterpret_cast<const float4*>(A + kb * 8);
-      const float4 fb = *reinterpret_cast<const float4*>(B + kb * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    for (int kb = 0; kb < kRecBK / 16; ++kb) {
+      const float4 a0 = *reinterpret_cast<const float4*>(A + kb * 16);
+      const float4 a1 = *reinterpret_cast<const float4*>(A + 16 * kRecLd + kb * 16);
+      const float4 b = *reinterpret_cast<const float4*>(B + kb * 16);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc[1], 0, 0, 0);
     }
   };
-  issue(0, ra0, rb0);
-  if (nchunks > 1) issue(1, ra1, rb1);
-  stage(0, 0, ra0, rb0);
+  issue(0);
+  stage(0, 0);
   __syncthreads();
-  for (int c = 0; c < nchunks; c += 2) {
-    // even chunk c (LDS 0): R0 is free (chunk c is staged), R1 holds chunk c + 1
-    if (c + 2 < nchunks) issue(c + 2, ra0, rb0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunks) issue(c + 1);
     __builtin_amdgcn_sched_barrier(0);
-    compute(0);
-    if (c + 1 < nchunks) stage(1, c + 1, ra1, rb1);
-    __syncthreads();
-    if (c + 1 >= nchunks) break;
-    // odd chunk c + 1 (LDS 1): R1 is free, R0 holds chunk c + 2
-    if (c + 3 < nchunks) issue(c + 3, ra1, rb1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(1);
-    if (c + 2 < nchunks) stage(0, c + 2, ra0, rb0);
+    compute(cur);
+    if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
     __syncthreads();
   }
-  // the slice's partial tile: rows past S_next hold garbage of a clamped row and are never read
+  // the slice's partial tile (element (row r, col c) of a 16 x 16 block: lane (r >> 2) * 16 + c,
+  // register r & 3); rows past S_next hold a clamped row's garbage and are never read
   float* P = q.part + (static_cast<int64_t>(blockIdx.y) * q.m_pad + m0) * q.H;
-  const int n = n0 + wave * 32 + acc_col(lane);
+  const int n = n0 + 16 * wave + r16;
   if (n < q.H) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) P[static_cast<int64_t>(acc_row(r, lane)) * q.H + n] = acc[r];
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        P[static_cast<int64_t>(16 * mb + 4 * kq + reg) * q.H + n] = acc[mb][reg];
   }
 }
 
@@ -1525,7 +1531,7 @@ void bwd_steps(BwdJob* jobs, int n) {
         rp.k_slice = ((K + splits - 1) / splits + kRecBK - 1) / kRecBK * kRecBK;
         splits = (K + rp.k_slice - 1) / rp.k_slice;
         rp.m_pad = m_tiles * kRecBM;
-        hipLaunchKernelGGL(bwd_rec_part_kernel, dim3(tiles, splits), dim3(kThreads), 0, j.st, rp);
+        hipLaunchKernelGGL(bwd_rec_part_kernel, dim3(tiles, splits), dim3(kRecThreads), 0, j.st, rp);
         gp.part = rp.part; gp.splits = splits; gp.m_pad = rp.m_pad;
       }
       const int64_t elems = static_cast<int64_t>(sp.S_t) * (H / 4);
