@@ -408,6 +408,7 @@ def train_bench(name, embed, rnn_type, n_steps, device):
   t0 = time.perf_counter()
   for b in use:
     model.train_emb(opt, *b)
+  str(model.logger)          # a reader: the last step's loss values have reached the host meters
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / n_steps
   work = [train_step_work(b, wl['img_dim'], embed, cfg['flags'], rnn_type == 'attention') for b in use]

@@ -54,6 +54,17 @@ class GruBwdJob(ctypes.Structure):
               ('stream', c_void_p), ('side_stream', c_void_p)]
 
 
+STEP_LOSS_MAX = 8       # CMHSE_STEP_LOSS_MAX
+
+
+class StepLosses(ctypes.Structure):
+  _fields_ = [('n_emb', c_int32), ('n_terms', c_int32), ('D', c_int32),
+              ('x', c_void_p * STEP_LOSS_MAX), ('rows', c_int32 * STEP_LOSS_MAX),
+              ('term_a', c_int32 * STEP_LOSS_MAX), ('term_b', c_int32 * STEP_LOSS_MAX),
+              ('weight', c_float * STEP_LOSS_MAX), ('margin', c_float),
+              ('max_violation', c_int32), ('norm', c_int32)]
+
+
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
@@ -83,6 +94,12 @@ SIGNATURES = {
     'cmhse_contrastive_blocks_fwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                     c_int32, c_float, c_int32, c_int32, c_void_p,
                                                     c_void_p, c_size_t, c_void_p]),
+    'cmhse_step_losses_workspace': (c_size_t, [ctypes.POINTER(StepLosses)]),
+    'cmhse_step_losses_fwd': (ctypes.c_int, [ctypes.POINTER(StepLosses), c_void_p, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
+    'cmhse_step_losses_bwd': (ctypes.c_int, [ctypes.POINTER(StepLosses), c_void_p,
+                                             ctypes.POINTER(c_void_p), c_void_p, c_size_t,
+                                             c_void_p]),
     'cmhse_contrastive_blocks_bwd_workspace': (c_size_t, [c_int32, c_int32]),
     'cmhse_contrastive_blocks_bwd': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                                     c_int32, c_int32, c_float, c_int32, c_int32,

@@ -22,6 +22,7 @@
 #include "nt_core.hpp"
 #include "tn_core.hpp"
 #include "tn_rows.hpp"
+#include "step_loss.hpp"
 
 namespace cmhse {
 
@@ -1739,6 +1740,140 @@ extern "C" int cmhse_contrastive_blocks_bwd(const float* im, const float* s, con
   hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid, n_blocks), dim3(kThreads), smem, st, t);
   t.a = q.G; t.b = im; t.c = d_s;
   hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid, n_blocks), dim3(kThreads), smem, st, t);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cmhse_step_losses_bwd: per-term upstream gradients, the batched ContrastiveLoss backward, then
+// F.normalize's backward over the sum of every use of each encoder output.
+// ---------------------------------------------------------------------------------------------
+struct StepNormBwdParams {
+  const float* x[CMHSE_STEP_LOSS_MAX];
+  float* dx[CMHSE_STEP_LOSS_MAX];
+  int32_t rows[CMHSE_STEP_LOSS_MAX];
+  int32_t term_a[CMHSE_STEP_LOSS_MAX], term_b[CMHSE_STEP_LOSS_MAX], term_off[CMHSE_STEP_LOSS_MAX];
+  float weight[CMHSE_STEP_LOSS_MAX];
+  int32_t n_emb, n_terms, D;
+  const float* d_im;  // [R, D]
+  const float* d_s;   // [R, D]
+};
+
+__global__ void step_gout_kernel(const StepNormBwdParams p, const float* grad_total, float* gout) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float g = *grad_total;
+#pragma unroll
+    for (int k = 0; k < CMHSE_STEP_LOSS_MAX; ++k)
+      if (k < p.n_terms) gout[k] = p.weight[k] * g;
+  }
+}
+
+// one workgroup per encoder-output row: g = sum over the terms that use the row (term order, left
+// operand before right), then l2norm_bwd_kernel's arithmetic
+__global__ __launch_bounds__(kThreads) void step_norm_bwd_kernel(const StepNormBwdParams p) {
+  int e = -1, i = 0, off = 0;
+  const float* xr = nullptr;
+  float* dxr = nullptr;
+#pragma unroll
+  for (int k = 0; k < CMHSE_STEP_LOSS_MAX; ++k) {
+    if (k < p.n_emb) {
+      const int r = static_cast<int>(blockIdx.x) - off;
+      if (r >= 0 && r < p.rows[k]) {
+        e = k;
+        i = r;
+        xr = p.x[k] + static_cast<int64_t>(r) * p.D;
+        dxr = p.dx[k] + static_cast<int64_t>(r) * p.D;
+      }
+      off += p.rows[k];
+    }
+  }
+  if (e < 0) return;
+  const float* use[2 * CMHSE_STEP_LOSS_MAX];
+#pragma unroll
+  for (int k = 0; k < CMHSE_STEP_LOSS_MAX; ++k) {
+    const bool live = k < p.n_terms;
+    const int64_t row = static_cast<int64_t>(p.term_off[k] + i) * p.D;
+    use[2 * k] = (live && p.term_a[k] == e) ? p.d_im + row : nullptr;
+    use[2 * k + 1] = (live && p.term_b[k] == e) ? p.d_s + row : nullptr;
+  }
+  auto grad = [&](int c) {
+    float g = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * CMHSE_STEP_LOSS_MAX; ++u)
+      if (use[u] != nullptr) g += use[u][c];
+    return g;
+  };
+  float ss = 0.f, sg = 0.f;
+  for (int c = threadIdx.x; c < p.D; c += kThreads) {
+    ss += xr[c] * xr[c];
+    sg += xr[c] * grad(c);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    ss += __shfl_xor(ss, o, 64);
+    sg += __shfl_xor(sg, o, 64);
+  }
+  __shared__ float p1[4], p2[4];
+  __shared__ float s_inv, s_dot;
+  if ((threadIdx.x & 63) == 0) {
+    p1[threadIdx.x >> 6] = ss;
+    p2[threadIdx.x >> 6] = sg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float n2 = p1[0] + p1[1] + p1[2] + p1[3];
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    s_inv = inv;
+    s_dot = (p2[0] + p2[1] + p2[2] + p2[3]) * inv * inv;
+  }
+  __syncthreads();
+  const float inv = s_inv, d = s_dot;
+  for (int c = threadIdx.x; c < p.D; c += kThreads) dxr[c] = (grad(c) - xr[c] * d) * inv;
+}
+
+extern "C" int cmhse_step_losses_bwd(const cmhse_step_losses* d, const float* grad_total,
+                                     float* const* dx, void* workspace, size_t workspace_bytes,
+                                     void* stream_) {
+  StepLossLayout L;
+  if (!grad_total || !dx || !workspace || !step_loss_layout(d, &L)) return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 || workspace_bytes < L.bytes)
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  char* ws = static_cast<char*>(workspace);
+  StepNormBwdParams p = {};
+  int64_t total_rows = 0;
+  for (int e = 0; e < d->n_emb; ++e) {
+    if (!d->x[e] || !dx[e]) return CMHSE_ERR_ARG;
+    p.x[e] = d->x[e];
+    p.dx[e] = dx[e];
+    p.rows[e] = d->rows[e];
+    total_rows += d->rows[e];
+  }
+  if (total_rows > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
+  int32_t off = 0;
+  for (int k = 0; k < d->n_terms; ++k) {
+    p.term_a[k] = d->term_a[k];
+    p.term_b[k] = d->term_b[k];
+    p.term_off[k] = off;
+    p.weight[k] = d->weight[k];
+    off += d->rows[d->term_a[k]];
+  }
+  p.n_emb = d->n_emb;
+  p.n_terms = d->n_terms;
+  p.D = d->D;
+  float* d_im = reinterpret_cast<float*>(ws + L.d_im);
+  float* d_s = reinterpret_cast<float*>(ws + L.d_s);
+  p.d_im = d_im;
+  p.d_s = d_s;
+  float* gout = reinterpret_cast<float*>(ws + L.gout);
+  hipLaunchKernelGGL(step_gout_kernel, dim3(1), dim3(64), 0, st, p, grad_total, gout);
+  const int rc = cmhse_contrastive_blocks_bwd(
+      reinterpret_cast<const float*>(ws + L.y_im), reinterpret_cast<const float*>(ws + L.y_s),
+      reinterpret_cast<const float*>(ws + L.fwd_ws), reinterpret_cast<const int32_t*>(ws + L.blk_off),
+      d->n_terms, L.max_n, d->D, d->margin, d->max_violation, d->norm, gout, d_im, d_s,
+      ws + L.bwd_ws, cmhse_contrastive_blocks_bwd_workspace(d->n_terms, L.max_n), stream_);
+  if (rc != CMHSE_OK) return rc;
+  hipLaunchKernelGGL(step_norm_bwd_kernel, dim3(static_cast<unsigned>(total_rows)), dim3(kThreads), 0,
+                     st, p);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 

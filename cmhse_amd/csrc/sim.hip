@@ -19,6 +19,7 @@
 #include "../../include/cmhse_hip.h"
 #include "gru_ws.hpp"
 #include "nt_core.hpp"
+#include "step_loss.hpp"
 
 namespace cmhse {
 
@@ -521,6 +522,75 @@ extern "C" int cmhse_contrastive_blocks_fwd(const float* im, const float* s,
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------
+// cmhse_step_losses_fwd: F.normalize of the step's encoder outputs written straight into the
+// row-blocked operands of the batched ContrastiveLoss, the losses, and their weighted total.
+// ---------------------------------------------------------------------------------------------
+struct StepNormParams {
+  const float* src[2][CMHSE_STEP_LOSS_MAX];  // [side][term]: the embedding that is the term's a / b
+  int32_t n[CMHSE_STEP_LOSS_MAX];            // term sizes
+  float weight[CMHSE_STEP_LOSS_MAX];
+  int32_t n_terms, D, R;
+  float* y[2];        // [R, D] each
+  int32_t* blk_off;   // [n_terms + 1]
+};
+
+// one workgroup per operand row (2R of them); the arithmetic of l2norm_rows_kernel, order included
+__global__ __launch_bounds__(kThreads) void step_norm_kernel(const StepNormParams p) {
+  const int side = (static_cast<int>(blockIdx.x) >= p.R) ? 1 : 0;
+  const int r = static_cast<int>(blockIdx.x) - side * p.R;
+  const float* xr = nullptr;
+  int off = 0;
+#pragma unroll
+  for (int k = 0; k < CMHSE_STEP_LOSS_MAX; ++k) {
+    if (k < p.n_terms) {
+      if (r >= off && r < off + p.n[k])
+        xr = (side ? p.src[1][k] : p.src[0][k]) + static_cast<int64_t>(r - off) * p.D;
+      off += p.n[k];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int o = 0;
+    p.blk_off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < CMHSE_STEP_LOSS_MAX; ++k)
+      if (k < p.n_terms) {
+        o += p.n[k];
+        p.blk_off[k + 1] = o;
+      }
+  }
+  float* yr = p.y[side] + static_cast<int64_t>(r) * p.D;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < p.D; c += kThreads) {
+    const float v = xr[c];
+    ss += v * v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
+  __shared__ float s_part[kThreads / 64];
+  __shared__ float s_inv;
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kThreads / 64; ++i) t += s_part[i];
+    s_inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  for (int c = threadIdx.x; c < p.D; c += kThreads) yr[c] = xr[c] * inv;
+}
+
+__global__ void step_total_kernel(const StepNormParams p, const float* values, float* total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CMHSE_STEP_LOSS_MAX; ++k)
+      if (k < p.n_terms) t += p.weight[k] * values[k];
+    *total = t;
+  }
+}
+
 // GroupWiseContrastiveLoss (loss.py:26-38): block (video i's clips x video j's captions) max or
 // mean of the clip x caption score matrix.  One workgroup per block; the arg-max (row-major first
 // maximum) is kept for the backward pass.
@@ -571,6 +641,43 @@ __global__ __launch_bounds__(kThreads) void block_reduce_kernel(const BlockReduc
     q.reduced[bi * q.B + bj] = q.use_max ? b : static_cast<float>(t / cnt);
     q.arg[bi * q.B + bj] = a;
   }
+}
+
+extern "C" size_t cmhse_step_losses_workspace(const cmhse_step_losses* d) {
+  StepLossLayout L;
+  return step_loss_layout(d, &L) ? L.bytes : 0;
+}
+
+extern "C" int cmhse_step_losses_fwd(const cmhse_step_losses* d, float* values, float* total,
+                                     void* workspace, size_t workspace_bytes, void* stream_) {
+  StepLossLayout L;
+  if (!values || !total || !workspace || !step_loss_layout(d, &L)) return CMHSE_ERR_ARG;
+  for (int e = 0; e < d->n_emb; ++e)
+    if (!d->x[e]) return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 || workspace_bytes < L.bytes)
+    return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char* ws = static_cast<char*>(workspace);
+  StepNormParams p = {};
+  for (int k = 0; k < d->n_terms; ++k) {
+    p.src[0][k] = d->x[d->term_a[k]];
+    p.src[1][k] = d->x[d->term_b[k]];
+    p.n[k] = d->rows[d->term_a[k]];
+    p.weight[k] = d->weight[k];
+  }
+  p.n_terms = d->n_terms;
+  p.D = d->D;
+  p.R = L.R;
+  p.y[0] = reinterpret_cast<float*>(ws + L.y_im);
+  p.y[1] = reinterpret_cast<float*>(ws + L.y_s);
+  p.blk_off = reinterpret_cast<int32_t*>(ws + L.blk_off);
+  hipLaunchKernelGGL(step_norm_kernel, dim3(2u * L.R), dim3(kThreads), 0, stream, p);
+  const int rc = cmhse_contrastive_blocks_fwd(
+      p.y[0], p.y[1], p.blk_off, d->n_terms, L.max_n, d->D, d->margin, d->max_violation, d->norm,
+      values, ws + L.fwd_ws, cmhse_contrastive_blocks_workspace(d->n_terms, L.max_n), stream_);
+  if (rc != CMHSE_OK) return rc;
+  hipLaunchKernelGGL(step_total_kernel, dim3(1), dim3(64), 0, stream, p, values, total);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
 extern "C" size_t cmhse_groupwise_workspace(int32_t n, int32_t B) {

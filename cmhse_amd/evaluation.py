@@ -50,13 +50,39 @@ class AverageMeter(object):
 class LogCollector(object):
   """Named AverageMeters in first-use order (/root/reference/evaluation.py:48-72): what
   VSE.forward_loss writes to (`model.logger.update('Le'+name, value, n)`, model.py:291) and what
-  train.py prints / sends to tensorboard."""
+  train.py prints / sends to tensorboard.
+
+  Values may arrive late: VSE.train_emb hands the step's loss values over as a copy that is still
+  in flight (`defer`), so that the host can queue the next step instead of waiting for this one.
+  Everything that READS the collector (`meters`, str(), tb_log) first settles what is outstanding,
+  and `update` calls made in the meantime wait in the same queue, so every reader sees exactly the
+  reference's sequence of updates."""
 
   def __init__(self):
-    self.meters = OrderedDict()
+    self._meters = OrderedDict()
+    self._deferred = []
+
+  def _update(self, k, v, n=0):
+    self._meters.setdefault(k, AverageMeter()).update(v, n)
 
   def update(self, k, v, n=0):
-    self.meters.setdefault(k, AverageMeter()).update(v, n)
+    if self._deferred:
+      self._deferred.append(lambda: self._update(k, v, n))
+    else:
+      self._update(k, v, n)
+
+  def defer(self, thunk):
+    """Queue `thunk()` (which calls `_update`) to run before the next read."""
+    self._deferred.append(thunk)
+
+  def settle(self):
+    while self._deferred:
+      self._deferred.pop(0)()
+
+  @property
+  def meters(self):
+    self.settle()
+    return self._meters
 
   def __str__(self):
     return '  '.join('%s %s' % (k, m) for k, m in self.meters.items())

@@ -75,6 +75,31 @@ def contrastive_losses(criterion, pairs):
                                     criterion.norm, need)
 
 
+class _StepLossesFn(torch.autograd.Function):
+  """normalize + the step's contrastive terms + their weighted total as one node
+  (ops.step_losses_fwd / _bwd): two host calls and ten launches for what model.py:333-343 and its
+  backward spell as ~40 small operators."""
+
+  @staticmethod
+  def forward(ctx, terms, margin, max_violation, norm, *xs):
+    values, total, st = ops.step_losses_fwd([x.detach() for x in xs], terms, margin, max_violation,
+                                            norm)
+    ctx.st = st
+    ctx.mark_non_differentiable(values)
+    return total.reshape(()), values
+
+  @staticmethod
+  def backward(ctx, grad_total, _):
+    return (None, None, None, None) + tuple(ops.step_losses_bwd(ctx.st, grad_total))
+
+
+def step_losses(criterion, xs, terms):
+  """(total, values): values[k] = criterion(normalize(xs[a_k]), normalize(xs[b_k])) for
+  terms[k] = (a_k, b_k, weight_k), total = sum_k weight_k * values[k], differentiable wrt xs."""
+  return _StepLossesFn.apply(tuple(terms), criterion.margin, criterion.max_violation,
+                             criterion.norm, *xs)
+
+
 class _L2NormFn(torch.autograd.Function):
   """F.normalize (model.py:333-343) with its backward on the HIP path."""
 

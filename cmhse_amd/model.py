@@ -17,7 +17,8 @@ import torch.nn as nn
 from . import ops
 from .decoder import DecoderSequence, EuclideanLoss
 from .layers import Attention, Maxout, Seq2Seq
-from .loss import ContrastiveLoss, GroupWiseContrastiveLoss, contrastive_losses, normalize
+from .loss import (ContrastiveLoss, GroupWiseContrastiveLoss, contrastive_losses, normalize,
+                   step_losses)
 
 
 def _make_rnn(rnn_type, in_dim, embed_size, bidirectional):
@@ -111,6 +112,9 @@ def _word_rows(table, tokens):
 TRAIN_SCHEDULE = ['interleaved']
 # the 4-7 contrastive losses of a step as one launch set (loss.contrastive_losses); False = one by one
 BATCHED_LOSSES = [True]
+# normalize + every contrastive term + the weighted total as ONE autograd node
+# (loss.step_losses); False = the operator-by-operator form above
+FUSED_LOSSES = [True]
 # torch.optim.Adam(fused=True): one launch for the whole update (VSE.__init__)
 FUSED_ADAM = [True]
 
@@ -258,10 +262,13 @@ class VSE(object):
     return frame_emb, word_emb
 
   # -- logger protocol (model.py:291: `self.logger.update('Le'+name, loss.item(), n)`) -------------
-  # The reference pays one host sync per loss (3-9 per step).  Inside train_emb the values are only
-  # needed by the time the step returns, so the (name, device scalar, n) triples are queued and
-  # replayed in the reference's order after ONE device-to-host copy of all of them, issued once the
-  # backward pass and the Adam update have been queued: the host never waits mid-step.
+  # The reference pays one host sync per loss (3-9 per step).  Inside train_emb the (name, device
+  # scalar, n) triples are queued instead and leave the device as ONE copy into pinned memory,
+  # issued once the backward pass and the Adam update have been queued.  A LogCollector of this
+  # package takes the copy while it is still in flight (LogCollector.defer) and replays it in the
+  # reference's order before anything reads the collector, so the host goes on to queue the next
+  # step while this one runs (the GPU was idle 0.45 ms per step waiting for the host otherwise);
+  # any other logger object gets the values before train_emb returns.
   def _log(self, key, loss, n):
     if self._pending_log is not None:
       self._pending_log.append((key, loss.detach(), n))
@@ -270,10 +277,33 @@ class VSE(object):
 
   def _flush_log(self):
     pending, self._pending_log = self._pending_log, None
-    if pending:
-      values = torch.stack([v.reshape(()) for _, v, _ in pending]).cpu().tolist()
-      for (key, _, n), v in zip(pending, values):
-        self.logger.update(key, v, n)
+    if not pending:
+      return
+    logger = self.logger
+    stacked = torch.stack([v.reshape(()) for _, v, _ in pending])
+    if not hasattr(logger, 'defer'):
+      for (key, _, n), v in zip(pending, stacked.cpu().tolist()):
+        logger.update(key, v, n)
+      return
+    logger.settle()            # the previous step's copy: long done, the GPU is a step behind us
+    slot = self._log_slot = (getattr(self, '_log_slot', 0) + 1) % 2
+    bufs = self.__dict__.setdefault('_log_pinned', [None, None])
+    owners = self.__dict__.setdefault('_log_owner', [None, None])
+    if owners[slot] is not None and owners[slot] is not logger:
+      owners[slot].settle()    # model.logger was swapped since: its copy still reads this buffer
+    owners[slot] = logger
+    if bufs[slot] is None or bufs[slot].numel() < len(pending):
+      bufs[slot] = torch.empty(max(16, len(pending)), dtype=torch.float32, pin_memory=True)
+    host = bufs[slot][:len(pending)]
+    host.copy_(stacked, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+
+    def replay():
+      done.synchronize()
+      for (key, _, n), v in zip(pending, host.tolist()):
+        logger._update(key, v, n)
+    logger.defer(replay)
 
   def forward_weak_loss(self, clip_emb, cap_emb, num_clips, num_caps, name, **kwargs):
     """model.py:294-299."""
@@ -404,9 +434,20 @@ class VSE(object):
     cap_emb, para_context, para_emb, cap_recon, sent_recon, word = out_t
     _tick('towers:joined')
     n = normalize
-    nv, npar = n(vid_emb), n(para_emb)
     weak = opts.low_level_loss and getattr(opts, 'weak_low_level_loss', False)
-    if BATCHED_LOSSES[0]:
+    if FUSED_LOSSES[0] and not weak:
+      # model.py:333-343 as one node: (name, a, b, weight in the total), a / b index `xs`
+      xs = [vid_emb, para_emb, vid_context, para_context]
+      terms = [('_vid', 0, 1, 1.0), ('_ctx_low_lvel', 2, 3, 1.0), ('_vid_inloss', 0, 0, 0.5),
+               ('_para_inloss', 1, 1, 0.5)]
+      if opts.low_level_loss:
+        xs += [clip_emb, cap_emb]
+        terms += [('_low_lvel', 4, 5, 1.0), ('_clip_inloss', 4, 4, 0.5), ('_cap_inloss', 5, 5, 0.5)]
+      loss, values = step_losses(self.criterion, xs, [t[1:] for t in terms])
+      for k, (name, a, _, _) in enumerate(terms):
+        self._log('Le' + name, values[k], xs[a].size(0))
+    elif BATCHED_LOSSES[0]:
+      nv, npar = n(vid_emb), n(para_emb)
       # model.py:333-343 — the same 4-7 ContrastiveLoss evaluations with the same weights, as ONE
       # launch set forward and one backward (loss.contrastive_losses); logged in the reference's
       # order.  (name, a, b, weight in the total)
@@ -431,6 +472,7 @@ class VSE(object):
       if loss_2 is not None:
         loss = loss + loss_2
     else:
+      nv, npar = n(vid_emb), n(para_emb)
       loss_1 = self.forward_loss(nv, npar, '_vid')
       loss_3 = self.forward_loss(n(vid_context), n(para_context), '_ctx_low_lvel')
       loss_5 = (self.forward_loss(nv, nv, '_vid_inloss') +

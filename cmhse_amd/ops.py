@@ -665,6 +665,48 @@ def contrastive_blocks_bwd(im, s, state, margin, max_violation, norm, grad_losse
   return d_im, d_s
 
 
+def step_losses_fwd(xs, terms, margin, max_violation, norm):
+  """cmhse_step_losses_fwd: xs = the step's encoder outputs ([rows_e, D] float32, un-normalised),
+  terms = [(a, b, weight)] indices into xs.  Returns (values [n_terms], total [1], state); the
+  state (descriptor + workspace) is what step_losses_bwd needs."""
+  lib = _lib.load()
+  xs = [_f32c(x, 'x') for x in xs]
+  if not 0 < len(xs) <= _lib.STEP_LOSS_MAX or not 0 < len(terms) <= _lib.STEP_LOSS_MAX:
+    raise ValueError('step_losses: 1..%d embeddings and terms' % _lib.STEP_LOSS_MAX)
+  d = _lib.StepLosses()
+  d.n_emb, d.n_terms, d.D = len(xs), len(terms), int(xs[0].shape[1])
+  for e, x in enumerate(xs):
+    if x.dim() != 2 or x.shape[1] != d.D:
+      raise ValueError('step_losses: every embedding is [rows, %d]' % d.D)
+    d.x[e], d.rows[e] = x.data_ptr(), int(x.shape[0])
+  for k, (a, b, w) in enumerate(terms):
+    d.term_a[k], d.term_b[k], d.weight[k] = int(a), int(b), float(w)
+  d.margin, d.max_violation, d.norm = float(margin), int(bool(max_violation)), int(bool(norm))
+  ws_bytes = lib.cmhse_step_losses_workspace(ctypes.byref(d))
+  if ws_bytes == 0:
+    raise ValueError('step_losses: terms must pair embeddings with equal row counts')
+  dev = xs[0].device
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+  out = torch.empty(len(terms) + 1, dtype=torch.float32, device=dev)
+  rc = lib.cmhse_step_losses_fwd(ctypes.byref(d), out.data_ptr(), out.data_ptr() + 4 * len(terms),
+                                 ws.data_ptr(), ws_bytes, _stream())
+  _lib.check(rc, 'cmhse_step_losses_fwd')
+  return out[:len(terms)], out[len(terms):], dict(desc=d, ws=ws, ws_bytes=ws_bytes, xs=xs)
+
+
+def step_losses_bwd(state, grad_total):
+  """d (grad_total * total) / d xs[e] for every e (cmhse_step_losses_bwd)."""
+  lib = _lib.load()
+  g = _f32c(grad_total, 'grad_total').reshape(-1)
+  xs = state['xs']
+  dxs = [torch.empty_like(x) for x in xs]
+  ptrs = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in dxs])
+  rc = lib.cmhse_step_losses_bwd(ctypes.byref(state['desc']), g.data_ptr(), ptrs,
+                                 state['ws'].data_ptr(), state['ws_bytes'], _stream())
+  _lib.check(rc, 'cmhse_step_losses_bwd')
+  return dxs
+
+
 def gru_pool_bwd(fctx, dout, dx_ptrs=None, d_emb_table=None, want_dh0=False):
   """cmhse_gru_pool_bwd for a forward run with save_for_backward=True.
   dx_ptrs: numpy uint64 [S] (input order) addresses receiving d x of step 0 of each sequence.

@@ -253,6 +253,33 @@ int cmhse_contrastive_blocks_bwd(const float* im, const float* s, const float* s
                                  const float* grad_out, float* d_im, float* d_s, void* workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* The contrastive block of one training step (model.py:333-343) in one call: F.normalize of the
+ * step's encoder outputs x[e] ([rows[e], D], device, contiguous) and the n_terms losses
+ *   values[k] = ContrastiveLoss(normalize(x[term_a[k]]), normalize(x[term_b[k]]))   (loss.py:86-117)
+ * plus their weighted total  *total = sum_k weight[k] * values[k]  (fp32, in term order) — the
+ * reference's  loss_1 + loss_3 + (loss_5a + loss_5b) / 2 + ...  with weight 1 or 0.5.  Values are
+ * those of cmhse_l2norm_rows + cmhse_contrastive_fwd per term, bit for bit (same kernels, the rows
+ * normalised straight into the row-blocked operands).  The workspace keeps the normalised rows and
+ * the stored scores for cmhse_step_losses_bwd, which must be given the same descriptor and
+ * workspace: it writes dx[e] = d total / d x[e] * *grad_total for every e (dx: HOST array of n_emb
+ * device pointers, each [rows[e], D]; an embedding no term uses gets zeros).  rows[term_a[k]] must
+ * equal rows[term_b[k]].  Five launches each way on `stream`, no host synchronisation. */
+#define CMHSE_STEP_LOSS_MAX 8
+typedef struct cmhse_step_losses {
+  int32_t n_emb, n_terms, D;
+  const float* x[CMHSE_STEP_LOSS_MAX];
+  int32_t rows[CMHSE_STEP_LOSS_MAX];
+  int32_t term_a[CMHSE_STEP_LOSS_MAX], term_b[CMHSE_STEP_LOSS_MAX];
+  float weight[CMHSE_STEP_LOSS_MAX];
+  float margin;
+  int32_t max_violation, norm;
+} cmhse_step_losses;
+size_t cmhse_step_losses_workspace(const cmhse_step_losses* d);
+int cmhse_step_losses_fwd(const cmhse_step_losses* d, float* values, float* total, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int cmhse_step_losses_bwd(const cmhse_step_losses* d, const float* grad_total, float* const* dx,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- backward pass (what loss.backward(), model.py:367, computes through the operators above) ---- */
 
 /* Parameter gradients of one encoder layer, same shapes as cmhse_gru_weights; overwritten. */

@@ -1559,6 +1559,58 @@ def test_train_step_on_a_packed_batch_is_bit_identical(dev, lowest):
 
 
 @pytest.mark.gpu
+def test_late_loss_values_reach_the_collector_in_the_reference_order(dev):
+  """VSE.train_emb with this package's LogCollector (the step's loss values leave the device as a
+  copy that is still in flight when train_emb returns) against a plain logger object (values
+  delivered before train_emb returns): after three steps the meters hold the same sequence —
+  names in the same first-use order, last value, running average and count — and a logger swapped
+  in mid-way (evaluation.encode_data does that, evaluation.py:101) does not lose a step."""
+  import copy
+  from cmhse_amd import synthetic
+  from cmhse_amd.evaluation import LogCollector
+  from cmhse_amd.model import VSE
+  opt = golden_opt('attention', low_level_loss=True, norm=True, reconstruct_loss=True,
+                   weight_recon=0.0005, decode_rnn_type='seq2seq')
+  torch.manual_seed(7)
+  model_a = VSE(opt)
+  model_b = VSE(opt)
+  model_b.load_state_dict(copy.deepcopy(model_a.state_dict(opt)), opt)
+  spec = synthetic.ragged_spec(9, seed=4, max_frames=11, max_video=13)
+  batches = synthetic.make_batches(spec, 3, opt.img_dim, opt.vocab_size, seed=5)
+  model_a.logger = MeterLog()
+  late = model_b.logger = LogCollector()
+  other = LogCollector()
+  for model in (model_a, model_b):
+    model.train_start(opt)
+  for k, b in enumerate(batches):
+    model_a.train_emb(opt, *b)
+    if k == 2:
+      model_b.logger = other          # the third step logs elsewhere; the second is still in flight
+    model_b.train_emb(opt, *b)
+  calls = model_a.logger.calls
+  first_two = [c for c in calls if c[0] not in ('Eit', 'lr')]
+  per_step = len(first_two) // 3
+  assert per_step >= 9
+  want = {}
+  for key, v, n in calls[:2 * (per_step + 2)]:
+    want.setdefault(key, []).append((v, n))
+  assert list(late.meters) == list(want)
+  for key, seq in want.items():
+    # (the embedding-table gradient is scattered with float atomics: from the second step on the
+    # two models agree to rounding, not bit for bit)
+    m = late.meters[key]
+    assert m.val == pytest.approx(seq[-1][0], rel=1e-4, abs=1e-7), key
+    if key.startswith('Le'):
+      assert m.count == sum(n for _, n in seq), key
+      assert m.avg == pytest.approx(sum(v * n for v, n in seq) / (m.count + 1e-4), rel=1e-4, abs=1e-7)
+  third = {k: v for k, v, _ in calls[2 * (per_step + 2):]}
+  got = {k: m.val for k, m in other.meters.items()}
+  assert list(got) == list(third)
+  for k in third:
+    assert got[k] == pytest.approx(third[k], rel=1e-4, abs=1e-7), k
+
+
+@pytest.mark.gpu
 def test_packed_loader_encodes_bit_identically(dev, monkeypatch):
   """evaluation.encode_data_device over a loader of collate_packed batches — pinned on the host
   (features pulled step-chunk by step-chunk) and already resident on the device — == over the
@@ -1672,6 +1724,62 @@ def test_small_batch_step_shapes_are_bit_identical(dev, S, H, tune):
   for o in outs[1:]:
     for a, b in zip(outs[0], o):
       assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('max_violation', [False, True])
+def test_step_losses_node_equals_normalize_plus_criterion(dev, max_violation):
+  """loss.step_losses (cmhse_step_losses_fwd / _bwd: F.normalize, the step's contrastive terms and
+  their weighted total as one autograd node) against normalize() + criterion(a, b) term by term
+  (model.py:333-343): values bit for bit, total and gradients wrt the un-normalised encoder outputs
+  to fp32 rounding (the node sums a row's uses in term order, autograd in its own), and both
+  against the NumPy oracle."""
+  from cmhse_amd.loss import ContrastiveLoss, normalize, step_losses
+  from oracle import cmhse_oracle as O
+  torch.manual_seed(5)
+  crit = ContrastiveLoss(margin=0.2, max_violation=max_violation, norm=True)
+  D = 160
+  rows = [32, 32, 32, 32, 117, 117, 9]
+  raw = [torch.randn(n, D, device=dev) * (0.5 + e) for e, n in enumerate(rows)]
+  raw[1] = raw[0] + 0.8 * torch.randn_like(raw[0])
+  raw[5] = raw[4] + 0.8 * torch.randn_like(raw[4])
+  terms = [(0, 1, 1.0), (2, 3, 1.0), (0, 0, 0.5), (1, 1, 0.5), (4, 5, 1.0), (4, 4, 0.5), (5, 5, 0.5)]
+  sep = [x.clone().requires_grad_(True) for x in raw]
+  ns = [normalize(x) for x in sep]
+  sep_vals = torch.stack([crit(ns[a], ns[b]) for a, b, _ in terms])
+  sep_total = sum(w * sep_vals[k] for k, (_, _, w) in enumerate(terms))
+  (sep_total * 1.5).backward()
+  fus = [x.clone().requires_grad_(True) for x in raw]
+  total, vals = step_losses(crit, fus, terms)
+  assert torch.equal(vals, sep_vals)
+  assert not vals.requires_grad
+  (total * 1.5).backward()
+  assert abs(float(total) - float(sep_total)) <= 1e-6 * max(1.0, abs(float(sep_total)))
+  for e in range(len(rows)):
+    g, r = fus[e].grad, sep[e].grad
+    if r is None:                      # an embedding no term uses: zeros
+      assert e == 6 and float(g.abs().max()) == 0.0
+      continue
+    assert float((g - r).abs().max()) <= 2e-6 * max(1e-3, float(r.abs().max())), e
+  # oracle: values of the seven terms, and the gradient wrt every encoder output (fp64)
+  host = [x.cpu().numpy().astype(np.float64) for x in raw]
+  y = [O.l2_normalize(x, dtype=np.float64) for x in host]
+  gy = [np.zeros_like(x) for x in host]
+  for k, (a, b, w) in enumerate(terms):
+    want = O.contrastive_loss(y[a], y[b], margin=0.2, max_violation=max_violation, norm=True,
+                              dtype=np.float64)
+    assert abs(float(vals[k]) - float(want)) <= 2e-5 * max(1.0, abs(float(want))), k
+    d_im, d_s = O.contrastive_loss_backward(y[a], y[b], margin=0.2, max_violation=max_violation,
+                                            norm=True)
+    gy[a] += 1.5 * w * d_im
+    gy[b] += 1.5 * w * d_s
+  for e in range(6):
+    want = O.l2_normalize_backward(host[e], gy[e])
+    got = fus[e].grad.cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-5 * max(1e-3, np.abs(want).max()), e
+  # mismatched pair sizes are refused, not mis-scored
+  with pytest.raises(ValueError):
+    step_losses(crit, raw, [(0, 4, 1.0)])
 
 
 @pytest.mark.gpu

@@ -288,3 +288,33 @@ def test_the_library_reads_no_environment_variable():
   assert 'getenv' not in native
   py = ''.join(open(f).read() for f in glob.glob(os.path.join(root, '*.py')))
   assert sorted(set(re.findall(r"environ(?:\.get)?\(\s*'(CMHSE_[A-Z0-9_]+)'", py))) == ['CMHSE_HIP_LIB', 'CMHSE_MATH']
+
+
+def test_log_collector_replays_late_values_in_order():
+  """evaluation.LogCollector with values still in flight (VSE.train_emb hands the step's losses
+  over as a pending copy): updates made meanwhile queue behind it, every reader settles first, and
+  the meters end up exactly as with immediate updates (evaluation.py:48-72 semantics)."""
+  from cmhse_amd.evaluation import LogCollector
+  a, b = LogCollector(), LogCollector()
+  ran = []
+  # immediate
+  a.update('Eit', 1); a.update('lr', 0.5); a.update('Le_vid', 2.0, 4); a.update('Eit', 2)
+  a.update('Le_vid', 4.0, 4)
+  # deferred: step 1's losses arrive late, step 2's 'Eit' is updated before they are read
+  b.update('Eit', 1); b.update('lr', 0.5)
+  b.defer(lambda: (ran.append(1), b._update('Le_vid', 2.0, 4)))
+  b.update('Eit', 2)
+  assert not ran and list(b._meters) == ['Eit', 'lr'] and b._meters['Eit'].val == 1
+  b.defer(lambda: (ran.append(2), b._update('Le_vid', 4.0, 4)))
+  assert str(b) == str(a) and ran == [1, 2]
+  assert list(b.meters) == ['Eit', 'lr', 'Le_vid']
+  assert b.meters['Le_vid'].avg == a.meters['Le_vid'].avg and abs(a.meters['Le_vid'].avg - 3.0) < 1e-3 and b.meters['Eit'].val == 2
+  b.update('Eit', 3)            # nothing outstanding: immediate again
+  assert b._meters['Eit'].val == 3
+
+  class Tb(object):
+    def __init__(self): self.got = []
+    def log_value(self, k, v, step=None): self.got.append((k, v, step))
+  b.defer(lambda: b._update('Le_vid', 6.0, 4))
+  tb = Tb(); b.tb_log(tb, prefix='t/', step=7)
+  assert ('t/Le_vid', 6.0, 7) in tb.got

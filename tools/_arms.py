@@ -4,6 +4,7 @@
   schedule             model.TRAIN_SCHEDULE  (interleaved | towers | grouped | serial)
   side_streams         ops.SIDE_STREAMS      (0 | 1)
   batched_losses       model.BATCHED_LOSSES  (0 | 1)
+  fused_losses         model.FUSED_LOSSES    (0 | 1)
   early_pool, group_towers, two_streams, pipeline_upload, upload_chunk   evaluation.* flags
   math                 ops.set_math_mode     (fp32 | bf16x3)
 Everything an arm does not mention is put back to its default."""
@@ -22,6 +23,7 @@ def apply(arm):
     ops.tune(k, int(arm.get('tune.' + k, v)))
   model_mod.TRAIN_SCHEDULE[0] = arm.get('schedule', 'interleaved')
   model_mod.BATCHED_LOSSES[0] = arm.get('batched_losses', '1') == '1'
+  model_mod.FUSED_LOSSES[0] = arm.get('fused_losses', '1') == '1'
   ops.SIDE_STREAMS[0] = arm.get('side_streams', '1') == '1'
   evaluation.EARLY_POOL[0] = arm.get('early_pool', '1') == '1'
   evaluation.GROUP_TOWERS[0] = arm.get('group_towers', '1') == '1'
@@ -30,7 +32,7 @@ def apply(arm):
   evaluation.UPLOAD_CHUNK[0] = int(arm.get('upload_chunk', '8'))
   ops.set_math_mode(arm.get('math', 'fp32'))
   unknown = [k for k in arm if not (k.startswith('tune.') and k[5:] in TUNE_DEFAULTS) and k not in
-             ('schedule', 'batched_losses', 'side_streams', 'early_pool', 'group_towers', 'two_streams',
+             ('schedule', 'batched_losses', 'fused_losses', 'side_streams', 'early_pool', 'group_towers', 'two_streams',
               'pipeline_upload', 'upload_chunk', 'math', 'label')]
   if unknown:
     raise SystemExit('unknown arm keys: %s' % unknown)
