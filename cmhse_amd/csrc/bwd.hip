@@ -419,6 +419,7 @@ struct BwdStepGroup {
 
 template <bool VEC, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gru_bwd_step_kernel(const BwdStepGroup grp) {
+  CHAIN_WAVE_PRIORITY();
   __shared__ float red[NW][16][64];
   int ji = 0;
 #pragma unroll
@@ -502,6 +503,7 @@ constexpr int kBwdMidNW = 8, kBwdMidRing = 2;
 
 template <int MB, int BU>
 __global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const BwdStepGroup grp) {
+  CHAIN_WAVE_PRIORITY();
   constexpr int NW = kBwdMidNW, BM = 16 * MB;
   constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);
   __shared__ f32x4v red[NW][MB][64];
@@ -630,6 +632,7 @@ struct RecPartParams {
 constexpr int kRecThreads = 512;   // 8 waves: two per SIMD, so one wave's chunk barrier and LDS round trip hide under the other's MFMAs
 
 __global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPartParams q) {
+  CHAIN_WAVE_PRIORITY();
   __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
   constexpr int ROWS = kRecBM + kRecBN, PIECES = ROWS * (kRecBK / 4), NP = (PIECES + kRecThreads - 1) / kRecThreads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -725,6 +728,7 @@ struct GatesBwdParams {
 
 // one thread per (sequence, 4 hidden units)
 __global__ __launch_bounds__(kThreads) void bwd_gates_kernel(const GatesBwdParams g) {
+  CHAIN_WAVE_PRIORITY();
   const BwdStepParams& q = g.s;
   const int H = q.H, K = 3 * H, h4 = H / 4;
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
@@ -1257,7 +1261,7 @@ extern "C" size_t cmhse_gru_pool_bwd_workspace(int32_t S, int32_t Tmax, int64_t 
                                                int32_t H, int32_t pool_mode) {
   (void)Tmax;
   if (S <= 0 || sum_T <= 0 || I <= 0 || H <= 0) return 0;
-  return bwd_ws_layout(S, sum_T, I, H, pool_mode & ~CMHSE_SAVE_FOR_BACKWARD).total;
+  return bwd_ws_layout(S, sum_T, I, H, pool_mode & kModeMask).total;
 }
 
 namespace {
@@ -1292,7 +1296,7 @@ int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
                 const uint64_t* dx_rows, float* d_emb_table, float* dh0, void* workspace,
                 size_t workspace_bytes, BwdJob* job) {
   if (!b || !w || !dout || !fwd_workspace || !g || !workspace) return CMHSE_ERR_ARG;
-  pool_mode &= ~CMHSE_SAVE_FOR_BACKWARD;
+  pool_mode &= kModeMask;
   if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX &&
       pool_mode != CMHSE_POOL_ALL)
     return CMHSE_ERR_ARG;
@@ -1468,7 +1472,8 @@ void bwd_chunk(BwdJob& j, hipStream_t st) {
 // narrower tiles LOSE here — the 32 dgh rows of K = 3H floats (384 KB) every workgroup pulls
 // dominate, and 128-256 workgroups of them cost more L2 bandwidth than the spread gains (train_emb
 // step, C3D: 16 units 12.8 ms, 8 units 16.0, 4 units 15.9; later, at 11.3 ms, 32 units — two column
-// blocks per wave — 11.9).
+// blocks per wave — 11.9; round 3, at 9.7 ms: 4 / 8 units only for steps with <= 2 / 4 ... 8 / 16
+// active sequences, the long tail of the sentence chain: 9.74-9.78 against 9.68).
 static int bwd_mid_max_seqs() { return tunables().bwd_mid_max_seqs.load(std::memory_order_relaxed); }
 constexpr int kBwdMidUnits = 16;
 // active sequences at or below which the 32 x 32-tile BPTT step (unaligned shapes, large batches)
@@ -1621,7 +1626,7 @@ extern "C" int cmhse_gru_pool_bwd_multi(const cmhse_gru_bwd_job* reqs, int32_t n
   bwd_steps(jobs, n_jobs);
   for (int k = 0; k < n_jobs; ++k) bwd_finish(jobs[k], jobs[k].st);
   for (int k = 0; k < n_jobs; ++k)
-    if (first_use(k)) stream_after(st, jobs[k].st);
+    if (first_use(k) && !(reqs[k].pool_mode & CMHSE_NO_JOIN)) stream_after(st, jobs[k].st);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 

@@ -382,6 +382,7 @@ constexpr int kTinyBU = 8;
 // is a pure latency chain (half the MFMA chain per wave, twice the waves on an under-filled chip).
 template <bool VEC, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGroup grp) {
+  CHAIN_WAVE_PRIORITY();
   constexpr int BM = kTinyBM, BU = kTinyBU;
   unsigned wg;
   const GruStepParams& p = grp.j[group_job(grp, &wg)];
@@ -522,6 +523,7 @@ constexpr int kMidSlices = 8;
 
 template <int MB, int BU, int NW>
 __global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGroup grp) {
+  CHAIN_WAVE_PRIORITY();
   constexpr int BM = 16 * MB, NB = (3 * BU + 15) / 16, VS = kMidSlices / NW;
   static_assert(NW * VS == kMidSlices, "4 or 8 waves");
   constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);   // outputs (per thread)
@@ -1831,7 +1833,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
   // join the requests' own streams (each once) back into the caller's
   for (int k = 0; k < n_jobs; ++k) {
     hipStream_t own = jobs[k].own_stream;
-    if (own == nullptr || own == stream) continue;
+    if (own == nullptr || own == stream || (reqs[k].pool_mode & CMHSE_NO_JOIN)) continue;
     bool seen = false;
     for (int m = 0; m < k; ++m) seen = seen || jobs[m].own_stream == own;
     if (!seen) stream_after(stream, own);

@@ -19,6 +19,21 @@
 
 #include "../../include/cmhse_hip.h"
 
+// Wave priority of the kernels on a recurrence's dependent chain (s_setprio; 0 = the hardware
+// default).  A chain step is a short latency-bound kernel that shares its CUs with throughput work
+// — the weight-gradient products and projection chunks on the side stream, the other tower's
+// chain: raised, its waves win the SIMD's issue arbitration against the resident GEMM waves, which
+// fill the bubbles.  Training step, priority 3 against 0 (tools/ab_train.py, two runs each): ICEP
+// 9.83 / 9.76 -> 9.58 / 9.61 ms, C3D 8.62 / 8.62 -> 8.49 / 8.58 ms.  The LDS-tiled step kernel of the
+// validation pass is throughput work itself and stays at the default.
+#ifndef CHAIN_PRIO
+#define CHAIN_PRIO 3
+#endif
+#define CHAIN_WAVE_PRIORITY()                                   \
+  do {                                                          \
+    if (CHAIN_PRIO > 0) __builtin_amdgcn_s_setprio(CHAIN_PRIO); \
+  } while (0)
+
 namespace cmhse {
 
 constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
@@ -56,7 +71,7 @@ static inline int64_t gx_rows_bound(int32_t S, int32_t Tmax, int64_t sum_T) {
   return b < sum_T ? b : sum_T;
 }
 
-constexpr int32_t kModeMask = ~(CMHSE_SAVE_FOR_BACKWARD | CMHSE_MATH_BF16X3);
+constexpr int32_t kModeMask = ~(CMHSE_SAVE_FOR_BACKWARD | CMHSE_MATH_BF16X3 | CMHSE_NO_JOIN);
 
 // row length (in float units) of a bf16x3 pre-split weight row: K rounded up to whole 16-k chunks
 __host__ __device__ static inline int64_t split_ld(int K) { return (static_cast<int64_t>(K) + 15) / 16 * 16; }

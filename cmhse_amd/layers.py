@@ -211,6 +211,124 @@ def run_grouped(calls, streams=None):
   return list(_GroupedGRUPoolFn.apply(specs, None if streams is None else list(streams), *flat))
 
 
+class _TowersFn(torch.autograd.Function):
+  """The two levels of several INDEPENDENT towers as ONE autograd node (VSE.train_emb: clip_enc ->
+  vid_seq_enc beside txt_enc -> txt_seq_enc, model.py:319-331).  Every tower lives on its own
+  stream from its first level-1 step to its last level-2 step, and back: level 2 of a tower starts
+  right behind its level 1 without waiting for the other tower (CMHSE_NO_JOIN), and in the backward
+  pass the gradient of the level-1 outputs — what the loss sends plus what level 2 sends — is summed
+  on the tower's stream, so nothing between the two levels runs on, or waits for, the caller's
+  stream.  As two grouped nodes the towers met on the caller's stream twice per direction (0.3 ms
+  forward, 0.45 ms backward of a 10 ms step: event hops and a dozen small autograd kernels).
+  Inputs: `meta` = per tower (level-1 SeqInput, rows of the first level-1 block, level-2 SeqInput),
+  `streams`, then twenty tensors per tower (the ten of _PackedGRUPoolFn for level 1, then for
+  level 2 with x / hidden / table None).  Outputs per tower: level-1 rows [:n], level-1 rows [n:],
+  level-2 output."""
+
+  @staticmethod
+  def forward(ctx, meta, streams, *flat):
+    hold = []
+    reqs1, svs1, reqs2, svs2 = [], [], [], []
+    for i, (spec1, n, spec2) in enumerate(meta):
+      req, sv = _fwd_request(spec1, *flat[20 * i:20 * i + 10])
+      # level 1 writes into a buffer known now, so that level 2's tables (addresses of its rows
+      # and initial states) are built and uploaded BEFORE the first chain launch: a copy queued on
+      # the caller's stream behind running chains was seen to wait for them
+      out1 = torch.empty(len(spec1.lens), req['H'], dtype=torch.float32, device=req['device'])
+      req['out'] = out1
+      reqs1.append(req)
+      svs1.append(sv)
+      req, sv = _fwd_request(spec2, out1[:n], out1[n:], None, *flat[20 * i + 13:20 * i + 20])
+      req['sched'] = ops.SeqSchedule(req['lens'], req['device'], req['x_ptrs'], None,
+                                     req['h0_ptrs'])
+      reqs2.append(req)
+      svs2.append(sv)
+    res1 = ops.gru_pool_fwd_multi(reqs1, job_streams=streams, join=False, hold=hold)
+    for i in range(len(meta)):
+      svs1[i].fctx = res1[i][1]
+    res2 = ops.gru_pool_fwd_multi(reqs2, job_streams=streams)   # joins everything queued above
+    outs = []
+    for i, (_, n, _) in enumerate(meta):
+      svs2[i].fctx = res2[i][1]
+      outs.extend([res1[i][0][:n], res1[i][0][n:], res2[i][0]])
+    ctx.svs1, ctx.svs2, ctx.streams, ctx.meta = svs1, svs2, streams, meta
+    del hold
+    return tuple(outs)
+
+  @staticmethod
+  def backward(ctx, *grads):
+    need = ctx.needs_input_grad[2:]
+    streams, hold = ctx.streams, []
+    inner = (True, True) + (False,) * 8       # level 2: wrt its rows and its initial state
+    # Everything that is queued on the caller's stream — zero fills, table uploads — for BOTH levels
+    # first: the towers' streams fork from it once, and nothing is left to wait for in between.
+    reqs2, dxs, reqs1, extra, douts = [], [], [], [], []
+    for i, (sv1, sv2) in enumerate(zip(ctx.svs1, ctx.svs2)):
+      g = grads[3 * i + 2]
+      if g is None:
+        g = torch.zeros(sv2.fctx['sched'].S, sv2.fctx['H'], dtype=torch.float32,
+                        device=sv2.fctx['device'])
+      req, dx, _ = _bwd_request(sv2, g, inner)
+      reqs2.append(req)
+      dxs.append(dx)
+      dout = torch.empty(sv1.fctx['sched'].S, sv1.fctx['H'], dtype=torch.float32,
+                         device=sv1.fctx['device'])
+      req, dx, dtable = _bwd_request(sv1, dout, need[20 * i:20 * i + 10])
+      reqs1.append(req)
+      extra.append((dx, dtable))
+      douts.append(dout)
+    prep2, prep1 = ops.prepare_bwd(reqs2), ops.prepare_bwd(reqs1)
+    res2 = ops.gru_pool_bwd_multi(reqs2, job_streams=streams, join=False, hold=hold, prepared=prep2)
+    for i, dout in enumerate(douts):
+      n = ctx.meta[i][1]
+      g_first, g_rest = grads[3 * i], grads[3 * i + 1]
+      dx2, dh0 = dxs[i], res2[i][1]
+      with torch.cuda.stream(streams[i]):   # the gradient of level 1's output, on the tower's stream
+        if g_first is None:
+          dout[:n].copy_(dx2)
+        else:
+          torch.add(g_first, dx2, out=dout[:n])
+        if g_rest is None:
+          dout[n:].copy_(dh0)
+        else:
+          torch.add(g_rest, dh0, out=dout[n:])
+    res1 = ops.gru_pool_bwd_multi(reqs1, job_streams=streams, prepared=prep1)   # joins everything
+    out = [None, None]
+    for i in range(len(ctx.svs1)):
+      out.extend(_grads_tuple(res1[i][0], extra[i][0], res1[i][1], extra[i][1]))
+      out.extend(_grads_tuple(res2[i][0], None, None, None))
+    del hold
+    return tuple(out)
+
+
+def run_towers(towers, streams):
+  """`towers`: list of (level-1 call, n, level-2 layer, counts): the level-1 call is a
+  (layer, SeqInput, x, hidden, table) description whose output rows [:n] are the rows of level 2
+  (sequence s = counts[s] consecutive rows) and rows [n:] its initial hidden states (one per
+  sequence).  Runs both levels of every tower as one autograd node on `streams` (one torch stream
+  per tower); returns per tower (rows [:n], rows [n:], level-2 output)."""
+  flat, meta, grad_modes = [], [], set()
+  for (layer, spec, x, hidden, table), n, layer2, counts in towers:
+    counts = np.asarray(counts, dtype=np.int64)
+    if int(counts.sum()) != n:
+      raise ValueError('run_towers: level-2 counts must cover the first %d level-1 rows' % n)
+    spec2 = SeqInput('rows', counts, layer2.POOL, counts=counts)
+    t1 = (x, hidden, table, layer.rnn.weight_ih_l0, layer.rnn.weight_hh_l0, layer.rnn.bias_ih_l0,
+          layer.rnn.bias_hh_l0) + tuple(layer._extra_weights())
+    t2 = (None, None, None, layer2.rnn.weight_ih_l0, layer2.rnn.weight_hh_l0,
+          layer2.rnn.bias_ih_l0, layer2.rnn.bias_hh_l0) + tuple(layer2._extra_weights())
+    g1 = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in t1)
+    g2 = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in t2)
+    spec.need_grad, spec2.need_grad = g1, g1 or g2
+    grad_modes.update([g1, g1 or g2])
+    meta.append((spec, n, spec2))
+    flat.extend(t1 + t2)
+  if len(grad_modes) > 1:
+    raise ValueError('run_towers: every layer of every tower must agree on requires_grad')
+  outs = _TowersFn.apply(meta, list(streams), *flat)
+  return [tuple(outs[3 * i:3 * i + 3]) for i in range(len(towers))]
+
+
 def _lens_numpy(q_len):
   if isinstance(q_len, torch.Tensor):
     return q_len.detach().cpu().numpy().astype(np.int64)   # lengths live on the host (layers.py:97)

@@ -97,11 +97,15 @@ def _word_rows(table, tokens):
 
 # A training step's two towers (encoders and decoders alike) are independent until the losses, and
 # at training batch sizes every GRU time step is a short, latency-bound launch.  How the two
-# chains are scheduled (TRAIN_SCHEDULE[0]; all four give the same values, and
+# chains are scheduled (TRAIN_SCHEDULE[0]; all five give the same values, and
 # bit-identical ones wherever the backward pass has no float atomics — tested):
-#   'interleaved'  (default) each level of the two towers is ONE call and ONE autograd node in which
-#                  every tower is a chain on a stream of its own, and the host queues step t of both
-#                  before step t + 1 of either: side by side from the first step, both directions;
+#   'interleaved'  (default) every tower is a chain on a stream of its own, and the host queues
+#                  step t of both before step t + 1 of either: side by side from the first step,
+#                  both directions.  The two encoder levels of both towers are ONE autograd node
+#                  (layers.run_towers): a tower goes from its level 1 to its level 2, and back,
+#                  without meeting the other tower or the caller's stream in between;
+#   'levels'       the same, but each level is a node of its own that joins the caller's stream
+#                  (what 'interleaved' was before: +0.3 ms forward, +0.45 ms backward of glue);
 #   'towers'       one call per tower and level, each tower on its own stream (round 2): the second
 #                  tower starts only when the host has queued the whole first one (~100 launches
 #                  forward, ~250 backward);
@@ -370,22 +374,31 @@ class VSE(object):
         sent_recon = self.sent_seq_dec.forward_repeat(cap_recon, lw)
       return cap_emb, para_context, para_emb, cap_recon, sent_recon, word
 
-    def grouped_towers(streams=None):
+    def grouped_towers(streams=None, one_node=False):
       from .layers import run_grouped as _run_grouped
       run_grouped = lambda calls: _run_grouped(calls, streams)
       _tick('vis:start')
-      vis, txt = run_grouped([
-          self.clip_enc.rnn.call_multi([clips, videos], [lengths_clip, lengths_video]),
-          self.txt_enc.rnn.call_tokens_multi([captions, paragraphs],
-                                             [lengths_cap, lengths_paragraph],
-                                             self.txt_enc.embed.weight)])
-      _tick('vis:level1')
-      clip_emb, vid_context = vis[:n_clip], vis[n_clip:]
-      cap_emb, para_context = txt[:n_cap], txt[n_cap:]
-      vid_emb, para_emb = run_grouped([
-          self.vid_seq_enc.rnn.call_rows(clip_emb, num_clips, vid_context),
-          self.txt_seq_enc.rnn.call_rows(cap_emb, num_caps, para_context)])
-      _tick('vis:level2')
+      level1 = [self.clip_enc.rnn.call_multi([clips, videos], [lengths_clip, lengths_video]),
+                self.txt_enc.rnn.call_tokens_multi([captions, paragraphs],
+                                                   [lengths_cap, lengths_paragraph],
+                                                   self.txt_enc.embed.weight)]
+      if one_node:
+        # both levels of both towers as one node: each tower stays on its stream between its
+        # levels, forward and backward (layers.run_towers)
+        from .layers import run_towers
+        (clip_emb, vid_context, vid_emb), (cap_emb, para_context, para_emb) = run_towers(
+            [(level1[0], n_clip, self.vid_seq_enc.rnn, num_clips),
+             (level1[1], n_cap, self.txt_seq_enc.rnn, num_caps)], streams)
+        _tick('vis:level2')
+      else:
+        vis, txt = run_grouped(level1)
+        _tick('vis:level1')
+        clip_emb, vid_context = vis[:n_clip], vis[n_clip:]
+        cap_emb, para_context = txt[:n_cap], txt[n_cap:]
+        vid_emb, para_emb = run_grouped([
+            self.vid_seq_enc.rnn.call_rows(clip_emb, num_clips, vid_context),
+            self.txt_seq_enc.rnn.call_rows(cap_emb, num_caps, para_context)])
+        _tick('vis:level2')
       word = (_word_rows(self.txt_enc.embed.weight.detach(), captions)
               if self.lowest_reconstruct_loss else None)
       clip_recon = cap_recon = frame_recon = sent_recon = None
@@ -401,10 +414,10 @@ class VSE(object):
               (cap_emb, para_context, para_emb, cap_recon, sent_recon, word))
 
     schedule = TRAIN_SCHEDULE[0]
-    if schedule not in ('interleaved', 'towers', 'grouped', 'serial'):
+    if schedule not in ('interleaved', 'levels', 'towers', 'grouped', 'serial'):
       raise ValueError('unknown training schedule %r' % (schedule,))
-    if schedule == 'interleaved':
-      out_v, out_t = grouped_towers(_tower_streams(clips.device))
+    if schedule in ('interleaved', 'levels'):
+      out_v, out_t = grouped_towers(_tower_streams(clips.device), schedule == 'interleaved')
     elif schedule == 'grouped':
       out_v, out_t = grouped_towers()
     elif schedule == 'towers':

@@ -447,7 +447,7 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, **kw):
                                   device=device, **kw)])[0]
 
 
-def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
+def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, hold=None):
   """cmhse_gru_pool_fwd_multi: `requests` is a list of keyword dicts (the arguments of
   gru_pool_fwd) for INDEPENDENT encoders; their time steps share launches.  Returns a list of
   (out, ctx), bit-identical to separate gru_pool_fwd calls.  With `tail_stream` (a torch stream,
@@ -455,7 +455,11 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
   has ended continue there while that request's pooling pass runs on the current stream; the
   call rejoins the current stream before it returns.  With `job_streams` (one torch stream per
   request) every request runs on its own stream, the launches of all requests interleaved step by
-  step (cmhse_gru_job.stream); forked from and joined into the current stream inside the call."""
+  step (cmhse_gru_job.stream); forked from and joined into the current stream inside the call.
+  join=False (CMHSE_NO_JOIN) leaves the job streams un-joined: the outputs are ready on their job
+  stream only — for a caller that queues the consumer on the same stream next and joins later; it
+  must pass `hold`, a list that receives everything the queued work uses and that it keeps until
+  that later join."""
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_fwd_multi takes 1..%d requests' % MAX_JOBS)
@@ -464,7 +468,7 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
   for k, (job, _) in enumerate(prepared):
     jobs[k].seqs = ctypes.pointer(job['b'])
     jobs[k].weights = ctypes.pointer(job['w'])
-    jobs[k].pool_mode = job['mode_flags']
+    jobs[k].pool_mode = job['mode_flags'] | (0 if join or job_streams is None else _lib.NO_JOIN)
     jobs[k].out = job['out'].data_ptr()
     jobs[k].workspace = job['ws'].data_ptr()
     jobs[k].workspace_bytes = job['ws_bytes']
@@ -493,6 +497,10 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None):
     rc = lib.cmhse_gru_pool_fwd_multi(jobs, len(prepared), _stream())
     _lib.check(rc, 'cmhse_gru_pool_fwd_multi')
   prepared[0][0]['b'].step_timer = None
+  if not join:
+    if hold is None:
+      raise ValueError('gru_pool_fwd_multi(join=False) needs a `hold` list')
+    hold.append(prepared)
   return [(job['out'], job['ctx']) for job, _ in prepared]
 
 
@@ -765,22 +773,32 @@ def side_stream(cur=None):
   return st[3] if cur.cuda_stream == st[1].cuda_stream else st[2]
 
 
-def gru_pool_bwd_multi(requests, job_streams=None):
+def prepare_bwd(requests):
+  """The allocations, zero fills and table uploads of gru_pool_bwd_multi(requests), done now —
+  everything of that call that is queued on the caller's stream; pass the result as `prepared`."""
+  return [_prepare_bwd(**r) for r in requests]
+
+
+def gru_pool_bwd_multi(requests, job_streams=None, join=True, hold=None, prepared=None):
   """cmhse_gru_pool_bwd_multi: `requests` = keyword dicts of gru_pool_bwd for INDEPENDENT encoders
   (the two towers of a training step); their BPTT steps share launches — or, with `job_streams`
   (one torch stream per request), run as separate chains on those streams with their launches
-  interleaved step by step.  Returns [(grads, dh0)]."""
+  interleaved step by step.  Returns [(grads, dh0)].  join / hold: as in gru_pool_fwd_multi."""
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_bwd_multi takes 1..%d requests' % MAX_JOBS)
+  if not join and hold is None:
+    raise ValueError('gru_pool_bwd_multi(join=False) needs a `hold` list')
   jobs = (_lib.GruBwdJob * len(requests))()
   keep, out = [], []
+  if prepared is None:
+    prepared = prepare_bwd(requests)
   for k, r in enumerate(requests):
-    grads, dh0, g, dx_dev, ws, ws_bytes, dout = _prepare_bwd(**r)
+    grads, dh0, g, dx_dev, ws, ws_bytes, dout = prepared[k]
     fctx = r['fctx']
     jobs[k].seqs = ctypes.pointer(fctx['batch'])
     jobs[k].weights = ctypes.pointer(fctx['weights'])
-    jobs[k].pool_mode = fctx['pool_mode']
+    jobs[k].pool_mode = fctx['pool_mode'] | (0 if join or job_streams is None else _lib.NO_JOIN)
     jobs[k].dout = dout.data_ptr()
     jobs[k].fwd_workspace = fctx['ws'].data_ptr()
     jobs[k].grads = ctypes.pointer(g)
@@ -798,6 +816,8 @@ def gru_pool_bwd_multi(requests, job_streams=None):
     out.append((grads, dh0))
   rc = lib.cmhse_gru_pool_bwd_multi(jobs, len(requests), _stream())
   _lib.check(rc, 'cmhse_gru_pool_bwd_multi')
+  if not join:
+    hold.append(keep)
   return out
 
 

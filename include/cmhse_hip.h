@@ -59,7 +59,15 @@ enum {
    * hi/lo split (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate): ~2^-17 relative error per
    * product, ~1e-6 on the embeddings (parity bar 1e-4), ~5x the matrix rate of exact fp32.
    * Default (flag clear) is exact fp32. */
-  CMHSE_MATH_BF16X3 = 0x200
+  CMHSE_MATH_BF16X3 = 0x200,
+  /* OR-ed into the pool_mode of a cmhse_gru_job / cmhse_gru_bwd_job that has its own `stream`: the
+   * call does NOT order its own stream argument behind that stream when it returns.  The job's
+   * results are then ready on the job's stream only; a later job on the same stream may consume
+   * them at once (level 2 of a tower right behind its level 1, without waiting for the other
+   * tower), anything else must be ordered by the caller — a later call on the same job stream
+   * without this flag does that for everything queued before it.  Buffers the job uses must stay
+   * allocated until then. */
+  CMHSE_NO_JOIN = 0x400
 };
 
 /* Weights of one encoder layer, laid out exactly as the reference's state-dict tensors

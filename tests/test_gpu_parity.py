@@ -511,7 +511,7 @@ def test_loss_backward_vs_golden(dev, n):
       grad_close(a2.grad.cpu().numpy(), g[tag + '.da_self'], tag + '.da_self')
 
 
-@pytest.mark.parametrize('schedule', ['interleaved', 'towers', 'grouped', 'serial'])
+@pytest.mark.parametrize('schedule', ['interleaved', 'levels', 'towers', 'grouped', 'serial'])
 @pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
 def test_train_emb_gradients_vs_golden(dev, rnn_type, schedule, monkeypatch):  # noqa: C901
   """One full VSE.train_emb step (forward, 7 losses, backward, Adam): the parameter gradients

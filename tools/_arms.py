@@ -1,7 +1,7 @@
 """A/B arms for the tools: an arm is "k=v,k=v" with keys
   tune.<name>          a cmhse_tune crossover (tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
                        tall_tile_min_wgs, bwd_mid_max_seqs)
-  schedule             model.TRAIN_SCHEDULE  (interleaved | towers | grouped | serial)
+  schedule             model.TRAIN_SCHEDULE  (interleaved | levels | towers | grouped | serial)
   side_streams         ops.SIDE_STREAMS      (0 | 1)
   batched_losses       model.BATCHED_LOSSES  (0 | 1)
   fused_losses         model.FUSED_LOSSES    (0 | 1)
