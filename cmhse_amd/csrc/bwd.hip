@@ -606,6 +606,161 @@ __global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The long few-sequence TAIL of a BPTT chain as ONE resident kernel.  The whole-paragraph /
+// whole-video sequences of a training batch run tens of steps past the last sentence / clip with
+// at most 16 sequences still active (ActivityNet, batch 32: ~75 of the text chain's 124 steps);
+// backward those steps come FIRST, each a dependent launch of gru_bwd_step_mid_kernel<1, 16> —
+// 12.8 us apiece on an idle chip, 24 us beside the other tower's chain — and the step's own work
+// is a 16 x 16 output tile per workgroup.  Here the H / 16 workgroups of that kernel stay resident
+// from step Tmax - 1 down to the first step with more than 16 active sequences:
+//   * the workgroup's W_hh^T slice (16 columns x 3H) is loaded into registers ONCE, in the MFMA
+//     operand layout of mid_phase;
+//   * per step, the rows dGh_{t+1} — written one step earlier by ALL workgroups — are the only
+//     operand that crosses workgroups.  The 8 XCDs' L2s are not coherent with each other, and the
+//     cache maintenance the HIP memory model prescribes for that (write-back + invalidate per
+//     fence) costs 24-74 us per step (tools/microbench/grid_barrier.hip).  But every dGh row is
+//     written exactly once, to an address nobody read before, and read only after the step's
+//     barrier: agent-scope (sc1) stores that write through and sc1 loads that bypass the
+//     non-coherent caches are enough — 1.8-4.2 us for the barrier itself (64 / 256 workgroups), no
+//     cache maintenance at all;
+//   * the barrier is a counter in the call's workspace: one agent-scope atomic add per workgroup
+//     and a bounded spin.  All workgroups are co-resident by construction (at most 256 of them,
+//     8 waves and 8 KB of LDS each; nothing they wait for waits for them), so the spin bound is
+//     never reached; if it ever were, the kernel traps — a loud failure, not a wrong gradient;
+//   * carry (dh_{t+1} z_{t+1}) lives in a register of the thread that owns the output.
+// Block ownership of the 8 waves, accumulation order and combine order are those of
+// gru_bwd_step_mid_kernel<1, 16>; the results agree with it to fp32 rounding (the compiler
+// contracts the gate arithmetic of the two kernels into different FMAs) and are bitwise
+// reproducible from run to run (tested).
+// ---------------------------------------------------------------------------------------------
+struct BwdTailParams {
+  const float* whh_t;       // [H, 3H]
+  const float* dpool;       // [sumT, H]
+  const float* gates;       // [sumT, 4H]
+  const float* hs;          // [sumT, H]
+  const int32_t* step_off;  // device [Tmax + 1]
+  float* carry;             // [S, H]: written for the rows of step t_lo when the kernel ends
+  float* dgx;               // [sumT, 3H]
+  float* dgh;               // [sumT, 3H]
+  unsigned* sync;           // [0] arrivals (zeroed by the caller)
+  int32_t H, t_hi, t_lo;    // steps t_hi = Tmax - 1 down to t_lo >= 1, at most 16 active sequences each
+};
+
+constexpr int kTailMaxSeqs = 16;
+constexpr unsigned kTailMaxSpins = 1u << 23;   // x s_sleep(1): ~0.3 s
+
+template <int KBMAX>
+__global__ __launch_bounds__(512) void gru_bwd_tail_kernel(const BwdTailParams q) {
+  CHAIN_WAVE_PRIORITY();
+  constexpr int NW = 8;
+  __shared__ f32x4v red[NW][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = q.H, K = 3 * H;
+  const int u0 = blockIdx.x * 16;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int nkb = K / 16;
+  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };   // mid_phase's ownership
+  int nmine = 0;
+  while (nmine < KBMAX && block_of(nmine) < nkb) ++nmine;
+  // B operand: column r16 of the tile = unit u0 + r16 of W_hh^T, resident for the whole tail
+  float4 wreg[KBMAX];
+  {
+    const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
+    const float* brow = q.whh_t + static_cast<int64_t>(uc) * K;
+#pragma unroll
+    for (int i = 0; i < KBMAX; ++i)
+      wreg[i] = (i < nmine) ? *reinterpret_cast<const float4*>(brow + block_of(i) * 16 + 4 * kq)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // the output this thread owns (threads 0..255): tile row er = sequence, unit u
+  const int er = tid >> 4, eu = tid & 15;
+  const int u = u0 + eu;
+  const bool owner = tid < 256 && u < H;
+  float carry = 0.f;
+  unsigned arrivals = 0;
+  int S_next = 0;
+  for (int t = q.t_hi; t >= q.t_lo; --t) {
+    const int off_cur = q.step_off[t], off_next = q.step_off[t + 1], off_prev = q.step_off[t - 1];
+    const int S_t = off_next - off_cur;
+    // the epilogue's own operands do not depend on the chain: request them before the product
+    float e_dpool = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_hp = 0.f;
+    const int64_t p = off_cur + er;
+    if (owner && er < S_t) {
+      e_dpool = q.dpool[p * H + u];
+      const float* gp = q.gates + p * 4 * H + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_g[g] = gp[static_cast<int64_t>(g) * H];
+      e_hp = q.hs[(static_cast<int64_t>(off_prev) + er) * H + u];
+    }
+    if (S_next > 0) {
+      // A operand: rows of step t + 1, published by every workgroup before the barrier below
+      const int mc = (r16 < S_next) ? r16 : (S_next - 1);
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(q.dgh + static_cast<int64_t>(off_next) * K), 0, 0x7fffffff, 0x00020000);
+      const int row_b = mc * K * 4;
+      typedef int i32x4v __attribute__((ext_vector_type(4)));
+      i32x4v areg[KBMAX];
+#pragma unroll
+      for (int i = 0; i < KBMAX; ++i)
+        if (i < nmine)
+          areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KBMAX; ++i) {
+        if (i >= nmine) continue;   // wave-uniform
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].x), wreg[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].y), wreg[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].z), wreg[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].w), wreg[i].w, acc, 0, 0, 0);
+      }
+      red[wave][lane] = acc;
+      __syncthreads();
+    }
+    if (owner && er < S_t) {
+      float rec = 0.f;
+      if (er < S_next) {
+        const int sl = (er >> 2) * 16 + eu, reg = er & 3;
+        float part = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) part += reinterpret_cast<const float*>(&red[w][sl])[reg];
+        rec = carry + part;
+      }
+      const float dh = rec + e_dpool;
+      const float rg = e_g[0], zg = e_g[1], ng = e_g[2], ghn = e_g[3];
+      const float dn_pre = dh * (1.0f - zg) * (1.0f - ng * ng);
+      const float dz_pre = dh * (e_hp - ng) * zg * (1.0f - zg);
+      const float dr_pre = dn_pre * ghn * rg * (1.0f - rg);
+      float* gx = q.dgx + p * K + u;
+      float* gh = q.dgh + p * K + u;
+      gx[0] = dr_pre;
+      gx[H] = dz_pre;
+      gx[2 * H] = dn_pre;
+      // the next step's A operand, in every workgroup: write through to where all XCDs see it
+      __hip_atomic_store(gh, dr_pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gh + H, dz_pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gh + 2 * H, dn_pre * rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      carry = dh * zg;
+    }
+    S_next = S_t;
+    if (t == q.t_lo) break;
+    // grid barrier: this workgroup's rows are written through, then everybody's are
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    arrivals += gridDim.x;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(q.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(q.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kTailMaxSpins) __builtin_trap();
+      }
+    }
+    __syncthreads();
+  }
+  if (owner && er < S_next) q.carry[static_cast<int64_t>(er) * H + u] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
 // BPTT step of a training-size batch (32 < S_t <= bwd_mid_max_seqs) as TWO launches that move a
 // third of the bytes.  The product of a step,  rec[S, H] = dGh_{t+1}[S, 3H] . W_hh[3H, H],  is a
 // skinny GEMM: a handful of row tiles, K = 3H.  gru_bwd_step_mid_kernel covers it with 32 x 16
@@ -1223,7 +1378,7 @@ static size_t wg_part_floats(int64_t sum_T, int I, int H) {
 
 struct BwdWs {
   size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, dxaddr, hsaddr, p_t, zero_row,
-      colsum, dx_part, wg_part, rec_part, total;
+      tail_sync, colsum, dx_part, wg_part, rec_part, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -1245,6 +1400,7 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.hsaddr = take(mode == CMHSE_POOL_ATTN ? static_cast<size_t>(sum_T) * 8 : 0);
   L.p_t = take(static_cast<size_t>(sum_T) * 4);
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
+  L.tail_sync = take(256);      // (right behind zero_row: one memset clears both)
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
   L.dx_part = take(det_split_scratch_bytes(sum_T, I));
   L.wg_part = take(wg_part_floats(sum_T, I, H) * sizeof(float));
@@ -1289,6 +1445,7 @@ struct BwdJob {
   int64_t chunk_hi;
   bool chunk_first;
   hipStream_t st;         // the stream of this request's chain (its own, or the call's)
+  int tail_lo;            // steps >= tail_lo run inside ONE resident kernel (gru_bwd_tail_kernel); -1 = none
 };
 
 int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode,
@@ -1348,7 +1505,7 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   const int pool_mode = j.pool_mode;
   const bool beside = j.side != st;
 
-  (void)hipMemsetAsync(zero_row, 0, static_cast<size_t>(H > I ? H : I) * 4, st);
+  (void)hipMemsetAsync(zero_row, 0, L.tail_sync + 256 - L.zero_row, st);   // zero_row and the tail kernel's barrier counter
   (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
   if (beside) stream_after(j.side, st);     // fork: the caller's inputs (and zero_row) are ready
   // per packed row: address of x_{t,s} and of h_{t-1,s} — the B operands of dW_ih / dW_hh
@@ -1480,6 +1637,35 @@ constexpr int kBwdMidUnits = 16;
 // splits K over 8 waves instead of 4: a pure latency chain on an under-filled chip
 constexpr int kBwdNw8Max = 256;
 
+// The steps t >= tail_lo >= 1 with at most kTailMaxSeqs active sequences, when there are at least
+// bwd_tail_min_steps of them (Tunables; 0 = never), run inside gru_bwd_tail_kernel on the chain's
+// stream; bwd_steps skips their launches and keeps its bookkeeping.
+static void bwd_tail(BwdJob& j) {
+  j.tail_lo = -1;
+  const cmhse_seq_batch* b = j.b;
+  const int H = b->H, Tmax = b->Tmax;
+  const int min_steps = tunables().bwd_tail_min_steps.load(std::memory_order_relaxed);
+  if (min_steps <= 0 || H % 16 != 0 || H / 16 > 256 || H > 1024 || !b->step_off) return;
+  int lo = Tmax;
+  while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= kTailMaxSeqs) --lo;
+  if (Tmax - lo < min_steps) return;
+  BwdTailParams q;
+  const BwdStepParams& sp = j.sp;
+  q.whh_t = sp.whh_t; q.dpool = sp.dpool; q.gates = sp.gates; q.hs = sp.hs;
+  q.step_off = b->step_off;
+  q.carry = sp.carry; q.dgx = sp.dgx; q.dgh = sp.dgh;
+  q.sync = reinterpret_cast<unsigned*>(j.ws + j.L.tail_sync);
+  q.H = H; q.t_hi = Tmax - 1; q.t_lo = lo;
+  const int kb = 2 * ((3 * H / 16 + 15) / 16);   // 16-k blocks per wave, whole pairs (mid_phase's ownership)
+  const dim3 grid(static_cast<unsigned>(H / 16)), block(512);
+  if (kb <= 2) hipLaunchKernelGGL(gru_bwd_tail_kernel<2>, grid, block, 0, j.st, q);
+  else if (kb <= 4) hipLaunchKernelGGL(gru_bwd_tail_kernel<4>, grid, block, 0, j.st, q);
+  else if (kb <= 6) hipLaunchKernelGGL(gru_bwd_tail_kernel<6>, grid, block, 0, j.st, q);
+  else if (kb <= 12) hipLaunchKernelGGL(gru_bwd_tail_kernel<12>, grid, block, 0, j.st, q);
+  else hipLaunchKernelGGL(gru_bwd_tail_kernel<24>, grid, block, 0, j.st, q);
+  j.tail_lo = lo;
+}
+
 // Phase 2: BPTT of all jobs, last step first.  Launch i serves step Tmax_k - 1 - i of every job k
 // that still has one (and the extra t = -1 launch of a job that wants d h0); jobs of equal block
 // size share the launch.
@@ -1505,6 +1691,8 @@ void bwd_steps(BwdJob* jobs, int n) {
       sp.dgh_next = sp.dgh + off_next * 3 * b->H;
       sp.off_cur = j.off;
       sp.off_prev = (t > 0) ? j.off - b->step_count_host[t - 1] : 0;
+      if (i == 0) bwd_tail(j);                 // the chain's few-sequence tail, if it has one: one kernel
+      if (j.tail_lo >= 0 && t >= j.tail_lo) continue;   // (kind 0) the resident kernel does this step
       grid_k[k] = static_cast<unsigned>((b->H + 31) / 32) * ((S_t + 31) / 32);
       // few active sequences: a pure latency chain on an under-filled chip -> 8 waves split K
       kind[k] = ((S_t <= nw8_max) ? 2 : 1) | ((b->H % 4 == 0) ? 0 : 4);

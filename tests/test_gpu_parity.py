@@ -574,6 +574,63 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
       grad_close(pp.grad.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('pool,cls,H,S', [('attention', 'Attention', 32, 11), ('maxout', 'Maxout', 48, 40),
+                                          ('seq2seq', 'Seq2Seq', 128, 23), ('attention', 'Attention', 1024, 32)])
+def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
+  """The few-sequence tail of a BPTT chain — the steps with at most 16 active sequences at the end
+  of whole-paragraph / whole-video sequences — inside ONE resident kernel (gru_bwd_tail_kernel:
+  grid barrier per step, the rows that cross workgroups written through / read past the
+  non-coherent L2s) against one launch per step (bwd_tail_min_steps = 0): every gradient equal to
+  fp32 rounding and bitwise reproducible run after run, for H = 32 ... 1024 (2 ... 24 16-k blocks per wave, ragged ownership at the
+  small ones), a chain that is ALL tail (S = 11), one whose tail starts mid-way, and against the
+  float64 oracle."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(5 + H)
+  I = 20 if H < 1024 else 64
+  T = 37
+  torch.manual_seed(9)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, 9, size=S)                 # most sequences end early ...
+  long_ones = rng.permutation(S)[:min(S, 13)]
+  lens[long_ones] = rng.randint(10, T + 1, size=len(long_ones))   # ... at most 13 run on
+  lens[long_ones[0]] = T
+  assert (lens > 9).sum() <= 16 and lens.max() == T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  w = rng.standard_normal((S, H)).astype(np.float32)
+
+  def run(min_steps):
+    tune(bwd_tail_min_steps=min_steps)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return [xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  per_step, resident, again = run(0), run(4), run(1)
+  for a, b, c in zip(per_step, resident, again):
+    # same block ownership and accumulation order as the per-step kernel; the compiler contracts
+    # the gate arithmetic of the two kernels into different FMAs: equal to fp32 rounding
+    assert float((a - b).abs().max()) <= 4e-6 * max(1e-6, float(a.abs().max()))
+    assert torch.equal(b, c), 'not reproducible from run to run'
+  if H <= 128:
+    _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+    grads, dx, dh0 = oracle.pooled_gru_backward(cache, w.astype(np.float64))
+    grad_close(resident[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
+    grad_close(resident[1].cpu().numpy(), dh0, pool + ' dh0')
+    for (pn, _), got in zip(layer.named_parameters(), resident[2:]):
+      grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
 @pytest.mark.parametrize('pool,cls', [('attention', 'Attention'), ('maxout', 'Maxout')])
 def test_weight_gradients_in_time_chunks_beside_the_chain(dev, oracle, pool, cls, monkeypatch):
   """The weight-gradient products (gemm_tn_rows_kernel) of a batch long enough to be taken in
