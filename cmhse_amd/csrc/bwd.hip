@@ -774,6 +774,10 @@ __global__ __launch_bounds__(512) void gru_bwd_tail_kernel(const BwdTailParams q
 //                         outputs x K x 4 x (1/128 + 1/32) = 76 MB at S_t = 152.
 //   bwd_gates_kernel      adds the partials in slice order (bitwise reproducible), then the gate
 //                         derivatives of step t exactly as the one-launch kernels' epilogue.
+// (Measured late in round 3: both in ONE launch — a ticket per tile, the last K slice to arrive adds
+// the slices and evaluates the tile's gates, partials exchanged through agent-scope stores / loads —
+// is correct and 0.1 ms per training step SLOWER: the epilogue then waits for the slowest slice and
+// runs on 32 workgroups instead of the whole chip; the second launch's gap is cheaper than that.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kRecBM = 32, kRecBN = 128, kRecBK = 32, kRecLd = kRecBK + 4;
 
@@ -1581,10 +1585,14 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   j.chunk_first = true;
 }
 
-// Packed rows a weight-gradient chunk should at least span (K of its products): long enough that
-// a tile's fill / drain and the read-modify-write of its C tile are amortised, short enough that
-// the products of the LAST chunk — the only ones the chain cannot hide — are brief.
-constexpr int64_t kChunkRows = 1024;
+// Packed rows a weight-gradient chunk should at least span (K of its products): Tunables::
+// bwd_chunk_rows, 2048.  Long enough that a tile's fill / drain and the read-modify-write of its C
+// tile are amortised; what bounds it from above is only the LAST chunk, which nothing hides.
+// Measured on the training step (ms, ICEP / C3D): 512 rows 9.85 / 8.50, 1024 9.62 / 8.39, 2048
+// 9.42 / 8.17, 4096 9.48 / 8.12, 8192 9.73 / 8.14, no chunking at all (every product after the chain)
+// 9.47 / 8.26 — with the two-launch step and the resident tail the chain and the products are
+// bound by the same L2 -> CU fabric, and the step time is the SUM of their stand-alone times
+// whether they run side by side or one after the other.
 
 // The rows [j.off, j.chunk_hi) are final (the BPTT step that wrote j.off .. has been launched on
 // `st`): contract them into dW_ih / db_ih, dW_hh / db_hh and scatter their d(input), on the side
@@ -1767,12 +1775,12 @@ void bwd_steps(BwdJob* jobs, int n) {
       }
     }
     // weight gradients of the rows this launch completed, beside the rest of the chain: a chunk
-    // closes when it spans kChunkRows rows, and at step 0
+    // closes when it spans bwd_chunk_rows rows, and at step 0
     for (int k = 0; k < n; ++k) {
       BwdJob& j = jobs[k];
       const int t = j.b->Tmax - 1 - i;
       if (t < 0) continue;
-      if (t == 0 || j.chunk_hi - j.off >= kChunkRows) bwd_chunk(j, j.st);
+      if (t == 0 || j.chunk_hi - j.off >= tunables().bwd_chunk_rows.load(std::memory_order_relaxed)) bwd_chunk(j, j.st);
     }
   }
 }

@@ -1940,7 +1940,8 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}};
+      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {
       const int old = (value >= 0) ? e.v->exchange(value) : e.v->load();

@@ -632,7 +632,7 @@ def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
 
 
 @pytest.mark.parametrize('pool,cls', [('attention', 'Attention'), ('maxout', 'Maxout')])
-def test_weight_gradients_in_time_chunks_beside_the_chain(dev, oracle, pool, cls, monkeypatch):
+def test_weight_gradients_in_time_chunks_beside_the_chain(dev, oracle, pool, cls, monkeypatch, tune):
   """The weight-gradient products (gemm_tn_rows_kernel) of a batch long enough to be taken in
   several chunks of time steps (sum T ~ 3.5 k packed rows: chunks close every >= 1024 rows, the
   last one mid-tile), with widths that are not tile multiples (3H = 216 rows of C, I = 36) and so
@@ -640,6 +640,7 @@ def test_weight_gradients_in_time_chunks_beside_the_chain(dev, oracle, pool, cls
   float64 oracle; bit-identical with the products on the chain's own stream instead of the side
   stream; and bitwise reproducible from run to run (no atomics on this path)."""
   from cmhse_amd import layers, ops
+  tune(bwd_chunk_rows=1024)      # (default 2048: this batch would be two chunks)
   rng = np.random.RandomState(77)
   S, T, I, H = 330, 14, 36, 72
   torch.manual_seed(8)
