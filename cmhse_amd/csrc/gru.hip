@@ -661,6 +661,165 @@ __global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGrou
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// The few-sequence TAIL of a training chain as ONE resident kernel (the forward twin of
+// gru_bwd_tail_kernel, bwd.hip — read its header for the why and for the coherence argument): the
+// steps t >= t_lo with at most 16 active sequences, each a 16 x 16-unit tile per workgroup.  The
+// workgroup's 48 rows of W_hh (3 gates x 16 units) sit in registers in mid_phase's operand layout;
+// per step only h_{t-1} crosses workgroups: written through (agent-scope stores — every hs row is
+// written once, to an address nobody read in this kernel), read past the non-coherent L2s
+// (sc1 buffer loads) behind the step's grid barrier.  Block ownership, accumulation and combine
+// order are gru_step_mid_kernel<1, 16, 8>'s.
+// ---------------------------------------------------------------------------------------------
+struct FwdTailParams {
+  GruStepParams p;           // as for a step of the chain; t / S_t / off_* are derived per step
+  const int32_t* step_off;   // device [Tmax + 1]
+  unsigned* sync;            // [0] arrivals (zeroed by the caller)
+  int32_t t_lo, t_hi;        // steps t_lo >= 1 ... t_hi = Tmax - 1
+};
+
+constexpr unsigned kTailMaxSpins = 1u << 23;   // x s_sleep(1): ~0.3 s
+
+template <int KBMAX>
+__global__ __launch_bounds__(512) void gru_fwd_tail_kernel(const FwdTailParams q) {
+  CHAIN_WAVE_PRIORITY();
+  constexpr int NW = 8, NB = 3, BU = 16;
+  const GruStepParams& p = q.p;
+  __shared__ f32x4v red[NW][NB][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H;
+  const int u0 = blockIdx.x * BU;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int nkb = H / 16;
+  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };   // mid_phase's ownership
+  int nmine = 0;
+  while (nmine < KBMAX && block_of(nmine) < nkb) ++nmine;
+  // B operand: column 16 j + r16 of the gate-major tile = row (gate j, unit u0 + r16) of W_hh
+  float4 wreg[NB][KBMAX];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
+    const float* brow = p.w_hh + (static_cast<int64_t>(j) * H + uc) * H;
+#pragma unroll
+    for (int i = 0; i < KBMAX; ++i)
+      wreg[j][i] = (i < nmine) ? *reinterpret_cast<const float4*>(brow + block_of(i) * 16 + 4 * kq)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // the output this thread owns (threads 0..255): tile row er = sorted sequence, unit u
+  const int er = tid >> 4, eu = tid & 15;
+  const int u = u0 + eu;
+  const bool owner = tid < 256 && u < H;
+  float e_b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (owner) {
+    e_b[0] = p.b_ih[u] + p.b_hh[u];
+    e_b[1] = p.b_ih[H + u] + p.b_hh[H + u];
+    e_b[2] = p.b_ih[2 * H + u];
+    e_b[3] = p.b_hh[2 * H + u];
+  }
+  float hprev = 0.f;
+  {
+    const int off_prev = q.step_off[q.t_lo - 1];
+    const int S_lo = q.step_off[q.t_lo + 1] - q.step_off[q.t_lo];
+    if (owner && er < S_lo) hprev = p.hs[(static_cast<int64_t>(off_prev) + er) * H + u];
+  }
+  unsigned arrivals = 0;
+  for (int t = q.t_lo; t <= q.t_hi; ++t) {
+    const int off_cur = q.step_off[t], off_prev = q.step_off[t - 1];
+    const int S_t = q.step_off[t + 1] - off_cur;
+    // the epilogue's own operands do not depend on the chain: request them first
+    float e_gx[3] = {0.f, 0.f, 0.f};
+    if (owner && er < S_t) {
+      const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(er)
+                                         : (static_cast<int64_t>(off_cur) + er - p.gx_p0);
+      const float* gxr = p.gx + gxrow * 3 * H;
+      e_gx[0] = gxr[u];
+      e_gx[1] = gxr[H + u];
+      e_gx[2] = gxr[2 * H + u];
+    }
+    {
+      // A operand: the rows of step t - 1 (the previous kernel's for t = t_lo, else published by
+      // every workgroup before the barrier at the end of the previous trip)
+      const int mc = (r16 < S_t) ? r16 : (S_t - 1);
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          p.hs + static_cast<int64_t>(off_prev) * H, 0, 0x7fffffff, 0x00020000);
+      const int row_b = mc * H * 4;
+      typedef int i32x4v __attribute__((ext_vector_type(4)));
+      i32x4v areg[KBMAX];
+#pragma unroll
+      for (int i = 0; i < KBMAX; ++i)
+        if (i < nmine)
+          areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
+      f32x4v acc[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KBMAX; ++i) {
+        if (i >= nmine) continue;   // wave-uniform
+        const float a4[4] = {__int_as_float(areg[i].x), __int_as_float(areg[i].y),
+                             __int_as_float(areg[i].z), __int_as_float(areg[i].w)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const float bv = (c == 0) ? wreg[j][i].x : (c == 1) ? wreg[j][i].y : (c == 2) ? wreg[j][i].z : wreg[j][i].w;
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], bv, acc[j], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) red[wave][j][lane] = acc[j];
+      __syncthreads();
+    }
+    if (owner && er < S_t) {
+      const int sl = (er >> 2) * 16 + eu, reg = er & 3;
+      float hg[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) hg[g] += reinterpret_cast<const float*>(&red[w][g][sl])[reg];
+      const float rg = sigmoidf_(e_gx[0] + hg[0] + e_b[0]);
+      const float zg = sigmoidf_(e_gx[1] + hg[1] + e_b[1]);
+      const float ghn = hg[2] + e_b[3];
+      const float ng = tanhf_(e_gx[2] + e_b[2] + rg * ghn);
+      const float hn = (1.0f - zg) * ng + zg * hprev;
+      hprev = hn;
+      const int64_t row = static_cast<int64_t>(off_cur) + er;
+      // next step's A operand, in every workgroup: write through to where all XCDs see it
+      __hip_atomic_store(&p.hs[row * H + u], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.gates != nullptr) {
+        float* gp = p.gates + row * 4 * H + u;
+        gp[0] = rg;
+        gp[H] = zg;
+        gp[2 * H] = ng;
+        gp[3 * H] = ghn;
+      }
+      if (p.pool_mode == CMHSE_POOL_MAX) {
+        float* op = p.out + static_cast<int64_t>(p.out_row[er]) * H + u;
+        if (hn > *op) {      // (t >= 1 here: the running maximum exists)
+          *op = hn;
+          if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(er) * H + u] = t;
+        }
+      } else if (p.pool_mode == CMHSE_POOL_LAST) {
+        if (t == p.lens[er] - 1) p.out[static_cast<int64_t>(p.out_row[er]) * H + u] = hn;
+      } else if (p.pool_mode == CMHSE_POOL_ALL) {
+        p.out[(static_cast<int64_t>(p.out_row[er]) + t) * H + u] = hn;
+      }
+    }
+    if (t == q.t_hi) break;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    arrivals += gridDim.x;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(q.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(q.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kTailMaxSpins) __builtin_trap();
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Hoisted input projection of the mid-size steps: gx[m][n] = sum_k x_row(m)[k] W_ih[n][k] for the
 // packed rows p0 + m of steps >= t_first (or, for a time-constant input, for the sequences
 // themselves), 64 x 192 tiles on the shared exact-fp32 NT tile loop.
@@ -1237,6 +1396,7 @@ struct FwdJob {
   hipStream_t side_stream;   // optional stream for throughput work beside a small-batch chain (projection chunks, attention)
   bool pooled;               // attention already launched (early, beside the others' tail)
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
+  int32_t tail_lo;           // steps >= tail_lo run inside ONE resident kernel (gru_fwd_tail_kernel); -1 = none
 };
 
 // 128-row tiles (2 workgroups per CU, 230 registers per lane) halve the weight bytes and cut the
@@ -1522,6 +1682,21 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
 
 // Rows of the input projection in front of a chunked chain / per later chunk (launch_steps)
 constexpr int64_t kXprojFirstRows = 512, kXprojChunkRows = 1536;
+static void launch_fwd_tail(FwdJob& j, hipStream_t stream) {
+  FwdTailParams q;
+  q.p = j.p;
+  q.step_off = j.b->step_off;
+  q.sync = reinterpret_cast<unsigned*>(j.wsb + j.L.tail_sync);
+  q.t_lo = j.tail_lo;
+  q.t_hi = j.b->Tmax - 1;
+  const int H = j.b->H;
+  const int kb = 2 * ((H / 16 + 15) / 16);   // 16-k blocks per wave, whole pairs (mid_phase's ownership)
+  const dim3 grid(static_cast<unsigned>(H / 16)), block(512);
+  if (kb <= 2) hipLaunchKernelGGL(gru_fwd_tail_kernel<2>, grid, block, 0, stream, q);
+  else if (kb <= 4) hipLaunchKernelGGL(gru_fwd_tail_kernel<4>, grid, block, 0, stream, q);
+  else hipLaunchKernelGGL(gru_fwd_tail_kernel<8>, grid, block, 0, stream, q);
+}
+
 struct XprojPlan {
   std::vector<int> step;        // first step of chunk c (c >= 1)
   std::vector<hipEvent_t> ev;   // recorded behind chunk c's launch on the side stream
@@ -1553,6 +1728,21 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (!seen) stream_after(jobs[k].own_stream, main_stream);
       js[k] = jobs[k].own_stream;
     }
+  // The few-sequence tail of a training chain on its own stream: one resident kernel (below).
+  for (int k = 0; k < n; ++k) {
+    FwdJob& j = jobs[k];
+    j.tail_lo = -1;
+    const cmhse_seq_batch* b = j.b;
+    const int min_steps = tunables().fwd_tail_min_steps.load(std::memory_order_relaxed);
+    if (min_steps <= 0 || !j.save || j.bf3 || !j.vec || js[k] == main_stream || j.t_mid != 0 ||
+        b->H % 16 != 0 || b->H > 1024 || b->step_events_host != nullptr || timer != nullptr)
+      continue;
+    int lo = b->Tmax;
+    while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= 16) --lo;
+    if (b->Tmax - lo < min_steps) continue;
+    j.tail_lo = lo;
+    (void)hipMemsetAsync(j.wsb + j.L.tail_sync, 0, 256, js[k]);   // the barrier counter, off the chain's path
+  }
   bool forked = false;
   auto fork = [&](int k) {
     if (side == nullptr || js[k] != main_stream) return;
@@ -1589,6 +1779,21 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (done[k]) continue;
       FwdJob& j = jobs[k];
       const int S_t = j.b->step_count_host[t];
+      if (j.tail_lo >= 0 && t >= j.tail_lo) {      // the resident kernel does this step
+        if (t == j.tail_lo) {
+          for (size_t c = 0; c < plan[k].step.size(); ++c)
+            if (plan[k].ev[c] != nullptr) {        // its rows' projection chunks, all of them
+              (void)hipStreamWaitEvent(js[k], plan[k].ev[c], 0);
+              event_put(plan[k].ev[c], false);
+              plan[k].ev[c] = nullptr;
+            }
+          launch_fwd_tail(j, js[k]);
+          ++launches;
+        }
+        j.off += S_t;
+        done[k] = true;
+        continue;
+      }
       const bool small = (kind[k] & 3) == 0 || (kind[k] & 3) == 3;
       if (small && any_tiled) fork(k);                                       // (a)
       hipStream_t stream = js[k];
@@ -1940,7 +2145,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps},
+      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps},
       {"bwd_chunk_rows", &t.bwd_chunk_rows}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

@@ -39,7 +39,7 @@ namespace cmhse {
 constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
 
 struct GruWs {
-  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, total;
+  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, tail_sync, total;
 };
 
 // Kernel-shape crossovers a caller may move (cmhse_tune, include/cmhse_hip.h): values, never
@@ -57,8 +57,9 @@ struct Tunables {
   std::atomic<int> tall_tile_min_wgs{2048};  // 64-row workgroups from which a tiled launch uses 128-row tiles (0 = never)
   std::atomic<int> bwd_mid_max_seqs{512};    // active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel
   std::atomic<int> bwd_chunk_rows{2048};     // packed rows a weight-gradient chunk spans before it is issued beside the chain
-  std::atomic<int> bwd_split_min_seqs{33};
-  std::atomic<int> bwd_tail_min_steps{4};    // steps with <= 16 active sequences at the end of a chain from which its BPTT runs them in one resident kernel (0 = never)   // ... and from which (up to bwd_mid_max_seqs) it runs as two launches with K split over the grid (0 = never)
+  std::atomic<int> bwd_split_min_seqs{33};   // ... and from which (up to bwd_mid_max_seqs) it runs as two launches with K split over the grid (0 = never)
+  std::atomic<int> bwd_tail_min_steps{4};    // steps with <= 16 active sequences at the end of a chain from which its BPTT runs them in one resident kernel (0 = never)
+  std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };
 Tunables& tunables();
 static inline int mid_max_seqs() { return tunables().mid_max_seqs.load(std::memory_order_relaxed); }
@@ -114,6 +115,8 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   L.gx = off;   // last region: the backward pass never looks at it (it calls this without Tmax)
   if (I % 4 == 0 && H % 4 == 0)
     off += ws_align(static_cast<size_t>(gx_rows_bound(S, Tmax, sum_T)) * 3 * H * sizeof(float));
+  L.tail_sync = off;   // barrier counter of gru_fwd_tail_kernel (training calls)
+  if (save) off += 256;
   L.total = off;
   return L;
 }

@@ -211,6 +211,16 @@ def run_grouped(calls, streams=None):
   return list(_GroupedGRUPoolFn.apply(specs, None if streams is None else list(streams), *flat))
 
 
+# tools/train_profile.py --timeline sets this to a function(name, stream): a mark on a tower's stream
+MARK = None
+
+
+def _mark(name, streams):
+  if MARK is not None:
+    for i, st in enumerate(streams):
+      MARK('%s[%d]' % (name, i), st)
+
+
 class _TowersFn(torch.autograd.Function):
   """The two levels of several INDEPENDENT towers as ONE autograd node (VSE.train_emb: clip_enc ->
   vid_seq_enc beside txt_enc -> txt_seq_enc, model.py:319-331).  Every tower lives on its own
@@ -244,6 +254,7 @@ class _TowersFn(torch.autograd.Function):
       reqs2.append(req)
       svs2.append(sv)
     res1 = ops.gru_pool_fwd_multi(reqs1, job_streams=streams, join=False, hold=hold)
+    _mark('fwd:level1', streams)
     for i in range(len(meta)):
       svs1[i].fctx = res1[i][1]
     res2 = ops.gru_pool_fwd_multi(reqs2, job_streams=streams)   # joins everything queued above
@@ -278,7 +289,9 @@ class _TowersFn(torch.autograd.Function):
       extra.append((dx, dtable))
       douts.append(dout)
     prep2, prep1 = ops.prepare_bwd(reqs2), ops.prepare_bwd(reqs1)
+    _mark('bwd:start', streams)
     res2 = ops.gru_pool_bwd_multi(reqs2, job_streams=streams, join=False, hold=hold, prepared=prep2)
+    _mark('bwd:level2', streams)
     for i, dout in enumerate(douts):
       n = ctx.meta[i][1]
       g_first, g_rest = grads[3 * i], grads[3 * i + 1]

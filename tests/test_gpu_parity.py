@@ -576,6 +576,57 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('pool,cls,H,S', [('attention', 'Attention', 32, 11), ('maxout', 'Maxout', 48, 40),
+                                          ('seq2seq', 'Seq2Seq', 256, 23), ('attention', 'Attention', 1024, 32)])
+def test_forward_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
+  """The few-sequence tail of a training chain's FORWARD pass inside one resident kernel
+  (gru_fwd_tail_kernel: chains on a stream of their own, cmhse_gru_job.stream) against one launch
+  per step (fwd_tail_min_steps = 0): outputs and every gradient (the kernel also writes the gate
+  activations the backward pass consumes) equal to fp32 rounding, bitwise reproducible, and the
+  outputs against the float64 oracle."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(11 + H)
+  I = 20 if H < 1024 else 64
+  T = 37
+  torch.manual_seed(9)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, 9, size=S)
+  long_ones = rng.permutation(S)[:min(S, 13)]
+  lens[long_ones] = rng.randint(10, T + 1, size=len(long_ones))
+  lens[long_ones[0]] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  w = rng.standard_normal((S, H)).astype(np.float32)
+  stream = ops.stream_set(dev)[0]
+
+  def run(min_steps):
+    tune(fwd_tail_min_steps=min_steps)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    spec = layers.SeqInput('padded', lens.astype(np.int64), layer.POOL)
+    out, = layers.run_grouped([(layer, spec, xt, ht, None)], [stream])
+    (out * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return [out.detach().clone(), xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  per_step, resident, again = run(0), run(4), run(1)
+  for a, b, c in zip(per_step, resident, again):
+    assert float((a - b).abs().max()) <= 4e-6 * max(1e-6, float(a.abs().max()))
+    assert torch.equal(b, c), 'not reproducible from run to run'
+  if H <= 256:
+    want, _ = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+    assert np.abs(resident[0].cpu().numpy() - want).max() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pool,cls,H,S', [('attention', 'Attention', 32, 11), ('maxout', 'Maxout', 48, 40),
                                           ('seq2seq', 'Seq2Seq', 128, 23), ('attention', 'Attention', 1024, 32)])
 def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
   """The few-sequence tail of a BPTT chain — the steps with at most 16 active sequences at the end

@@ -72,8 +72,16 @@ def main():
     for b in use[3:6]:
       torch.cuda.synchronize()
       model_mod.TRACE = []
+      from cmhse_amd import layers as layers_mod
+
+      def mark(name, stream, _tr=model_mod.TRACE):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        _tr.append((name, time.perf_counter(), ev))
+      layers_mod.MARK = mark
       model.train_emb(opt, *b)
       torch.cuda.synchronize()
+      layers_mod.MARK = None
       tr, model_mod.TRACE = model_mod.TRACE, None
       h0, e0 = tr[0][1], tr[0][2]
       print('  ' + '  '.join('%s h%.2f g%.2f' % (n, (h - h0) * 1e3, e0.elapsed_time(e))
