@@ -422,6 +422,8 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             which its BPTT runs them inside ONE resident kernel (a grid barrier
  *                             per step instead of a launch); 0 = never.  The kernel holds H / 16
  *                             workgroups resident (one per CU): at most four such chains at once
+ *   "fwd_tail_min_steps"   4  the same for the forward chain of a training call
+ *                             (CMHSE_SAVE_FOR_BACKWARD, job on its own stream)
  *   "bwd_chunk_rows"    2048  packed rows a weight-gradient chunk spans before its products are
  *                             issued beside the chain (changes the order in which chunks are
  *                             accumulated, i.e. the gradients to fp32 rounding)
