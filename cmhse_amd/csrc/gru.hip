@@ -497,7 +497,12 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 // H = 1024): deeper rings are SLOWER (4 waves x 4 blocks in flight: 22.0 at S_t = 96; 8 x 2: 17.2;
 // 8 x 4: 19.9; 8 x 8 on the 4-unit tile: 21.5 against 9.5 at S_t = 16), with non-temporal loads
 // too (slower still at every depth: the second half of a line does hit L1): the loop wants many
-// waves with little in flight each.
+// waves with little in flight each.  Also measured (late round 3): the BPTT step's form — the
+// product as 32 x 128 LDS-staged tiles with K split over the grid (bwd_rec_part_kernel on
+// h_{t-1} . W_hh^T) plus a gates kernel, two launches — for the steps of a training chain with
+// more than 32 sequences: correct, and 0.4 ms per training step SLOWER (ICEP 9.19 -> 9.60 ms, C3D
+// 7.88 -> 8.33): with K = H instead of 3H there are 96 tiles of two short slices, and the second
+// launch costs more than the better-coalesced loads save.
 // ---------------------------------------------------------------------------------------------
 // MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active.
 // BU = hidden units per workgroup (16, 8 or 4).  The 3 BU gate columns (gate-major: column
