@@ -319,7 +319,8 @@ def run_towers(towers, streams):
   (layer, SeqInput, x, hidden, table) description whose output rows [:n] are the rows of level 2
   (sequence s = counts[s] consecutive rows) and rows [n:] its initial hidden states (one per
   sequence).  Runs both levels of every tower as one autograd node on `streams` (one torch stream
-  per tower); returns per tower (rows [:n], rows [n:], level-2 output)."""
+  per tower); returns per tower (rows [:n], rows [n:], level-2 output) — or None when the layers do
+  not agree on requires_grad (a frozen encoder), which one node cannot express."""
   flat, meta, grad_modes = [], [], set()
   for (layer, spec, x, hidden, table), n, layer2, counts in towers:
     counts = np.asarray(counts, dtype=np.int64)
@@ -337,7 +338,7 @@ def run_towers(towers, streams):
     meta.append((spec, n, spec2))
     flat.extend(t1 + t2)
   if len(grad_modes) > 1:
-    raise ValueError('run_towers: every layer of every tower must agree on requires_grad')
+    return None      # e.g. one frozen encoder: the caller runs the levels as separate nodes
   outs = _TowersFn.apply(meta, list(streams), *flat)
   return [tuple(outs[3 * i:3 * i + 3]) for i in range(len(towers))]
 

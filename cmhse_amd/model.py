@@ -382,13 +382,15 @@ class VSE(object):
                 self.txt_enc.rnn.call_tokens_multi([captions, paragraphs],
                                                    [lengths_cap, lengths_paragraph],
                                                    self.txt_enc.embed.weight)]
+      towers = None
       if one_node:
         # both levels of both towers as one node: each tower stays on its stream between its
         # levels, forward and backward (layers.run_towers)
         from .layers import run_towers
-        (clip_emb, vid_context, vid_emb), (cap_emb, para_context, para_emb) = run_towers(
-            [(level1[0], n_clip, self.vid_seq_enc.rnn, num_clips),
-             (level1[1], n_cap, self.txt_seq_enc.rnn, num_caps)], streams)
+        towers = run_towers([(level1[0], n_clip, self.vid_seq_enc.rnn, num_clips),
+                             (level1[1], n_cap, self.txt_seq_enc.rnn, num_caps)], streams)
+      if towers is not None:
+        (clip_emb, vid_context, vid_emb), (cap_emb, para_context, para_emb) = towers
         _tick('vis:level2')
       else:
         vis, txt = run_grouped(level1)

@@ -1668,6 +1668,44 @@ def test_train_step_on_a_packed_batch_is_bit_identical(dev, lowest):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('whole_tower', [False, True])
+def test_train_step_with_a_frozen_encoder(dev, whole_tower):
+  """A fine-tuning set-up the reference allows (requires_grad = False on one encoder's parameters):
+  the two encoder levels then cannot be one autograd node (layers.run_towers declines) and the
+  step falls back to a node per level — same loss values, no gradient on the frozen parameters,
+  the other gradients equal to the all-trainable step's wherever they do not pass through the
+  frozen encoder's inputs."""
+  import copy
+  from cmhse_amd import synthetic
+  from cmhse_amd.model import VSE
+  opt = golden_opt('attention', low_level_loss=True, norm=True)
+  torch.manual_seed(3)
+  model_a = VSE(opt)
+  model_b = VSE(opt)
+  model_b.load_state_dict(copy.deepcopy(model_a.state_dict(opt)), opt)
+  frozen = list(model_b.txt_enc.rnn.parameters())
+  if whole_tower:      # nothing of the text tower trains: the towers disagree on requires_grad
+    frozen = list(model_b.txt_enc.parameters()) + list(model_b.txt_seq_enc.parameters())
+  for p in frozen:
+    p.requires_grad_(False)
+  spec = synthetic.ragged_spec(9, seed=6, max_frames=11, max_video=13)
+  batch = synthetic.make_batches(spec, 9, opt.img_dim, opt.vocab_size, seed=7)[0]
+  logs = []
+  for model in (model_a, model_b):
+    model.logger = MeterLog()
+    model.train_start(opt)
+    model.train_emb(opt, *batch)
+    logs.append([c for c in model.logger.calls if c[0].startswith('Le')])
+  assert len(logs[0]) >= 7
+  for (ka, va, na), (kb, vb, nb) in zip(logs[0], logs[1]):
+    assert ka == kb and na == nb and va == pytest.approx(vb, rel=1e-6, abs=1e-9)
+  assert all(p.grad is None for p in frozen)
+  for (na, pa), (nb, pb) in zip(model_a.clip_enc.named_parameters(), model_b.clip_enc.named_parameters()):
+    assert pb.grad is not None
+    assert float((pa.grad - pb.grad).abs().max()) <= 2e-5 * max(1e-6, float(pa.grad.abs().max())), na
+
+
+@pytest.mark.gpu
 def test_late_loss_values_reach_the_collector_in_the_reference_order(dev):
   """VSE.train_emb with this package's LogCollector (the step's loss values leave the device as a
   copy that is still in flight when train_emb returns) against a plain logger object (values
