@@ -608,7 +608,8 @@ __global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const 
 // ---------------------------------------------------------------------------------------------
 // The long few-sequence TAIL of a BPTT chain as ONE resident kernel.  The whole-paragraph /
 // whole-video sequences of a training batch run tens of steps past the last sentence / clip with
-// at most 16 sequences still active (ActivityNet, batch 32: ~75 of the text chain's 124 steps);
+// at most 32 sequences still active (ActivityNet, batch 32: ~95 of the text chain's 124 steps,
+// and every step of the level-2 encoders and of the decoders);
 // backward those steps come FIRST, each a dependent launch of gru_bwd_step_mid_kernel<1, 16> —
 // 12.8 us apiece on an idle chip, 24 us beside the other tower's chain — and the step's own work
 // is a 16 x 16 output tile per workgroup.  Here the H / 16 workgroups of that kernel stay resident
@@ -643,17 +644,17 @@ struct BwdTailParams {
   float* dgx;               // [sumT, 3H]
   float* dgh;               // [sumT, 3H]
   unsigned* sync;           // [0] arrivals (zeroed by the caller)
-  int32_t H, t_hi, t_lo;    // steps t_hi = Tmax - 1 down to t_lo >= 1, at most 16 active sequences each
+  int32_t H, t_hi, t_lo;    // steps t_hi = Tmax - 1 down to t_lo >= 1, at most 32 active sequences each
 };
 
-constexpr int kTailMaxSeqs = 16;
+constexpr int kTailMaxSeqs = 32;   // two 16-row blocks per workgroup
 constexpr unsigned kTailMaxSpins = 1u << 23;   // x s_sleep(1): ~0.3 s
 
-template <int KBMAX>
+template <int KBMAX, int MB>
 __global__ __launch_bounds__(512) void gru_bwd_tail_kernel(const BwdTailParams q) {
   CHAIN_WAVE_PRIORITY();
   constexpr int NW = 8;
-  __shared__ f32x4v red[NW][64];
+  __shared__ f32x4v red[NW][MB][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = q.H, K = 3 * H;
   const int u0 = blockIdx.x * 16;
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(512) void gru_bwd_tail_kernel(const BwdTailParams q
   // the output this thread owns (threads 0..255): tile row er = sequence, unit u
   const int er = tid >> 4, eu = tid & 15;
   const int u = u0 + eu;
-  const bool owner = tid < 256 && u < H;
+  const bool owner = er < 16 * MB && u < H;     // threads 0..255 at MB = 1, all 512 at MB = 2
   float carry = 0.f;
   unsigned arrivals = 0;
   int S_next = 0;
@@ -693,36 +694,43 @@ __global__ __launch_bounds__(512) void gru_bwd_tail_kernel(const BwdTailParams q
       e_hp = q.hs[(static_cast<int64_t>(off_prev) + er) * H + u];
     }
     if (S_next > 0) {
-      // A operand: rows of step t + 1, published by every workgroup before the barrier below
-      const int mc = (r16 < S_next) ? r16 : (S_next - 1);
+      // A operand: rows of step t + 1, published by every workgroup before the barrier below;
+      // one 16-row block at a time (its 96 registers are reused by the second block)
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(q.dgh + static_cast<int64_t>(off_next) * K), 0, 0x7fffffff, 0x00020000);
-      const int row_b = mc * K * 4;
       typedef int i32x4v __attribute__((ext_vector_type(4)));
-      i32x4v areg[KBMAX];
 #pragma unroll
-      for (int i = 0; i < KBMAX; ++i)
-        if (i < nmine)
-          areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
-      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      for (int mb = 0; mb < MB; ++mb) {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        if (16 * mb < S_next) {      // (workgroup-uniform)
+          const int m = 16 * mb + r16;
+          const int row_b = ((m < S_next) ? m : (S_next - 1)) * K * 4;
+          i32x4v areg[KBMAX];
 #pragma unroll
-      for (int i = 0; i < KBMAX; ++i) {
-        if (i >= nmine) continue;   // wave-uniform
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].x), wreg[i].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].y), wreg[i].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].z), wreg[i].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].w), wreg[i].w, acc, 0, 0, 0);
+          for (int i = 0; i < KBMAX; ++i)
+            if (i < nmine)
+              areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
+#pragma unroll
+          for (int i = 0; i < KBMAX; ++i) {
+            if (i >= nmine) continue;   // wave-uniform
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].x), wreg[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].y), wreg[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].z), wreg[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].w), wreg[i].w, acc, 0, 0, 0);
+          }
+        }
+        red[wave][mb][lane] = acc;
       }
-      red[wave][lane] = acc;
       __syncthreads();
     }
     if (owner && er < S_t) {
       float rec = 0.f;
       if (er < S_next) {
-        const int sl = (er >> 2) * 16 + eu, reg = er & 3;
+        const int mb = er >> 4, rr = er & 15;
+        const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
         float part = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) part += reinterpret_cast<const float*>(&red[w][sl])[reg];
+        for (int w = 0; w < NW; ++w) part += reinterpret_cast<const float*>(&red[w][mb][sl])[reg];
         rec = carry + part;
       }
       const float dh = rec + e_dpool;
@@ -1645,7 +1653,7 @@ constexpr int kBwdMidUnits = 16;
 // splits K over 8 waves instead of 4: a pure latency chain on an under-filled chip
 constexpr int kBwdNw8Max = 256;
 
-// The steps t >= tail_lo >= 1 with at most kTailMaxSeqs active sequences, when there are at least
+// The steps t >= tail_lo >= 1 with at most kTailMaxSeqs (32) active sequences, when there are at least
 // bwd_tail_min_steps of them (Tunables; 0 = never), run inside gru_bwd_tail_kernel on the chain's
 // stream; bwd_steps skips their launches and keeps its bookkeeping.
 static void bwd_tail(BwdJob& j) {
@@ -1666,11 +1674,18 @@ static void bwd_tail(BwdJob& j) {
   q.H = H; q.t_hi = Tmax - 1; q.t_lo = lo;
   const int kb = 2 * ((3 * H / 16 + 15) / 16);   // 16-k blocks per wave, whole pairs (mid_phase's ownership)
   const dim3 grid(static_cast<unsigned>(H / 16)), block(512);
-  if (kb <= 2) hipLaunchKernelGGL(gru_bwd_tail_kernel<2>, grid, block, 0, j.st, q);
-  else if (kb <= 4) hipLaunchKernelGGL(gru_bwd_tail_kernel<4>, grid, block, 0, j.st, q);
-  else if (kb <= 6) hipLaunchKernelGGL(gru_bwd_tail_kernel<6>, grid, block, 0, j.st, q);
-  else if (kb <= 12) hipLaunchKernelGGL(gru_bwd_tail_kernel<12>, grid, block, 0, j.st, q);
-  else hipLaunchKernelGGL(gru_bwd_tail_kernel<24>, grid, block, 0, j.st, q);
+  const bool two = b->step_count_host[lo] > 16;    // 17 ... 32 sequences at the tail's widest step
+#define BWD_TAIL_(KB)                                                                       \
+  do {                                                                                      \
+    if (two) hipLaunchKernelGGL((gru_bwd_tail_kernel<KB, 2>), grid, block, 0, j.st, q);     \
+    else hipLaunchKernelGGL((gru_bwd_tail_kernel<KB, 1>), grid, block, 0, j.st, q);         \
+  } while (0)
+  if (kb <= 2) BWD_TAIL_(2);
+  else if (kb <= 4) BWD_TAIL_(4);
+  else if (kb <= 6) BWD_TAIL_(6);
+  else if (kb <= 12) BWD_TAIL_(12);
+  else BWD_TAIL_(24);
+#undef BWD_TAIL_
   j.tail_lo = lo;
 }
 

@@ -670,7 +670,8 @@ __global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGrou
 // ---------------------------------------------------------------------------------------------
 // The few-sequence TAIL of a training chain as ONE resident kernel (the forward twin of
 // gru_bwd_tail_kernel, bwd.hip — read its header for the why and for the coherence argument): the
-// steps t >= t_lo with at most 16 active sequences, each a 16 x 16-unit tile per workgroup.  The
+// steps t >= t_lo with at most 32 active sequences, each a 16- or 32-sequence x 16-unit tile per
+// workgroup.  The
 // workgroup's 48 rows of W_hh (3 gates x 16 units) sit in registers in mid_phase's operand layout;
 // per step only h_{t-1} crosses workgroups: written through (agent-scope stores — every hs row is
 // written once, to an address nobody read in this kernel), read past the non-coherent L2s
@@ -685,13 +686,14 @@ struct FwdTailParams {
 };
 
 constexpr unsigned kTailMaxSpins = 1u << 23;   // x s_sleep(1): ~0.3 s
+constexpr int kFwdTailMaxSeqs = 32;             // two 16-row blocks per workgroup
 
-template <int KBMAX>
+template <int KBMAX, int MB>
 __global__ __launch_bounds__(512) void gru_fwd_tail_kernel(const FwdTailParams q) {
   CHAIN_WAVE_PRIORITY();
   constexpr int NW = 8, NB = 3, BU = 16;
   const GruStepParams& p = q.p;
-  __shared__ f32x4v red[NW][NB][64];
+  __shared__ f32x4v red[NW][MB * NB][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H;
   const int u0 = blockIdx.x * BU;
@@ -711,10 +713,11 @@ __global__ __launch_bounds__(512) void gru_fwd_tail_kernel(const FwdTailParams q
       wreg[j][i] = (i < nmine) ? *reinterpret_cast<const float4*>(brow + block_of(i) * 16 + 4 * kq)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // the output this thread owns (threads 0..255): tile row er = sorted sequence, unit u
+  // the output this thread owns (16 MB x 16 of them: threads 0..255 at MB = 1, all 512 at MB = 2):
+  // tile row er = sorted sequence, unit u
   const int er = tid >> 4, eu = tid & 15;
   const int u = u0 + eu;
-  const bool owner = tid < 256 && u < H;
+  const bool owner = er < 16 * MB && u < H;
   float e_b[4] = {0.f, 0.f, 0.f, 0.f};
   if (owner) {
     e_b[0] = p.b_ih[u] + p.b_hh[u];
@@ -745,43 +748,54 @@ __global__ __launch_bounds__(512) void gru_fwd_tail_kernel(const FwdTailParams q
     {
       // A operand: the rows of step t - 1 (the previous kernel's for t = t_lo, else published by
       // every workgroup before the barrier at the end of the previous trip)
-      const int mc = (r16 < S_t) ? r16 : (S_t - 1);
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           p.hs + static_cast<int64_t>(off_prev) * H, 0, 0x7fffffff, 0x00020000);
-      const int row_b = mc * H * 4;
       typedef int i32x4v __attribute__((ext_vector_type(4)));
-      i32x4v areg[KBMAX];
+      i32x4v areg[MB][KBMAX];
 #pragma unroll
-      for (int i = 0; i < KBMAX; ++i)
-        if (i < nmine)
-          areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
-      f32x4v acc[NB];
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = 16 * mb + r16;
+        const int row_b = ((m < S_t) ? m : (S_t - 1)) * H * 4;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < KBMAX; ++i)
+          if (i < nmine && 16 * mb < S_t)
+            areg[mb][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
+      }
+      f32x4v acc[MB][NB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[mb][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < KBMAX; ++i) {
         if (i >= nmine) continue;   // wave-uniform
-        const float a4[4] = {__int_as_float(areg[i].x), __int_as_float(areg[i].y),
-                             __int_as_float(areg[i].z), __int_as_float(areg[i].w)};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const float bv = (c == 0) ? wreg[j][i].x : (c == 1) ? wreg[j][i].y : (c == 2) ? wreg[j][i].z : wreg[j][i].w;
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], bv, acc[j], 0, 0, 0);
+          for (int mb = 0; mb < MB; ++mb) {
+            if (16 * mb >= S_t) continue;   // (workgroup-uniform) an empty row block
+            const int ai = (c == 0) ? areg[mb][i].x : (c == 1) ? areg[mb][i].y : (c == 2) ? areg[mb][i].z : areg[mb][i].w;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const float bv = (c == 0) ? wreg[j][i].x : (c == 1) ? wreg[j][i].y : (c == 2) ? wreg[j][i].z : wreg[j][i].w;
+              acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(ai), bv, acc[mb][j], 0, 0, 0);
+            }
           }
       }
 #pragma unroll
-      for (int j = 0; j < NB; ++j) red[wave][j][lane] = acc[j];
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) red[wave][mb * NB + j][lane] = acc[mb][j];
       __syncthreads();
     }
     if (owner && er < S_t) {
-      const int sl = (er >> 2) * 16 + eu, reg = er & 3;
+      const int mb = er >> 4, rr = er & 15;
+      const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
       float hg[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) hg[g] += reinterpret_cast<const float*>(&red[w][g][sl])[reg];
+        for (int w = 0; w < NW; ++w) hg[g] += reinterpret_cast<const float*>(&red[w][mb * NB + g][sl])[reg];
       const float rg = sigmoidf_(e_gx[0] + hg[0] + e_b[0]);
       const float zg = sigmoidf_(e_gx[1] + hg[1] + e_b[1]);
       const float ghn = hg[2] + e_b[3];
@@ -1698,9 +1712,16 @@ static void launch_fwd_tail(FwdJob& j, hipStream_t stream) {
   const int H = j.b->H;
   const int kb = 2 * ((H / 16 + 15) / 16);   // 16-k blocks per wave, whole pairs (mid_phase's ownership)
   const dim3 grid(static_cast<unsigned>(H / 16)), block(512);
-  if (kb <= 2) hipLaunchKernelGGL(gru_fwd_tail_kernel<2>, grid, block, 0, stream, q);
-  else if (kb <= 4) hipLaunchKernelGGL(gru_fwd_tail_kernel<4>, grid, block, 0, stream, q);
-  else hipLaunchKernelGGL(gru_fwd_tail_kernel<8>, grid, block, 0, stream, q);
+  const bool two = j.b->step_count_host[j.tail_lo] > 16;   // 17 ... 32 sequences at the tail's first step
+#define FWD_TAIL_(KB)                                                                         \
+  do {                                                                                        \
+    if (two) hipLaunchKernelGGL((gru_fwd_tail_kernel<KB, 2>), grid, block, 0, stream, q);     \
+    else hipLaunchKernelGGL((gru_fwd_tail_kernel<KB, 1>), grid, block, 0, stream, q);         \
+  } while (0)
+  if (kb <= 2) FWD_TAIL_(2);
+  else if (kb <= 4) FWD_TAIL_(4);
+  else FWD_TAIL_(8);
+#undef FWD_TAIL_
 }
 
 struct XprojPlan {
@@ -1744,7 +1765,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         b->H % 16 != 0 || b->H > 1024 || b->step_events_host != nullptr || timer != nullptr)
       continue;
     int lo = b->Tmax;
-    while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= 16) --lo;
+    while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= kFwdTailMaxSeqs) --lo;
     if (b->Tmax - lo < min_steps) continue;
     j.tail_lo = lo;
     (void)hipMemsetAsync(j.wsb + j.L.tail_sync, 0, 256, js[k]);   // the barrier counter, off the chain's path

@@ -418,7 +418,7 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             backward kernel
  *   "bwd_split_min_seqs"  33  active sequences from which (up to bwd_mid_max_seqs) a BPTT step runs
  *                             as two launches with K split over the grid; 0 = never
- *   "bwd_tail_min_steps"   4  steps with at most 16 active sequences at the end of a chain from
+ *   "bwd_tail_min_steps"   4  steps with at most 32 active sequences at the end of a chain from
  *                             which its BPTT runs them inside ONE resident kernel (a grid barrier
  *                             per step instead of a launch); 0 = never.  The kernel holds H / 16
  *                             workgroups resident (one per CU): at most four such chains at once

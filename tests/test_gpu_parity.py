@@ -575,9 +575,10 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('pool,cls,H,S', [('attention', 'Attention', 32, 11), ('maxout', 'Maxout', 48, 40),
-                                          ('seq2seq', 'Seq2Seq', 256, 23), ('attention', 'Attention', 1024, 32)])
-def test_forward_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
+@pytest.mark.parametrize('pool,cls,H,S,n_long', [('attention', 'Attention', 32, 11, 13), ('maxout', 'Maxout', 48, 40, 13),
+                                                 ('seq2seq', 'Seq2Seq', 256, 23, 13), ('attention', 'Attention', 1024, 32, 13),
+                                                 ('maxout', 'Maxout', 64, 40, 29), ('attention', 'Attention', 1024, 32, 30)])
+def test_forward_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, n_long, tune):
   """The few-sequence tail of a training chain's FORWARD pass inside one resident kernel
   (gru_fwd_tail_kernel: chains on a stream of their own, cmhse_gru_job.stream) against one launch
   per step (fwd_tail_min_steps = 0): outputs and every gradient (the kernel also writes the gate
@@ -595,7 +596,7 @@ def test_forward_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune)
   sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
   layer = layer.to(dev)
   lens = rng.randint(1, 9, size=S)
-  long_ones = rng.permutation(S)[:min(S, 13)]
+  long_ones = rng.permutation(S)[:min(S, n_long)]   # n_long > 16: a tail of two 16-row blocks
   lens[long_ones] = rng.randint(10, T + 1, size=len(long_ones))
   lens[long_ones[0]] = T
   x = np.zeros((S, T, I), dtype=np.float32)
@@ -618,19 +619,23 @@ def test_forward_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune)
 
   per_step, resident, again = run(0), run(4), run(1)
   for a, b, c in zip(per_step, resident, again):
-    assert float((a - b).abs().max()) <= 4e-6 * max(1e-6, float(a.abs().max()))
+    # (the hidden states differ in their last bits; the attention softmax and 37 steps of BPTT
+    # carry that into the gradients)
+    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max()))
     assert torch.equal(b, c), 'not reproducible from run to run'
+  assert float((per_step[0] - resident[0]).abs().max()) <= 2e-6 * float(per_step[0].abs().max())
   if H <= 256:
     want, _ = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
     assert np.abs(resident[0].cpu().numpy() - want).max() <= 2e-5
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('pool,cls,H,S', [('attention', 'Attention', 32, 11), ('maxout', 'Maxout', 48, 40),
-                                          ('seq2seq', 'Seq2Seq', 128, 23), ('attention', 'Attention', 1024, 32)])
-def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
+@pytest.mark.parametrize('pool,cls,H,S,n_long', [('attention', 'Attention', 32, 11, 13), ('maxout', 'Maxout', 48, 40, 13),
+                                                 ('seq2seq', 'Seq2Seq', 128, 23, 13), ('attention', 'Attention', 1024, 32, 13),
+                                                 ('maxout', 'Maxout', 64, 40, 29), ('attention', 'Attention', 1024, 32, 30)])
+def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, n_long, tune):
   """The few-sequence tail of a BPTT chain — the steps with at most 16 active sequences at the end
-  of whole-paragraph / whole-video sequences — inside ONE resident kernel (gru_bwd_tail_kernel:
+  of whole-paragraph / whole-video sequences (up to 32: one or two 16-row blocks per workgroup) — inside ONE resident kernel (gru_bwd_tail_kernel:
   grid barrier per step, the rows that cross workgroups written through / read past the
   non-coherent L2s) against one launch per step (bwd_tail_min_steps = 0): every gradient equal to
   fp32 rounding and bitwise reproducible run after run, for H = 32 ... 1024 (2 ... 24 16-k blocks per wave, ragged ownership at the
@@ -648,10 +653,10 @@ def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, tune):
   sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
   layer = layer.to(dev)
   lens = rng.randint(1, 9, size=S)                 # most sequences end early ...
-  long_ones = rng.permutation(S)[:min(S, 13)]
+  long_ones = rng.permutation(S)[:min(S, n_long)]   # n_long > 16: a tail of two 16-row blocks
   lens[long_ones] = rng.randint(10, T + 1, size=len(long_ones))   # ... at most 13 run on
   lens[long_ones[0]] = T
-  assert (lens > 9).sum() <= 16 and lens.max() == T
+  assert (lens > 9).sum() <= 32 and lens.max() == T
   x = np.zeros((S, T, I), dtype=np.float32)
   for i, l in enumerate(lens):
     x[i, :l] = rng.standard_normal((l, I))
