@@ -84,6 +84,11 @@ class LogCollector(object):
     self.settle()
     return self._meters
 
+  @meters.setter
+  def meters(self, value):      # `collector.meters = OrderedDict()`: a reset
+    self._deferred = []
+    self._meters = value
+
   def __str__(self):
     return '  '.join('%s %s' % (k, m) for k, m in self.meters.items())
 
