@@ -201,6 +201,7 @@ class VSE(object):
     self.Eiters = 0
     self.logger = None
     self._pending_log = None
+    self._log_slot, self._log_pinned, self._log_owner = 0, [None, None], [None, None]
     self._loss_weights = {}     # weight vectors of the batched losses, by number of terms
 
   # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
@@ -290,9 +291,8 @@ class VSE(object):
         logger.update(key, v, n)
       return
     logger.settle()            # the previous step's copy: long done, the GPU is a step behind us
-    slot = self._log_slot = (getattr(self, '_log_slot', 0) + 1) % 2
-    bufs = self.__dict__.setdefault('_log_pinned', [None, None])
-    owners = self.__dict__.setdefault('_log_owner', [None, None])
+    slot = self._log_slot = (self._log_slot + 1) % 2
+    bufs, owners = self._log_pinned, self._log_owner
     if owners[slot] is not None and owners[slot] is not logger:
       owners[slot].settle()    # model.logger was swapped since: its copy still reads this buffer
     owners[slot] = logger
