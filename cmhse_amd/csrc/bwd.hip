@@ -375,16 +375,18 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_out_kernel(const NtOutParams
     }
 }
 
-// out row m (at c_addr[m]) = part[0][m] + part[1][m] + ... in segment order (bitwise reproducible)
+// out row m (at c_addr[m], or c + m * ldc) = [its old value +] part[0][m] + part[1][m] + ... in segment
+// order (bitwise reproducible)
 __global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(const float* __restrict__ part,
                                                                  const uint64_t* __restrict__ c_addr,
+                                                                 float* __restrict__ c, int64_t ldc, int add,
                                                                  int splits, int M, int N) {
   const int m = blockIdx.x;
-  float* dst = reinterpret_cast<float*>(c_addr[m]);
+  float* dst = c_addr ? reinterpret_cast<float*>(c_addr[m]) : c + m * ldc;
   for (int n = threadIdx.x; n < N; n += kThreads) {
     float s = 0.f;
     for (int y = 0; y < splits; ++y) s += part[(static_cast<int64_t>(y) * M + m) * N + n];
-    dst[n] = s;
+    dst[n] = add ? dst[n] + s : s;
   }
 }
 
@@ -1261,17 +1263,21 @@ static void launch_nt_out(const float* a, int64_t lda, const float* b, int64_t l
 // handful of CUs (200 us for 0.75 GFLOP).  K is cut into segments, every segment's partial goes
 // to scratch, and a second small launch adds the segments in order — no atomics, reproducible.
 constexpr int kDetSplitRows = 256, kDetSplitMax = 12;
-static size_t det_split_scratch_bytes(int64_t sum_T, int I) {
+static size_t det_split_scratch_bytes(int64_t sum_T, int N) {
   const int64_t rows = sum_T < kDetSplitRows ? sum_T : kDetSplitRows;
-  return static_cast<size_t>(kDetSplitMax) * rows * I * sizeof(float);
+  return static_cast<size_t>(kDetSplitMax) * rows * N * sizeof(float);
 }
+// rows scattered through c_addr and written once (c == nullptr), or the contiguous rows of c
+// added to (the attention backward's dpool += du . W_lin of a level-2 batch: 8 tiles used to walk
+// K = H on 8 CUs, 89 us on the path between the levels)
 static void launch_nt_rows_once(const float* a, int64_t lda, const float* b, int64_t ldb,
                                 const uint64_t* c_addr, int M, int N, int K, float* scratch,
-                                hipStream_t st) {
+                                hipStream_t st, float* c = nullptr, int64_t ldc = 0) {
   int splits = K / 256;
   if (splits > kDetSplitMax) splits = kDetSplitMax;
   if (M > kDetSplitRows || splits < 2) {
-    launch_nt_out(a, lda, b, ldb, nullptr, 0, c_addr, M, N, K, 0, st);
+    if (c != nullptr) launch_nt_out(a, lda, b, ldb, c, ldc, nullptr, M, N, K, 1, st);
+    else launch_nt_out(a, lda, b, ldb, nullptr, 0, c_addr, M, N, K, 0, st);
     return;
   }
   NtOutParams q;
@@ -1286,7 +1292,8 @@ static void launch_nt_rows_once(const float* a, int64_t lda, const float* b, int
     hipLaunchKernelGGL(gemm_nt_out_kernel<true>, dim3(grid, splits), dim3(kThreads), smem, st, q);
   else
     hipLaunchKernelGGL(gemm_nt_out_kernel<false>, dim3(grid, splits), dim3(kThreads), smem, st, q);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(kThreads), 0, st, scratch, c_addr, splits, M, N);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M), dim3(kThreads), 0, st, scratch, c_addr, c, ldc,
+                     c != nullptr ? 1 : 0, splits, M, N);
 }
 
 // One launch of gemm_tn_rows_kernel: up to kTnRowsMaxProblems products over the packed rows
@@ -1414,7 +1421,7 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
   L.tail_sync = take(256);      // (right behind zero_row: one memset clears both)
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
-  L.dx_part = take(det_split_scratch_bytes(sum_T, I));
+  L.dx_part = take(det_split_scratch_bytes(sum_T, I > H ? I : H));   // (also the attention backward's dpool product: N = H)
   L.wg_part = take(wg_part_floats(sum_T, I, H) * sizeof(float));
   L.rec_part = take(rec_part_floats(S, H) * sizeof(float));
   L.total = off;
@@ -1547,7 +1554,8 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
                        de, v, w->w_att, du, sum_T, H);
     // the chain needs dpool += du . W_lin  (NT on W_lin^T) ...
     launch_transpose(w->w_lin, wlin_t, H, H, st);
-    launch_nt_out(du, H, wlin_t, H, dpool, H, nullptr, static_cast<int>(sum_T), H, H, 1, st);
+    launch_nt_rows_once(du, H, wlin_t, H, nullptr, static_cast<int>(sum_T), H, H,
+                        reinterpret_cast<float*>(ws + L.dx_part), st, dpool, H);
     // ... but not d W_lin[n][k] = sum_p du[p][n] hs[p][k], d b_lin = sum_p du[p], d att_w = sum_p de_p v_p
     if (beside) stream_after(j.side, st);
     TnRowsLaunch tl;
