@@ -48,7 +48,7 @@ python bench.py --gpus 2 --n_videos 1230 --steps 3 --warmup 1 --fast_steps 0 --t
 for c in c3d icep icep_recon; do
   python tools/ab_train.py --config $c --rounds 5 --steps 10 --modes "schedule=towers,side_streams=0,tune.bwd_split_min_seqs=0;schedule=interleaved,side_streams=0,tune.bwd_split_min_seqs=0;schedule=interleaved,side_streams=1,tune.bwd_split_min_seqs=0;schedule=interleaved,side_streams=1" 2>&1 | grep -v amdgpu >> $D/train_ab.txt
   # the late-round-3 ladder: node per level + operator-by-operator losses + per-step tail + 1024-row chunks, then one change at a time
-  python tools/ab_train.py --config $c --rounds 5 --steps 10 --modes "schedule=levels,fused_losses=0,tune.bwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;schedule=levels,tune.bwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;tune.bwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;tune.bwd_chunk_rows=1024;label=default" 2>&1 | grep -v amdgpu >> $D/train_ab_late.txt
+  python tools/ab_train.py --config $c --rounds 5 --steps 10 --modes "schedule=levels,fused_losses=0,tune.bwd_tail_min_steps=0,tune.fwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;schedule=levels,tune.bwd_tail_min_steps=0,tune.fwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;tune.bwd_tail_min_steps=0,tune.fwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;tune.fwd_tail_min_steps=0,tune.bwd_chunk_rows=1024;tune.bwd_chunk_rows=1024;label=default" 2>&1 | grep -v amdgpu >> $D/train_ab_late.txt
 done
 python tools/step_sweep.py --sizes 1,8,16,32,64,152,320,512,1024 --dims 500,300,1024 --arms "tune.mid_max_seqs=0;tune.mid_units=16;tune.mid_units=0" > $D/step_sweep.txt 2>&1
 python tools/tile_trace.py 22419 2048 1024 > $D/tile_trace.txt 2>&1
