@@ -5,7 +5,6 @@ fallback — tensors must live on the MI355X.
 from __future__ import annotations
 
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -108,12 +107,12 @@ class tuned(object):
       tune(k, v)
 
 
-_MATH_MODE = [os.environ.get('CMHSE_MATH', 'fp32')]
+_MATH_MODE = ['fp32']
 
 
 def math_mode():
   """'fp32' (exact, default) or 'bf16x3' (3-term bf16 split on the matrix pipe for the large
-  inference GEMMs; ~1e-6 on the embeddings).  Set with set_math_mode() or CMHSE_MATH."""
+  inference GEMMs; ~1e-6 on the embeddings).  Set with set_math_mode()."""
   return _MATH_MODE[0]
 
 

@@ -280,14 +280,14 @@ def test_tune_is_the_one_configuration_entry_point():
 
 def test_the_library_reads_no_environment_variable():
   """Experiment switches were retired in round 3: the native sources contain no getenv, and the
-  package reads exactly two variables (the library path and the math mode)."""
+  package reads exactly one variable (the library path)."""
   import glob
   import re
   root = os.path.join(REPO, 'cmhse_amd')
   native = ''.join(open(f).read() for f in glob.glob(os.path.join(root, 'csrc', '*')))
   assert 'getenv' not in native
   py = ''.join(open(f).read() for f in glob.glob(os.path.join(root, '*.py')))
-  assert sorted(set(re.findall(r"environ(?:\.get)?\(\s*'(CMHSE_[A-Z0-9_]+)'", py))) == ['CMHSE_HIP_LIB', 'CMHSE_MATH']
+  assert sorted(set(re.findall(r"environ(?:\.get)?\(\s*'(CMHSE_[A-Z0-9_]+)'", py))) == ['CMHSE_HIP_LIB']
 
 
 def test_log_collector_replays_late_values_in_order():
