@@ -1671,7 +1671,7 @@ static void bwd_tail(BwdJob& j) {
   const cmhse_seq_batch* b = j.b;
   const int H = b->H, Tmax = b->Tmax;
   const int min_steps = tunables().bwd_tail_min_steps.load(std::memory_order_relaxed);
-  if (min_steps <= 0 || H % 16 != 0 || H / 16 > 256 || H > 1024 || !b->step_off) return;
+  if (min_steps <= 0 || H % 16 != 0 || H > 1024 || !b->step_off || !resident_fits(H / 16)) return;
   int lo = Tmax;
   while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= kTailMaxSeqs) --lo;
   if (Tmax - lo < min_steps) return;

@@ -1367,6 +1367,18 @@ void event_put(hipEvent_t ev, bool timing) {
   g_event_free[dev][timing ? 1 : 0].push_back(ev);
 }
 
+bool resident_fits(int wgs) {
+  static std::atomic<int> cus[64];      // per device, 0 = not asked yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n >= 4 * wgs;
+}
+
 void stream_after(hipStream_t waiter, hipStream_t signal) {
   hipEvent_t ev = event_get(false);
   bool ordered = false;
@@ -1762,7 +1774,8 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     const cmhse_seq_batch* b = j.b;
     const int min_steps = tunables().fwd_tail_min_steps.load(std::memory_order_relaxed);
     if (min_steps <= 0 || !j.save || j.bf3 || !j.vec || js[k] == main_stream || j.t_mid != 0 ||
-        b->H % 16 != 0 || b->H > 1024 || b->step_events_host != nullptr || timer != nullptr)
+        b->H % 16 != 0 || b->H > 1024 || b->step_events_host != nullptr || timer != nullptr ||
+        !resident_fits(b->H / 16))
       continue;
     int lo = b->Tmax;
     while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= kFwdTailMaxSeqs) --lo;

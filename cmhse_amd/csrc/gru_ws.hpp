@@ -129,6 +129,11 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
 // one; event_put() returns it to that device's list (an event may be re-recorded as soon as
 // nothing waits for its old use: the launcher's wait-events are consumed by hipStreamWaitEvent at
 // enqueue time, the timers' events are read before their handle is destroyed).
+// A resident kernel (gru_fwd_tail_kernel / gru_bwd_tail_kernel) needs all its `wgs` workgroups on the
+// chip at once, one per CU, and the package may run four such chains side by side: true when the
+// current device has the CUs for that (a full MI355X: 256; a partitioned one may not).
+bool resident_fits(int wgs);
+
 hipEvent_t event_get(bool timing);
 void event_put(hipEvent_t ev, bool timing);
 
