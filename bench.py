@@ -433,6 +433,10 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           'mfma_floor_ms': mfma_floor_ms, 'chain_floor_ms': chain_floor_ms,
           'chain_step_us': step_us,
           'frac_of_floor': (floor / (dt * 1e3)) if floor > 0 else None,
+          # chains and products are bound by the same L2 -> CU fabric and do not overlap for free
+          # (every product after the chains is as fast as beside them): the sum of the
+          # two floors is the tighter yardstick
+          'frac_of_sum_of_floors': ((mfma_floor_ms + (chain_floor_ms or 0.0)) / (dt * 1e3)),
           'bound': 'max(FLOPs / 157.3 TFLOP/s fp32 MFMA, dependent steps x the measured latency '
                    'of one small-batch step launch on an idle chip)',
           'last_losses': losses}
