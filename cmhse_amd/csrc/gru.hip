@@ -1602,6 +1602,10 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
     if (waves == 4) alone = false;
     if (waves == 8) alone = true;
     const int bu = mid_units(j.b->H, mid_blocks);
+    // many sequences: 64 per workgroup, so that the step is ONE round of workgroups (H / 16 x
+    // ceil(S_t / 64) <= 256 up to 256 sequences at H = 1024) instead of two of 32-sequence ones
+    const int tall = tunables().mid_tall_min_seqs.load(std::memory_order_relaxed);
+    if (tall > 0 && S_t >= tall && bu == 16 && alone && j.save) return 3 | 512 | 8192;   // (training calls: the validation pass keeps its shapes)
     return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0) |
            (alone ? 512 : 0);
   }
@@ -1653,7 +1657,9 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
     else                                                                                              \
       hipLaunchKernelGGL((gru_step_mid_kernel<MB, BU, 4>), dim3(grid), dim3(256), 0, stream, g);      \
   } while (0)
-      if ((kind & 32) != 0) {
+      if ((kind & 8192) != 0) {       // 64 sequences per workgroup (only with 16 units, 8 waves)
+        hipLaunchKernelGGL((gru_step_mid_kernel<4, 16, 8>), dim3(grid), dim3(512), 0, stream, g);
+      } else if ((kind & 32) != 0) {
         if (bu == 4) MID_LAUNCH_(1, 4);
         else if (bu == 8) MID_LAUNCH_(1, 8);
         else MID_LAUNCH_(1, 16);
@@ -1698,7 +1704,7 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
 unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   const int H = j.b->H;
   if ((kind & 3) == 3) {
-    const int bm = (kind & 32) != 0 ? 16 : 32;
+    const int bm = (kind & 8192) != 0 ? 64 : ((kind & 32) != 0 ? 16 : 32);
     const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
     return static_cast<unsigned>((H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
   }
@@ -2185,7 +2191,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps},
+      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
       {"bwd_chunk_rows", &t.bwd_chunk_rows}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

@@ -59,6 +59,7 @@ struct Tunables {
   std::atomic<int> bwd_chunk_rows{2048};     // packed rows a weight-gradient chunk spans before it is issued beside the chain
   std::atomic<int> bwd_split_min_seqs{33};   // ... and from which (up to bwd_mid_max_seqs) it runs as two launches with K split over the grid (0 = never)
   std::atomic<int> bwd_tail_min_steps{4};    // steps with <= 32 active sequences at the end of a chain from which its BPTT runs them in one resident kernel (0 = never)
+  std::atomic<int> mid_tall_min_seqs{129};   // active sequences from which the mid-size forward step takes 64 sequences per workgroup (0 = never)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };
 Tunables& tunables();

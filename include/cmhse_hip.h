@@ -413,6 +413,8 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             projection + split-K 16x16x4 tiles); 0 disables that kernel
  *   "mid_units"            0  16 | 8 | 4 forces the mid-size step's hidden units per workgroup
  *   "mid_waves"            0  4 | 8 forces its waves per workgroup
+ *   "mid_tall_min_seqs"  129  active sequences from which the mid-size step of a training call
+ *                             takes 64 sequences per workgroup instead of 32 (bit-identical)
  *   "tall_tile_min_wgs" 2048  64-row workgroups from which an LDS-tiled launch uses 128-row tiles
  *   "bwd_mid_max_seqs"   512  active sequences at or below which a BPTT step runs on the mid-size
  *                             backward kernel

@@ -575,6 +575,39 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
 
 
 @pytest.mark.gpu
+def test_tall_mid_step_tile_is_bit_identical(dev, tune):
+  """A training chain with more than 128 active sequences (DiDeMo: every clip has 80 frames, ~220
+  sequences at every step) takes 64 sequences per workgroup in the mid-size forward step
+  (gru_step_mid_kernel<4, 16, 8>: one round of workgroups instead of two): outputs and gradients
+  bit-identical to the 32-sequence tile (mid_tall_min_seqs = 0)."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(3)
+  S, T, I, H = 203, 9, 40, 1024
+  torch.manual_seed(2)
+  layer = layers.Attention(I, H).to(dev)
+  lens = rng.randint(5, T + 1, size=S)
+  lens[:150] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  w = rng.standard_normal((S, H)).astype(np.float32)
+  stream = ops.stream_set(dev)[0]
+
+  def run(tall):
+    tune(mid_tall_min_seqs=tall)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    spec = layers.SeqInput('padded', lens.astype(np.int64), layer.POOL)
+    out, = layers.run_grouped([(layer, spec, xt, None, None)], [stream])
+    (out * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return [out.detach().clone(), xt.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  for a, b in zip(run(0), run(129)):
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('pool,cls,H,S,n_long', [('attention', 'Attention', 32, 11, 13), ('maxout', 'Maxout', 48, 40, 13),
                                                  ('seq2seq', 'Seq2Seq', 256, 23, 13), ('attention', 'Attention', 1024, 32, 13),
                                                  ('maxout', 'Maxout', 64, 40, 29), ('attention', 'Attention', 1024, 32, 30)])

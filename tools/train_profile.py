@@ -28,6 +28,9 @@ CONFIGS = {
     'icep_recon': dict(workload='anet_icep_val', low_level_loss=True, norm=True,
                        reconstruct_loss=True, weight_recon=0.0005, decode_rnn_type='seq2seq'),
     'icep': dict(workload='anet_icep_val', low_level_loss=True, norm=True),
+    # BASELINE configs[3]: DiDeMo ICEP, all clips 80 frames
+    'didemo_recon': dict(workload='didemo_icep_val', low_level_loss=True, norm=True,
+                         reconstruct_loss=True, weight_recon=0.0005, decode_rnn_type='seq2seq'),
 }
 
 
