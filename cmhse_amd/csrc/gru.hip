@@ -502,7 +502,8 @@ __global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGro
 // h_{t-1} . W_hh^T) plus a gates kernel, two launches — for the steps of a training chain with
 // more than 32 sequences: correct, and 0.4 ms per training step SLOWER (ICEP 9.19 -> 9.60 ms, C3D
 // 7.88 -> 8.33): with K = H instead of 3H there are 96 tiles of two short slices, and the second
-// launch costs more than the better-coalesced loads save.  And 16 waves on 16 K slices (1024
+// launch costs more than the better-coalesced loads save (DiDeMo, ~210 sequences at every step:
+// 10.82 -> 11.19 ms).  And 16 waves on 16 K slices (1024
 // threads) instead of 8 on 8: 21.0 -> 21.6 us at S_t = 117, 30.9 -> 34.1 at 152.
 // ---------------------------------------------------------------------------------------------
 // MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active.
