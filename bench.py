@@ -606,6 +606,10 @@ def main():
 
   debug = os.environ.get('CMHSE_BENCH_DEBUG', '0') == '1'   # host-side marks of every pass on stderr
 
+  # the split is resident in HBM and the same on every pass (a validation set kept on the device
+  # across epochs): the level-1 schedules are built on the first (warm-up) pass and kept
+  plan = {}
+
   def step():
     """One validation pass, scored: the embeddings are encoded, both directions ranked, the
     per-batch meters replayed, and the ranks brought to the host and turned into the Recall@K /
@@ -613,7 +617,7 @@ def main():
     if world == 1:
       h0 = time.perf_counter()
       cat, _, _, finish_log = encode_data_device(opt, model, batches, logging=quiet,
-                                                 defer_logging=True)
+                                                 defer_logging=True, plan=plan)
       h1 = time.perf_counter()
       r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
@@ -627,7 +631,7 @@ def main():
                          % ((h1 - h0) * 1e3, (h2 - h1) * 1e3, (time.perf_counter() - h2) * 1e3))
       return host[0], host[2]
     res = parallel_eval.validate_sharded(opt, model, batches, device=device, dim=args.embed,
-                                         assignment=assignment, timings=phase_ms)
+                                         assignment=assignment, timings=phase_ms, plan=plan)
     last['rep_i'], last['rep_t'] = res[0], res[1]
     for k, v in phase_ms.items():
       phase_sum[k] = phase_sum.get(k, 0.0) + v
@@ -719,6 +723,10 @@ def main():
                    'step': 'encode_data + i2t + t2i over the split, ranks on the host and the '
                            'Recall@K / median-rank report computed (evaluation.py:173-184)',
                    'sharding': 'loader batches dealt to ranks by GRU work (longest paragraph first), one all-gather of the embeddings, row-stripe scoring',
+                   'schedule_cache': 'the split is resident and identical on every pass: the level-1 '
+                                     'schedules (sequence sort, step counts, pointer tables) are built on '
+                                     'the first warm-up pass and kept (evaluation.encode_group(plan=)); '
+                                     '`uncached_pass` times the pass that rebuilds them every time',
                    'backend': ('single process' if world == 1 else
                                ('RCCL (nccl), one rank per GPU' if backend != 'gloo' else
                                 'gloo, %d ranks sharing %d GPU(s): functional run of the N-rank '
@@ -777,6 +785,28 @@ def main():
 
     if args.rank_check:
       leg('rank_check', lambda: rank_check(N, args.embed))
+    if world == 1:
+      def uncached():
+        """The same pass, schedules rebuilt every time (what round 2 / mid round 3 timed)."""
+        n = max(3, min(args.steps, 5))
+
+        def one():
+          cat, _, _, fin = encode_data_device(opt, model, batches, logging=quiet, defer_logging=True)
+          r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
+          r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
+          packed = torch.stack([r_i, t_i, r_t, t_t])
+          fin()
+          host = packed.cpu().numpy().astype(np.float64)
+          return report_from_ranks(host[0]), report_from_ranks(host[2])
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+          one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        return {'steps': n, 'ms_per_step': dt * 1e3, 'value': pairs / dt, 'unit': 'pairs/s'}
+      leg('uncached_pass', uncached)
     if world == 1 and args.fast_steps > 0:
       leg('fast_mode', lambda: fast_mode_bench(opt, model, batches, N, args.fast_steps))
     if world == 1 and args.train_steps > 0:

@@ -174,12 +174,31 @@ def _dev_seq(t, device, dtype):
   return ops.seq_keep(_to_dev(t, device), dtype)
 
 
-def encode_group(model, group, contextual_model=True, device=None):
+def _plan_key(group):
+  """What a cached plan of `group` is valid for: the same batch objects (first / last feature and
+  token storage, counts of rows) — a caller that keeps a plan promises not to edit the batches'
+  lengths in place."""
+  a, z = group[0], group[-1]
+  return (len(group), id(a[0]), id(z[3]), _base_ptr(a[0]), _base_ptr(z[3]),
+          sum(len(b[8]) for b in group))
+
+
+def _base_ptr(t):
+  return t.data.data_ptr() if isinstance(t, ops.Ragged) else t.data_ptr()
+
+
+def encode_group(model, group, contextual_model=True, device=None, plan=None):
   """Encode a list of loader batches (12-tuples) as ONE super-batch.  Returns a dict of device
   tensors: the six un-normalised embedding matrices plus their L2-normalised versions, rows in
   loader order.  Arithmetic per sequence is identical to per-batch encoding (sequences are
-  independent), only the launch granularity differs."""
+  independent), only the launch granularity differs.
+  `plan`: a dict the caller keeps between passes over the SAME resident batches (a validation set
+  held in HBM across epochs; bench.py): the level-1 schedules (sort, step counts, the uploaded
+  pointer tables) are built on the first pass and reused afterwards — 2 ms of host work in front
+  of the first launch, 5 % of a rank's 45 ms share of the split."""
   device = device or torch.device('cuda', torch.cuda.current_device())
+  if plan is not None and plan.get('key') == _plan_key(group) and GROUP_TOWERS[0] and not TWO_STREAMS[0]:
+    return _encode_group_planned(model, group, contextual_model, device, plan)
   clips_l, caps_l, vids_l, pars_l = [], [], [], []
   len_clip, len_cap, len_vid, len_par = [], [], [], []
   num_clips, num_caps = [], []
@@ -286,11 +305,22 @@ def encode_group(model, group, contextual_model=True, device=None):
     # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
     # side stream while the visual attention pass runs on this one, instead of after it.
     tail = _tail_stream(device) if EARLY_POOL[0] else None
+    v_lens, t_lens = np.concatenate(len_clip + len_vid), np.concatenate(len_cap + len_par)
+    t_sched = None
+    if plan is not None and not pull:     # resident batches: the schedules outlive this pass
+      v_sched = ops.SeqSchedule(v_lens, device, x_ptrs=v_ptrs)
+      t_sched = ops.SeqSchedule(t_lens, device, tok_ptrs=t_ptrs)
+      plan.clear()
+      plan.update(key=_plan_key(group), v_sched=v_sched, t_sched=t_sched, v_lens=v_lens,
+                  t_lens=t_lens, v_ptrs=v_ptrs, t_ptrs=t_ptrs, img_dim=img_dim, n_clip=n_clip,
+                  n_cap=n_cap, n_vid=n_vid, num_clips=np.asarray(num_clips, dtype=np.int64),
+                  num_caps=np.asarray(num_caps, dtype=np.int64),
+                  batch_sizes=[len(b[8]) for b in group], keep=(clips_l, vids_l, caps_l, pars_l))
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
-        clip_rnn.request_ptrs(np.concatenate(len_clip + len_vid), img_dim, device, x_ptrs=v_ptrs,
+        clip_rnn.request_ptrs(v_lens, img_dim, device, x_ptrs=v_ptrs,
                               sched=v_sched, step_events=v_events),
-        txt_rnn.request_ptrs(np.concatenate(len_cap + len_par), table.shape[1], device,
-                             tok_ptrs=t_ptrs, table=table)], tail_stream=tail)
+        txt_rnn.request_ptrs(t_lens, table.shape[1], device,
+                             tok_ptrs=t_ptrs, table=table, sched=t_sched)], tail_stream=tail)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
 
@@ -314,6 +344,38 @@ def encode_group(model, group, contextual_model=True, device=None):
               batch_sizes=[len(b[8]) for b in group])
 
 
+def _encode_group_planned(model, group, contextual_model, device, plan):
+  """encode_group's grouped schedule with the level-1 schedules of an earlier pass over the same
+  batches (encode_group(plan=...)): same launches, same values."""
+  clip_rnn, txt_rnn = model.clip_enc.rnn, model.txt_enc.rnn
+  H1v = clip_rnn.rnn.weight_hh_l0.shape[1]
+  H1t = txt_rnn.rnn.weight_hh_l0.shape[1]
+  table = model.txt_enc.embed.weight.detach()
+  n_clip, n_cap = plan['n_clip'], plan['n_cap']
+  tail = _tail_stream(device) if EARLY_POOL[0] else None
+  (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
+      clip_rnn.request_ptrs(plan['v_lens'], plan['img_dim'], device, x_ptrs=plan['v_ptrs'],
+                            sched=plan['v_sched']),
+      txt_rnn.request_ptrs(plan['t_lens'], table.shape[1], device, tok_ptrs=plan['t_ptrs'],
+                           table=table, sched=plan['t_sched'])], tail_stream=tail)
+  clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
+  cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
+
+  def level2_request(enc, rows, counts, ctx_rows, Hin):
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    x_ptrs = np.uint64(rows.data_ptr()) + starts * np.uint64(Hin * 4)
+    h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
+    return enc.rnn.request_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
+
+  (vid_emb, _), (para_emb, _) = ops.gru_pool_fwd_multi([
+      level2_request(model.vid_seq_enc, clip_emb, plan['num_clips'], vid_ctx, H1v),
+      level2_request(model.txt_seq_enc, cap_emb, plan['num_caps'], para_ctx, H1t)])
+  n = ops.l2norm_rows
+  return dict(vid_emb=n(vid_emb), para_emb=n(para_emb), clip_emb=n(clip_emb), cap_emb=n(cap_emb),
+              vid_ctx=n(vid_ctx), para_ctx=n(para_ctx), n_vid=plan['n_vid'],
+              batch_sizes=plan['batch_sizes'])
+
+
 def _group_batches(batches, max_bytes):
   """Split the loader's batches into super-batches of at most `max_bytes` of padded features."""
   groups, cur, cur_bytes = [], [], 0
@@ -330,13 +392,14 @@ def _group_batches(batches, max_bytes):
 
 
 def encode_data_device(opt, model, data_loader, log_step=10, logging=print, contextual_model=True,
-                       superbatch_bytes=48 << 30, defer_logging=False):
+                       superbatch_bytes=48 << 30, defer_logging=False, plan=None):
   """Device-resident core of encode_data: returns (dict of six [N,*] normalised embedding tensors
   on the GPU, num_clips_total, cur_vid_total).  With `defer_logging` the per-batch 'Letest' values
   travel to the host asynchronously and a fourth return value, `finish()`, replays the logger
   updates: a caller that scores the embeddings right away (bench.py, parallel_eval) queues its
   ranking kernels first and calls finish() afterwards, so the GPU does not idle through that
-  device-to-host round trip."""
+  device-to-host round trip.  `plan`: a dict kept by a caller that encodes the SAME resident
+  batches again and again (encode_group): schedules built once."""
   batch_time = AverageMeter()
   val_logger = LogCollector()
   model.val_start(opt)
@@ -368,9 +431,10 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
         state['i'] += 1
 
   with torch.no_grad():
-    for group in _group_batches(batches, superbatch_bytes):
+    for gi, group in enumerate(_group_batches(batches, superbatch_bytes)):
       model.logger = val_logger                     # evaluation.py:99
-      enc = encode_group(model, group, contextual_model)
+      enc = encode_group(model, group, contextual_model,
+                         plan=None if plan is None else plan.setdefault(gi, {}))
       for k in outs:
         outs[k].append(enc[k])
       # per-loader-batch 'Letest' loss (evaluation.py:129), all on device, one sync per group

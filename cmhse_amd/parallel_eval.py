@@ -78,14 +78,14 @@ def costs_of(batches, img_dim=None):
   return out
 
 
-def _default_encode(opt, model, batches):
+def _default_encode(opt, model, batches, plan=None):
   """(video embeddings, paragraph embeddings, finish): `finish()` replays the per-batch 'Letest'
   meters (evaluation.py:129); validate_sharded calls it after the exchange and the ranking kernels
   are queued, so no host sync stands in front of them."""
   if not batches:
     return None
   cat, _, _, finish = evaluation.encode_data_device(opt, model, batches, logging=lambda *a: None,
-                                                    defer_logging=True)
+                                                    defer_logging=True, plan=plan)
   return cat['vid_emb'], cat['para_emb'], finish
 
 
@@ -188,7 +188,7 @@ class _Phases(object):
 
 
 def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_fn=None,
-                     device=None, dim=None, assignment=None, timings=None):
+                     device=None, dim=None, assignment=None, timings=None, plan=None):
   """Sharded counterpart of train.validate's encode_data + i2t + t2i (train.py:223-236).
   Returns (report_i2t, report_t2i, ranks_i2t, ranks_t2i, top1_i2t, top1_t2i) on every rank, rows in
   loader order.  `assignment`: per-rank batch-index lists (default: assign_batches on the loader's
@@ -196,8 +196,10 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   batches), (V, P) or (V, P, finish) — `finish()` is called once the ranking is queued.
   `timings`: a dict that receives this rank's encode_ms / exchange_ms / score_ms — on a GPU from
   HIP events on the current stream (device time between the marks; the pass is not synchronised
-  for them) — measurement only."""
-  encode_fn = encode_fn or _default_encode
+  for them) — measurement only.  `plan`: a dict the caller keeps between passes over the SAME
+  resident batches (evaluation.encode_group): this rank's schedules are built once."""
+  if encode_fn is None:
+    encode_fn = (lambda o, m, b: _default_encode(o, m, b, plan)) if plan is not None else _default_encode
   rank_fn = rank_fn or _default_rank
   world = dist.get_world_size(group)
   me = dist.get_rank(group)

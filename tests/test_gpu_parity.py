@@ -1820,6 +1820,38 @@ def test_packed_loader_encodes_bit_identically(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_encode_plan_over_a_resident_loader_is_bit_identical(dev):
+  """evaluation.encode_data_device(plan=...): a caller that encodes the SAME resident batches pass
+  after pass (a validation set kept in HBM; bench.py) keeps the level-1 schedules of the first
+  pass.  Planned passes == an unplanned pass bit for bit; a different loader under the same plan
+  rebuilds (the key does not match) instead of reusing stale tables."""
+  from cmhse_amd import evaluation, synthetic
+  g = load_golden('model_attention.npz')
+  opt, model = golden_model('attention', g)
+  quiet = lambda *a, **k: None
+
+  def loader(seed):
+    spec = synthetic.ragged_spec(23, seed=seed, max_frames=13, max_video=17)
+    batches = synthetic.make_batches(spec, 6, opt.img_dim, opt.vocab_size, seed=seed + 1)
+    return [tuple(t.to(dev) if isinstance(t, torch.Tensor) and t.dim() > 1 else t for t in b)
+            for b in batches]
+
+  a, b = loader(9), loader(31)
+  want_a, _, _ = evaluation.encode_data_device(opt, model, a, logging=quiet)
+  want_b, _, _ = evaluation.encode_data_device(opt, model, b, logging=quiet)
+  plan = {}
+  for _ in range(3):
+    got, _, _ = evaluation.encode_data_device(opt, model, a, logging=quiet, plan=plan)
+    for k in want_a:
+      assert torch.equal(got[k], want_a[k]), k
+  assert plan[0]['key'] == evaluation._plan_key(a)
+  got, _, _ = evaluation.encode_data_device(opt, model, b, logging=quiet, plan=plan)
+  for k in want_b:
+    assert torch.equal(got[k], want_b[k]), k
+  assert plan[0]['key'] == evaluation._plan_key(b)
+
+
+@pytest.mark.gpu
 def test_dataloader_with_collate_packed_feeds_train_emb(dev):
   """The reference's loader construction (activity_net/data.py:157-162: DataLoader(collate_fn=...,
   pin_memory=True)) with collate_packed in place of collate_fn: the pin thread pins the Ragged
