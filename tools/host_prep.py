@@ -19,13 +19,15 @@ from cmhse_amd.model import VSE  # noqa: E402
 
 
 def main():
+  n_videos = int(sys.argv[sys.argv.index('--n_videos') + 1]) if '--n_videos' in sys.argv else 0
+  plan = {} if '--plan' in sys.argv else None
   dev = torch.device('cuda', 0)
   torch.cuda.set_device(0)
   wl = dict(bench.WORKLOADS['anet_icep_val'])
   opt = bench.make_opt(wl, 'attention', 1024)
   torch.manual_seed(1)
   model = VSE(opt)
-  spec = synthetic.anet_like_spec(wl['n_videos'], seed=0, dataset='anet')
+  spec = synthetic.anet_like_spec(n_videos or wl['n_videos'], seed=0, dataset='anet')
   nb = (spec.n_videos + 31) // 32
   batches = bench.build_loader(spec, wl, dev, 0, nb)
   quiet = lambda *a, **k: None
@@ -44,7 +46,7 @@ def main():
     torch.cuda.synchronize()
     marks.clear()
     t0 = time.perf_counter()
-    cat, _, _, fin = encode_data_device(opt, model, batches, logging=quiet, defer_logging=True)
+    cat, _, _, fin = encode_data_device(opt, model, batches, logging=quiet, defer_logging=True, plan=plan)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -55,7 +57,7 @@ def main():
   pr = cProfile.Profile()
   torch.cuda.synchronize()
   pr.enable()
-  cat, _, _, fin = encode_data_device(opt, model, batches, logging=quiet, defer_logging=True)
+  cat, _, _, fin = encode_data_device(opt, model, batches, logging=quiet, defer_logging=True, plan=plan)
   pr.disable()
   torch.cuda.synchronize()
   fin()
