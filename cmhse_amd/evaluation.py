@@ -179,8 +179,9 @@ def _plan_key(group):
   token storage, counts of rows) — a caller that keeps a plan promises not to edit the batches'
   lengths in place."""
   a, z = group[0], group[-1]
-  return (len(group), id(a[0]), id(z[3]), _base_ptr(a[0]), _base_ptr(z[3]),
-          sum(len(b[8]) for b in group))
+  shape = hash(tuple((len(b[4]), len(b[5]), len(b[8]), int(b[4][0]), int(b[4][-1]), int(b[5][0]),
+                      int(b[5][-1]), int(b[7][0]), int(b[7][-1])) for b in group))
+  return (len(group), id(a[0]), id(z[3]), _base_ptr(a[0]), _base_ptr(z[3]), shape)
 
 
 def _base_ptr(t):
