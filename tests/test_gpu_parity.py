@@ -575,6 +575,46 @@ def test_gru_backward_vs_oracle_tiled_sizes(dev, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+def test_resident_tails_fuzz(dev, seed, tune):
+  """Random small batches (1-32 sequences, ragged lengths, every pooling, with and without an
+  initial state, H = 32 ... 128) through a chain on its own stream: resident tail kernels on
+  (forward and backward) against one launch per step — outputs and gradients to fp32 rounding."""
+  from cmhse_amd import layers, ops
+  rng = np.random.RandomState(100 + seed)
+  cls = ['Attention', 'Maxout', 'Seq2Seq'][seed % 3]
+  H = int(rng.choice([32, 48, 64, 128]))
+  S, T, I = int(rng.randint(1, 33)), int(rng.randint(5, 41)), int(rng.choice([8, 20, 36]))
+  torch.manual_seed(seed)
+  layer = getattr(layers, cls)(I, H).to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[rng.randint(S)] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32) if seed % 2 else None
+  w = rng.standard_normal((S, H)).astype(np.float32)
+  stream = ops.stream_set(dev)[1]
+
+  def run(min_steps):
+    tune(fwd_tail_min_steps=min_steps, bwd_tail_min_steps=min_steps)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True) if h0 is not None else None
+    spec = layers.SeqInput('padded', lens.astype(np.int64), layer.POOL)
+    out, = layers.run_grouped([(layer, spec, xt, ht, None)], [stream])
+    (out * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return ([out.detach().clone(), xt.grad.clone()] + ([ht.grad.clone()] if ht is not None else []) +
+            [p.grad.clone() for p in layer.parameters()])
+
+  per_step, resident, again = run(0), run(2), run(2)
+  for a, b, c in zip(per_step, resident, again):
+    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max())), (cls, H, S, T)
+    assert torch.equal(b, c)
+
+
+@pytest.mark.gpu
 def test_tall_mid_step_tile_is_bit_identical(dev, tune):
   """A training chain with more than 128 active sequences (DiDeMo: every clip has 80 frames, ~220
   sequences at every step) takes 64 sequences per workgroup in the mid-size forward step
