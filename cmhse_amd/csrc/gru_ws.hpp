@@ -24,7 +24,8 @@
 // — the weight-gradient products and projection chunks on the side stream, the other tower's
 // chain: raised, its waves win the SIMD's issue arbitration against the resident GEMM waves, which
 // fill the bubbles.  Training step, priority 3 against 0 (tools/ab_train.py, two runs each): ICEP
-// 9.83 / 9.76 -> 9.58 / 9.61 ms, C3D 8.62 / 8.62 -> 8.49 / 8.58 ms.  The LDS-tiled step kernel of the
+// 9.83 / 9.76 -> 9.58 / 9.61 ms, C3D 8.62 / 8.62 -> 8.49 / 8.58 ms (priorities 1, 2 and 3 measure equal;
+// a rank's 615-video share of the validation split 45.2 -> 42.6 ms with it).  The LDS-tiled step kernel of the
 // validation pass is throughput work itself and stays at the default.
 #ifndef CHAIN_PRIO
 #define CHAIN_PRIO 3
