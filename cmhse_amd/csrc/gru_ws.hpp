@@ -25,7 +25,7 @@
 // chain: raised, its waves win the SIMD's issue arbitration against the resident GEMM waves, which
 // fill the bubbles.  Training step, priority 3 against 0 (tools/ab_train.py, two runs each): ICEP
 // 9.83 / 9.76 -> 9.58 / 9.61 ms, C3D 8.62 / 8.62 -> 8.49 / 8.58 ms (priorities 1, 2 and 3 measure equal;
-// a rank's 615-video share of the validation split 45.2 -> 42.6 ms with it).  The LDS-tiled step kernel of the
+// the validation pass does not move: a 615-video share 41.9-42.0 ms at 0, 42.1 at 3).  The LDS-tiled step kernel of the
 // validation pass is throughput work itself and stays at the default.
 #ifndef CHAIN_PRIO
 #define CHAIN_PRIO 3
