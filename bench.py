@@ -35,9 +35,13 @@ The JSON line also carries
                 of a 256-row sample (mismatches must be 0);
   pcie_inclusive the same pass with the loader batches in pinned HOST memory, uploaded inside the
                 timed pass (the reference's loader hands over host tensors, model.py:225-227);
-  cpu_baseline  the NumPy oracle (oracle/, "port") timed on this host's cores on a bounded
+  cpu_baseline  the torch-CPU restatement of the path (oracle/cmhse_torch_cpu.py: nn.GRU over
+                pack_padded_sequence, kind "torch-cpu") timed on this host's cores on a bounded
                 sample of the same workload, extrapolated to the full split (encode ~ N,
-                scoring ~ N^2) — a reported baseline, never the thing measured as `value`.
+                scoring ~ N^2) — a reported baseline, never the thing measured as `value`;
+                cpu_baseline_numpy: the NumPy oracle ("port") the same way;
+  cached_schedule_pass  the pass for a resident, unchanged split with the level-1 schedules kept
+                between passes (opt-in; the headline pass rebuilds them like the reference).
 """
 import argparse
 import json
@@ -143,12 +147,25 @@ def gru_flops_per_step(I, H):
   return 2 * 3 * H * I + 2 * 3 * H * H + 14 * H
 
 
-def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
-  """NumPy oracle on the host cores over the first `n_sample_batches` loader batches (BASELINE.md
-  §3: a 512-video subset, one warm-up pass, median of >= 3 timed passes, scaled encode ~ N and
-  scoring ~ N^2)."""
+def _host_cpu_model():
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('model name'):
+        return line.split(':', 1)[1].strip()
+  except OSError:
+    pass
+  return ''
+
+
+def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
+  """The CPU restatements of the path on this host's cores over the first `n_sample_batches`
+  loader batches (a 512-video subset, one warm-up pass, median of >= 3 timed
+  passes, scaled encode ~ N and scoring ~ N^2).
+    kind 'torch-cpu'  oracle/cmhse_torch_cpu.py: nn.GRU over pack_padded_sequence + the pooling on
+                      CPU tensors, one loader batch at a time — the stand-in for "the reference
+                      PyTorch CPU path" north_star names (layers.py:75-79,93-119);
+    kind 'port'       oracle/cmhse_oracle.py: the NumPy oracle (OpenBLAS)."""
   sys.path.insert(0, os.path.join(REPO, 'oracle'))
-  import cmhse_oracle as oracle
   sub = synthetic.SplitSpec(spec.num_clips, spec.frames_per_clip, spec.frames_per_video,
                             spec.words_per_sent)
   nv = min(spec.n_videos, n_sample_batches * wl['batch'])
@@ -159,28 +176,51 @@ def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
   sub.frames_per_video = sub.frames_per_video[:nv]
   batches = synthetic.make_batches(sub, wl['batch'], wl['img_dim'], wl['vocab'], seed=0,
                                    feat=wl['feat'])
-  np_batches = [tuple(x.numpy() if hasattr(x, 'numpy') else x for x in b) for b in batches]
   sds = [{k: v.detach().cpu().numpy() for k, v in sd.items()} for sd in model.state_dict(opt)]
-  # BLAS thread count: the per-step GEMMs are small, so all host cores oversubscribe; calibrate on
-  # one loader batch and keep the fastest setting (that count is what `cores` reports)
-  from threadpoolctl import threadpool_limits
   ncpu = os.cpu_count() or 1
-  best_n, best_t = ncpu, None
-  for n_thr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
-    with threadpool_limits(limits=n_thr):
+  counts = sorted({min(ncpu, c) for c in (16, 32)})
+  if kind == 'torch-cpu':
+    import cmhse_torch_cpu as impl
+    cpu_model = impl.Model(opt.rnn_type, sds)
+    data = batches
+    encode = lambda bs: impl.encode_data(opt.rnn_type, sds, bs, margin=opt.margin, model=cpu_model)
+    old_threads = torch.get_num_threads()
+
+    class limit(object):
+      def __init__(self, n):
+        self.n = n
+
+      def __enter__(self):
+        torch.set_num_threads(self.n)
+
+      def __exit__(self, *a):
+        torch.set_num_threads(old_threads)
+    what = 'torch CPU restatement (oracle/cmhse_torch_cpu.py: nn.GRU + pack_padded_sequence, torch.set_num_threads'
+  else:
+    import cmhse_oracle as impl
+    from threadpoolctl import threadpool_limits
+    data = [tuple(x.numpy() if hasattr(x, 'numpy') else x for x in b) for b in batches]
+    encode = lambda bs: impl.encode_data(opt.rnn_type, sds, bs, margin=opt.margin)
+    limit = lambda n: threadpool_limits(limits=n)
+    what = 'NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS threads'
+  # thread count: the per-step GEMMs are small, so all host cores oversubscribe; calibrate on one
+  # loader batch over two settings and keep the faster (that count is what `cores` reports)
+  best_n, best_t = counts[0], None
+  for n_thr in counts:
+    with limit(n_thr):
       t0 = time.time()
-      oracle.encode_data(opt.rnn_type, sds, np_batches[:1], margin=opt.margin)
+      encode(data[:1])
       dt = time.time() - t0
     if best_t is None or dt < best_t:
       best_n, best_t = n_thr, dt
   enc_s, score_s = [], []
-  with threadpool_limits(limits=best_n):
+  with limit(best_n):
     for rep in range(repeats + 1):        # pass 0 is the warm-up
       t0 = time.time()
-      res = oracle.encode_data(opt.rnn_type, sds, np_batches, margin=opt.margin)
+      res = encode(data)
       t1 = time.time()
-      oracle.i2t(res[0], res[1])
-      oracle.t2i(res[0], res[1])
+      impl.i2t(res[0], res[1])
+      impl.t2i(res[0], res[1])
       t2 = time.time()
       if rep > 0:
         enc_s.append(t1 - t0)
@@ -188,24 +228,15 @@ def cpu_baseline(wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
   t_enc, t_score = float(np.median(enc_s)), float(np.median(score_s))
   scale = n_full / float(nv)
   t_full = t_enc * scale + t_score * scale * scale
-  cpu_model = ''
-  try:
-    for line in open('/proc/cpuinfo'):
-      if line.startswith('model name'):
-        cpu_model = line.split(':', 1)[1].strip()
-        break
-  except OSError:
-    pass
   return {
       'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': best_n,
-      'kind': 'port', 'host_cpu': cpu_model, 'host_logical_cpus': ncpu,
+      'kind': kind, 'host_cpu': _host_cpu_model(), 'host_logical_cpus': ncpu,
       'videos_per_s': nv / t_enc, 'passes': repeats,
-      'sample': ('NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS limited to %d threads = fastest of '
-                 'a calibration over {8,16,32,64,%d} on this %d-core host) on the first %d videos '
-                 '(%d loader batches) of the same split: 1 warm-up pass, median of %d timed passes: '
-                 'encode %.2f s, i2t+t2i %.3f s; extrapolated to N=%d with encode ~ N and '
-                 'scoring ~ N^2' % (best_n, ncpu, ncpu, nv, len(batches), repeats, t_enc, t_score,
-                                    n_full)),
+      'sample': ('%s = %d, the faster of {%s} on one loader batch of this %d-CPU host) on the first '
+                 '%d videos (%d loader batches) of the same split: 1 warm-up pass, median of %d timed '
+                 'passes: encode %.2f s, i2t+t2i %.3f s; extrapolated to N=%d with encode ~ N and '
+                 'scoring ~ N^2' % (what, best_n, ','.join(str(c) for c in counts), ncpu, nv,
+                                    len(batches), repeats, t_enc, t_score, n_full)),
   }
 
 
@@ -433,9 +464,8 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           'mfma_floor_ms': mfma_floor_ms, 'chain_floor_ms': chain_floor_ms,
           'chain_step_us': step_us,
           'frac_of_floor': (floor / (dt * 1e3)) if floor > 0 else None,
-          # chains and products are bound by the same L2 -> CU fabric and do not overlap for free
-          # (every product after the chains is as fast as beside them): the sum of the
-          # two floors is the tighter yardstick
+          # the LOOSER yardstick (it assumes chains and products cannot overlap at all); the bar is
+          # frac_of_floor, against max() of the two floors
           'frac_of_sum_of_floors': ((mfma_floor_ms + (chain_floor_ms or 0.0)) / (dt * 1e3)),
           'bound': 'max(FLOPs / 157.3 TFLOP/s fp32 MFMA, dependent steps x the measured latency '
                    'of one small-batch step launch on an idle chip)',
@@ -544,20 +574,24 @@ def main():
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
-  ap.add_argument('--fast_steps', type=int, default=10,
-                  help='also time this many passes in the bf16x3 math mode (0 = skip)')
+  ap.add_argument('--fast_steps', type=int, default=0,
+                  help='also time this many passes in the opt-in bf16x3 math mode (default 0 = skip: the '
+                       'mode is outside the bit-identical-ranks contract, DESIGN.md section 9)')
   ap.add_argument('--train_steps', type=int, default=10,
                   help='also time this many VSE.train_emb steps per BASELINE training config (0 = skip)')
   ap.add_argument('--train_configs', default='anet_c3d_tau0,anet_icep_tau0,anet_icep_recon,didemo_icep_recon',
                   help='comma-separated subset of %s' % ', '.join(sorted(TRAIN_CONFIGS)))
-  ap.add_argument('--host_steps', type=int, default=2,
+  ap.add_argument('--host_steps', type=int, default=10,
                   help='also time this many passes with the loader batches in pinned HOST memory '
                        '(PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--rank_check', type=int, default=1,
                   help='check HIP ranks on correlated embeddings against fp64 NumPy (0 = skip)')
   ap.add_argument('--cpu_batches', type=int, default=16,
-                  help='loader batches in the CPU-baseline sample (16 x 32 = the 512-video subset '
-                       'of BASELINE.md section 3; 0 = skip)')
+                  help='loader batches in the torch-CPU baseline sample (16 x 32 = the 512-video subset '
+                       'of BASELINE.md section 3; the NumPy port beside it takes half of them; 0 = skip)')
+  ap.add_argument('--cached_steps', type=int, default=5,
+                  help='also time this many passes that reuse the level-1 schedules of a resident '
+                       'split (evaluation.encode_group(plan=)); 0 = skip')
   args = ap.parse_args()
 
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -606,18 +640,16 @@ def main():
 
   debug = os.environ.get('CMHSE_BENCH_DEBUG', '0') == '1'   # host-side marks of every pass on stderr
 
-  # the split is resident in HBM and the same on every pass (a validation set kept on the device
-  # across epochs): the level-1 schedules are built on the first (warm-up) pass and kept
-  plan = {}
-
-  def step():
+  def step(plan=None, src=None):
     """One validation pass, scored: the embeddings are encoded, both directions ranked, the
     per-batch meters replayed, and the ranks brought to the host and turned into the Recall@K /
-    median-rank report (evaluation.py:173-184) — all inside the timed region."""
+    median-rank report (evaluation.py:173-184) — all inside the timed region.  A pass does all the
+    work the reference's pass does, the sort / step counts / pointer tables of its packed schedules
+    included (layers.py:94-97); only the `cached_schedule_pass` leg passes a `plan` that keeps them."""
     if world == 1:
       h0 = time.perf_counter()
-      cat, _, _, finish_log = encode_data_device(opt, model, batches, logging=quiet,
-                                                 defer_logging=True, plan=plan)
+      cat, _, _, finish_log = encode_data_device(opt, model, batches if src is None else src,
+                                                 logging=quiet, defer_logging=True, plan=plan)
       h1 = time.perf_counter()
       r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
@@ -723,10 +755,9 @@ def main():
                    'step': 'encode_data + i2t + t2i over the split, ranks on the host and the '
                            'Recall@K / median-rank report computed (evaluation.py:173-184)',
                    'sharding': 'loader batches dealt to ranks by GRU work (longest paragraph first), one all-gather of the embeddings, row-stripe scoring',
-                   'schedule_cache': 'the split is resident and identical on every pass: the level-1 '
-                                     'schedules (sequence sort, step counts, pointer tables) are built on '
-                                     'the first warm-up pass and kept (evaluation.encode_group(plan=)); '
-                                     '`uncached_pass` times the pass that rebuilds them every time',
+                   'schedule_cache': 'none: every timed pass rebuilds its packed schedules (sequence sort, '
+                                     'step counts, pointer tables) as the reference does (layers.py:94-97); '
+                                     '`cached_schedule_pass` times the opt-in that keeps them for a resident split',
                    'backend': ('single process' if world == 1 else
                                ('RCCL (nccl), one rank per GPU' if backend != 'gloo' else
                                 'gloo, %d ranks sharing %d GPU(s): functional run of the N-rank '
@@ -775,38 +806,35 @@ def main():
         'traffic': measured_traffic('sim_kernel<1'),
         'note': '2*nrows*M*D FLOP per direction / HIP-event time of the counting pass alone '
                 '(cmhse_sim_rank_ex timer); rank 0\'s stripe when n_gpus > 1'}
+    leg_seconds = out['leg_seconds'] = {}
+
     def leg(name, fn):
       """A supplementary leg must never cost the headline line: a failure is reported in its place."""
+      t_leg = time.perf_counter()
       try:
         out[name] = fn()
       except Exception as e:      # noqa: BLE001  (reported, not swallowed)
         out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         sys.stderr.write('bench.py: leg %s failed: %r\n' % (name, e))
+      leg_seconds[name] = round(time.perf_counter() - t_leg, 2)
 
     if args.rank_check:
       leg('rank_check', lambda: rank_check(N, args.embed))
-    if world == 1:
-      def uncached():
-        """The same pass, schedules rebuilt every time (what round 2 / mid round 3 timed)."""
-        n = max(3, min(args.steps, 5))
-
-        def one():
-          cat, _, _, fin = encode_data_device(opt, model, batches, logging=quiet, defer_logging=True)
-          r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
-          r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
-          packed = torch.stack([r_i, t_i, r_t, t_t])
-          fin()
-          host = packed.cpu().numpy().astype(np.float64)
-          return report_from_ranks(host[0]), report_from_ranks(host[2])
-        one()
+    if world == 1 and args.cached_steps > 0:
+      def cached():
+        """The same pass for a split that stays resident and unchanged between passes: the level-1
+        schedules are built once (the first pass below) and reused — an opt-in of this package
+        (encode_group(plan=)), not what the reference does, hence not the headline."""
+        plan = {}
+        step(plan)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n):
-          one()
+        for _ in range(args.cached_steps):
+          step(plan)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        return {'steps': n, 'ms_per_step': dt * 1e3, 'value': pairs / dt, 'unit': 'pairs/s'}
-      leg('uncached_pass', uncached)
+        dt = (time.perf_counter() - t0) / args.cached_steps
+        return {'steps': args.cached_steps, 'ms_per_step': dt * 1e3, 'value': pairs / dt, 'unit': 'pairs/s'}
+      leg('cached_schedule_pass', cached)
     if world == 1 and args.fast_steps > 0:
       leg('fast_mode', lambda: fast_mode_bench(opt, model, batches, N, args.fast_steps))
     if world == 1 and args.train_steps > 0:
@@ -818,11 +846,13 @@ def main():
       for name in args.train_configs.split(','):
         if not name:
           continue
+        t_leg = time.perf_counter()
         try:
           out['train_steps'][name] = train_bench(name, args.embed, args.rnn_type, args.train_steps, device)
         except Exception as e:    # noqa: BLE001
           out['train_steps'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
           sys.stderr.write('bench.py: train leg %s failed: %r\n' % (name, e))
+        leg_seconds['train_steps.' + name] = round(time.perf_counter() - t_leg, 2)
       if 'anet_icep_tau0' in out['train_steps']:      # round 2's key, same configuration
         out['train_step'] = out['train_steps']['anet_icep_tau0']
     if world == 1 and args.host_steps > 0:
@@ -832,15 +862,11 @@ def main():
         host = [tuple(t.cpu().pin_memory() if isinstance(t, torch.Tensor) and t.is_cuda else t
                       for t in b) for b in batches]
 
-        def host_pass():
-          cat, _, _ = encode_data_device(opt, model, host, logging=quiet)
-          return ops.sim_rank(cat['vid_emb'], cat['para_emb'])[0], \
-              ops.sim_rank(cat['para_emb'], cat['vid_emb'])[0]
-        host_pass()
+        step(src=host)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.host_steps):
-          host_pass()
+          step(src=host)        # the headline pass itself (report on the host included), fed from the host
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / args.host_steps
         nbytes = sum(t.numel() * t.element_size() for b in host for t in b[:4])
@@ -850,7 +876,11 @@ def main():
                         'step pipeline inside the timed pass; not the headline value'}
       leg('pcie_inclusive', pcie_leg)
     if world == 1 and args.cpu_batches > 0:
-      leg('cpu_baseline', lambda: cpu_baseline(wl, opt, model, spec, args.cpu_batches, N))
+      # north_star's baseline: "the reference PyTorch CPU path" -> the torch-CPU restatement; the NumPy
+      # port (rounds 1-3's cpu_baseline) beside it on half the sample
+      leg('cpu_baseline', lambda: cpu_baseline('torch-cpu', wl, opt, model, spec, args.cpu_batches, N))
+      leg('cpu_baseline_numpy', lambda: cpu_baseline('port', wl, opt, model, spec,
+                                                     max(1, args.cpu_batches // 2), N))
     print(json.dumps(out))
     sys.stdout.flush()
   if world > 1:

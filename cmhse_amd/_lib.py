@@ -69,6 +69,9 @@ class StepLosses(ctypes.Structure):
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
+    'cmhse_gru_pool_ws_region': (ctypes.c_int, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
+                                                ctypes.c_char_p, ctypes.POINTER(c_size_t),
+                                                ctypes.POINTER(c_size_t)]),
     'cmhse_gru_pool_fwd': (ctypes.c_int, [ctypes.POINTER(SeqBatch), ctypes.POINTER(GruWeights),
                                           c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     'cmhse_gru_pool_fwd_multi': (ctypes.c_int, [ctypes.POINTER(GruJob), c_int32, c_void_p]),

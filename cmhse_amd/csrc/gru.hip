@@ -1409,6 +1409,25 @@ extern "C" size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_
   return gru_ws_layout(S, sum_T, H, pool_mode, I, Tmax).total;
 }
 
+extern "C" int cmhse_gru_pool_ws_region(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I, int32_t H,
+                                        int32_t pool_mode, const char* name, size_t* offset,
+                                        size_t* bytes) {
+  if (sum_T <= 0 || H <= 0 || S <= 0 || I <= 0 || !name || !offset || !bytes) return CMHSE_ERR_ARG;
+  const GruWs L = gru_ws_layout(S, sum_T, H, pool_mode, I, Tmax);
+  if (!strcmp(name, "hs")) {
+    *offset = L.hs, *bytes = static_cast<size_t>(sum_T) * H * sizeof(float);
+  } else if (!strcmp(name, "gates")) {
+    *offset = L.gates, *bytes = L.argmax > L.gates ? static_cast<size_t>(sum_T) * 4 * H * sizeof(float) : 0;
+  } else if (!strcmp(name, "argmax")) {
+    *offset = L.argmax, *bytes = L.v > L.argmax ? static_cast<size_t>(S) * H * sizeof(int32_t) : 0;
+  } else if (!strcmp(name, "v")) {
+    *offset = L.v, *bytes = L.wih_s > L.v ? static_cast<size_t>(sum_T) * H * sizeof(float) : 0;
+  } else {
+    return CMHSE_ERR_ARG;
+  }
+  return CMHSE_OK;
+}
+
 namespace {
 
 // One validated cmhse_gru_pool_fwd request: step-kernel parameters plus what the pooling tail needs.

@@ -14,6 +14,7 @@ MI355X-first differences in HOW (not WHAT) things are computed:
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import time
 from collections import OrderedDict
@@ -175,13 +176,26 @@ def _dev_seq(t, device, dtype):
 
 
 def _plan_key(group):
-  """What a cached plan of `group` is valid for: the same batch objects (first / last feature and
-  token storage, counts of rows) — a caller that keeps a plan promises not to edit the batches'
-  lengths in place."""
-  a, z = group[0], group[-1]
-  shape = hash(tuple((len(b[4]), len(b[5]), len(b[8]), int(b[4][0]), int(b[4][-1]), int(b[5][0]),
-                      int(b[5][-1]), int(b[7][0]), int(b[7][-1])) for b in group))
-  return (len(group), id(a[0]), id(z[3]), _base_ptr(a[0]), _base_ptr(z[3]), shape)
+  """What a cached plan of `group` is valid for: EVERY batch's four length arrays and clip /
+  sentence counts (hashed in full) and the base addresses of its four feature / token tensors.  An
+  in-place edit of any batch's lengths, a swapped or re-uploaded batch anywhere in the list, or a
+  different number of batches gives a different key, and encode_group rebuilds the plan
+  (tests/test_gpu_parity.py::test_plan_key_*).  What the key cannot see is an in-place edit of the
+  feature VALUES — those are read afresh on every pass anyway (a plan holds addresses and
+  schedules, not data).  A plan keeps its group's device tensors alive (`keep`): the whole resident
+  split, 14.7 GB for ActivityNet-ICEP val; drop the plan dict to release them."""
+  h = hashlib.blake2b(digest_size=16)
+  ptrs = np.empty(4 * len(group), dtype=np.uint64)
+  for i, b in enumerate(group):
+    for k in (4, 5, 6, 7, 8, 9):
+      v = b[k]
+      a = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+      h.update(np.ascontiguousarray(a, dtype=np.int64).data)
+      h.update(b'|')
+    for k in range(4):
+      ptrs[4 * i + k] = _base_ptr(b[k])
+  h.update(ptrs.data)
+  return (len(group), h.hexdigest())
 
 
 def _base_ptr(t):

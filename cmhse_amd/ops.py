@@ -432,7 +432,7 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     b.step_events_host = ctypes.cast(ev_arr, ctypes.c_void_p)
     keep.append((ev_arr, step_events))
   ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
-             device=device)
+             device=device, mode_flags=mode_flags)
   job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx)
   meta = (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None, S)
   return job, meta
@@ -502,6 +502,26 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, 
       raise ValueError('gru_pool_fwd_multi(join=False) needs a `hold` list')
     hold.append(prepared)
   return [(job['out'], job['ctx']) for job, _ in prepared]
+
+
+def saved_region(fctx, name):
+  """A named region of a forward call's workspace (cmhse_gru_pool_ws_region) as a tensor view:
+  'hs' [sum_T, H], 'gates' [sum_T, 4H], 'v' [sum_T, H] float32, 'argmax' [S, H] int32 (rows in the
+  schedule's SORTED order: fctx['sched'].order maps them to input order).  None when the call's mode
+  did not keep it.  For tests and tools."""
+  lib = _lib.load()
+  sched, H, I = fctx['sched'], fctx['H'], fctx['I']
+  flags = fctx.get('mode_flags', fctx['pool_mode'])
+  off, nbytes = ctypes.c_size_t(0), ctypes.c_size_t(0)
+  rc = lib.cmhse_gru_pool_ws_region(sched.S, sched.Tmax, sched.sum_T, I, H, flags, name.encode(),
+                                    ctypes.byref(off), ctypes.byref(nbytes))
+  _lib.check(rc, 'cmhse_gru_pool_ws_region(%s)' % name)
+  if nbytes.value == 0:
+    return None
+  raw = fctx['ws'][off.value:off.value + nbytes.value]
+  if name == 'argmax':
+    return raw.view(torch.int32).view(sched.S, H)
+  return raw.view(torch.float32).view(-1, 4 * H if name == 'gates' else H)
 
 
 def l2norm_rows(x, out=None):

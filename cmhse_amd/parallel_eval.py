@@ -143,14 +143,25 @@ def all_gather_pair(a, b, counts, group=None):
   return A, B
 
 
+def _collective_device(group, device):
+  """Where a small control tensor of a collective must live: a gloo group reduces CPU tensors; any
+  other backend (nccl = RCCL) only device tensors — on `device`, or, when the caller gave none
+  (validate_sharded(opt, model, val_loader) under backend='nccl'), on the
+  calling thread's current GPU (a CPU tensor there raises "No backend type associated with device
+  type cpu")."""
+  if dist.get_backend(group) == 'gloo':
+    return torch.device('cpu')
+  if device is not None and torch.device(device).type == 'cuda':
+    return torch.device(device)
+  return torch.device('cuda', torch.cuda.current_device())
+
+
 def _same_on_all_ranks(assignment, group, device):
   """Raise on every rank if the ranks derived different deals (a collective entered with
   mismatched shapes would hang instead)."""
   import zlib
   h = zlib.crc32(repr(assignment).encode()) & 0x7fffffff
-  on_gpu = dist.get_backend(group) != 'gloo' and device is not None and \
-      torch.device(device).type == 'cuda'
-  t = torch.tensor([h, -h], dtype=torch.int64, device=device if on_gpu else 'cpu')
+  t = torch.tensor([h, -h], dtype=torch.int64, device=_collective_device(group, device))
   dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
   if int(t[0]) != h or int(t[1]) != -h:
     raise RuntimeError('validate_sharded: the ranks derived different batch-to-rank deals from '
@@ -222,8 +233,10 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
       ph.mark()
     enc = encode_fn(opt, model, [batches[i] for i in assignment[me]])
     if enc is None:
+      if device is None and dist.get_backend(group) != 'gloo' and torch.cuda.is_available():
+        device = torch.device('cuda', torch.cuda.current_device())
       if device is None or dim is None:
-        raise ValueError('a rank with an empty shard needs `device` and `dim`')
+        raise ValueError('a rank with an empty shard needs `dim` (and, on a gloo group, `device`)')
       v_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
       p_loc = torch.zeros(0, dim, dtype=torch.float32, device=device)
     else:

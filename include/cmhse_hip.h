@@ -125,6 +125,15 @@ typedef struct cmhse_seq_batch {
 size_t cmhse_gru_pool_workspace(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I, int32_t H,
                                 int32_t pool_mode);
 
+/* Where a named region of that workspace lives (tests and tools that inspect what a training
+ * forward kept: the gate activations, the arg-max step of the max pooling ...).  name: "hs"
+ * [sum_T, H] f32 | "gates" [sum_T, 4H] f32 (r, z, n, W_hn h + b_hn) | "argmax" [S, H] int32, rows in
+ * SORTED sequence order (CMHSE_POOL_MAX with CMHSE_SAVE_FOR_BACKWARD) | "v" [sum_T, H] f32
+ * (CMHSE_POOL_ATTN with CMHSE_SAVE_FOR_BACKWARD).  *bytes = 0 when the mode does not keep the
+ * region.  Unknown name: CMHSE_ERR_ARG.  No effect on any computation. */
+int cmhse_gru_pool_ws_region(int32_t S, int32_t Tmax, int64_t sum_T, int32_t I, int32_t H,
+                             int32_t pool_mode, const char* name, size_t* offset, size_t* bytes);
+
 /* Replaces the body of layers.{Seq2Seq,Attention,Maxout}.forward (layers.py:47-66, 93-119,
  * 185-204): 1-layer unidirectional GRU over the packed batch (nn.GRU, layers.py:31-34) followed
  * by the pooling `pool_mode`.  out[out_row[s], :] (row stride H) receives the un-normalised

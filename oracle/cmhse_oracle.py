@@ -479,8 +479,40 @@ def contrastive_loss_backward(im, s, margin=0.0, max_violation=False, norm=True,
   return G @ s, G.T @ im
 
 
+def apply_argmax_route(caches, argmax_route, report=None):
+  """Max pooling sends each output's gradient to ONE step, the arg-max — a discrete choice.  Where
+  two steps of a (sequence, unit) pair tie to within fp32 rounding, an fp32 forward and this fp64
+  one may choose differently, and the parameter gradients then differ by a routing change, not by
+  an arithmetic error.  To compare gradients element-wise, a test hands over the routing the fp32
+  forward actually used: `argmax_route[name]` = int array [S, H] (input order) for name in
+  `caches` ('clip', 'vid', 'cap', 'par', 'v2', 'p2').  The backward pass below then routes through
+  it.  `report[name]` receives (number of pairs routed differently from this forward's own
+  arg-max, the largest fp64 gap hs[own] - hs[routed] among them, number of pairs): a routing that
+  differs anywhere but at a near-tie shows up as a large gap."""
+  if not argmax_route:
+    return
+  for name, c in caches.items():
+    if c.get('rnn_type') != 'maxout' or name not in argmax_route:
+      continue
+    own = c['argmax']
+    route = np.asarray(argmax_route[name]).astype(own.dtype)
+    if route.shape != own.shape:
+      raise ValueError('argmax_route[%s]: shape %s, want %s' % (name, route.shape, own.shape))
+    if (route < 0).any() or (route >= c['lens'][:, None]).any():
+      raise ValueError('argmax_route[%s]: a step outside its sequence' % name)
+    diff = route != own
+    if report is not None:
+      s_idx, u_idx = np.nonzero(diff)
+      gap = 0.0
+      if len(s_idx):
+        gap = float((c['hs'][s_idx, own[s_idx, u_idx], u_idx] -
+                     c['hs'][s_idx, route[s_idx, u_idx], u_idx]).max())
+      report[name] = (int(diff.sum()), gap, int(diff.size))
+    c['argmax'] = route
+
+
 def train_step_grads(rnn_type, params, batch, margin=0.2, max_violation=False, norm=False,
-                     low_level_loss=False, dtype=np.float64):
+                     low_level_loss=False, dtype=np.float64, argmax_route=None, route_report=None):
   """Parameter gradients of the total loss of VSE.train_emb (model.py:319-344, no reconstruction):
   a list of four dicts keyed like the reference's state-dicts."""
   (clips, captions, videos, paragraphs, lengths_clip, lengths_cap, lengths_video,
@@ -495,6 +527,8 @@ def train_step_grads(rnn_type, params, batch, margin=0.2, max_violation=False, n
   x_p = scatter_rows(cap_emb, num_caps, dtype)
   vid_emb, c_v2 = fw(params[2], x_v, num_clips, vid_ctx)
   para_emb, c_p2 = fw(params[3], x_p, num_caps, para_ctx)
+  apply_argmax_route(dict(clip=c_clip, cap=c_cap, vid=c_vid, par=c_par, v2=c_v2, p2=c_p2),
+                     argmax_route, route_report)
 
   d = {k: 0.0 for k in ['vid', 'para', 'vctx', 'pctx', 'clip', 'cap']}
   raw = dict(vid=vid_emb, para=para_emb, vctx=vid_ctx, pctx=para_ctx, clip=clip_emb, cap=cap_emb)
@@ -579,7 +613,8 @@ def euclidean_loss_backward(a, b, norm=True, dtype=np.float64):
 
 def train_step_recon(rnn_type, params, batch, margin=0.2, max_violation=False, norm=False,
                      low_level_loss=False, lowest=False, weight_recon=0.0005,
-                     lowest_weight_recon=0.0001, dtype=np.float64):
+                     lowest_weight_recon=0.0001, dtype=np.float64, argmax_route=None,
+                     route_report=None):
   """VSE.train_emb with --reconstruct_loss (and optionally --lowest_reconstruct_loss),
   model.py:319-364.  `params`: the 6 (or 8) state-dicts.  Returns (logger triples, total loss,
   list of per-module gradient dicts)."""
@@ -594,6 +629,8 @@ def train_step_recon(rnn_type, params, batch, margin=0.2, max_violation=False, n
   para_ctx, c_par = fw(params[1], table[np.asarray(paragraphs)], lengths_paragraph)
   vid_emb, c_v2 = fw(params[2], scatter_rows(clip_emb, num_clips, dtype), num_clips, vid_ctx)
   para_emb, c_p2 = fw(params[3], scatter_rows(cap_emb, num_caps, dtype), num_caps, para_ctx)
+  apply_argmax_route(dict(clip=c_clip, cap=c_cap, vid=c_vid, par=c_par, v2=c_v2, p2=c_p2),
+                     argmax_route, route_report)
   clip_recon, d_vdec = decoder_forward_cache(vid_emb, num_clips, params[4], dtype)
   cap_recon, d_tdec = decoder_forward_cache(para_emb, num_caps, params[5], dtype)
   if lowest:

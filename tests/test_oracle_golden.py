@@ -210,3 +210,76 @@ def test_groupwise_loss(oracle, n):
       np.testing.assert_allclose(loss, g[tag + '.loss'], rtol=2e-6, atol=1e-6)
       np.testing.assert_allclose(oracle.l2_normalize_backward(a, ga), g[tag + '.da'], **GTOL)
       np.testing.assert_allclose(oracle.l2_normalize_backward(b, gb), g[tag + '.db'], **GTOL)
+
+
+# ---- the torch-CPU baseline (oracle/cmhse_torch_cpu.py: bench.py's `cpu_baseline`) ----------------
+@pytest.fixture(scope='module')
+def torch_cpu():
+  import os
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+  import cmhse_torch_cpu
+  return cmhse_torch_cpu
+
+
+@pytest.mark.parametrize('cls,rnn_type', [('Attention', 'attention'), ('Maxout', 'maxout'),
+                                          ('Seq2Seq', 'seq2seq')])
+@pytest.mark.parametrize('tag', ['ragged', 'equal', 'one'])
+def test_torch_cpu_layers_forward(torch_cpu, cls, rnn_type, tag):
+  import torch
+  g = load_golden('layers.npz')
+  p = {k[len(cls) + 4:]: g[k] for k in g.files if k.startswith(cls + '.sd.')}
+  enc = torch_cpu.Encoder(rnn_type, p)
+  key = '%s.%s' % (cls, tag)
+  x, lens, h0 = torch.from_numpy(g[key + '.x']), g[key + '.lens'], torch.from_numpy(g[key + '.h0'])
+  with torch.no_grad():
+    np.testing.assert_allclose(enc(x, lens).numpy(), g[key + '.out'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(enc(x, lens, h0).numpy(), g[key + '.out_h0'], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout', 'seq2seq'])
+def test_torch_cpu_encode_and_rank(torch_cpu, rnn_type):
+  g = load_golden('model_%s.npz' % rnn_type)
+  res = torch_cpu.encode_data(rnn_type, golden_state_dicts(g), golden_batches(g), margin=0.2,
+                              max_violation=False, norm=False)
+  for i, nm in enumerate(['vid_embs', 'para_embs', 'clip_embs', 'cap_embs', 'vid_contexts',
+                          'para_contexts']):
+    np.testing.assert_allclose(res[i], g['enc.' + nm], atol=TOL, rtol=0, err_msg=nm)
+  np.testing.assert_allclose(res[8], g['enc.test_losses'], rtol=1e-5, atol=1e-6)
+  for nm, fn in [('i2t', torch_cpu.i2t), ('t2i', torch_cpu.t2i)]:
+    rep, top1, ranks = fn(res[0], res[1])
+    np.testing.assert_array_equal(ranks, g['enc.%s.ranks' % nm])
+    np.testing.assert_array_equal(top1, g['enc.%s.top1' % nm])
+
+
+def test_argmax_route_override(oracle):
+  """oracle.apply_argmax_route (what the full-dimension maxout gradient tests hand the oracle: the
+  routing the fp32 forward used).  Its own routing handed back changes nothing and reports no
+  difference; a routing moved off the arg-max for one (sequence, unit) pair is reported with the
+  fp64 gap it jumps across and changes the gradients; a step outside the sequence is refused."""
+  g = load_golden('model_maxout.npz')
+  sds = golden_state_dicts(g)
+  batch = golden_batches(g)[1]
+  kw = dict(margin=0.2, max_violation=False, norm=True, low_level_loss=True)
+  base = oracle.train_step_grads('maxout', sds, batch, **kw)
+  # recover the oracle's own routing of the clip encoder
+  _, c = oracle.pooled_gru_forward_cache('maxout', batch[0], batch[4], sds[0], None, np.float64)
+  own = c['argmax'].copy()
+  rep = {}
+  same = oracle.train_step_grads('maxout', sds, batch, argmax_route={'clip': own}, route_report=rep, **kw)
+  assert rep['clip'][0] == 0 and rep['clip'][2] == own.size
+  for i in range(4):
+    for k in base[i]:
+      np.testing.assert_array_equal(same[i][k], base[i][k])
+  lens = np.asarray(batch[4])
+  s = int(np.argmax(lens > 1))
+  moved = own.copy()
+  moved[s, 0] = (own[s, 0] + 1) % lens[s]
+  rep = {}
+  other = oracle.train_step_grads('maxout', sds, batch, argmax_route={'clip': moved}, route_report=rep, **kw)
+  assert rep['clip'][0] == 1 and rep['clip'][1] > 0
+  assert np.abs(other[0]['rnn.rnn.weight_hh_l0'] - base[0]['rnn.rnn.weight_hh_l0']).max() > 0
+  bad = own.copy()
+  bad[s, 0] = lens[s]
+  with pytest.raises(ValueError):
+    oracle.train_step_grads('maxout', sds, batch, argmax_route={'clip': bad}, **kw)
