@@ -157,6 +157,27 @@ def _host_cpu_model():
   return ''
 
 
+_CPU_SAMPLE = {}
+
+
+def cpu_sample(wl, spec, n_batches):
+  """The first `n_batches` loader batches of the split as host 12-tuples (generated once, shared by
+  the two CPU legs)."""
+  key = (wl['img_dim'], wl['vocab'], wl['batch'], n_batches)
+  if key not in _CPU_SAMPLE:
+    sub = synthetic.SplitSpec(spec.num_clips, spec.frames_per_clip, spec.frames_per_video,
+                              spec.words_per_sent)
+    nv = min(spec.n_videos, n_batches * wl['batch'])
+    sub.num_clips = sub.num_clips[:nv]
+    nc = sum(sub.num_clips)
+    sub.frames_per_clip = sub.frames_per_clip[:nc]
+    sub.words_per_sent = sub.words_per_sent[:nc]
+    sub.frames_per_video = sub.frames_per_video[:nv]
+    _CPU_SAMPLE[key] = synthetic.make_batches(sub, wl['batch'], wl['img_dim'], wl['vocab'], seed=0,
+                                              feat=wl['feat'])
+  return _CPU_SAMPLE[key]
+
+
 def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
   """The CPU restatements of the path on this host's cores over the first `n_sample_batches`
   loader batches (a 512-video subset, one warm-up pass, median of >= 3 timed
@@ -166,16 +187,8 @@ def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3
                       PyTorch CPU path" north_star names (layers.py:75-79,93-119);
     kind 'port'       oracle/cmhse_oracle.py: the NumPy oracle (OpenBLAS)."""
   sys.path.insert(0, os.path.join(REPO, 'oracle'))
-  sub = synthetic.SplitSpec(spec.num_clips, spec.frames_per_clip, spec.frames_per_video,
-                            spec.words_per_sent)
   nv = min(spec.n_videos, n_sample_batches * wl['batch'])
-  sub.num_clips = sub.num_clips[:nv]
-  nc = sum(sub.num_clips)
-  sub.frames_per_clip = sub.frames_per_clip[:nc]
-  sub.words_per_sent = sub.words_per_sent[:nc]
-  sub.frames_per_video = sub.frames_per_video[:nv]
-  batches = synthetic.make_batches(sub, wl['batch'], wl['img_dim'], wl['vocab'], seed=0,
-                                   feat=wl['feat'])
+  batches = cpu_sample(wl, spec, max(n_sample_batches, 16))[:n_sample_batches]
   sds = [{k: v.detach().cpu().numpy() for k, v in sd.items()} for sd in model.state_dict(opt)]
   ncpu = os.cpu_count() or 1
   counts = sorted({min(ncpu, c) for c in (16, 32)})
@@ -215,16 +228,19 @@ def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3
       best_n, best_t = n_thr, dt
   enc_s, score_s = [], []
   with limit(best_n):
-    for rep in range(repeats + 1):        # pass 0 is the warm-up
+    # warm-up: thread pools, allocator, caches — two loader batches through the whole path (a full
+    # pass more would double this leg's share of the default run for nothing)
+    res = encode(data[:2])
+    impl.i2t(res[0], res[1])
+    for rep in range(repeats):
       t0 = time.time()
       res = encode(data)
       t1 = time.time()
       impl.i2t(res[0], res[1])
       impl.t2i(res[0], res[1])
       t2 = time.time()
-      if rep > 0:
-        enc_s.append(t1 - t0)
-        score_s.append(t2 - t1)
+      enc_s.append(t1 - t0)
+      score_s.append(t2 - t1)
   t_enc, t_score = float(np.median(enc_s)), float(np.median(score_s))
   scale = n_full / float(nv)
   t_full = t_enc * scale + t_score * scale * scale
@@ -233,7 +249,7 @@ def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3
       'kind': kind, 'host_cpu': _host_cpu_model(), 'host_logical_cpus': ncpu,
       'videos_per_s': nv / t_enc, 'passes': repeats,
       'sample': ('%s = %d, the faster of {%s} on one loader batch of this %d-CPU host) on the first '
-                 '%d videos (%d loader batches) of the same split: 1 warm-up pass, median of %d timed '
+                 '%d videos (%d loader batches) of the same split: a 2-batch warm-up, median of %d timed '
                  'passes: encode %.2f s, i2t+t2i %.3f s; extrapolated to N=%d with encode ~ N and '
                  'scoring ~ N^2' % (what, best_n, ','.join(str(c) for c in counts), ncpu, nv,
                                     len(batches), repeats, t_enc, t_score, n_full)),
@@ -432,16 +448,31 @@ def train_bench(name, embed, rnn_type, n_steps, device):
   # (two warm-up rounds: building the model left the GPU idle for a second, and a round of ten
   # steps is too short to bring it back to its working clocks)
   use = [batches[i % len(batches)] for i in range(n_steps)]
-  for _ in range(2):
-    for b in use:
+
+  def timed(loader_of):
+    """ms per step over `n_steps` steps of the loop `for b in loader_of(): train_emb(opt, *b)`
+    (what train.py:185-193 runs), after two untimed rounds."""
+    for _ in range(2):
+      for b in loader_of():
+        model.train_emb(opt, *b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in loader_of():
       model.train_emb(opt, *b)
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for b in use:
-    model.train_emb(opt, *b)
-  str(model.logger)          # a reader: the last step's loss values have reached the host meters
-  torch.cuda.synchronize()
-  dt = (time.perf_counter() - t0) / n_steps
+    str(model.logger)          # a reader: the last step's loss values have reached the host meters
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_steps
+  dt = timed(lambda: use)
+  # PCIe-inclusive twins: the SAME steps fed from pinned host memory, as the reference's loader
+  # hands batches over (activity_net/data.py:157-162 pin_memory=True; model.py:225-227 uploads inside
+  # the step) — the padded 12-tuples of its own collate_fn, the larger of the two host forms
+  from cmhse_amd import collate
+  host = [tuple(t.cpu().pin_memory() if isinstance(t, torch.Tensor) and t.is_cuda else t for t in b)
+          for b in batches]
+  host_use = [host[i % len(host)] for i in range(n_steps)]
+  host_bytes = float(np.mean([sum(t.numel() * t.element_size() for t in b[:4]) for b in host_use]))
+  dt_prefetch = timed(lambda: collate.DevicePrefetcher(host_use, prepare=model.prepare_batch))
+  dt_pull = timed(lambda: host_use)
   work = [train_step_work(b, wl['img_dim'], embed, cfg['flags'], rnn_type == 'attention') for b in use]
   fwd = float(np.mean([w[0] for w in work]))
   bwd = float(np.mean([w[1] for w in work]))
@@ -458,6 +489,17 @@ def train_bench(name, embed, rnn_type, n_steps, device):
                             for k, v in sorted(cfg['flags'].items())),
           'rnn_type': rnn_type, 'batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': embed,
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt,
+          'pcie_inclusive': {
+              'ms_per_step': dt_prefetch * 1e3, 'vs_resident': dt_prefetch / dt,
+              'host_bytes_per_step': host_bytes,
+              'feed': 'pinned host 12-tuples (collate_fn form) through collate.DevicePrefetcher(loader, '
+                      'prepare=model.prepare_batch): one batch ahead on the copy stream, schedules built '
+                      'a step early — the one-line change to train.py:185 INTEGRATION.md shows'},
+          'pcie_inclusive_unwrapped': {
+              'ms_per_step': dt_pull * 1e3, 'vs_resident': dt_pull / dt,
+              'host_bytes_per_step': host_bytes,
+              'feed': 'the same pinned host 12-tuples handed straight to train_emb (train.py unchanged): '
+                      'frame rows pulled time-chunk by time-chunk under the visual chain (model.HOST_PULL)'},
           'tflop_per_step': (fwd + bwd) / 1e12, 'tflop_forward': fwd / 1e12,
           'tflop_backward': bwd / 1e12, 'achieved_tflops': (fwd + bwd) / dt / 1e12,
           'dependent_steps': chain,

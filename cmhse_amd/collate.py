@@ -146,6 +146,143 @@ def upload_packed(batch, device=None, non_blocking=True):
   return (view(clips), view(captions), view(videos), view(paragraphs)) + tuple(batch[4:])
 
 
+class DevicePrefetcher(object):
+  """One-batch look-ahead over a loader of 12-tuples: while the training step of batch k runs, batch
+  k + 1 is already crossing PCIe on a copy stream, so `train_emb` always receives device-resident
+  tensors and runs at resident speed.  What a train.py-style loop changes is one line:
+
+      for i, train_data in enumerate(DevicePrefetcher(train_loader)):      # train.py:185
+        model.train_emb(opt, *train_data)                                  # train.py:193
+
+  The reference uploads inside the step (model.py:225-227: `.cuda()` of the loader's pinned tensors,
+  activity_net/data.py:157-162); that copy — 79 MB packed / 100 MB padded per batch-32 ICEP step,
+  1.4-1.75 ms at the 57 GB/s of the link — would otherwise stand in front of the first kernel.
+  Works with collate_fn batches (four tensors) and collate_packed batches (one block, one copy:
+  upload_packed).  The four big members are uploaded; members 4-11 (lengths, counts, ids) stay on
+  the host, where the schedule reads them.  `prepare(batch)` (optional; VSE.prepare_batch) runs
+  right after the upload is queued, one step ahead of its use.
+  The device tensors of a yielded batch are views of one of TWO persistent upload slots that
+  alternate: a batch stays valid until the loop has drawn two more (train.py's loop keeps none;
+  clone what must live longer).  Work the loop body queues on streams other than the current one
+  must be joined into it before the body ends (train_emb does).
+  The copy stream is the package's own (ops.copy_stream): a stream beside the four of the stream
+  set — on [3], which shares the null stream's hardware queue, an upload still in flight at a step
+  boundary stands in front of the next step's first launches (+9 % per step, tools/host_lead.py)."""
+
+  def __init__(self, loader, device=None, prepare=None, model=None, when='before', stream=None):
+    """`model`: a VSE — shorthand for prepare=model.prepare_batch, and needed for when='mid'.
+    `when`: 'before' queues the upload of batch k + 1 before step k is queued (it then runs as soon
+    as the copy stream is free, typically under the END of step k - 1); 'mid' queues it from inside
+    step k, between its forward and backward passes (VSE.train_emb calls the hook), so that it
+    runs under step k's backward pass.  `stream`: the copy stream (default: ops.copy_stream)."""
+    self.loader, self.prepare = loader, prepare
+    if model is not None and prepare is None:
+      self.prepare = model.prepare_batch
+    if when not in ('before', 'mid') or (when == 'mid' and model is None):
+      raise ValueError("DevicePrefetcher: when = 'before' | 'mid' (the latter needs model=)")
+    self.model, self.when, self.stream = model, when, stream
+    self._slots = [None, None]
+    self.device = torch.device(device) if device is not None else None
+
+  def __len__(self):
+    return len(self.loader)
+
+  def _slot(self, k, device, copy, nbytes):
+    """Upload slot k % 2: a persistent device block (grown when a batch needs more), the event its
+    upload records and the event the consumer records when the batch's step has been queued.  Two
+    slots alternate, so a training loop allocates nothing and creates no HIP event per step (either
+    can stall the host for tens of ms while the GPU is busy, see ops.upload)."""
+    slot = self._slots[k % 2]
+    if slot is None:
+      slot = self._slots[k % 2] = {'buf': None, 'ready': torch.cuda.Event(), 'done': None}
+    if slot['buf'] is None or slot['buf'].numel() < nbytes:
+      with torch.cuda.stream(copy):
+        old, slot['buf'] = slot['buf'], torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+      if old is not None:
+        old.record_stream(torch.cuda.current_stream(device))
+    return slot
+
+  def _stage(self, batch, k, device, copy):
+    big = [t for t in batch[:4]]
+    if not all(isinstance(t, (torch.Tensor, ops.Ragged)) and not t.is_cuda for t in big):
+      return batch, None, None     # already resident (or not tensors): handed through
+    datas = [t.data if isinstance(t, ops.Ragged) else t for t in big]
+    if not all(d.is_contiguous() for d in datas):
+      datas = [d.contiguous() for d in datas]
+    sizes = [d.numel() * d.element_size() for d in datas]
+    offs, off = [], 0
+    for n in sizes:
+      offs.append(off)
+      off += (n + 255) // 256 * 256
+    slot = self._slot(k, device, copy, off)
+    with torch.cuda.stream(copy):
+      if slot['done'] is not None:
+        copy.wait_event(slot['done'])      # the step that last read this slot has been passed
+      base = datas[0].untyped_storage()
+      one_block = all(d.untyped_storage().data_ptr() == base.data_ptr() for d in datas)
+      views = []
+      if one_block:                        # collate_packed: ONE copy of the span the members cover
+        lo = min(d.data_ptr() for d in datas)
+        hi = max(d.data_ptr() + n for d, n in zip(datas, sizes))
+        host = torch.empty(0, dtype=torch.uint8).set_(base)[lo - base.data_ptr():hi - base.data_ptr()]
+        if slot['buf'].numel() < hi - lo:
+          slot = self._slot(k, device, copy, hi - lo)
+        slot['buf'][:hi - lo].copy_(host, non_blocking=True)
+        offs = [d.data_ptr() - lo for d in datas]
+      for d, o, n in zip(datas, offs, sizes):
+        v = slot['buf'][o:o + n].view(d.dtype).view(d.shape)
+        if not one_block:
+          v.copy_(d, non_blocking=True)
+        views.append(v)
+      slot['ready'].record(copy)
+    staged = tuple(ops.Ragged(v, t.lens) if isinstance(t, ops.Ragged) else v
+                   for v, t in zip(views, big)) + tuple(batch[4:])
+    if self.prepare is not None:
+      self.prepare(staged)
+    return staged, slot['ready'], slot
+
+  def __iter__(self):
+    device = self.device or torch.device('cuda', torch.cuda.current_device())
+    copy = self.stream or ops.copy_stream(device)
+    it = iter(self.loader)
+    state = {'nxt': None, 'asked': True, 'k': 0}
+
+    def stage_next():
+      if state['asked']:
+        return
+      state['asked'] = True
+      for following in it:
+        state['nxt'] = self._stage(following, state['k'], device, copy)
+        state['k'] += 1
+        break
+
+    state['asked'] = False
+    stage_next()
+    try:
+      if self.when == 'mid':
+        self.model._mid_step_hook = stage_next
+      while state['nxt'] is not None:
+        (cur, ready, slot), state['nxt'] = state['nxt'], None
+        state['asked'] = False
+        if self.when == 'before':
+          stage_next()               # queue the NEXT upload before this batch's step is queued
+        main = torch.cuda.current_stream(device)
+        if ready is not None:
+          main.wait_event(ready)
+        yield cur
+        if slot is not None:         # everything the loop body queued reads this slot before here
+          if slot['done'] is None:
+            slot['done'] = torch.cuda.Event()
+          slot['done'].record(torch.cuda.current_stream(device))
+        stage_next()                 # 'mid': the step did not call the hook (no train_emb on this batch)
+    finally:
+      if self.when == 'mid' and self.model._mid_step_hook is stage_next:
+        self.model._mid_step_hook = None
+      for slot in self._slots:       # the last steps may still read the slots when they are released
+        if slot is not None and slot['buf'] is not None:
+          slot['buf'].record_stream(torch.cuda.current_stream(device))
+
+
 def split_samples(batch):
   """Inverse of collate_fn for a padded 12-tuple: the per-video samples a Dataset would have
   returned (used by the tests and by synthetic loaders to exercise both collate forms)."""

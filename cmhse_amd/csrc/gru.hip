@@ -1800,7 +1800,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     const cmhse_seq_batch* b = j.b;
     const int min_steps = tunables().fwd_tail_min_steps.load(std::memory_order_relaxed);
     if (min_steps <= 0 || !j.save || j.bf3 || !j.vec || js[k] == main_stream || j.t_mid != 0 ||
-        b->H % 16 != 0 || b->H > 1024 || b->step_events_host != nullptr || timer != nullptr ||
+        b->H % 16 != 0 || b->H > 1024 || timer != nullptr ||
         !resident_fits(b->H / 16))
       continue;
     int lo = b->Tmax;
@@ -1866,11 +1866,6 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (j.b->step_events_host != nullptr && j.b->step_events_host[t] != nullptr)
         (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[t])), 0);
       if (t == j.t_mid) {
-        // the hoisted projection reads the inputs of ALL remaining steps: wait for their uploads
-        if (j.b->step_events_host != nullptr)
-          for (int q = t + 1; q < j.b->Tmax; ++q)
-            if (j.b->step_events_host[q] != nullptr)
-              (void)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[q])), 0);
         // A chain that is small-batch from its first step (a training batch) with a side stream:
         // only the projection of the first steps stands in front of the chain; the rest is cut
         // into chunks of time steps that run on the side stream BESIDE the chain, step t waiting
@@ -1878,7 +1873,18 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         // the whole 80-step chain it used to precede.
         const bool chunked = j.side_stream != nullptr && j.side_stream != stream && t == 0 &&
                              j.t_mid == 0 && !j.p.gx_per_seq && j.sum_T >= 4 * kXprojChunkRows;
+        // the hoisted projection reads the inputs of the steps it covers: wait for their uploads
+        // (cmhse_pull_steps chunks still in flight) — all remaining steps for the one-launch form,
+        // chunk by chunk for the chunked one (a host-fed training step: the chain starts as soon as
+        // the first steps' rows have crossed PCIe, the rest arrives under it)
+        auto wait_uploads = [&](hipStream_t st, int q0, int q1) {
+          if (j.b->step_events_host == nullptr) return;
+          for (int q = q0; q < q1; ++q)
+            if (j.b->step_events_host[q] != nullptr)
+              (void)hipStreamWaitEvent(st, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[q])), 0);
+        };
         if (!chunked) {
+          wait_uploads(stream, t + 1, j.b->Tmax);
           launch_xproj(j, stream);
         } else {
           XprojPlan& xp = plan[k];
@@ -1889,9 +1895,11 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
             const int64_t want = (t0 == 0) ? kXprojFirstRows : kXprojChunkRows;
             if (row - chunk_begin >= want || q == j.b->Tmax - 1) {
               if (t0 == 0) {
+                wait_uploads(stream, 1, q + 1);
                 launch_xproj(j, stream, 0, row);
                 stream_after(j.side_stream, stream);     // fork: the inputs are ready
               } else {
+                wait_uploads(j.side_stream, t0, q + 1);
                 launch_xproj(j, j.side_stream, chunk_begin, row);
                 hipEvent_t ev = event_get(false);
                 if (ev != nullptr && hipEventRecord(ev, j.side_stream) == hipSuccess) {

@@ -30,10 +30,15 @@ class SeqInput(object):
                    videos share clip_enc, sentences + paragraphs share txt_enc (model.py:319-320),
                    so one pass over max(T) steps serves both instead of two passes."""
 
-  def __init__(self, kind, lens, pool, tokens=None, counts=None, tensors=None):
+  def __init__(self, kind, lens, pool, tokens=None, counts=None, tensors=None, sched=None,
+               step_events=None, side=True):
     self.kind, self.lens, self.pool, self.tokens, self.counts = kind, lens, pool, tokens, counts
     self.tensors = tensors
     self.need_grad = False
+    # a prebuilt ops.SeqSchedule for these sequences (built ahead of the step, or by the host pull
+    # that fills `tensors` chunk by chunk: then `step_events` = {step: event} of ops.pull_steps);
+    # side=False: this request gets no companion stream (it is taken by that pull)
+    self.sched, self.step_events, self.side = sched, step_events, side
 
 
 class _Saved(object):
@@ -102,6 +107,10 @@ def _fwd_request(spec, x, hidden, table, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, w
   req = dict(weights=weights, pool_mode=pool, lens=spec.lens, I=I, H=H, device=device,
              x_ptrs=x_ptrs, tok_ptrs=tok_ptrs, emb_table=emb, h0_ptrs=h0_ptrs,
              save_for_backward=need_grad, constant_input=(spec.kind == 'repeat'))
+  if spec.sched is not None:
+    req.update(sched=spec.sched, step_events=spec.step_events)
+  if not spec.side:
+    req['side'] = False
   sv.spec, sv.keep = spec, keep
   sv.x_shape = None if x is None else tuple(x.shape)
   sv.table_shape = None if table is None else tuple(table.shape)
@@ -410,13 +419,15 @@ class _GRUPoolBase(nn.Module):
     return weights
 
   # -- call descriptions for run_grouped(): (layer, SeqInput, x, hidden, table) -------------------
-  def call_multi(self, tensors, lens_list):
+  def call_multi(self, tensors, lens_list, sched=None, step_events=None):
     lens = np.concatenate([_lens_numpy(l) for l in lens_list])
-    return (self, SeqInput('multi', lens, self.POOL, tensors=list(tensors)), None, None, None)
+    return (self, SeqInput('multi', lens, self.POOL, tensors=list(tensors), sched=sched,
+                           step_events=step_events), None, None, None)
 
-  def call_tokens_multi(self, token_tensors, lens_list, table):
+  def call_tokens_multi(self, token_tensors, lens_list, table, sched=None, side=True):
     lens = np.concatenate([_lens_numpy(l) for l in lens_list])
-    return (self, SeqInput('multi', lens, self.POOL, tokens=list(token_tensors)), None, None, table)
+    return (self, SeqInput('multi', lens, self.POOL, tokens=list(token_tensors), sched=sched,
+                           side=side), None, None, table)
 
   def call_rows(self, rows, counts, hidden=None):
     counts = np.asarray(counts, dtype=np.int64)

@@ -87,6 +87,10 @@ class EncoderText(nn.Module):
     return outputs, cap_emb
 
 
+def _base_ptr(t):
+  return t.data.data_ptr() if isinstance(t, ops.Ragged) else t.data_ptr()
+
+
 def _word_rows(table, tokens):
   """table[tokens]: [S, L, word_dim] for padded ids; for a packed batch (ops.Ragged) the word
   vectors of the valid tokens only, back to back, as a Ragged of [sum(lens), word_dim]."""
@@ -121,6 +125,17 @@ BATCHED_LOSSES = [True]
 FUSED_LOSSES = [True]
 # torch.optim.Adam(fused=True): one launch for the whole update (VSE.__init__)
 FUSED_ADAM = [True]
+# train_emb on the loader's pinned HOST tensors (train.py unchanged: DataLoader(pin_memory=True),
+# activity_net/data.py:157-162): the frame features are not copied in front of the step; device
+# buffers are allocated unfilled and the rows cross PCIe time-chunk by time-chunk under the visual
+# chain (ops.pull_steps on the text tower's companion stream; the projection chunk that covers a
+# range of steps waits for exactly its rows).  False = `.cuda(non_blocking=True)` in front of the
+# step, as the reference does (model.py:225-227).  A loop that can look one batch ahead should wrap
+# its loader in collate.DevicePrefetcher instead: the next batch is then resident before its step
+# starts and neither path is taken.
+HOST_PULL = [True]
+HOST_PULL_CHUNK = [8]
+HOST_PULL_STREAM = [None]     # None = ops.copy_stream(device); tools/host_lead.py tries others
 
 
 def _tower_streams(device):
@@ -203,6 +218,7 @@ class VSE(object):
     self._pending_log = None
     self._log_slot, self._log_pinned, self._log_owner = 0, [None, None], [None, None]
     self._loss_weights = {}     # weight vectors of the batched losses, by number of terms
+    self._mid_step_hook = None  # called between the forward and backward passes (collate.DevicePrefetcher)
 
   # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
   def _modules(self):
@@ -327,6 +343,64 @@ class VSE(object):
     self._log('Le' + name, loss, clip_emb.size(0))
     return loss
 
+  def prepare_batch(self, batch):
+    """Host work of a training step that depends on the batch alone, done AHEAD of the step
+    (collate.DevicePrefetcher(loader, prepare=model.prepare_batch) calls it one step early): the
+    level-1 schedules of both towers — sort by length, step counts, per-sequence address tables,
+    their upload (layers.py:94-97 does this inside every forward).  They ride on the batch's first
+    member and train_losses picks them up; a batch that is not device-resident is left alone.
+    Returns `batch`."""
+    clips, captions, videos, paragraphs = batch[:4]
+    if not all(isinstance(t, (torch.Tensor, ops.Ragged)) and t.is_cuda
+               for t in (clips, captions, videos, paragraphs)):
+      return batch
+    if clips.dtype != torch.float32 or videos.dtype != torch.float32 or \
+        captions.dtype != torch.int64 or paragraphs.dtype != torch.int64 or \
+        not all(t.is_contiguous() for t in (clips, captions, videos, paragraphs)):
+      return batch
+    lens = lambda a, b: np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1),
+                                        np.asarray(b, dtype=np.int64).reshape(-1)])
+    device = clips.device
+    v_lens, t_lens = lens(batch[4], batch[6]), lens(batch[5], batch[7])
+    prep = dict(
+        v_sched=ops.SeqSchedule(v_lens, device, x_ptrs=ops.seq_row_ptrs_many([clips, videos])),
+        t_sched=ops.SeqSchedule(t_lens, device, tok_ptrs=ops.seq_row_ptrs_many([captions, paragraphs])),
+        v_lens=v_lens, t_lens=t_lens,
+        ptrs=tuple(_base_ptr(t) for t in (clips, captions, videos, paragraphs)))
+    clips._cmhse_prep = prep
+    return batch
+
+  def _pull_visual(self, clips, videos, lengths_clip, lengths_video):
+    """The hand-over of a host-fed training step (HOST_PULL): when `clips` and `videos` are the
+    loader's pinned float32 host tensors (padded, or the ops.Ragged members of collate_packed),
+    returns (device clips, device videos, schedule, {step: event}) — device storage allocated but
+    not filled, the level-1 visual schedule built with the host rows as sources, and one
+    cmhse_pull_steps launch per time chunk queued on the copy stream; None
+    otherwise (resident tensors, pageable memory, HOST_PULL off).  The pulls go to the package's
+    copy stream (ops.copy_stream)."""
+    from .evaluation import _empty_like_on, _pinned_f32
+    if not (HOST_PULL[0] and _pinned_f32(clips) and _pinned_f32(videos)):
+      return None
+    device = next(iter(self.params)).device
+    main = torch.cuda.current_stream(device)
+    copy = HOST_PULL_STREAM[0] or ops.copy_stream(device)
+    lens = np.concatenate([np.asarray(lengths_clip, dtype=np.int64).reshape(-1),
+                           np.asarray(lengths_video, dtype=np.int64).reshape(-1)])
+    # Everything of the hand-over lives on the copy stream — the device buffers come from ITS pool —
+    # so nothing here waits for the caller's stream: the host runs about a step ahead of the GPU,
+    # and the rows of step k + 1 start crossing PCIe while step k's backward pass still computes.
+    # (A block of that pool is reused only when the streams that read it have passed its release:
+    # record_stream below; the towers' streams are joined into the caller's before the step ends.)
+    with torch.cuda.stream(copy):
+      cd, vd = _empty_like_on(clips, device), _empty_like_on(videos, device)
+      sched = ops.SeqSchedule(lens, device, x_ptrs=ops.seq_row_ptrs_many([cd, vd]),
+                              src_ptrs=ops.seq_row_ptrs_many([clips, videos]))
+      events = ops.pull_steps(sched, int(clips.shape[2]), copy, HOST_PULL_CHUNK[0])
+    for t in (cd, vd, sched.meta):
+      t.record_stream(main)          # allocated on the copy stream, consumed on the caller's (and its forks)
+    self._pull_on_s3 = copy.cuda_stream == ops.stream_set(device)[3].cuda_stream
+    return cd, vd, sched, events
+
   def train_losses(self, opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
                    lengths_video, lengths_paragraph, num_clips, num_caps, ind=None, cur_vid=None,
                    *args):
@@ -335,10 +409,30 @@ class VSE(object):
     # model.py:319-320 run clip_enc on the clips and again on the whole-video streams (same for
     # txt_enc on sentences / paragraphs).  The sequences are independent, so both batches go
     # through each encoder in ONE packed pass: max(T) steps instead of T_clip + T_video.
-    clips = clips.cuda(non_blocking=True)
-    videos = videos.cuda(non_blocking=True)
+    schedule = TRAIN_SCHEDULE[0]
+    if schedule not in ('interleaved', 'levels', 'towers', 'grouped', 'serial'):
+      raise ValueError('unknown training schedule %r' % (schedule,))
+    v_sched = v_events = None
+    pulled = (self._pull_visual(clips, videos, lengths_clip, lengths_video)
+              if schedule in ('interleaved', 'levels') else None)
+    if pulled is not None:
+      clips, videos, v_sched, v_events = pulled
+    else:
+      clips = clips.cuda(non_blocking=True)
+      videos = videos.cuda(non_blocking=True)
+    prep = getattr(clips, '_cmhse_prep', None) if pulled is None else None
     captions = captions.cuda(non_blocking=True)
     paragraphs = paragraphs.cuda(non_blocking=True)
+    t_sched = None
+    if prep is not None and schedule in ('interleaved', 'levels'):
+      # schedules built a step ahead (prepare_batch): valid for exactly these tensors and lengths
+      same = prep['ptrs'] == tuple(_base_ptr(t) for t in (clips, captions, videos, paragraphs)) and \
+          np.array_equal(prep['v_lens'][:len(lengths_clip)], np.asarray(lengths_clip).reshape(-1)) and \
+          np.array_equal(prep['v_lens'][len(lengths_clip):], np.asarray(lengths_video).reshape(-1)) and \
+          np.array_equal(prep['t_lens'][:len(lengths_cap)], np.asarray(lengths_cap).reshape(-1)) and \
+          np.array_equal(prep['t_lens'][len(lengths_cap):], np.asarray(lengths_paragraph).reshape(-1))
+      if same:
+        v_sched, t_sched = prep['v_sched'], prep['t_sched']
     n_clip, n_cap = clips.shape[0], captions.shape[0]
     lc = np.asarray(lengths_clip, dtype=np.int64)
     lw = np.asarray(lengths_cap, dtype=np.int64)
@@ -378,10 +472,12 @@ class VSE(object):
       from .layers import run_grouped as _run_grouped
       run_grouped = lambda calls: _run_grouped(calls, streams)
       _tick('vis:start')
-      level1 = [self.clip_enc.rnn.call_multi([clips, videos], [lengths_clip, lengths_video]),
+      level1 = [self.clip_enc.rnn.call_multi([clips, videos], [lengths_clip, lengths_video],
+                                             sched=v_sched, step_events=v_events),
                 self.txt_enc.rnn.call_tokens_multi([captions, paragraphs],
                                                    [lengths_cap, lengths_paragraph],
-                                                   self.txt_enc.embed.weight)]
+                                                   self.txt_enc.embed.weight, sched=t_sched,
+                                                   side=not (v_events is not None and self._pull_on_s3))]
       towers = None
       if one_node:
         # both levels of both towers as one node: each tower stays on its stream between its
@@ -415,9 +511,6 @@ class VSE(object):
       return ((clip_emb, vid_context, vid_emb, clip_recon, frame_recon),
               (cap_emb, para_context, para_emb, cap_recon, sent_recon, word))
 
-    schedule = TRAIN_SCHEDULE[0]
-    if schedule not in ('interleaved', 'levels', 'towers', 'grouped', 'serial'):
-      raise ValueError('unknown training schedule %r' % (schedule,))
     if schedule in ('interleaved', 'levels'):
       out_v, out_t = grouped_towers(_tower_streams(clips.device), schedule == 'interleaved')
     elif schedule == 'grouped':
@@ -544,6 +637,8 @@ class VSE(object):
                                lengths_cap, lengths_video, lengths_paragraph, num_clips, num_caps,
                                ind, cur_vid)
       _tick('losses:done')
+      if self._mid_step_hook is not None:
+        self._mid_step_hook()      # e.g. the next batch's upload: it runs under this backward pass
       loss.backward()
       _tick('backward:done')
       if self.grad_clip > 0:

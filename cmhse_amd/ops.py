@@ -381,7 +381,7 @@ def pull_steps(sched, row_floats, copy_stream, chunk=8):
 
 def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
-                 constant_input=False, sched=None, step_events=None):
+                 constant_input=False, sched=None, step_events=None, side=True):
   """Build the ctypes request of one cmhse_gru_pool_fwd call.  Returns (job dict, timer meta).
   `sched`: a prebuilt SeqSchedule for these sequences (else built here); `step_events`:
   {step: torch.cuda.Event} the step's launch must wait for (chunked upload, pull_steps)."""
@@ -433,7 +433,7 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     keep.append((ev_arr, step_events))
   ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
              device=device, mode_flags=mode_flags)
-  job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx)
+  job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx, side=side)
   meta = (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None, S)
   return job, meta
 
@@ -474,7 +474,7 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, 
     jobs[k].workspace_bytes = job['ws_bytes']
     if job_streams is not None:
       jobs[k].stream = ctypes.c_void_p(job_streams[k].cuda_stream)
-    if job['mode_flags'] & SAVE_FOR_BACKWARD:      # a training call: throughput work beside the chain
+    if job['mode_flags'] & SAVE_FOR_BACKWARD and job['side']:   # a training call: throughput work beside the chain
       side = side_stream(job_streams[k] if job_streams is not None else None)
       if side is not None:
         jobs[k].side_stream = ctypes.c_void_p(side.cuda_stream)
@@ -777,6 +777,29 @@ def stream_set(device=None):
       with torch.cuda.stream(s):
         torch.zeros(1, device=dev)
     _STREAM_SET[key] = st
+  return st
+
+
+_COPY_STREAM = {}
+
+
+def copy_stream(device=None):
+  """The package's host-to-device hand-over stream for TRAINING (collate.DevicePrefetcher, the host
+  pull of VSE.train_emb): a fifth stream, created after the set of four and used once right away.
+  Why not [3] of the set: [3] shares the caller's (null) stream's hardware queue, and a 1.7 ms
+  batch upload queued there sits in front of the next step's first launches on the null stream
+  (measured, tools/host_lead.py: a prefetched ICEP step 1.087x the resident one on [3], 1.010x on a
+  stream of its own)."""
+  device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+  key = device.index if device.index is not None else torch.cuda.current_device()
+  st = _COPY_STREAM.get(key)
+  if st is None:
+    stream_set(device)
+    dev = torch.device('cuda', key)
+    st = torch.cuda.Stream(dev)
+    with torch.cuda.stream(st):
+      torch.zeros(1, device=dev)
+    _COPY_STREAM[key] = st
   return st
 
 

@@ -2183,3 +2183,72 @@ def test_batched_losses_equal_the_separate_calls(dev, max_violation):
   contrastive_losses(crit, [(x2, x2)])[0].backward()
   assert torch.equal(x1.grad, x2.grad)
 
+
+
+@pytest.mark.gpu
+def test_host_fed_train_step_is_bit_identical(dev, monkeypatch):
+  """a training step fed from the loader's pinned HOST tensors (model.py:225-227,
+  activity_net/data.py:157-162) must equal the step on resident tensors bit for bit — logged losses
+  and every parameter gradient (the word table's is scattered with float atomics: close, not
+  equal) — whichever way the batch crosses PCIe:
+    pull      train.py unchanged: train_emb pulls the frame rows time-chunk by time-chunk under the
+              visual chain (model.HOST_PULL; the projection chunks wait for exactly their rows);
+    upload    the reference's `.cuda()` in front of the step (HOST_PULL off);
+    prefetch  collate.DevicePrefetcher(loader, prepare=model.prepare_batch): one batch ahead on the
+              copy stream, schedules built a step early;
+    packed    the same through collate_packed's un-padded block (ops.Ragged members), pulled.
+  Sized so that the forward projection IS cut into time chunks (>= 6144 packed rows)."""
+  import copy
+  from cmhse_amd import collate, model as model_mod, ops, synthetic
+  from cmhse_amd.model import VSE
+  opt = golden_opt('attention', low_level_loss=True, norm=True, img_dim=64, embed_size=64,
+                   img_first_size=64, cap_first_size=64, reconstruct_loss=True, weight_recon=0.0005)
+  spec = synthetic.anet_like_spec(64, seed=2)
+  batches = synthetic.make_batches(spec, 32, opt.img_dim, opt.vocab_size, seed=3)
+  assert len(batches) == 2 and int(np.asarray(batches[0][4]).sum() + np.asarray(batches[0][6]).sum()) >= 6144
+  pin = lambda b: tuple(t.pin_memory() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b))
+  host = [pin(b) for b in batches]
+  resident = [tuple(t.to(dev) if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b))
+              for b in batches]
+  packed = [collate.collate_packed(collate.split_samples(b), pin=True) for b in batches]
+  assert isinstance(packed[0][0], ops.Ragged) and packed[0][0].is_pinned()
+  torch.manual_seed(5)
+  ref = VSE(opt)
+  sd0 = copy.deepcopy(ref.state_dict(opt))
+
+  def run(feed):
+    model = VSE(opt)
+    model.load_state_dict(copy.deepcopy(sd0), opt)
+    model.logger = MeterLog()
+    model.train_start(opt)
+    pulls = []
+    real = ops.pull_steps
+    monkeypatch.setattr(ops, 'pull_steps', lambda *a, **k: (pulls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(model_mod, 'HOST_PULL', [feed != 'upload'])
+    loader = {'resident': resident, 'pull': host, 'upload': host, 'packed': packed,
+              'prefetch': collate.DevicePrefetcher(host, prepare=model.prepare_batch)}[feed]
+    grads = None
+    for k, b in enumerate(loader):
+      if feed == 'prefetch':
+        assert b[0].is_cuda and hasattr(b[0], '_cmhse_prep')
+      model.train_emb(opt, *b)
+      if k == 0:
+        torch.cuda.synchronize()
+        grads = {(i, n): p.grad.detach().clone() for i, m in enumerate(model._modules())
+                 for n, p in m.named_parameters()}
+    torch.cuda.synchronize()
+    assert bool(pulls) == (feed in ('pull', 'packed')), (feed, len(pulls))
+    return [c for c in model.logger.calls if c[0].startswith('Le')], grads
+
+  want_log, want_g = run('resident')
+  n_first = len(want_log) // 2
+  for feed in ['pull', 'upload', 'prefetch', 'packed']:
+    log, g = run(feed)
+    assert log[:n_first] == want_log[:n_first], feed          # first step: bit-identical losses
+    for a, b in zip(log[n_first:], want_log[n_first:]):       # second: after an update with atomics upstream
+      assert a[0] == b[0] and a[2] == b[2] and loss_close(a[1], b[1]), (feed, a, b)
+    for key, w in want_g.items():
+      if key[1] == 'embed.weight':
+        assert float((g[key] - w).abs().max()) <= 1e-6 * max(1.0, float(w.abs().max())), (feed, key)
+      else:
+        assert torch.equal(g[key], w), (feed, key)

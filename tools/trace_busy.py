@@ -59,6 +59,25 @@ def main():
     streams[st] += e - s
   print('\nper stream busy ms / step: ' + ', '.join('%d: %.3f' % (k, v / 1e6 / steps)
                                                       for k, v in sorted(streams.items())))
+  # Host lead: how long after the optimizer update of step k (the last multi_tensor / fused-Adam
+  # launch of a step) the first projection / chain kernel of step k + 1 starts.
+  is_adam = lambda n: 'multi_tensor_apply' in n or 'FusedAdam' in n or 'fused_adam' in n
+  is_chain = lambda n: ('xproj_kernel' in n or 'gru_step' in n or 'gru_chain' in n or
+                        'gru_fwd_tail' in n or 'pull_steps' in n)
+  leads, last_adam_end, armed = [], None, False
+  for s_, e_, n_, _ in sel:
+    if is_adam(n_):
+      last_adam_end = e_ if last_adam_end is None or not armed else max(last_adam_end, e_)
+      armed = True
+    elif armed and is_chain(n_):
+      leads.append((s_ - last_adam_end) / 1e3)
+      armed = False
+  if leads:
+    leads_sorted = sorted(leads)
+    print('\nfirst projection / chain kernel of a step after the previous step\'s Adam: median %.1f us, '
+          'max %.1f us over %d step boundaries (%s)'
+          % (leads_sorted[len(leads) // 2], leads_sorted[-1], len(leads),
+             ', '.join('%.0f' % v for v in leads)))
   if '--timeline' in sys.argv:
     # last step = launches after the region's last gap of >= 0.25 of the mean step... simpler:
     # the final 1/steps of the wall

@@ -40,6 +40,10 @@ def main():
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--rnn_type', default='attention')
   ap.add_argument('--resident', type=int, default=1, help='1: batches resident in HBM (what bench.py times); 0: pinned host batches')
+  ap.add_argument('--feed', default='', choices=['', 'resident', 'pull', 'upload', 'prefetch'],
+                  help="how a batch reaches train_emb: resident (in HBM); pinned host tensors pulled "
+                       "under the chain (pull) or .cuda()'d in front of the step (upload); pinned host "
+                       "tensors through collate.DevicePrefetcher + prepare_batch (prefetch)")
   ap.add_argument('--timeline', type=int, default=0, help='host (h) / GPU (g) ms at phase marks')
   args = ap.parse_args()
   cfg = dict(CONFIGS[args.config])
@@ -52,27 +56,31 @@ def main():
   model = VSE(opt)
   spec = synthetic.anet_like_spec(32 * 4, seed=0, dataset=wl['dataset'])
   batches = synthetic.make_batches(spec, 32, wl['img_dim'], wl['vocab'], seed=0, feat=wl['feat'])
-  if args.resident:
+  feed = args.feed or ('resident' if args.resident else 'pull')
+  if feed == 'resident':
     batches = [tuple(t.cuda() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)) for b in batches]
   else:
-    batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in b) for b in batches]
+    batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)) for b in batches]
+  from cmhse_amd import collate, model as model_mod
+  model_mod.HOST_PULL[0] = feed != 'upload'
+  wrap = (lambda bs: collate.DevicePrefetcher(bs, prepare=model.prepare_batch)) if feed == 'prefetch' else (lambda bs: bs)
   model.logger = LogCollector()
   model.train_start(opt)
-  use = [batches[i % len(batches)] for i in range(args.steps + 3)]
-  for b in use[:3]:
+  use = [batches[i % len(batches)] for i in range(args.steps + 6)]
+  for b in wrap(use[:6]):
     model.train_emb(opt, *b)
   torch.cuda.synchronize()
   time.sleep(0.3)
   t0 = time.perf_counter()
-  for b in use[3:]:
+  for b in wrap(use[6:]):
     model.train_emb(opt, *b)
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / args.steps
-  print('%s: %.2f ms per train_emb step (%d steps, batch 32, img_dim %d, %s)'
-        % (args.config, dt * 1e3, args.steps, wl['img_dim'], args.rnn_type))
+  print('%s [%s]: %.2f ms per train_emb step (%d steps, batch 32, img_dim %d, %s)'
+        % (args.config, feed, dt * 1e3, args.steps, wl['img_dim'], args.rnn_type))
   if args.timeline:
     from cmhse_amd import model as model_mod
-    for b in use[3:6]:
+    for b in use[6:9]:
       torch.cuda.synchronize()
       model_mod.TRACE = []
       from cmhse_amd import layers as layers_mod
