@@ -69,6 +69,7 @@ class StepLosses(ctypes.Structure):
 # every symbol include/cmhse_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
+    'cmhse_async_status': (ctypes.c_int, [c_int32]),
     'cmhse_gru_pool_ws_region': (ctypes.c_int, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
                                                 ctypes.c_char_p, ctypes.POINTER(c_size_t),
                                                 ctypes.POINTER(c_size_t)]),

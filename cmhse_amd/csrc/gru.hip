@@ -36,6 +36,7 @@
 
 #include "../../include/cmhse_hip.h"
 #include "gru_ws.hpp"
+#include "grid_sync.hpp"
 #include "nt_core.hpp"
 
 namespace cmhse {
@@ -682,11 +683,10 @@ __global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGrou
 struct FwdTailParams {
   GruStepParams p;           // as for a step of the chain; t / S_t / off_* are derived per step
   const int32_t* step_off;   // device [Tmax + 1]
-  unsigned* sync;            // [0] arrivals (zeroed by the caller)
+  GridSync sync;             // grid barrier words (zeroed by the caller)
   int32_t t_lo, t_hi;        // steps t_lo >= 1 ... t_hi = Tmax - 1
 };
 
-constexpr unsigned kTailMaxSpins = 1u << 23;   // x s_sleep(1): ~0.3 s
 constexpr int kFwdTailMaxSeqs = 32;             // two 16-row blocks per workgroup
 
 template <int KBMAX, int MB>
@@ -827,17 +827,8 @@ __global__ __launch_bounds__(512) void gru_fwd_tail_kernel(const FwdTailParams q
     }
     if (t == q.t_hi) break;
     __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
     arrivals += gridDim.x;
-    if (tid == 0) {
-      __hip_atomic_fetch_add(q.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      while (__hip_atomic_load(q.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kTailMaxSpins) __builtin_trap();
-      }
-    }
-    __syncthreads();
+    if (!grid_sync_wait(q.sync, arrivals)) return;
   }
 }
 
@@ -1368,17 +1359,72 @@ void event_put(hipEvent_t ev, bool timing) {
   g_event_free[dev][timing ? 1 : 0].push_back(ev);
 }
 
-bool resident_fits(int wgs) {
+static int device_cus();
+bool resident_fits(int wgs) { return device_cus() >= 4 * wgs; }
+
+static int device_cus() {
   static std::atomic<int> cus[64];      // per device, 0 = not asked yet
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   int n = cus[dev].load(std::memory_order_relaxed);
   if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
     cus[dev].store(n, std::memory_order_relaxed);
   }
-  return n >= 4 * wgs;
+  return n;
 }
+
+bool resident_fits_wgs(int wgs) { return device_cus() >= wgs; }
+
+// The device's host-visible status word (grid_sync.hpp): 64 bytes of pinned, mapped host memory per
+// device, allocated at the first resident launch and kept for the life of the process.
+namespace {
+std::mutex g_status_mutex;
+unsigned* g_status_host[kMaxDevices];
+unsigned* g_status_dev[kMaxDevices];
+}  // namespace
+
+unsigned* resident_status_word() {
+  const int dev = event_device();
+  if (dev < 0) return nullptr;
+  std::lock_guard<std::mutex> lock(g_status_mutex);
+  if (g_status_host[dev] == nullptr) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h != nullptr) (void)hipHostFree(h);
+      return nullptr;
+    }
+    memset(h, 0, 64);
+    g_status_host[dev] = static_cast<unsigned*>(h);
+    g_status_dev[dev] = static_cast<unsigned*>(d);
+  }
+  return g_status_dev[dev];
+}
+
+GridSync make_grid_sync(unsigned* counter, unsigned* abort_word) {
+  GridSync g;
+  g.counter = counter;
+  g.abort_word = abort_word;
+  g.status_host = resident_status_word();
+  const int ms = tunables().resident_timeout_ms.load(std::memory_order_relaxed);
+  g.timeout_ticks = static_cast<uint64_t>(ms > 0 ? ms : 1) * 100000ull;   // s_memrealtime: 100 MHz
+  return g;
+}
+
+static int resident_status(bool clear) {
+  const int dev = event_device();
+  if (dev < 0) return CMHSE_OK;
+  std::lock_guard<std::mutex> lock(g_status_mutex);
+  volatile unsigned* w = g_status_host[dev];
+  if (w == nullptr || *w == 0) return CMHSE_OK;
+  if (clear) *w = 0;
+  return CMHSE_ERR_TIMEOUT;
+}
+
+int resident_check() { return resident_status(false); }
 
 void stream_after(hipStream_t waiter, hipStream_t signal) {
   hipEvent_t ev = event_get(false);
@@ -1625,7 +1671,14 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
     // many sequences: 64 per workgroup, so that the step is ONE round of workgroups (H / 16 x
     // ceil(S_t / 64) <= 256 up to 256 sequences at H = 1024) instead of two of 32-sequence ones
     const int tall = tunables().mid_tall_min_seqs.load(std::memory_order_relaxed);
-    if (tall > 0 && S_t >= tall && bu == 16 && alone && j.save) return 3 | 512 | 8192;   // (training calls: the validation pass keeps its shapes)
+    if (tall > 0 && S_t >= tall && bu == 16 && alone && j.save) {   // (training calls: the validation pass keeps its shapes)
+      // ... and 48 per workgroup where three row blocks give that one round (129-192 sequences at
+      // H = 1024: 192 or 256 workgroups of 74 KB of LDS, two of which fit a CU, against 192 of the
+      // 64-sequence shape whose 98 KB let the two towers' workgroups exclude each other)
+      const int mid3 = tunables().mid_tall_rows48.load(std::memory_order_relaxed);
+      if (mid3 > 0 && ((j.b->H + 15) / 16) * ((S_t + 47) / 48) <= kChipCUs) return 3 | 512 | 16384;
+      return 3 | 512 | 8192;
+    }
     return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0) |
            (alone ? 512 : 0);
   }
@@ -1679,6 +1732,8 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   } while (0)
       if ((kind & 8192) != 0) {       // 64 sequences per workgroup (only with 16 units, 8 waves)
         hipLaunchKernelGGL((gru_step_mid_kernel<4, 16, 8>), dim3(grid), dim3(512), 0, stream, g);
+      } else if ((kind & 16384) != 0) {   // 48 sequences per workgroup (likewise)
+        hipLaunchKernelGGL((gru_step_mid_kernel<3, 16, 8>), dim3(grid), dim3(512), 0, stream, g);
       } else if ((kind & 32) != 0) {
         if (bu == 4) MID_LAUNCH_(1, 4);
         else if (bu == 8) MID_LAUNCH_(1, 8);
@@ -1724,7 +1779,7 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
 unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   const int H = j.b->H;
   if ((kind & 3) == 3) {
-    const int bm = (kind & 8192) != 0 ? 64 : ((kind & 32) != 0 ? 16 : 32);
+    const int bm = (kind & 8192) != 0 ? 64 : ((kind & 16384) != 0 ? 48 : ((kind & 32) != 0 ? 16 : 32));
     const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
     return static_cast<unsigned>((H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
   }
@@ -1744,7 +1799,8 @@ static void launch_fwd_tail(FwdJob& j, hipStream_t stream) {
   FwdTailParams q;
   q.p = j.p;
   q.step_off = j.b->step_off;
-  q.sync = reinterpret_cast<unsigned*>(j.wsb + j.L.tail_sync);
+  unsigned* words = reinterpret_cast<unsigned*>(j.wsb + j.L.tail_sync);
+  q.sync = make_grid_sync(words, words + 63);
   q.t_lo = j.tail_lo;
   q.t_hi = j.b->Tmax - 1;
   const int H = j.b->H;
@@ -2087,8 +2143,11 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
 
 }  // namespace
 
+extern "C" int cmhse_async_status(int32_t clear) { return resident_status(clear != 0); }
+
 extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_jobs, void* stream_) {
   if (!reqs || n_jobs <= 0 || n_jobs > kMaxJobs) return CMHSE_ERR_ARG;
+  if (resident_check() != CMHSE_OK) return CMHSE_ERR_TIMEOUT;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FwdJob jobs[kMaxJobs];
   for (int k = 0; k < n_jobs; ++k) {
@@ -2219,8 +2278,9 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}};
+      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs}, {"mid_tall_rows48", &t.mid_tall_rows48},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps},
+      {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {
       const int old = (value >= 0) ? e.v->exchange(value) : e.v->load();

@@ -61,6 +61,14 @@ struct Tunables {
   std::atomic<int> bwd_split_min_seqs{33};   // ... and from which (up to bwd_mid_max_seqs) it runs as two launches with K split over the grid (0 = never)
   std::atomic<int> bwd_tail_min_steps{4};    // steps with <= 32 active sequences at the end of a chain from which its BPTT runs them in one resident kernel (0 = never)
   std::atomic<int> mid_tall_min_seqs{129};   // active sequences from which the mid-size forward step takes 64 sequences per workgroup (0 = never)
+  std::atomic<int> mid_tall_rows48{1};       // 1: ... 48 per workgroup where that gives one round of workgroups (0 = only the 64-sequence shape)
+  // training-size BPTT steps (33-256 active sequences) from which one request of a call runs them in
+  // resident chain kernels (gru_bwd_chain_kernel); 0 = never — the DEFAULT: measured slower than the
+  // two launches per step it replaces (profiles/r04_chain_resident.txt: 39 against 22 us per step
+  // stand-alone at 152 sequences, +0.4 ... +1.0 ms per training step): every exchange between
+  // workgroups is a round trip past the non-coherent L2s plus a grid barrier, twice per step
+  std::atomic<int> bwd_chain_min_steps{0};
+  std::atomic<int> resident_timeout_ms{5000};  // wall time one grid barrier of a resident kernel may take before the launch gives up (grid_sync.hpp)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };
 Tunables& tunables();
@@ -135,6 +143,8 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
 // chip at once, one per CU, and the package may run four such chains side by side: true when the
 // current device has the CUs for that (a full MI355X: 256; a partitioned one may not).
 bool resident_fits(int wgs);
+// ... and for the chain kernels, whose workgroups share their CU with others: at least `wgs` CUs
+bool resident_fits_wgs(int wgs);
 
 hipEvent_t event_get(bool timing);
 void event_put(hipEvent_t ev, bool timing);

@@ -730,8 +730,12 @@ extern "C" const char* cmhse_strerror(int code) {
     case CMHSE_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
     case CMHSE_ERR_LAUNCH: return "HIP launch/runtime error";
     case CMHSE_ERR_UNSUPPORTED: return "shape not supported";
+    case CMHSE_ERR_TIMEOUT:
+      return "a resident chain kernel gave up at a grid barrier (its workgroups were not all on the chip: "
+             "shared GPU, CU mask?); results of that call are invalid; clear with cmhse_async_status(1) and "
+             "set the *_tail_min_steps / *_chain_min_steps tunables to 0 on such a GPU";
     default: return "unknown error";
   }
 }
 
-extern "C" const char* cmhse_version(void) { return "cmhse_hip 0.1.0 gfx950"; }
+extern "C" const char* cmhse_version(void) { return "cmhse_hip 0.4.0 gfx950"; }

@@ -267,6 +267,7 @@ class _TowersFn(torch.autograd.Function):
     for i in range(len(meta)):
       svs1[i].fctx = res1[i][1]
     res2 = ops.gru_pool_fwd_multi(reqs2, job_streams=streams)   # joins everything queued above
+    _mark('fwd:level2', streams)
     outs = []
     for i, (_, n, _) in enumerate(meta):
       svs2[i].fctx = res2[i][1]
@@ -315,6 +316,7 @@ class _TowersFn(torch.autograd.Function):
         else:
           torch.add(g_rest, dh0, out=dout[n:])
     res1 = ops.gru_pool_bwd_multi(reqs1, job_streams=streams, prepared=prep1)   # joins everything
+    _mark('bwd:level1', streams)
     out = [None, None]
     for i in range(len(ctx.svs1)):
       out.extend(_grads_tuple(res1[i][0], extra[i][0], res1[i][1], extra[i][1]))

@@ -17,7 +17,9 @@
  *     returns.  Host-side objects a call may take and give back before it returns: HIP events for
  *     stream fork / join (`tail_stream`, `stream`, `side_stream` of the job structs) and the event
  *     pairs owned by a cmhse_timer handle when the caller passes one (measurement only);
- *   - process-wide state, all of it host-side and mutex- or atomic-guarded: (i) per-device free
+ *   - process-wide state, all of it host-side and mutex- or atomic-guarded: (o) 64 bytes of pinned
+ *     host memory per device for cmhse_async_status, allocated at the first resident launch;
+ *     (i) per-device free
  *     lists of those HIP events (creating an event while the GPU is busy can stall the host for
  *     tens of milliseconds, so events are recycled; an event returns to the list of the device
  *     that is current in the calling thread — use one device per thread across a call); (ii) the
@@ -41,7 +43,9 @@ enum {
   CMHSE_ERR_ARG = -1,        /* invalid argument (null pointer, non-positive size, bad mode) */
   CMHSE_ERR_WORKSPACE = -2,  /* workspace too small or misaligned */
   CMHSE_ERR_LAUNCH = -3,     /* HIP launch / runtime error (hipGetLastError text via strerror) */
-  CMHSE_ERR_UNSUPPORTED = -4 /* shape outside what the kernels support */
+  CMHSE_ERR_UNSUPPORTED = -4, /* shape outside what the kernels support */
+  CMHSE_ERR_TIMEOUT = -5      /* an earlier resident-kernel launch on this device gave up at a grid
+                                 barrier (see cmhse_async_status) */
 };
 
 /* pooling applied on top of the GRU hidden states (reference: model.py:27-34 `rnn_type`) */
@@ -424,6 +428,8 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *   "mid_waves"            0  4 | 8 forces its waves per workgroup
  *   "mid_tall_min_seqs"  129  active sequences from which the mid-size step of a training call
  *                             takes 64 sequences per workgroup instead of 32 (bit-identical)
+ *   "mid_tall_rows48"      1  1: of those steps, the ones whose grid then fits one round (up to 192
+ *                             sequences at H = 1024) take 48 sequences per workgroup (bit-identical)
  *   "tall_tile_min_wgs" 2048  64-row workgroups from which an LDS-tiled launch uses 128-row tiles
  *   "bwd_mid_max_seqs"   512  active sequences at or below which a BPTT step runs on the mid-size
  *                             backward kernel
@@ -435,12 +441,32 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             workgroups resident (one per CU): at most four such chains at once
  *   "fwd_tail_min_steps"   4  the same for the forward chain of a training call
  *                             (CMHSE_SAVE_FOR_BACKWARD, job on its own stream)
+ *   "bwd_chain_min_steps"  0  (opt-in; measured slower than the default two launches per step,
+ *                             profiles/r04_chain_resident.txt) BPTT steps with 33-256 active sequences from which ONE request of a call
+ *                             (the one with the most) runs them inside resident kernels — (H / 128) x
+ *                             (3H / 128) workgroups that keep their W_hh^T slice in LDS, two grid
+ *                             barriers per step instead of two launches; H % 128 == 0; 0 = never.
+ *                             Gradients equal the per-step path's to fp32 rounding
+ *   "resident_timeout_ms" 5000  wall time a grid barrier of a resident kernel may take before the
+ *                             launch gives up (cmhse_async_status)
  *   "bwd_chunk_rows"    2048  packed rows a weight-gradient chunk spans before its products are
  *                             issued beside the chain (changes the order in which chunks are
  *                             accumulated, i.e. the gradients to fp32 rounding)
  * Process-wide (atomics): set them between calls, not while calls that size workspaces with them
  * (`*_workspace` reads mid_max_seqs) are in flight on other threads.  Unknown name: CMHSE_ERR_ARG. */
 int cmhse_tune(const char* name, int32_t value, int32_t* old_value);
+
+/* The kernels that stay resident over several time steps of a chain (the few-sequence tails and
+ * the training-size BPTT runs: "*_tail_min_steps", "bwd_chain_min_steps") synchronise their
+ * workgroups with a grid barrier, which needs all of them on the chip at once.  The launchers check
+ * the CU count; what they cannot see — another process holding CUs, a CU mask — ends in a timeout
+ * ("resident_timeout_ms", default 5000): the kernel's workgroups all leave, the call's results are
+ * invalid, and a word in pinned host memory is raised.  This function returns CMHSE_ERR_TIMEOUT
+ * while that word is set for the calling thread's current device (CMHSE_OK otherwise) and clears
+ * it when `clear` != 0; cmhse_gru_pool_fwd[_multi] / cmhse_gru_pool_bwd[_multi] check it on entry
+ * and return CMHSE_ERR_TIMEOUT without launching.  The status is asynchronous: it reflects launches
+ * that have RUN, so poll it after a stream synchronisation (or once per step, one step late). */
+int cmhse_async_status(int32_t clear);
 
 /* Text for an error code returned by the functions above (static storage). */
 const char* cmhse_strerror(int code);

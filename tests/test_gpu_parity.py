@@ -633,18 +633,25 @@ def test_tall_mid_step_tile_is_bit_identical(dev, tune):
   w = rng.standard_normal((S, H)).astype(np.float32)
   stream = ops.stream_set(dev)[0]
 
-  def run(tall):
-    tune(mid_tall_min_seqs=tall)
+  def run(tall, rows48=1, n_seq=S):
+    tune(mid_tall_min_seqs=tall, mid_tall_rows48=rows48)
+    lens_ = lens[:n_seq]
     layer.zero_grad()
-    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
-    spec = layers.SeqInput('padded', lens.astype(np.int64), layer.POOL)
+    xt = torch.from_numpy(x[:n_seq]).to(dev).requires_grad_(True)
+    spec = layers.SeqInput('padded', lens_.astype(np.int64), layer.POOL)
     out, = layers.run_grouped([(layer, spec, xt, None, None)], [stream])
-    (out * torch.from_numpy(w).to(dev)).sum().backward()
+    (out * torch.from_numpy(w[:n_seq]).to(dev)).sum().backward()
     torch.cuda.synchronize()
     return [out.detach().clone(), xt.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
 
   for a, b in zip(run(0), run(129)):
     assert torch.equal(a, b)
+  # 129-192 sequences: 48 per workgroup (gru_step_mid_kernel<3, 16, 8>, one round of 192 / 256
+  # workgroups that leave room for the other tower's) — bit-identical to both other shapes
+  for n_seq in (150, 192, 131):
+    ref = run(0, 0, n_seq)
+    for a, b, c in zip(ref, run(129, 1, n_seq), run(129, 0, n_seq)):
+      assert torch.equal(a, b) and torch.equal(a, c), n_seq
 
 
 @pytest.mark.gpu
@@ -757,6 +764,70 @@ def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, n_long, 
     grad_close(resident[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
     grad_close(resident[1].cpu().numpy(), dh0, pool + ' dh0')
     for (pn, _), got in zip(layer.named_parameters(), resident[2:]):
+      grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pool,cls,H,S,T', [('attention', 'Attention', 128, 70, 21), ('maxout', 'Maxout', 256, 150, 17),
+                                            ('seq2seq', 'Seq2Seq', 128, 300, 9), ('attention', 'Attention', 1024, 152, 23),
+                                            ('maxout', 'Maxout', 512, 256, 7)])
+def test_bptt_training_size_steps_as_resident_chain_kernel(dev, oracle, pool, cls, H, S, T, tune):
+  """The BPTT steps of a training-size batch (33-256 active sequences) inside resident kernels
+  (gru_bwd_chain_kernel: W_hh^T slices in LDS, two grid barriers per step, the gate-derivative rows
+  and the K-slice partials written through / read past the non-coherent L2s; a new run behind every
+  weight-gradient chunk) against two launches per step (bwd_chain_min_steps = 0): every gradient
+  equal to fp32 rounding (K is cut into 128-wide slices here, wider ones there), bitwise
+  reproducible run after run, and against the float64 oracle where that is cheap.  Shapes: 1 / 2 /
+  3 / 6 gate elements per thread (H = 1024 ... 128), ragged lengths so that the active count grows
+  through the range step by step, a batch that starts ABOVE the range (S = 300: the first steps
+  per-step launches, then the chain), one that also has a few-sequence tail (H = 128, S = 70), small
+  weight-gradient chunks so that a chain is cut into several runs, initial states."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(17 + H + S)
+  I = 24 if H < 1024 else 64
+  torch.manual_seed(4)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[:40] = T                                    # >= 40 sequences at every step ...
+  if S == 70:
+    lens[:] = rng.randint(1, 6, size=S)            # ... except here: a tail of 20, then 60-70 active
+    lens[:20] = T
+    lens[20:60] = rng.randint(8, 12, size=40)
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  w = rng.standard_normal((S, H)).astype(np.float32)
+
+  def run(min_steps, chunk_rows=512):
+    tune(bwd_chain_min_steps=min_steps, bwd_chunk_rows=chunk_rows)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    from cmhse_amd import _lib
+    assert _lib.load().cmhse_async_status(0) == 0
+    return [xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  per_step, chain, again = run(0), run(2), run(2)
+  for a, b, c in zip(per_step, chain, again):
+    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max()))
+    assert torch.equal(b, c), 'not reproducible from run to run'
+  one_run = run(2, chunk_rows=1 << 30)             # the whole chain as ONE run
+  for a, b in zip(chain, one_run):
+    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max()))
+  if H <= 256:
+    _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+    grads, dx, dh0 = oracle.pooled_gru_backward(cache, w.astype(np.float64))
+    grad_close(chain[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
+    grad_close(chain[1].cpu().numpy(), dh0, pool + ' dh0')
+    for (pn, _), got in zip(layer.named_parameters(), chain[2:]):
       grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
 
 

@@ -97,6 +97,50 @@ def main():
       h0, e0 = tr[0][1], tr[0][2]
       print('  ' + '  '.join('%s h%.2f g%.2f' % (n, (h - h0) * 1e3, e0.elapsed_time(e))
                              for n, h, e in tr))
+  if args.timeline >= 2:
+    # Steady state, NO synchronisation between steps (the host keeps its lead): GPU time of every
+    # phase mark relative to the step's first mark, mean over the steps.  Marks on the caller's
+    # stream (model._tick) are join points; marks [0] / [1] sit on the visual / text tower's stream.
+    from cmhse_amd import layers as layers_mod, model as model_mod
+    n = args.steps
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(32 * n)]
+    for ev in pool:
+      ev.record()
+    torch.cuda.synchronize()
+    trace = []
+
+    def mark(name, stream=None):
+      ev = pool.pop()
+      ev.record(stream) if stream is not None else ev.record()
+      trace.append((name, time.perf_counter(), ev))
+    model_mod._tick = lambda name: mark(name)
+    layers_mod.MARK = mark
+    t0 = time.perf_counter()
+    for b in wrap(use[6:]):
+      model.train_emb(opt, *b)
+    torch.cuda.synchronize()
+    layers_mod.MARK = None
+    dt2 = (time.perf_counter() - t0) / n
+    steps_tr, cur = [], None
+    for name, h, ev in trace:
+      if name == 'step:start':
+        cur = []
+        steps_tr.append(cur)
+      if cur is not None:
+        cur.append((name, h, ev))
+    names = [x[0] for x in steps_tr[-1]]
+    print('  steady state, %.2f ms per step (marks on): mean GPU ms after step:start [host ms]' % (dt2 * 1e3))
+    for k, nm in enumerate(names):
+      g = [st[0][2].elapsed_time(st[k][2]) for st in steps_tr[2:] if len(st) == len(names)]
+      h = [(st[k][1] - st[0][1]) * 1e3 for st in steps_tr[2:] if len(st) == len(names)]
+      if g:
+        print('    %-16s g %6.2f  h %6.2f' % (nm, sum(g) / len(g), sum(h) / len(h)))
+    # how far the host is ahead: GPU time of step k's start minus host time of its queueing, as lag
+    lag = []
+    for st in steps_tr[2:]:
+      lag.append(steps_tr[2][0][2].elapsed_time(st[0][2]) - (st[0][1] - steps_tr[2][0][1]) * 1e3)
+    print('    GPU start of a step lags its host queueing by (ms, relative to the first): ' +
+          ' '.join('%.1f' % v for v in lag))
   print(str(model.logger))
 
 
