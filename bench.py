@@ -218,19 +218,21 @@ def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3
     what = 'NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS threads'
   # thread count: the per-step GEMMs are small, so all host cores oversubscribe; calibrate on one
   # loader batch over two settings and keep the faster (that count is what `cores` reports)
+  with limit(counts[0]):
+    encode(data[:1])          # cold start (thread pools, first-touch) outside the calibration
   best_n, best_t = counts[0], None
   for n_thr in counts:
     with limit(n_thr):
       t0 = time.time()
-      encode(data[:1])
+      encode(data[:2])
       dt = time.time() - t0
     if best_t is None or dt < best_t:
       best_n, best_t = n_thr, dt
   enc_s, score_s = [], []
   with limit(best_n):
-    # warm-up: thread pools, allocator, caches — two loader batches through the whole path (a full
-    # pass more would double this leg's share of the default run for nothing)
-    res = encode(data[:2])
+    # warm-up: the calibration above ran the encoders; the scoring path once (a full warm-up pass
+    # would double this leg's share of the default run for nothing)
+    res = encode(data[:1])
     impl.i2t(res[0], res[1])
     for rep in range(repeats):
       t0 = time.time()
@@ -248,7 +250,7 @@ def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3
       'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': best_n,
       'kind': kind, 'host_cpu': _host_cpu_model(), 'host_logical_cpus': ncpu,
       'videos_per_s': nv / t_enc, 'passes': repeats,
-      'sample': ('%s = %d, the faster of {%s} on one loader batch of this %d-CPU host) on the first '
+      'sample': ('%s = %d, the faster of {%s} on two loader batches of this %d-CPU host) on the first '
                  '%d videos (%d loader batches) of the same split: a 2-batch warm-up, median of %d timed '
                  'passes: encode %.2f s, i2t+t2i %.3f s; extrapolated to N=%d with encode ~ N and '
                  'scoring ~ N^2' % (what, best_n, ','.join(str(c) for c in counts), ncpu, nv,
@@ -450,19 +452,21 @@ def train_bench(name, embed, rnn_type, n_steps, device):
   use = [batches[i % len(batches)] for i in range(n_steps)]
 
   def timed(loader_of):
-    """ms per step over `n_steps` steps of the loop `for b in loader_of(): train_emb(opt, *b)`
-    (what train.py:185-193 runs), after two untimed rounds."""
-    for _ in range(2):
-      for b in loader_of():
-        model.train_emb(opt, *b)
+    """ms per step over the LAST `n_steps` steps of ONE loop `for b in loader: train_emb(opt, *b)`
+    (what train.py:185-193 runs) over three rounds of the batches: the first two rounds are the
+    warm-up, and a loader that looks ahead (DevicePrefetcher) is in its steady state when the clock
+    starts — an epoch is hundreds of steps, not ten."""
+    it = iter(loader_of(3))
+    for _ in range(2 * n_steps):
+      model.train_emb(opt, *next(it))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for b in loader_of():
+    for b in it:
       model.train_emb(opt, *b)
     str(model.logger)          # a reader: the last step's loss values have reached the host meters
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n_steps
-  dt = timed(lambda: use)
+  dt = timed(lambda r: use * r)
   # PCIe-inclusive twins: the SAME steps fed from pinned host memory, as the reference's loader
   # hands batches over (activity_net/data.py:157-162 pin_memory=True; model.py:225-227 uploads inside
   # the step) — the padded 12-tuples of its own collate_fn, the larger of the two host forms
@@ -471,8 +475,8 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           for b in batches]
   host_use = [host[i % len(host)] for i in range(n_steps)]
   host_bytes = float(np.mean([sum(t.numel() * t.element_size() for t in b[:4]) for b in host_use]))
-  dt_prefetch = timed(lambda: collate.DevicePrefetcher(host_use, prepare=model.prepare_batch))
-  dt_pull = timed(lambda: host_use)
+  dt_prefetch = timed(lambda r: collate.DevicePrefetcher(host_use * r, prepare=model.prepare_batch))
+  dt_pull = timed(lambda r: host_use * r)
   work = [train_step_work(b, wl['img_dim'], embed, cfg['flags'], rnn_type == 'attention') for b in use]
   fwd = float(np.mean([w[0] for w in work]))
   bwd = float(np.mean([w[1] for w in work]))
@@ -628,9 +632,16 @@ def main():
                        '(PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--rank_check', type=int, default=1,
                   help='check HIP ranks on correlated embeddings against fp64 NumPy (0 = skip)')
-  ap.add_argument('--cpu_batches', type=int, default=16,
-                  help='loader batches in the torch-CPU baseline sample (16 x 32 = the 512-video subset '
-                       'of BASELINE.md section 3; the NumPy port beside it takes half of them; 0 = skip)')
+  ap.add_argument('--cpu_batches', type=int, default=8,
+                  help='loader batches in the sample of the two CPU baselines (default 8 x 32 = 256 videos, so '
+                       'that the default run stays near a minute; 16 = the 512-video subset of BASELINE.md '
+                       'section 3; 0 = skip)')
+  ap.add_argument('--pin_shapes', type=int, default=0,
+                  help='1: every GRU step on the LDS-tiled kernel whatever its active count (tiny_max_seqs = '
+                       'mid_max_seqs = 0) — the encoders are then bit-identical for ANY partition of the split, '
+                       'so ranks_crc32 of an N-rank run equals the single-process one exactly (by default a '
+                       "rank's share runs more of its steps on the small-batch kernels, whose sums are ordered "
+                       'differently: embeddings equal to fp32 rounding)')
   ap.add_argument('--cached_steps', type=int, default=5,
                   help='also time this many passes that reuse the level-1 schedules of a resident '
                        'split (evaluation.encode_group(plan=)); 0 = skip')
@@ -657,6 +668,9 @@ def main():
     else:
       dist.init_process_group('nccl', device_id=device)
 
+  if args.pin_shapes:
+    ops.tune('tiny_max_seqs', 0)
+    ops.tune('mid_max_seqs', 0)
   wl = dict(WORKLOADS[args.workload])
   if args.n_videos:
     wl['n_videos'] = args.n_videos
@@ -800,6 +814,7 @@ def main():
                    'schedule_cache': 'none: every timed pass rebuilds its packed schedules (sequence sort, '
                                      'step counts, pointer tables) as the reference does (layers.py:94-97); '
                                      '`cached_schedule_pass` times the opt-in that keeps them for a resident split',
+                   'pin_shapes': bool(args.pin_shapes),
                    'backend': ('single process' if world == 1 else
                                ('RCCL (nccl), one rank per GPU' if backend != 'gloo' else
                                 'gloo, %d ranks sharing %d GPU(s): functional run of the N-rank '
@@ -919,10 +934,9 @@ def main():
       leg('pcie_inclusive', pcie_leg)
     if world == 1 and args.cpu_batches > 0:
       # north_star's baseline: "the reference PyTorch CPU path" -> the torch-CPU restatement; the NumPy
-      # port (rounds 1-3's cpu_baseline) beside it on half the sample
+      # port (rounds 1-3's cpu_baseline) beside it on the same sample
       leg('cpu_baseline', lambda: cpu_baseline('torch-cpu', wl, opt, model, spec, args.cpu_batches, N))
-      leg('cpu_baseline_numpy', lambda: cpu_baseline('port', wl, opt, model, spec,
-                                                     max(1, args.cpu_batches // 2), N))
+      leg('cpu_baseline_numpy', lambda: cpu_baseline('port', wl, opt, model, spec, args.cpu_batches, N))
     print(json.dumps(out))
     sys.stdout.flush()
   if world > 1:

@@ -990,12 +990,11 @@ struct BwdChainParams {
   int32_t H, Tmax, t_hi, t_lo, n_tiles, splits;
 };
 
-// NE = phase B elements per thread (1 at H = 1024, 2 / 3 / 6 at H = 512 / 256 / 128).  Held to 128
-// registers: the workgroup then leaves half of its CU's register file (and 58 KB of its LDS) to the
-// kernels that run beside the chain — the other tower's steps, the weight-gradient products.
+// NE = phase B elements per thread (1 at H = 1024: 132 registers, so the workgroup leaves a wave
+// slot per SIMD and 58 KB of LDS to the kernels that run beside the chain; 2 / 3 / 6 at
+// H = 512 / 256 / 128).
 template <int NE>
-__global__ __launch_bounds__(kChainThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void gru_bwd_chain_kernel(const BwdChainParams q) {
+__global__ __launch_bounds__(kChainThreads) void gru_bwd_chain_kernel(const BwdChainParams q) {
   CHAIN_WAVE_PRIORITY();
   __shared__ __attribute__((aligned(16))) float Wl[kChainBN * kChainLd];
   __shared__ __attribute__((aligned(16))) float Al[2][kChainBM * kChainLd];

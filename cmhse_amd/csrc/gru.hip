@@ -1794,7 +1794,8 @@ unsigned step_grid(const FwdJob& j, int kind, int S_t) {
 int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool);
 
 // Rows of the input projection in front of a chunked chain / per later chunk (launch_steps)
-constexpr int64_t kXprojFirstRows = 512, kXprojChunkRows = 1536;
+constexpr int64_t kXprojFirstRows = 512;
+static int64_t xproj_chunk_rows() { return tunables().xproj_chunk_rows.load(std::memory_order_relaxed); }
 static void launch_fwd_tail(FwdJob& j, hipStream_t stream) {
   FwdTailParams q;
   q.p = j.p;
@@ -1928,7 +1929,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         // (event) for the chunk that holds its rows.  A GEMM of img_dim = 2048 rows is as long as
         // the whole 80-step chain it used to precede.
         const bool chunked = j.side_stream != nullptr && j.side_stream != stream && t == 0 &&
-                             j.t_mid == 0 && !j.p.gx_per_seq && j.sum_T >= 4 * kXprojChunkRows;
+                             j.t_mid == 0 && !j.p.gx_per_seq && xproj_chunk_rows() > 0 && j.sum_T >= 4 * xproj_chunk_rows();
         // the hoisted projection reads the inputs of the steps it covers: wait for their uploads
         // (cmhse_pull_steps chunks still in flight) — all remaining steps for the one-launch form,
         // chunk by chunk for the chunked one (a host-fed training step: the chain starts as soon as
@@ -1948,7 +1949,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
           int t0 = 0;
           for (int q = 0; q < j.b->Tmax; ++q) {
             row += j.b->step_count_host[q];
-            const int64_t want = (t0 == 0) ? kXprojFirstRows : kXprojChunkRows;
+            const int64_t want = (t0 == 0) ? kXprojFirstRows : xproj_chunk_rows();
             if (row - chunk_begin >= want || q == j.b->Tmax - 1) {
               if (t0 == 0) {
                 wait_uploads(stream, 1, q + 1);
@@ -2279,7 +2280,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
       {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs}, {"mid_tall_rows48", &t.mid_tall_rows48},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"xproj_chunk_rows", &t.xproj_chunk_rows},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

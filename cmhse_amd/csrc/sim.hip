@@ -58,9 +58,37 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
 // small matrices of the training losses (n = 32 ... ~130: ONE 128 x 128 workgroup there is a
 // 62 us MFMA chain per wave, four to nine 64 x 64 workgroups run it in a quarter of that).  Same k
 // order per output: bit-identical.
+#ifdef TILE_TRACE_BUILD
+// Timing-only debug build (tools/tile_trace.py --sim): per-workgroup stamps of the counting pass —
+// [0] first instruction, [1] K loop start, [3] K loop end, [4] epilogue done (s_memrealtime, 10 ns);
+// [5] / [7] s_memtime at [1] / [3]; [6] HW_ID | XCC_ID << 32.
+__device__ uint64_t* g_sim_trace = nullptr;
+#define SIM_MARK(i)                                                                                     \
+  do {                                                                                                  \
+    if (MODE == kSimRank && threadIdx.x == 0 && g_sim_trace)                                            \
+      g_sim_trace[static_cast<size_t>(blockIdx.x) * 8 + (i)] = wall_clock64();                          \
+  } while (0)
+#define SIM_CLOCK(i)                                                                                    \
+  do {                                                                                                  \
+    if (MODE == kSimRank && threadIdx.x == 0 && g_sim_trace)                                            \
+      g_sim_trace[static_cast<size_t>(blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();            \
+  } while (0)
+#else
+#define SIM_MARK(i) do {} while (0)
+#define SIM_CLOCK(i) do {} while (0)
+#endif
+
 template <int MODE, bool VEC, int TS = 2>
 __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
   constexpr int BM = 64 * TS, BN = 64 * TS;
+  SIM_MARK(0);
+#ifdef TILE_TRACE_BUILD
+  if (MODE == kSimRank && threadIdx.x == 0 && g_sim_trace) {
+    g_sim_trace[static_cast<size_t>(blockIdx.x) * 8 + 6] =
+        static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+        (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
+  }
+#endif
   SimParams p = p_;
   if (p.blk_off != nullptr) {
     const int off = p.blk_off[blockIdx.y];
@@ -125,7 +153,11 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
   int b_row0[TS];
 #pragma unroll
   for (int ns = 0; ns < TS; ++ns) b_row0[ns] = wn * 32 * TS + 32 * ns;
+  SIM_MARK(1);
+  SIM_CLOCK(5);
   nt_phase<BM, BN, TS, TS, TS, TS - 1, VEC>(smem, ar, av, br, bv, p.D, wm * 32 * TS, b_row0, acc);
+  SIM_MARK(3);
+  SIM_CLOCK(7);
 
 #pragma unroll
   for (int ms = 0; ms < TS; ++ms) {
@@ -176,6 +208,10 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
       }
     }
   }
+#ifdef TILE_TRACE_BUILD
+  __builtin_amdgcn_s_waitcnt(0);
+  SIM_MARK(4);
+#endif
 }
 
 __global__ void top1_finalize_kernel(const unsigned long long* key, int32_t* top1, int n) {
@@ -722,6 +758,12 @@ extern "C" int cmhse_groupwise_fwd(const float* im, const float* s, int32_t n, i
   hipLaunchKernelGGL(contrastive_final_kernel, dim3(1), dim3(64), 0, stream, lp);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
+
+#ifdef TILE_TRACE_BUILD
+extern "C" int cmhse_debug_set_sim_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(cmhse::g_sim_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" const char* cmhse_strerror(int code) {
   switch (code) {

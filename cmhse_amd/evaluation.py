@@ -93,6 +93,19 @@ class LogCollector(object):
   def __str__(self):
     return '  '.join('%s %s' % (k, m) for k, m in self.meters.items())
 
+  # A collector that still holds late values (closures over device events) cannot be pickled or
+  # deep-copied as it is: both first settle what is outstanding, so the copy carries plain meters.
+  def __getstate__(self):
+    self.settle()
+    return {'_meters': self._meters, '_deferred': []}
+
+  def __deepcopy__(self, memo):
+    import copy
+    self.settle()
+    other = LogCollector()
+    other._meters = copy.deepcopy(self._meters, memo)
+    return other
+
   def tb_log(self, tb_logger, prefix='', step=None):
     for k, m in self.meters.items():
       tb_logger.log_value(prefix + k, m.val, step=step)

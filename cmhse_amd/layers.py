@@ -262,6 +262,8 @@ class _TowersFn(torch.autograd.Function):
                                      req['h0_ptrs'])
       reqs2.append(req)
       svs2.append(sv)
+    if MARK is not None:
+      MARK('fwd:queued', None)     # on the caller's stream: everything in front of the first chain launch
     res1 = ops.gru_pool_fwd_multi(reqs1, job_streams=streams, join=False, hold=hold)
     _mark('fwd:level1', streams)
     for i in range(len(meta)):

@@ -318,6 +318,15 @@ def test_log_collector_replays_late_values_in_order():
   b.defer(lambda: b._update('Le_vid', 6.0, 4))
   tb = Tb(); b.tb_log(tb, prefix='t/', step=7)
   assert ('t/Le_vid', 6.0, 7) in tb.got
+  # a collector with values still outstanding can be pickled / deep-copied: both settle first
+  import copy
+  import pickle
+  b.defer(lambda: b._update('Le_vid', 8.0, 4))
+  c = copy.deepcopy(b)
+  assert c.meters['Le_vid'].val == 8.0 and not b._deferred
+  b.defer(lambda: b._update('Le_vid', 10.0, 4))
+  d = pickle.loads(pickle.dumps(b))
+  assert d.meters['Le_vid'].val == 10.0 and str(d) == str(b)
 
 
 def test_plan_key_sees_every_batch():

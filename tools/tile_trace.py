@@ -17,6 +17,70 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def sim_trace(lib, dev, N, D=1024):
+  """--sim [N]: the counting pass of the ranking kernel (sim_kernel<Rank>, 128 x 128 tiles, K = D) on
+  synthetic.correlated_embeddings(N, D): where a tile's time goes, the clock it runs at, how many
+  workgroups share a CU — the explanation of roofline_sim.frac."""
+  import torch
+  from cmhse_amd import ops, synthetic
+  lib.cmhse_debug_set_sim_trace.restype = ctypes.c_int
+  lib.cmhse_debug_set_sim_trace.argtypes = [ctypes.c_void_p]
+  a, b = synthetic.correlated_embeddings(N, D, 3.0, seed=0)
+  ad, bd = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+  n_tiles = (N + 127) // 128
+  n_wg = 8 * ((n_tiles * n_tiles * 2 + 7) // 8) + 64       # the grouped deal pads the grid
+  trace = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
+  for it in range(4):
+    if it == 3:
+      assert lib.cmhse_debug_set_sim_trace(trace.data_ptr()) == 0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ops.sim_rank(ad, bd)
+    ev1.record()
+    torch.cuda.synchronize()
+  lib.cmhse_debug_set_sim_trace(None)
+  tr = trace.cpu().numpy().reshape(n_wg, 8)
+  tr = tr[tr[:, 4] != 0]
+  t = tr[:, [0, 1, 3, 4]].astype(np.float64) * 0.01
+  t -= t[:, 0].min()
+  clk = (tr[:, 7] - tr[:, 5]) / ((tr[:, 3] - tr[:, 1]) * 10.0)
+  hw, xcc = tr[:, 6] & 0xffffffff, (tr[:, 6] >> 32) & 0xf
+  cu_key = xcc * 1000 + ((hw >> 13) & 0x7) * 100 + ((hw >> 12) & 0x1) * 16 + ((hw >> 8) & 0xf)
+  keys = np.unique(cu_key)
+  span = t[:, 3].max()
+  flop_tile = 2.0 * 128 * 128 * D
+  mfma_us = flop_tile / (157.3e12 / 256) * 1e6
+  print('sim_kernel<Rank>  N=%d D=%d: %d tiles that ran, %d distinct CUs, call (diag + counting pass + finalize) %.1f us by events'
+        % (N, D, len(tr), len(keys), ev0.elapsed_time(ev1) * 1e3))
+  print('counting-pass span %.1f us; algorithmic %.1f GFLOP -> %.1f TFLOP/s over the span' %
+        (span, 2.0 * N * N * D / 1e9, 2.0 * N * N * D / span / 1e6))
+  for nme, d in [('first instr -> K loop', t[:, 1] - t[:, 0]), ('K loop (D = %d)' % D, t[:, 2] - t[:, 1]),
+                 ('epilogue (count / arg-max / atomics)', t[:, 3] - t[:, 2]), ('whole tile', t[:, 3] - t[:, 0])]:
+    print('%-38s mean %7.2f us   p10 %7.2f   p50 %7.2f   p90 %7.2f' % (nme, d.mean(), *np.percentile(d, [10, 50, 90])))
+  print('MFMA-only time of one 128 x 128 x %d tile on one CU at peak: %.2f us' % (D, mfma_us))
+  print('in-kernel shader clock over the K loops: median %.3f GHz (p10 %.3f, p90 %.3f)'
+        % (np.median(clk), *np.percentile(clk, [10, 90])))
+  per_cu = np.array([np.sum(cu_key == k) for k in keys])
+  print('tiles per CU: min %d mean %.2f max %d (a perfectly even deal: %.2f)' %
+        (per_cu.min(), per_cu.mean(), per_cu.max(), len(tr) / 256.0))
+  grid = np.linspace(0, span, 2000)
+  resident = np.zeros_like(grid)
+  inloop = np.zeros_like(grid)
+  for a_, b_, c_, d_ in t:
+    resident += (grid >= a_) & (grid < d_)
+    inloop += (grid >= b_) & (grid < c_)
+  print('workgroups resident per CU over the span: mean %.2f; inside their K loops: mean %.2f' %
+        (resident.mean() / len(keys), inloop.mean() / len(keys)))
+  for frac in (0.1, 0.3, 0.5, 0.7, 0.9, 0.97):
+    i = int(frac * (len(grid) - 1))
+    print('  at %3.0f %% of the span: resident/CU %.2f  in-loop/CU %.2f' % (100 * frac, resident[i] / len(keys), inloop[i] / len(keys)))
+  last_end = np.array([t[cu_key == k, 3].max() for k in keys])
+  print('per-CU last end: min %.1f mean %.1f max %.1f us' % (last_end.min(), last_end.mean(), last_end.max()))
+  loop = t[:, 2] - t[:, 1]
+  print('share of a tile\'s time outside its K loop: %.1f %%; K loop at the MFMA rate of the measured clock would take %.1f us'
+        % (100.0 * (1.0 - loop.sum() / (t[:, 3] - t[:, 0]).sum()), mfma_us * 2.4 / np.median(clk)))
+
+
 def main():
   argv = [a for a in sys.argv[1:] if not a.startswith('--')]
   S = int(argv[0]) if len(argv) > 0 else 22419
@@ -44,6 +108,8 @@ def main():
   lib.cmhse_debug_set_trace.argtypes = [ctypes.c_void_p]
   _lib._lib = lib   # route ops through the trace build for this process only
   dev = torch.device('cuda', 0)
+  if '--sim' in sys.argv:
+    return sim_trace(lib, dev, int(argv[0]) if argv else 4917)
   T = 2
   x = torch.randn(S, T, I, device=dev)
   scale = float(os.environ.get('TRACE_DATA_SCALE', '1'))   # 0: all-zero operands (clock ceiling check)
