@@ -56,516 +56,21 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+sys.path.insert(0, os.path.join(REPO, 'tools'))
+
 from cmhse_amd import ops, parallel_eval, synthetic  # noqa: E402
 from cmhse_amd.evaluation import encode_data_device  # noqa: E402
 from cmhse_amd.model import VSE  # noqa: E402
-
-WORKLOADS = {
-    'anet_c3d_val': dict(n_videos=4917, batch=32, img_dim=500, feat='normal', vocab=13058,
-                         dataset='anet'),
-    'anet_icep_val': dict(n_videos=4917, batch=32, img_dim=2048, feat='relu', vocab=13058,
-                          dataset='anet'),
-    'didemo_icep_val': dict(n_videos=1004, batch=32, img_dim=2048, feat='relu', vocab=7205,
-                            dataset='didemo'),
-    'plumbing': dict(n_videos=64, batch=16, img_dim=500, feat='normal', vocab=13058,
-                     dataset='uniform'),
-}
-FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
-
-
-def make_opt(wl, rnn_type, embed):
-  return argparse.Namespace(
-      margin=0.2, word_dim=300, embed_size=embed, grad_clip=0.0, learning_rate=0.001,
-      max_violation=False, img_dim=wl['img_dim'], measure='cosine', rnn_type=rnn_type,
-      img_first_size=embed, cap_first_size=embed, low_level_loss=False, weak_low_level_loss=False,
-      reconstruct_loss=False, lowest_reconstruct_loss=False, norm=False,
-      data_name='anet_precomp', vocab_size=wl['vocab'])
-
-
-def device_batch(spec, b0, b1, clip_pos, img_dim, vocab, feat, gen, device):
-  """One loader batch of the 12-tuple contract, generated directly in HBM."""
-  nclips = spec.num_clips[b0:b1]
-  sumC = sum(nclips)
-  fpc = torch.tensor(spec.frames_per_clip[clip_pos:clip_pos + sumC], dtype=torch.int64)
-  wps = torch.tensor(spec.words_per_sent[clip_pos:clip_pos + sumC], dtype=torch.int64)
-  fpv = torch.tensor(spec.frames_per_video[b0:b1], dtype=torch.int64)
-  B = b1 - b0
-
-  def feats(lens):
-    T = int(lens.max())
-    x = torch.randn(len(lens), T, img_dim, generator=gen, device=device)
-    if feat == 'relu':
-      x = (0.5 * x).abs_()
-    mask = torch.arange(T, device=device)[None, :] < lens.to(device)[:, None]
-    return x * mask[:, :, None]
-
-  clips, videos = feats(fpc), feats(fpv)
-  Lc = int(wps.max())
-  caps = torch.randint(4, vocab, (sumC, Lc), generator=gen, device=device)
-  caps = caps * (torch.arange(Lc, device=device)[None, :] < wps.to(device)[:, None])
-  starts = np.concatenate([[0], np.cumsum(nclips)])
-  par_len = torch.tensor([int(wps[starts[v]:starts[v + 1]].sum()) for v in range(B)],
-                         dtype=torch.int64)
-  pars = torch.zeros(B, int(par_len.max()), dtype=torch.int64, device=device)
-  caps_h, wps_l = caps.cpu(), wps.tolist()
-  for v in range(B):
-    toks = torch.cat([caps_h[j, :wps_l[j]] for j in range(starts[v], starts[v + 1])])
-    pars[v, :len(toks)] = toks.to(device)
-  return (clips, caps, videos, pars, fpc, wps, fpv, par_len, tuple(nclips), tuple(nclips),
-          tuple(range(b0, b1)), tuple('v_%06d' % k for k in range(b0, b1)))
-
-
-def build_loader(spec, wl, device, own_lo, own_hi=None, seed=0):
-  """All loader batches of the split; only the batches this rank owns — [own_lo, own_hi), or the
-  index collection `own_lo` when `own_hi` is None — are materialised (the others carry just
-  num_clips, which is all parallel_eval needs from them)."""
-  own = set(range(own_lo, own_hi)) if own_hi is not None else set(own_lo)
-  gen = torch.Generator(device=device)
-  batches, clip_pos = [], 0
-  n, bs = spec.n_videos, wl['batch']
-  for bi, b0 in enumerate(range(0, n, bs)):
-    b1 = min(n, b0 + bs)
-    nclips = spec.num_clips[b0:b1]
-    if bi in own:
-      gen.manual_seed(seed * 100003 + bi)
-      batches.append(device_batch(spec, b0, b1, clip_pos, wl['img_dim'], wl['vocab'], wl['feat'],
-                                  gen, device))
-    else:
-      stub = [None] * 12
-      stub[8] = tuple(nclips)
-      batches.append(tuple(stub))
-    clip_pos += sum(nclips)
-  return batches
-
+# workloads / synthetic loader batches (tools/bench_common.py) and the supplementary legs
+# (tools/bench_legs.py); re-exported here because the tools and the full-size tests import them from bench
+from bench_common import (BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS, WORKLOADS, build_loader,  # noqa: E402,F401
+                          device_batch, gru_flops_per_step, make_opt)
+from bench_legs import (TRAIN_CONFIGS, cpu_baseline, fast_mode_bench, measured_clock_ghz,  # noqa: E402,F401
+                        measured_step_latency_us, measured_traffic, rank_check, train_bench,
+                        train_step_work)
 
 def costs_sum(costs, idx):
   return float(sum(costs[i][0] for i in idx))
-
-
-def gru_flops_per_step(I, H):
-  """algorithmic FLOPs of one GRU (sequence, timestep)."""
-  return 2 * 3 * H * I + 2 * 3 * H * H + 14 * H
-
-
-def _host_cpu_model():
-  try:
-    for line in open('/proc/cpuinfo'):
-      if line.startswith('model name'):
-        return line.split(':', 1)[1].strip()
-  except OSError:
-    pass
-  return ''
-
-
-_CPU_SAMPLE = {}
-
-
-def cpu_sample(wl, spec, n_batches):
-  """The first `n_batches` loader batches of the split as host 12-tuples (generated once, shared by
-  the two CPU legs)."""
-  key = (wl['img_dim'], wl['vocab'], wl['batch'], n_batches)
-  if key not in _CPU_SAMPLE:
-    sub = synthetic.SplitSpec(spec.num_clips, spec.frames_per_clip, spec.frames_per_video,
-                              spec.words_per_sent)
-    nv = min(spec.n_videos, n_batches * wl['batch'])
-    sub.num_clips = sub.num_clips[:nv]
-    nc = sum(sub.num_clips)
-    sub.frames_per_clip = sub.frames_per_clip[:nc]
-    sub.words_per_sent = sub.words_per_sent[:nc]
-    sub.frames_per_video = sub.frames_per_video[:nv]
-    _CPU_SAMPLE[key] = synthetic.make_batches(sub, wl['batch'], wl['img_dim'], wl['vocab'], seed=0,
-                                              feat=wl['feat'])
-  return _CPU_SAMPLE[key]
-
-
-def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3):
-  """The CPU restatements of the path on this host's cores over the first `n_sample_batches`
-  loader batches (a 512-video subset, one warm-up pass, median of >= 3 timed
-  passes, scaled encode ~ N and scoring ~ N^2).
-    kind 'torch-cpu'  oracle/cmhse_torch_cpu.py: nn.GRU over pack_padded_sequence + the pooling on
-                      CPU tensors, one loader batch at a time — the stand-in for "the reference
-                      PyTorch CPU path" north_star names (layers.py:75-79,93-119);
-    kind 'port'       oracle/cmhse_oracle.py: the NumPy oracle (OpenBLAS)."""
-  sys.path.insert(0, os.path.join(REPO, 'oracle'))
-  nv = min(spec.n_videos, n_sample_batches * wl['batch'])
-  batches = cpu_sample(wl, spec, max(n_sample_batches, 16))[:n_sample_batches]
-  sds = [{k: v.detach().cpu().numpy() for k, v in sd.items()} for sd in model.state_dict(opt)]
-  ncpu = os.cpu_count() or 1
-  counts = sorted({min(ncpu, c) for c in (16, 32)})
-  if kind == 'torch-cpu':
-    import cmhse_torch_cpu as impl
-    cpu_model = impl.Model(opt.rnn_type, sds)
-    data = batches
-    encode = lambda bs: impl.encode_data(opt.rnn_type, sds, bs, margin=opt.margin, model=cpu_model)
-    old_threads = torch.get_num_threads()
-
-    class limit(object):
-      def __init__(self, n):
-        self.n = n
-
-      def __enter__(self):
-        torch.set_num_threads(self.n)
-
-      def __exit__(self, *a):
-        torch.set_num_threads(old_threads)
-    what = 'torch CPU restatement (oracle/cmhse_torch_cpu.py: nn.GRU + pack_padded_sequence, torch.set_num_threads'
-  else:
-    import cmhse_oracle as impl
-    from threadpoolctl import threadpool_limits
-    data = [tuple(x.numpy() if hasattr(x, 'numpy') else x for x in b) for b in batches]
-    encode = lambda bs: impl.encode_data(opt.rnn_type, sds, bs, margin=opt.margin)
-    limit = lambda n: threadpool_limits(limits=n)
-    what = 'NumPy oracle (oracle/cmhse_oracle.py, OpenBLAS threads'
-  # thread count: the per-step GEMMs are small, so all host cores oversubscribe; calibrate on one
-  # loader batch over two settings and keep the faster (that count is what `cores` reports)
-  with limit(counts[0]):
-    encode(data[:1])          # cold start (thread pools, first-touch) outside the calibration
-  best_n, best_t = counts[0], None
-  for n_thr in counts:
-    with limit(n_thr):
-      t0 = time.time()
-      encode(data[:2])
-      dt = time.time() - t0
-    if best_t is None or dt < best_t:
-      best_n, best_t = n_thr, dt
-  enc_s, score_s = [], []
-  with limit(best_n):
-    # warm-up: the calibration above ran the encoders; the scoring path once (a full warm-up pass
-    # would double this leg's share of the default run for nothing)
-    res = encode(data[:1])
-    impl.i2t(res[0], res[1])
-    for rep in range(repeats):
-      t0 = time.time()
-      res = encode(data)
-      t1 = time.time()
-      impl.i2t(res[0], res[1])
-      impl.t2i(res[0], res[1])
-      t2 = time.time()
-      enc_s.append(t1 - t0)
-      score_s.append(t2 - t1)
-  t_enc, t_score = float(np.median(enc_s)), float(np.median(score_s))
-  scale = n_full / float(nv)
-  t_full = t_enc * scale + t_score * scale * scale
-  return {
-      'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': best_n,
-      'kind': kind, 'host_cpu': _host_cpu_model(), 'host_logical_cpus': ncpu,
-      'videos_per_s': nv / t_enc, 'passes': repeats,
-      'sample': ('%s = %d, the faster of {%s} on two loader batches of this %d-CPU host) on the first '
-                 '%d videos (%d loader batches) of the same split: a 2-batch warm-up, median of %d timed '
-                 'passes: encode %.2f s, i2t+t2i %.3f s; extrapolated to N=%d with encode ~ N and '
-                 'scoring ~ N^2' % (what, best_n, ','.join(str(c) for c in counts), ncpu, nv,
-                                    len(batches), repeats, t_enc, t_score, n_full)),
-  }
-
-
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
-
-
-def fast_mode_bench(opt, model, batches, N, n_steps):
-  """Supplementary: the same validation pass with CMHSE_MATH_BF16X3 (3-term bf16 hi/lo split on
-  the bf16 matrix pipe, fp32 accumulate, for the large encoder GEMMs; ranking stays exact fp32),
-  with its measured deviation from the exact-fp32 embeddings and ranks, and its own roofline: the
-  tiled step kernel's algorithmic FLOPs over its HIP-event time against the bf16 MFMA peak / 3
-  (three MFMAs per product).  Never the headline `value`."""
-  quiet = lambda *a, **k: None
-
-  def one_pass():
-    cat, _, _ = encode_data_device(opt, model, batches, logging=quiet)
-    r_i, _ = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
-    r_t, _ = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
-    return cat, r_i, r_t
-
-  ref_cat, ref_i, ref_t = one_pass()          # exact fp32
-  try:
-    ops.set_math_mode('bf16x3')
-    with ops.StepTimers() as wt:
-      one_pass()
-      torch.cuda.synchronize()
-    wt.collect()
-    t0 = time.perf_counter()
-    with ops.StepTimers() as timers:
-      for _ in range(n_steps):
-        cat, r_i, r_t = one_pass()
-      torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n_steps
-    spans = timers.collect()
-  finally:
-    ops.set_math_mode('fp32')
-  ms = sum(s[3][0] for s in spans)
-  flops = sum(s[3][1] for s in spans)
-  launches = sum(s[3][3] for s in spans)
-  achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-  peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-  diff = max(float((cat[k] - ref_cat[k]).abs().max()) for k in ['vid_emb', 'para_emb', 'clip_emb',
-                                                                 'cap_emb', 'vid_ctx', 'para_ctx'])
-  moved = int((r_i != ref_i).sum()) + int((r_t != ref_t).sum())
-  # ranks of a trained model's embeddings: the same perturbation applied to SURVEY S5's correlated
-  # embeddings (R@1 ~ 33 %): re-rank normalize(a + (bf16x3 - fp32 deviation of the video rows)),
-  # which shows whether a 1e-6 deviation moves any rank where the scores are spread like a real
-  # model's (with random-init encoders on random inputs all scores sit within ~1e-3 of each other)
-  a, b = synthetic.correlated_embeddings(N, cat['vid_emb'].shape[1], 3.0, seed=0)
-  ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
-  dev_v = cat['vid_emb'] - ref_cat['vid_emb']
-  dev_p = cat['para_emb'] - ref_cat['para_emb']
-  base_i, _ = ops.sim_rank(ad, bd)
-  base_t, _ = ops.sim_rank(bd, ad)
-  pert_i, _ = ops.sim_rank(ops.l2norm_rows(ad + dev_v), ops.l2norm_rows(bd + dev_p))
-  pert_t, _ = ops.sim_rank(ops.l2norm_rows(bd + dev_p), ops.l2norm_rows(ad + dev_v))
-  moved_corr = int((pert_i != base_i).sum()) + int((pert_t != base_t).sum())
-  return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
-                  'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
-                  'attention projection); ranking kernel exact fp32',
-          'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
-          'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
-          'rank_rows_moved_vs_fp32_random_init': moved, 'rank_rows_total': 2 * N,
-          'rank_rows_moved_on_correlated_embeddings': moved_corr,
-          'roofline': {'kernel': 'gru_step_kernel<bf16x3>', 'bound': 'mfma', 'achieved': achieved,
-                       'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent products)',
-                       'frac': achieved / peak, 'launches': launches,
-                       'avg_launch_us': (ms * 1e3 / launches) if launches else None,
-                       'kernel_time_share': (ms * 1e-3) / (dt * n_steps) if dt > 0 else None,
-                       'note': 'peak = dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product'}}
-
-
-def rank_check(N, D, n_sample=256, seed=0):
-  """In-run correctness signal: HIP ranks (both directions) on SURVEY §8d S5's scoring inputs
-  (normalize(z + 3 eps) pairs: R@1 ~ 33 %, a non-trivial rank distribution) against an fp64
-  recomputation of `n_sample` rows, rank_i = #{j : d_ij > d_ii} (evaluation.py:164-171)."""
-  a, b = synthetic.correlated_embeddings(N, D, 3.0, seed=seed)
-  ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
-  rows = np.random.RandomState(seed).choice(N, min(n_sample, N), replace=False)
-  a64, b64 = a.astype(np.float64), b.astype(np.float64)
-  mism, r1 = 0, None
-  for q, g, q64, g64 in [(ad, bd, a64, b64), (bd, ad, b64, a64)]:
-    rank, top1 = ops.sim_rank(q, g)
-    rank, top1 = rank.cpu().numpy(), top1.cpu().numpy()
-    d = q64[rows] @ g64.T
-    dii = d[np.arange(len(rows)), rows]
-    want = (d > dii[:, None]).sum(1)
-    mism += int((rank[rows] != want).sum()) + int((top1[rows] != d.argmax(1)).sum())
-    if r1 is None:
-      r1 = 100.0 * float((rank < 1).mean())
-  return {'rows': int(len(rows)) * 2, 'mismatches': mism, 'r1_i2t': r1,
-          'inputs': 'synthetic.correlated_embeddings(%d, %d, 3.0), both directions, ranks and '
-                    'top-1 vs fp64 NumPy' % (N, D)}
-
-
-TRAIN_CONFIGS = {
-    # BASELINE configs[1]: README "HSE tau=0 on ActivityNet with C3D": --low_level_loss --norm
-    'anet_c3d_tau0': dict(img_dim=500, feat='normal', vocab=13058, dataset='anet',
-                          flags=dict(low_level_loss=True, norm=True),
-                          baseline='configs[1]: ActivityNet C3D (img_dim=500, embed=1024) HSE tau=0, batch 32'),
-    # the metric's model (ICEP dims) with configs[1]'s losses: round 2's train_step leg, kept for continuity
-    'anet_icep_tau0': dict(img_dim=2048, feat='relu', vocab=13058, dataset='anet',
-                           flags=dict(low_level_loss=True, norm=True),
-                           baseline='ICEP dims with configs[1] losses (no reconstruction)'),
-    # BASELINE configs[2]
-    'anet_icep_recon': dict(img_dim=2048, feat='relu', vocab=13058, dataset='anet',
-                            flags=dict(low_level_loss=True, norm=True, reconstruct_loss=True,
-                                       weight_recon=5e-4),
-                            baseline='configs[2]: ActivityNet ICEP HSE tau=5e-4 --low_level_loss '
-                                     '--reconstruct_loss --norm, batch 32'),
-    # BASELINE configs[3]: DiDeMo ICEP, tau = 5e-4 (same flags as configs[2]; all-80-frame clips,
-    # short sentences, vocab 7205)
-    'didemo_icep_recon': dict(img_dim=2048, feat='relu', vocab=7205, dataset='didemo',
-                              flags=dict(low_level_loss=True, norm=True, reconstruct_loss=True,
-                                         weight_recon=5e-4),
-                              baseline='configs[3]: DiDeMo ICEP HSE tau=5e-4, batch 32'),
-}
-
-
-def train_step_work(batch, img_dim, H, flags, attention, word_dim=300):
-  """Algorithmic FLOPs of one VSE.train_emb step on `batch` (model.py:309-369) and the number of
-  DEPENDENT GRU steps on its longest tower (each a kernel launch that cannot start before the
-  previous one has finished: the latency floor of a small-batch step).
-
-  Per packed (sequence, step) row of an encoder with input width I:
-    forward   2*3H*(I+H) + 14H            (+ 2H^2 + 6H for the attention projection)
-    backward  2*3H*H   dh_{t-1} = dGh . W_hh               (the BPTT chain)
-              2*3H*I   dW_ih += dGx^T x,   2*3H*H  dW_hh += dGh^T h_{t-1}
-              2*3H*I   dx = dGx . W_ih     (only where the input needs a gradient: level 2, the
-                                            word-embedding table, the decoders)
-              4H^2     attention: dW_lin += du^T h and dpool += du . W_lin
-  A decoder's input is constant over its steps (model.py:261-265): its input projection and dx are
-  counted once per SEQUENCE."""
-  lc, lw, lv, lp = (np.asarray(batch[i]) for i in (4, 5, 6, 7))
-  n_clips, B = len(lc), len(lv)
-  att = (2.0 * H * H + 6.0 * H) if attention else 0.0
-  att_b = 4.0 * H * H if attention else 0.0
-
-  def enc(rows, I, need_dx, seqs=None):
-    if seqs is None:    # ordinary input
-      fwd = rows * (6.0 * H * (I + H) + 14.0 * H + att)
-      bwd = rows * (6.0 * H * H + 6.0 * H * I + 6.0 * H * H + (6.0 * H * I if need_dx else 0.0) + att_b)
-    else:               # time-constant input: projection / dW_ih / dx once per sequence
-      fwd = rows * (6.0 * H * H + 14.0 * H) + seqs * 6.0 * H * I
-      bwd = rows * (12.0 * H * H) + seqs * 12.0 * H * I
-    return fwd, bwd
-  parts = [enc(float(lc.sum() + lv.sum()), img_dim, False),        # clip_enc on clips + whole videos
-           enc(float(lw.sum() + lp.sum()), word_dim, True),        # txt_enc (+ d embedding table)
-           enc(float(n_clips), H, True), enc(float(n_clips), H, True)]   # level 2, h0 = context
-  vis_chain = int(max(lc.max(), lv.max())) + int(max(batch[8]))
-  txt_chain = int(max(lw.max(), lp.max())) + int(max(batch[9]))
-  if flags.get('reconstruct_loss'):
-    attention_saved, att, att_b = att, 0.0, 0.0                      # decoders pool nothing
-    parts += [enc(float(n_clips), H, True, seqs=B), enc(float(n_clips), H, True, seqs=B)]
-    att = attention_saved
-    vis_chain += int(max(batch[8]))
-    txt_chain += int(max(batch[9]))
-  fwd = sum(p[0] for p in parts)
-  bwd = sum(p[1] for p in parts)
-  return fwd, bwd, 2 * max(vis_chain, txt_chain)      # forward + backward launches of that tower
-
-
-def train_bench(name, embed, rnn_type, n_steps, device):
-  """One BASELINE training configuration as driver-timed VSE.train_emb steps (model.py:309-369:
-  forward, 4-7 contrastive (+2 reconstruction) losses, backward, Adam) on batch-32 loader batches
-  of an ActivityNet- / DiDeMo-shaped split — forward and backward on the HIP path.  Priced with
-  the step's algorithmic FLOPs against the exact-fp32 MFMA peak and with its dependent-step count."""
-  from cmhse_amd.evaluation import LogCollector
-  cfg = TRAIN_CONFIGS[name]
-  wl = dict(batch=32, img_dim=cfg['img_dim'], vocab=cfg['vocab'], feat=cfg['feat'])
-  opt = make_opt(wl, rnn_type, embed)
-  for k, v in cfg['flags'].items():
-    setattr(opt, k, v)
-  torch.manual_seed(1)
-  model = VSE(opt)
-  model.logger = LogCollector()
-  model.train_start(opt)
-  # the first loader batches of the same val-shaped split the validation pass runs on (round 2's
-  # train_step leg used exactly these, so the figures compare across rounds)
-  spec = synthetic.anet_like_spec(1004 if cfg['dataset'] == 'didemo' else 4917, seed=0,
-                                  dataset=cfg['dataset'])
-  gen = torch.Generator(device=device)
-  batches, clip_pos = [], 0
-  n_batches = max(1, min(n_steps, 10))
-  for bi, b0 in enumerate(range(0, n_batches * wl['batch'], wl['batch'])):
-    gen.manual_seed(bi)       # (build_loader's seeding: the same batches as the validation split's)
-    b1 = min(spec.n_videos, b0 + wl['batch'])
-    batches.append(device_batch(spec, b0, b1, clip_pos, wl['img_dim'], wl['vocab'], wl['feat'], gen,
-                                device))
-    clip_pos += sum(spec.num_clips[b0:b1])
-  # steady state: every batch shape of the timed steps has been seen once (the caching allocator
-  # and the event pools grow on first sight of a shape — tens of ms that belong to start-up)
-  # (two warm-up rounds: building the model left the GPU idle for a second, and a round of ten
-  # steps is too short to bring it back to its working clocks)
-  use = [batches[i % len(batches)] for i in range(n_steps)]
-
-  def timed(loader_of):
-    """ms per step over the LAST `n_steps` steps of ONE loop `for b in loader: train_emb(opt, *b)`
-    (what train.py:185-193 runs) over three rounds of the batches: the first two rounds are the
-    warm-up, and a loader that looks ahead (DevicePrefetcher) is in its steady state when the clock
-    starts — an epoch is hundreds of steps, not ten."""
-    it = iter(loader_of(3))
-    for _ in range(2 * n_steps):
-      model.train_emb(opt, *next(it))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in it:
-      model.train_emb(opt, *b)
-    str(model.logger)          # a reader: the last step's loss values have reached the host meters
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n_steps
-  dt = timed(lambda r: use * r)
-  # PCIe-inclusive twins: the SAME steps fed from pinned host memory, as the reference's loader
-  # hands batches over (activity_net/data.py:157-162 pin_memory=True; model.py:225-227 uploads inside
-  # the step) — the padded 12-tuples of its own collate_fn, the larger of the two host forms
-  from cmhse_amd import collate
-  host = [tuple(t.cpu().pin_memory() if isinstance(t, torch.Tensor) and t.is_cuda else t for t in b)
-          for b in batches]
-  host_use = [host[i % len(host)] for i in range(n_steps)]
-  host_bytes = float(np.mean([sum(t.numel() * t.element_size() for t in b[:4]) for b in host_use]))
-  dt_prefetch = timed(lambda r: collate.DevicePrefetcher(host_use * r, prepare=model.prepare_batch))
-  dt_pull = timed(lambda r: host_use * r)
-  work = [train_step_work(b, wl['img_dim'], embed, cfg['flags'], rnn_type == 'attention') for b in use]
-  fwd = float(np.mean([w[0] for w in work]))
-  bwd = float(np.mean([w[1] for w in work]))
-  chain = float(np.mean([w[2] for w in work]))
-  mfma_floor_ms = (fwd + bwd) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
-  step_us = measured_step_latency_us()       # (forward, backward) us per dependent launch
-  chain_floor_ms = chain * 0.5 * (step_us[0] + step_us[1]) * 1e-3 if step_us else None
-  floor = max(mfma_floor_ms, chain_floor_ms or 0.0)
-  losses = {k: float(m.val) for k, m in model.logger.meters.items() if k.startswith('Le')}
-  del model
-  torch.cuda.empty_cache()
-  return {'config': cfg['baseline'],
-          'flags': ' '.join('--%s' % k if v is True else '--%s %g' % (k, v)
-                            for k, v in sorted(cfg['flags'].items())),
-          'rnn_type': rnn_type, 'batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': embed,
-          'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt,
-          'pcie_inclusive': {
-              'ms_per_step': dt_prefetch * 1e3, 'vs_resident': dt_prefetch / dt,
-              'host_bytes_per_step': host_bytes,
-              'feed': 'pinned host 12-tuples (collate_fn form) through collate.DevicePrefetcher(loader, '
-                      'prepare=model.prepare_batch): one batch ahead on the copy stream, schedules built '
-                      'a step early — the one-line change to train.py:185 INTEGRATION.md shows'},
-          'pcie_inclusive_unwrapped': {
-              'ms_per_step': dt_pull * 1e3, 'vs_resident': dt_pull / dt,
-              'host_bytes_per_step': host_bytes,
-              'feed': 'the same pinned host 12-tuples handed straight to train_emb (train.py unchanged): '
-                      'frame rows pulled time-chunk by time-chunk under the visual chain (model.HOST_PULL)'},
-          'tflop_per_step': (fwd + bwd) / 1e12, 'tflop_forward': fwd / 1e12,
-          'tflop_backward': bwd / 1e12, 'achieved_tflops': (fwd + bwd) / dt / 1e12,
-          'dependent_steps': chain,
-          'mfma_floor_ms': mfma_floor_ms, 'chain_floor_ms': chain_floor_ms,
-          'chain_step_us': step_us,
-          'frac_of_floor': (floor / (dt * 1e3)) if floor > 0 else None,
-          # the LOOSER yardstick (it assumes chains and products cannot overlap at all); the bar is
-          # frac_of_floor, against max() of the two floors
-          'frac_of_sum_of_floors': ((mfma_floor_ms + (chain_floor_ms or 0.0)) / (dt * 1e3)),
-          'bound': 'max(FLOPs / 157.3 TFLOP/s fp32 MFMA, dependent steps x the measured latency '
-                   'of one small-batch step launch on an idle chip)',
-          'last_losses': losses}
-
-
-def measured_step_latency_us():
-  """Latency of ONE dependent small-batch GRU step launch, forward and BPTT (the mid-size step
-  kernels at a handful of sequences on an idle chip, launch gap included), from the committed
-  sweep of the newest round (profiles/r*_step_latency.json: {"forward_us": x, "backward_us": y}).
-  None if absent."""
-  import glob
-  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_step_latency.json')))
-  if not paths:
-    return None
-  try:
-    d = json.load(open(paths[-1]))
-    return float(d['forward_us']), float(d['backward_us'])
-  except (ValueError, KeyError, OSError):
-    return None
-
-
-def measured_traffic(kernel='gru_step'):
-  """Fabric bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-  (profiles/r*_pmc_hbm_traffic.json, newest round: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units,
-  FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md §HBM).  None if absent."""
-  import glob
-  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_hbm_traffic.json')))
-  if not paths:
-    return None
-  d = json.load(open(paths[-1]))
-  tot, n = 0.0, 0
-  for k, v in d.items():
-    if kernel in k:
-      tot += v['launches'] * (v['hbm_read_bytes_per_launch_corrected'] +
-                              v['hbm_write_bytes_per_launch'])
-      n += v['launches']
-  return tot / n if n else None
-
-
-def measured_clock_ghz():
-  """In-kernel shader clock of the tiled GRU step under load (median over workgroups), from the
-  committed tools/tile_trace.py run (profiles/r*_tile_trace.txt, newest round).  None if absent."""
-  import glob
-  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_tile_trace.txt')))
-  if not paths:
-    return None
-  for line in open(paths[-1]):
-    if line.startswith('in-kernel shader clock') and 'median' in line:
-      try:
-        return float(line.split('median')[1].split('GHz')[0])
-      except ValueError:
-        return None
-  return None
 
 
 def launch_ranks(n):
@@ -916,8 +421,11 @@ def main():
       def pcie_leg():
         # the reference's loader contract hands over host tensors (activity_net/data.py:114-150):
         # same pass, inputs pulled from pinned host memory inside the timed region
-        host = [tuple(t.cpu().pin_memory() if isinstance(t, torch.Tensor) and t.is_cuda else t
-                      for t in b) for b in batches]
+        def to_pinned(t):      # straight into page-locked memory (no pageable stop-over: 14.7 GB)
+          return torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t)
+        host = [tuple(to_pinned(t) if isinstance(t, torch.Tensor) and t.is_cuda else t for t in b)
+                for b in batches]
+        torch.cuda.synchronize()
 
         step(src=host)
         torch.cuda.synchronize()

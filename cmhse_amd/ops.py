@@ -91,6 +91,14 @@ def tune(name, value=-1):
   return int(old.value)
 
 
+def async_status(clear=False):
+  """cmhse_async_status: 0, or CMHSE_ERR_TIMEOUT (-5) once a resident-kernel launch on the current
+  device has given up at a grid barrier (its workgroups were not all on the chip: a shared GPU, a CU
+  mask).  The status is asynchronous — it reflects launches that have run — and sticky until
+  cleared; the gru forward / backward entry points check it themselves and raise."""
+  return int(_lib.load().cmhse_async_status(1 if clear else 0))
+
+
 class tuned(object):
   """Context manager: `with ops.tuned(tiny_max_seqs=0, mid_max_seqs=0): ...` moves crossovers for
   the block and puts the previous values back."""
