@@ -153,11 +153,25 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
   int b_row0[TS];
 #pragma unroll
   for (int ns = 0; ns < TS; ++ns) b_row0[ns] = wn * 32 * TS + 32 * ns;
+  // counting pass: the diagonal scores of the tile's rows, ONE coalesced request in front of the K
+  // loop (the epilogue used to load diag[row] inside its 32-iteration loop: 32 dependent global
+  // round trips per lane, ~50 of the 62 us the epilogue took — profiles/r04_sim_kernel_trace.txt);
+  // they go through LDS once the tile buffers are free
+  float my_diag = 0.f;
+  if (MODE == kSimRank && tid < BM) my_diag = (i0 + tid < p.nrows) ? p.diag[i0 + tid] : 0.f;
   SIM_MARK(1);
   SIM_CLOCK(5);
   nt_phase<BM, BN, TS, TS, TS, TS - 1, VEC>(smem, ar, av, br, bv, p.D, wm * 32 * TS, b_row0, acc);
   SIM_MARK(3);
   SIM_CLOCK(7);
+  if (MODE == kSimRank) {
+    // (what is left of the epilogue is ~12 us of vector / scalar work on its own and 48 beside two
+    // workgroups inside their MFMA loops on the same SIMDs; raising its wave priority changes
+    // nothing: 404 / 407 us per launch)
+    __syncthreads();                 // every wave has read its last fragments
+    if (tid < BM) smem[tid] = my_diag;
+    __syncthreads();
+  }
 
 #pragma unroll
   for (int ms = 0; ms < TS; ++ms) {
@@ -179,31 +193,46 @@ __global__ __launch_bounds__(kThreads) void sim_kernel(const SimParams p_) {
           if (rok && j < p.M) p.scores[static_cast<int64_t>(li) * p.M + j] = acc[ms][ns][r];
         }
       } else {
-        const float dii = rok ? p.diag[li] : 0.f;
+        // The 32 lanes of a half-wave hold the 32 columns of ONE row (lanes 0-31: row acc_row(r, 0),
+        // lanes 32-63: the row four below), so the row's count is a population count of the compare
+        // mask (v_cmp writes the mask; scalar s_bcnt1) and its arg-max one 32-bit max reduction plus
+        // an equality mask whose lowest set lane is the smallest column among the maxima — instead
+        // of five shuffle steps on (count, 64-bit key) per element: the epilogue was 27 % of a
+        // tile's time, VALU work beside the other workgroups' MFMA loops
+        // (profiles/r04_sim_kernel_trace.txt).  Same count, same key (ordered bits of the score,
+        // then the smaller column), same atomics.
+        const float dii = smem[li - i0];          // (0 for rows past the stripe: never counted)
+        const bool hi = lane >= 32;
         int cnt = 0;
-        unsigned long long best = 0ull;
+        unsigned ob[TS];
+        unsigned obmax = 0u;
 #pragma unroll
         for (int ns = 0; ns < TS; ++ns) {
           const int j = j0 + b_row0[ns] + acc_col(lane);
           const float v = acc[ms][ns][r];
-          if (rok && j < p.M) {
-            cnt += (j != gi && v > dii) ? 1 : 0;
-            const unsigned long long key =
-                (static_cast<unsigned long long>(ordered_bits(v)) << 32) |
-                static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<unsigned>(j));
-            best = (key > best) ? key : best;
-          }
+          const bool valid = rok && j < p.M;
+          const unsigned long long gt = __ballot(valid && j != gi && v > dii);
+          cnt += __popc(hi ? static_cast<unsigned>(gt >> 32) : static_cast<unsigned>(gt));
+          ob[ns] = valid ? ordered_bits(v) : 0u;
+          obmax = ob[ns] > obmax ? ob[ns] : obmax;
         }
-        // reduce over the 32 lanes that share this row (xor masks < 32 stay inside a half-wave)
 #pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) {
-          cnt += __shfl_xor(cnt, d, 64);
-          const unsigned long long o = __shfl_xor(best, d, 64);
-          best = (o > best) ? o : best;
+        for (int d = 16; d >= 1; d >>= 1) {      // (xor masks < 32 stay inside a half-wave)
+          const unsigned o = __shfl_xor(obmax, d, 64);
+          obmax = o > obmax ? o : obmax;
+        }
+        int jbest = -1;
+#pragma unroll
+        for (int ns = 0; ns < TS; ++ns) {        // ns = 0 holds the smaller columns
+          const unsigned long long eq = __ballot(obmax != 0u && ob[ns] == obmax);
+          const unsigned m = hi ? static_cast<unsigned>(eq >> 32) : static_cast<unsigned>(eq);
+          if (jbest < 0 && m != 0u) jbest = j0 + b_row0[ns] + (__ffs(m) - 1);
         }
         if (rok && (lane & 31) == 0) {
           if (cnt) atomicAdd(&p.rank[li], cnt);
-          atomicMax(&p.top1key[li], best);
+          if (jbest >= 0)
+            atomicMax(&p.top1key[li], (static_cast<unsigned long long>(obmax) << 32) |
+                                          static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<unsigned>(jbest)));
         }
       }
     }
