@@ -146,6 +146,82 @@ def upload_packed(batch, device=None, non_blocking=True):
   return (view(clips), view(captions), view(videos), view(paragraphs)) + tuple(batch[4:])
 
 
+class DeviceStager(object):
+  """Two persistent device slots for the four big members of a loader batch (clips, captions,
+  videos, paragraphs), alternated: `stage` copies a batch's host tensors into slot k % 2 on a copy
+  stream and returns device views of it, `done` marks the point on the consumer's stream behind
+  which the slot may be overwritten.  A training loop then allocates nothing and creates no HIP
+  event per step (either can stall the host for tens of ms while the GPU is busy, see ops.upload).
+  Padded 12-tuples: four copies; collate_packed batches (ops.Ragged members of ONE block): one."""
+
+  def __init__(self):
+    self._slots = [None, None]
+    self._k = 0
+
+  def _slot(self, k, device, copy, nbytes):
+    slot = self._slots[k % 2]
+    if slot is None:
+      slot = self._slots[k % 2] = {'buf': None, 'ready': torch.cuda.Event(), 'done': None}
+    if slot['buf'] is None or slot['buf'].numel() < nbytes:
+      with torch.cuda.stream(copy):
+        old, slot['buf'] = slot['buf'], torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+      if old is not None:
+        old.record_stream(torch.cuda.current_stream(device))
+    return slot
+
+  @staticmethod
+  def stageable(big):
+    return all(isinstance(t, (torch.Tensor, ops.Ragged)) and not t.is_cuda for t in big)
+
+  def stage(self, big, device, copy):
+    """`big`: the four host members.  Returns (device members, ready event, slot): the consumer's
+    stream waits for `ready`, and calls done(slot, stream) when its last reader has been queued."""
+    k, self._k = self._k, self._k + 1
+    datas = [t.data if isinstance(t, ops.Ragged) else t for t in big]
+    if not all(d.is_contiguous() for d in datas):
+      datas = [d.contiguous() for d in datas]
+    sizes = [d.numel() * d.element_size() for d in datas]
+    offs, off = [], 0
+    for n in sizes:
+      offs.append(off)
+      off += (n + 255) // 256 * 256
+    slot = self._slot(k, device, copy, off)
+    with torch.cuda.stream(copy):
+      if slot['done'] is not None:
+        copy.wait_event(slot['done'])      # the step that last read this slot has been passed
+      base = datas[0].untyped_storage()
+      one_block = all(d.untyped_storage().data_ptr() == base.data_ptr() for d in datas)
+      views = []
+      if one_block:                        # collate_packed: ONE copy of the span the members cover
+        lo = min(d.data_ptr() for d in datas)
+        hi = max(d.data_ptr() + n for d, n in zip(datas, sizes))
+        host = torch.empty(0, dtype=torch.uint8).set_(base)[lo - base.data_ptr():hi - base.data_ptr()]
+        if slot['buf'].numel() < hi - lo:
+          slot = self._slot(k, device, copy, hi - lo)
+        slot['buf'][:hi - lo].copy_(host, non_blocking=True)
+        offs = [d.data_ptr() - lo for d in datas]
+      for d, o, n in zip(datas, offs, sizes):
+        v = slot['buf'][o:o + n].view(d.dtype).view(d.shape)
+        if not one_block:
+          v.copy_(d, non_blocking=True)
+        views.append(v)
+      slot['ready'].record(copy)
+    staged = [ops.Ragged(v, t.lens) if isinstance(t, ops.Ragged) else v for v, t in zip(views, big)]
+    return staged, slot['ready'], slot
+
+  @staticmethod
+  def done(slot, stream):
+    if slot['done'] is None:
+      slot['done'] = torch.cuda.Event()
+    slot['done'].record(stream)
+
+  def release(self, stream):
+    """The slots are about to be dropped while the last steps may still read them."""
+    for slot in self._slots:
+      if slot is not None and slot['buf'] is not None:
+        slot['buf'].record_stream(stream)
+
+
 class DevicePrefetcher(object):
   """One-batch look-ahead over a loader of 12-tuples: while the training step of batch k runs, batch
   k + 1 is already crossing PCIe on a copy stream, so `train_emb` always receives device-resident
@@ -181,79 +257,34 @@ class DevicePrefetcher(object):
     if when not in ('before', 'mid') or (when == 'mid' and model is None):
       raise ValueError("DevicePrefetcher: when = 'before' | 'mid' (the latter needs model=)")
     self.model, self.when, self.stream = model, when, stream
-    self._slots = [None, None]
+    self._stager = DeviceStager()
     self.device = torch.device(device) if device is not None else None
 
   def __len__(self):
     return len(self.loader)
 
-  def _slot(self, k, device, copy, nbytes):
-    """Upload slot k % 2: a persistent device block (grown when a batch needs more), the event its
-    upload records and the event the consumer records when the batch's step has been queued.  Two
-    slots alternate, so a training loop allocates nothing and creates no HIP event per step (either
-    can stall the host for tens of ms while the GPU is busy, see ops.upload)."""
-    slot = self._slots[k % 2]
-    if slot is None:
-      slot = self._slots[k % 2] = {'buf': None, 'ready': torch.cuda.Event(), 'done': None}
-    if slot['buf'] is None or slot['buf'].numel() < nbytes:
-      with torch.cuda.stream(copy):
-        old, slot['buf'] = slot['buf'], torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-      if old is not None:
-        old.record_stream(torch.cuda.current_stream(device))
-    return slot
-
-  def _stage(self, batch, k, device, copy):
-    big = [t for t in batch[:4]]
-    if not all(isinstance(t, (torch.Tensor, ops.Ragged)) and not t.is_cuda for t in big):
+  def _stage(self, batch, device, copy):
+    big = list(batch[:4])
+    if not DeviceStager.stageable(big):
       return batch, None, None     # already resident (or not tensors): handed through
-    datas = [t.data if isinstance(t, ops.Ragged) else t for t in big]
-    if not all(d.is_contiguous() for d in datas):
-      datas = [d.contiguous() for d in datas]
-    sizes = [d.numel() * d.element_size() for d in datas]
-    offs, off = [], 0
-    for n in sizes:
-      offs.append(off)
-      off += (n + 255) // 256 * 256
-    slot = self._slot(k, device, copy, off)
-    with torch.cuda.stream(copy):
-      if slot['done'] is not None:
-        copy.wait_event(slot['done'])      # the step that last read this slot has been passed
-      base = datas[0].untyped_storage()
-      one_block = all(d.untyped_storage().data_ptr() == base.data_ptr() for d in datas)
-      views = []
-      if one_block:                        # collate_packed: ONE copy of the span the members cover
-        lo = min(d.data_ptr() for d in datas)
-        hi = max(d.data_ptr() + n for d, n in zip(datas, sizes))
-        host = torch.empty(0, dtype=torch.uint8).set_(base)[lo - base.data_ptr():hi - base.data_ptr()]
-        if slot['buf'].numel() < hi - lo:
-          slot = self._slot(k, device, copy, hi - lo)
-        slot['buf'][:hi - lo].copy_(host, non_blocking=True)
-        offs = [d.data_ptr() - lo for d in datas]
-      for d, o, n in zip(datas, offs, sizes):
-        v = slot['buf'][o:o + n].view(d.dtype).view(d.shape)
-        if not one_block:
-          v.copy_(d, non_blocking=True)
-        views.append(v)
-      slot['ready'].record(copy)
-    staged = tuple(ops.Ragged(v, t.lens) if isinstance(t, ops.Ragged) else v
-                   for v, t in zip(views, big)) + tuple(batch[4:])
+    views, ready, slot = self._stager.stage(big, device, copy)
+    staged = tuple(views) + tuple(batch[4:])
     if self.prepare is not None:
       self.prepare(staged)
-    return staged, slot['ready'], slot
+    return staged, ready, slot
 
   def __iter__(self):
     device = self.device or torch.device('cuda', torch.cuda.current_device())
     copy = self.stream or ops.copy_stream(device)
     it = iter(self.loader)
-    state = {'nxt': None, 'asked': True, 'k': 0}
+    state = {'nxt': None, 'asked': True}
 
     def stage_next():
       if state['asked']:
         return
       state['asked'] = True
       for following in it:
-        state['nxt'] = self._stage(following, state['k'], device, copy)
-        state['k'] += 1
+        state['nxt'] = self._stage(following, device, copy)
         break
 
     state['asked'] = False
@@ -271,16 +302,12 @@ class DevicePrefetcher(object):
           main.wait_event(ready)
         yield cur
         if slot is not None:         # everything the loop body queued reads this slot before here
-          if slot['done'] is None:
-            slot['done'] = torch.cuda.Event()
-          slot['done'].record(torch.cuda.current_stream(device))
+          DeviceStager.done(slot, torch.cuda.current_stream(device))
         stage_next()                 # 'mid': the step did not call the hook (no train_emb on this batch)
     finally:
       if self.when == 'mid' and self.model._mid_step_hook is stage_next:
         self.model._mid_step_hook = None
-      for slot in self._slots:       # the last steps may still read the slots when they are released
-        if slot is not None and slot['buf'] is not None:
-          slot['buf'].record_stream(torch.cuda.current_stream(device))
+      self._stager.release(torch.cuda.current_stream(device))
 
 
 def split_samples(batch):

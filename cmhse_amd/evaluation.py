@@ -55,9 +55,9 @@ class LogCollector(object):
 
   Values may arrive late: VSE.train_emb hands the step's loss values over as a copy that is still
   in flight (`defer`), so that the host can queue the next step instead of waiting for this one.
-  Everything that READS the collector (`meters`, str(), tb_log) first settles what is outstanding,
-  and `update` calls made in the meantime wait in the same queue, so every reader sees exactly the
-  reference's sequence of updates."""
+  Everything that READS the collector (`meters`, str()) first settles what is outstanding, and
+  `update` / `tb_log` calls made in the meantime wait in the same queue, so every reader — and the
+  tensorboard sink — sees exactly the reference's sequence of updates."""
 
   def __init__(self):
     self._meters = OrderedDict()
@@ -107,7 +107,17 @@ class LogCollector(object):
     return other
 
   def tb_log(self, tb_logger, prefix='', step=None):
-    for k, m in self.meters.items():
+    """evaluation.py:68-72.  train.py calls this after EVERY step (train.py:215).  While the step's
+    loss values are still in flight the call takes its place in the queue instead of waiting for
+    them: the sink receives exactly the (key, value, step) triples it would have, a step later in
+    wall time, and the host goes on queueing the next step."""
+    if self._deferred:
+      self._deferred.append(lambda: self._tb_log_now(tb_logger, prefix, step))
+    else:
+      self._tb_log_now(tb_logger, prefix, step)
+
+  def _tb_log_now(self, tb_logger, prefix, step):
+    for k, m in self._meters.items():
       tb_logger.log_value(prefix + k, m.val, step=step)
 
 

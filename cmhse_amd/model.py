@@ -136,6 +136,17 @@ FUSED_ADAM = [True]
 HOST_PULL = [True]
 HOST_PULL_CHUNK = [8]
 HOST_PULL_STREAM = [None]     # None = ops.copy_stream(device); tools/host_lead.py tries others
+# ... and WHICH hand-over a pinned batch gets (HOST_PULL on):
+#   'auto'   (default) when the host runs ahead of the GPU — the previous step has not finished when
+#            this one is being queued, the normal state of a loop that does not read the logger
+#            every step (a step is queued after a third of its run time) — the whole
+#            batch is copied by the DMA engine on the copy stream into one of two persistent device
+#            slots (collate.DeviceStager) and is resident long before the GPU reaches this step:
+#            the look-ahead of collate.DevicePrefetcher without touching the loop; when the GPU is
+#            already waiting for the host (a loop that synchronises every step), the chunked pull
+#            under the visual chain, which starts the chain after the first steps' rows;
+#   'ahead'  always the former;  'pull'  always the latter.
+HOST_FEED = ['auto']
 
 
 def _tower_streams(device):
@@ -219,6 +230,9 @@ class VSE(object):
     self._log_slot, self._log_pinned, self._log_owner = 0, [None, None], [None, None]
     self._loss_weights = {}     # weight vectors of the batched losses, by number of terms
     self._mid_step_hook = None  # called between the forward and backward passes (collate.DevicePrefetcher)
+    # host-fed steps (HOST_FEED): the device slots of the batch hand-over, the slot this step reads,
+    # and an event behind every step's last launch (is the GPU still busy when the next is queued?)
+    self._stager, self._stage_slot, self._step_done, self._step_done_pool = None, None, None, []
 
   # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
   def _modules(self):
@@ -237,12 +251,22 @@ class VSE(object):
       m.load_state_dict(sd)
 
   def train_start(self, opt=None):
+    self._settle_logger()
     for m in self._modules():
       m.train()
 
   def val_start(self, opt=None):
+    self._settle_logger()
     for m in self._modules():
       m.eval()
+
+  def _settle_logger(self):
+    """Mode switches are where a train.py-style loop changes loggers (train.py:189, evaluation.py:99):
+    whatever the current one still expects (the last step's loss values, a queued tb_log) is
+    delivered first."""
+    settle = getattr(self.logger, 'settle', None)
+    if settle is not None:
+      settle()
 
   # -- forward --------------------------------------------------------------------------------
   def forward_emb(self, clips, captions, lengths_clip, lengths_cap, return_word=False):
@@ -370,6 +394,31 @@ class VSE(object):
     clips._cmhse_prep = prep
     return batch
 
+  def _stage_ahead(self, clips, captions, videos, paragraphs):
+    """HOST_FEED 'auto' / 'ahead': the four pinned host members of the batch copied into a device
+    slot on the copy stream (see HOST_FEED); returns the device members, or None when this
+    hand-over does not apply (not pinned host tensors, HOST_PULL off, 'pull', or — 'auto' — the GPU
+    has already finished the previous step and is waiting for this one)."""
+    from .collate import DeviceStager
+    from .evaluation import _pinned_f32
+    mode = HOST_FEED[0]
+    if mode not in ('auto', 'ahead', 'pull'):
+      raise ValueError("model.HOST_FEED: 'auto' | 'ahead' | 'pull'")
+    if not HOST_PULL[0] or mode == 'pull' or not (_pinned_f32(clips) and _pinned_f32(videos)):
+      return None
+    big = [clips, captions, videos, paragraphs]
+    if not DeviceStager.stageable(big) or not all(t.is_pinned() for t in (captions, paragraphs)):
+      return None
+    if mode == 'auto' and (self._step_done is None or self._step_done.query()):
+      return None                 # the GPU is idle: start the chain on the first rows instead
+    device = next(iter(self.params)).device
+    if self._stager is None:
+      self._stager = DeviceStager()
+    staged, ready, slot = self._stager.stage(big, device, HOST_PULL_STREAM[0] or ops.copy_stream(device))
+    torch.cuda.current_stream(device).wait_event(ready)
+    self._stage_slot = slot
+    return staged
+
   def _pull_visual(self, clips, videos, lengths_clip, lengths_video):
     """The hand-over of a host-fed training step (HOST_PULL): when `clips` and `videos` are the
     loader's pinned float32 host tensors (padded, or the ops.Ragged members of collate_packed),
@@ -413,8 +462,13 @@ class VSE(object):
     if schedule not in ('interleaved', 'levels', 'towers', 'grouped', 'serial'):
       raise ValueError('unknown training schedule %r' % (schedule,))
     v_sched = v_events = None
-    pulled = (self._pull_visual(clips, videos, lengths_clip, lengths_video)
-              if schedule in ('interleaved', 'levels') else None)
+    pulled = None
+    if schedule in ('interleaved', 'levels'):
+      staged = self._stage_ahead(clips, captions, videos, paragraphs)
+      if staged is not None:
+        clips, captions, videos, paragraphs = staged
+      else:
+        pulled = self._pull_visual(clips, videos, lengths_clip, lengths_video)
     if pulled is not None:
       clips, videos, v_sched, v_events = pulled
     else:
@@ -622,6 +676,19 @@ class VSE(object):
       loss = loss + (l_fr + l_wd) * opts.lowest_weight_recon
     return loss
 
+  def _mark_step_done(self):
+    """An event behind the step's last launch (two, alternated: no event is created per step), and
+    the release point of the slot a staged batch was read from."""
+    if len(self._step_done_pool) < 2:
+      self._step_done_pool.append(torch.cuda.Event())
+    ev = self._step_done_pool[self.Eiters % 2] if len(self._step_done_pool) == 2 else self._step_done_pool[-1]
+    ev.record()
+    self._step_done = ev
+    if self._stage_slot is not None:
+      from .collate import DeviceStager
+      DeviceStager.done(self._stage_slot, torch.cuda.current_stream())
+      self._stage_slot = None
+
   def train_emb(self, opts, clips, captions, videos, paragraphs, lengths_clip, lengths_cap,
                 lengths_video, lengths_paragraph, num_clips, num_caps, ind, cur_vid, *args):
     """model.py:309-369: one optimisation step.  Forward, losses and backward run on the HIP
@@ -645,9 +712,14 @@ class VSE(object):
         torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
       self.optimizer.step()
       _tick('adam:done')
+      self._mark_step_done()
     except BaseException:
       # a failed step logs nothing: copying the queued loss values down here could raise a second
       # error (an asynchronous HIP fault) that hides the first, and would record a partial step
       self._pending_log = None
+      if self._stage_slot is not None:      # whatever was queued may still read the batch's slot
+        from .collate import DeviceStager
+        DeviceStager.done(self._stage_slot, torch.cuda.current_stream())
+        self._stage_slot = None
       raise
     self._flush_log()

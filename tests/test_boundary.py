@@ -143,7 +143,19 @@ def test_train_py_shaped_loop_through_the_dropin_imports(dropin_modules, tmp_pat
   assert set(train_logger.meters) == want
   assert all(np.isfinite(m.val) for m in train_logger.meters.values())
 
+  # train.py's own loop reads the logger only on log steps but calls tb_log after EVERY step
+  # (train.py:198-215): the tensorboard sink must still receive every step's values under that
+  # step's number — delivered late (the call queues behind the loss values in flight), at the
+  # latest when the loop switches modes for validation
+  for i, train_data in enumerate(train_loader):
+    model.logger = train_logger
+    model.train_emb(opt, *train_data)
+    model.logger.tb_log(tb, step=model.Eiters)
+  assert model.Eiters == 4
   score, embs, ranks = validate(model)
+  for step in (1, 2, 3, 4):
+    got = {r[0]: r[1] for r in tb.rows if r[2] == step}
+    assert want <= set(got) and got['Eit'] == step and np.isfinite(got['Le_vid']), (step, sorted(got))
   assert np.isfinite(score) and any(r[0] == 'seqr1' for r in tb.rows)
   assert any(l.startswith('Test: [0/') for l in lines)            # evaluation.py:135-141 log line
 

@@ -2263,7 +2263,10 @@ def test_host_fed_train_step_is_bit_identical(dev, monkeypatch):
   and every parameter gradient (the word table's is scattered with float atomics: close, not
   equal) — whichever way the batch crosses PCIe:
     pull      train.py unchanged: train_emb pulls the frame rows time-chunk by time-chunk under the
-              visual chain (model.HOST_PULL; the projection chunks wait for exactly their rows);
+              visual chain (model.HOST_FEED 'pull'; the projection chunks wait for exactly their rows);
+    ahead     train.py unchanged: train_emb copies the batch into one of its two device slots on
+              the copy stream ('ahead'; what 'auto', the default, does while the host runs ahead of
+              the GPU — 'auto' itself is exercised too: pull for the first step, then either);
     upload    the reference's `.cuda()` in front of the step (HOST_PULL off);
     prefetch  collate.DevicePrefetcher(loader, prepare=model.prepare_batch): one batch ahead on the
               copy stream, schedules built a step early;
@@ -2296,7 +2299,9 @@ def test_host_fed_train_step_is_bit_identical(dev, monkeypatch):
     real = ops.pull_steps
     monkeypatch.setattr(ops, 'pull_steps', lambda *a, **k: (pulls.append(1), real(*a, **k))[1])
     monkeypatch.setattr(model_mod, 'HOST_PULL', [feed != 'upload'])
-    loader = {'resident': resident, 'pull': host, 'upload': host, 'packed': packed,
+    monkeypatch.setattr(model_mod, 'HOST_FEED', [{'ahead': 'ahead', 'auto': 'auto', 'packed_ahead': 'ahead'}.get(feed, 'pull')])
+    loader = {'resident': resident, 'pull': host, 'upload': host, 'packed': packed, 'ahead': host,
+              'auto': host, 'packed_ahead': packed,
               'prefetch': collate.DevicePrefetcher(host, prepare=model.prepare_batch)}[feed]
     grads = None
     for k, b in enumerate(loader):
@@ -2308,12 +2313,13 @@ def test_host_fed_train_step_is_bit_identical(dev, monkeypatch):
         grads = {(i, n): p.grad.detach().clone() for i, m in enumerate(model._modules())
                  for n, p in m.named_parameters()}
     torch.cuda.synchronize()
-    assert bool(pulls) == (feed in ('pull', 'packed')), (feed, len(pulls))
+    if feed != 'auto':
+      assert bool(pulls) == (feed in ('pull', 'packed')), (feed, len(pulls))
     return [c for c in model.logger.calls if c[0].startswith('Le')], grads
 
   want_log, want_g = run('resident')
   n_first = len(want_log) // 2
-  for feed in ['pull', 'upload', 'prefetch', 'packed']:
+  for feed in ['pull', 'upload', 'prefetch', 'packed', 'ahead', 'auto', 'packed_ahead']:
     log, g = run(feed)
     assert log[:n_first] == want_log[:n_first], feed          # first step: bit-identical losses
     for a, b in zip(log[n_first:], want_log[n_first:]):       # second: after an update with atomics upstream

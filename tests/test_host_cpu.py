@@ -315,9 +315,20 @@ def test_log_collector_replays_late_values_in_order():
   class Tb(object):
     def __init__(self): self.got = []
     def log_value(self, k, v, step=None): self.got.append((k, v, step))
+  # tb_log after every step (train.py:215) does not wait for values in flight: it queues behind them
+  # and delivers the same triples when they have arrived
   b.defer(lambda: b._update('Le_vid', 6.0, 4))
   tb = Tb(); b.tb_log(tb, prefix='t/', step=7)
-  assert ('t/Le_vid', 6.0, 7) in tb.got
+  assert tb.got == []
+  b.update('Eit', 4)
+  b.defer(lambda: b._update('Le_vid', 7.0, 4))
+  b.tb_log(tb, prefix='t/', step=8)
+  b.settle()
+  assert ('t/Le_vid', 6.0, 7) in tb.got and ('t/Eit', 3, 7) in tb.got
+  assert ('t/Le_vid', 7.0, 8) in tb.got and ('t/Eit', 4, 8) in tb.got
+  assert [g[2] for g in tb.got] == [7] * 3 + [8] * 3
+  b.tb_log(tb, prefix='t/', step=9)      # nothing outstanding: immediate
+  assert tb.got[-1][2] == 9
   # a collector with values still outstanding can be pickled / deep-copied: both settle first
   import copy
   import pickle

@@ -346,8 +346,8 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           for b in batches]
   host_use = [host[i % len(host)] for i in range(n_steps)]
   host_bytes = float(np.mean([sum(t.numel() * t.element_size() for t in b[:4]) for b in host_use]))
+  dt_auto = timed(lambda r: host_use * r)
   dt_prefetch = timed(lambda r: collate.DevicePrefetcher(host_use * r, prepare=model.prepare_batch))
-  dt_pull = timed(lambda r: host_use * r)
   work = [train_step_work(b, wl['img_dim'], embed, cfg['flags'], rnn_type == 'attention') for b in use]
   fwd = float(np.mean([w[0] for w in work]))
   bwd = float(np.mean([w[1] for w in work]))
@@ -365,16 +365,17 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           'rnn_type': rnn_type, 'batch': wl['batch'], 'img_dim': wl['img_dim'], 'embed': embed,
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'videos_per_s': wl['batch'] / dt,
           'pcie_inclusive': {
+              'ms_per_step': dt_auto * 1e3, 'vs_resident': dt_auto / dt,
+              'host_bytes_per_step': host_bytes,
+              'feed': 'pinned host 12-tuples (collate_fn form: what DataLoader(pin_memory=True) hands over, '
+                      'activity_net/data.py:157-162) straight into train_emb — train.py unchanged: while the host '
+                      'runs ahead of the GPU the batch is copied into one of two persistent device slots on the '
+                      "copy stream and is resident before its step starts (model.HOST_FEED 'auto')"},
+          'pcie_inclusive_prefetcher': {
               'ms_per_step': dt_prefetch * 1e3, 'vs_resident': dt_prefetch / dt,
               'host_bytes_per_step': host_bytes,
-              'feed': 'pinned host 12-tuples (collate_fn form) through collate.DevicePrefetcher(loader, '
-                      'prepare=model.prepare_batch): one batch ahead on the copy stream, schedules built '
-                      'a step early — the one-line change to train.py:185 INTEGRATION.md shows'},
-          'pcie_inclusive_unwrapped': {
-              'ms_per_step': dt_pull * 1e3, 'vs_resident': dt_pull / dt,
-              'host_bytes_per_step': host_bytes,
-              'feed': 'the same pinned host 12-tuples handed straight to train_emb (train.py unchanged): '
-                      'frame rows pulled time-chunk by time-chunk under the visual chain (model.HOST_PULL)'},
+              'feed': 'the same batches through collate.DevicePrefetcher(loader, prepare=model.prepare_batch): '
+                      'the look-ahead form for a loop that synchronises with the GPU every step'},
           'tflop_per_step': (fwd + bwd) / 1e12, 'tflop_forward': fwd / 1e12,
           'tflop_backward': bwd / 1e12, 'achieved_tflops': (fwd + bwd) / dt / 1e12,
           'dependent_steps': chain,

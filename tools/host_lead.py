@@ -11,7 +11,10 @@ Arms, each `--steps` un-synchronised steps after warm-up, interleaved `--rounds`
                     collate.DevicePrefetcher: when = before | mid; stream = copy (ops.copy_stream,
                     the default) | s3 (stream_set[3]) | new (a fresh torch stream) | s2; noprep =
                     without prepare_batch
-  pull:<stream>     model.HOST_PULL on that stream
+  pull:<stream>     model.HOST_FEED 'pull' on that stream
+  <arm>+tb          the arm with model.logger.tb_log(sink, step) after every step, as train.py:215 does
+  auto | ahead      model.HOST_FEED 'auto' (the default: the batch copied ahead on the copy stream while
+                    the host leads the GPU, else the pull) | 'ahead' (always the copy)
 Also prints the host time spent inside train_emb per step (the launch-queueing cost).
 
   python tools/host_lead.py --config icep --steps 30 --rounds 2
@@ -39,7 +42,7 @@ def main():
   ap.add_argument('--config', default='icep', choices=sorted(CONFIGS))
   ap.add_argument('--steps', type=int, default=30)
   ap.add_argument('--rounds', type=int, default=2)
-  ap.add_argument('--arms', default='resident,resident+spin1000,upload,pull:copy,pull:s3,pull:new,pull:s2,'
+  ap.add_argument('--arms', default='resident,resident+spin1000,upload,auto,ahead,pull:copy,pull:s3,'
                                     'prefetch:before:copy,prefetch:before:s3,prefetch:before:new,'
                                     'prefetch:mid:copy')
   args = ap.parse_args()
@@ -61,12 +64,19 @@ def main():
   res = [tuple(t.cuda() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b))
          for b in batches]
   extra = torch.cuda.Stream(dev)
+
+  class Sink(object):
+    def log_value(self, name, value, step=None):
+      pass
+  sink = Sink()
   n = args.steps
   pick = lambda src: [src[i % len(src)] for i in range(n)]
 
   def loop(arm):
     model_mod.HOST_PULL[0] = True
     spin = 0
+    tb_every_step = arm.endswith('+tb')      # train.py:215: model.logger.tb_log(...) after every step
+    arm = arm[:-3] if tb_every_step else arm
     if arm.startswith('resident'):
       src = pick(res)
       if '+spin' in arm:
@@ -74,7 +84,12 @@ def main():
     elif arm == 'upload':
       model_mod.HOST_PULL[0] = False
       src = pick(host)
+    elif arm in ('auto', 'ahead'):
+      model_mod.HOST_FEED[0] = arm
+      model_mod.HOST_PULL_STREAM[0] = None
+      src = pick(host)
     elif arm.startswith('pull'):
+      model_mod.HOST_FEED[0] = 'pull'
       which = arm.split(':')[1] if ':' in arm else 'copy'
       model_mod.HOST_PULL_STREAM[0] = {'copy': None, 's3': ops.stream_set(dev)[3], 'new': extra,
                                        's2': ops.stream_set(dev)[2]}[which]
@@ -94,6 +109,8 @@ def main():
           pass
       h0 = time.perf_counter()
       model.train_emb(opt, *b)
+      if tb_every_step:
+        model.logger.tb_log(sink, step=model.Eiters)
       in_step += time.perf_counter() - h0
     str(model.logger)
     torch.cuda.synchronize()

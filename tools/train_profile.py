@@ -40,7 +40,7 @@ def main():
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--rnn_type', default='attention')
   ap.add_argument('--resident', type=int, default=1, help='1: batches resident in HBM (what bench.py times); 0: pinned host batches')
-  ap.add_argument('--feed', default='', choices=['', 'resident', 'pull', 'upload', 'prefetch'],
+  ap.add_argument('--feed', default='', choices=['', 'resident', 'pull', 'auto', 'ahead', 'upload', 'prefetch'],
                   help="how a batch reaches train_emb: resident (in HBM); pinned host tensors pulled "
                        "under the chain (pull) or .cuda()'d in front of the step (upload); pinned host "
                        "tensors through collate.DevicePrefetcher + prepare_batch (prefetch)")
@@ -56,13 +56,15 @@ def main():
   model = VSE(opt)
   spec = synthetic.anet_like_spec(32 * 4, seed=0, dataset=wl['dataset'])
   batches = synthetic.make_batches(spec, 32, wl['img_dim'], wl['vocab'], seed=0, feat=wl['feat'])
-  feed = args.feed or ('resident' if args.resident else 'pull')
+  feed = args.feed or ('resident' if args.resident else 'auto')
   if feed == 'resident':
     batches = [tuple(t.cuda() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)) for b in batches]
   else:
     batches = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)) for b in batches]
   from cmhse_amd import collate, model as model_mod
   model_mod.HOST_PULL[0] = feed != 'upload'
+  if feed in ('pull', 'auto', 'ahead'):
+    model_mod.HOST_FEED[0] = feed
   wrap = (lambda bs: collate.DevicePrefetcher(bs, prepare=model.prepare_batch)) if feed == 'prefetch' else (lambda bs: bs)
   model.logger = LogCollector()
   model.train_start(opt)
