@@ -28,6 +28,8 @@ def main():
   ap.add_argument('--epochs', type=int, default=3)
   ap.add_argument('--steps', type=int, default=300)
   ap.add_argument('--val_videos', type=int, default=256)
+  ap.add_argument('--pin', type=int, default=1, help='1: training batches in pinned host memory, as a '
+                  'DataLoader(pin_memory=True) hands them over (the host-fed path of train_emb); 0: pageable')
   args = ap.parse_args()
   cfg = dict(CONFIGS[args.config])
   wl = dict(bench.WORKLOADS[cfg.pop('workload')])
@@ -39,15 +41,28 @@ def main():
   model = VSE(opt)
   spec = synthetic.anet_like_spec(32 * 8, seed=0, dataset=wl['dataset'])
   train = synthetic.make_batches(spec, 32, wl['img_dim'], wl['vocab'], seed=0, feat=wl['feat'])
+  if args.pin:
+    train = [tuple(t.pin_memory() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b))
+             for b in train]
   vspec = synthetic.anet_like_spec(args.val_videos, seed=5, dataset=wl['dataset'])
   val = synthetic.make_batches(vspec, 32, wl['img_dim'], wl['vocab'], seed=5, feat=wl['feat'])
   quiet = lambda *a, **k: None
+
+  class Sink(object):
+    def __init__(self):
+      self.n, self.bad = 0, 0
+
+    def log_value(self, name, value, step=None):
+      self.n += 1
+      self.bad += 0 if np.isfinite(value) else 1
+  sink = Sink()
   t0 = time.time()
   for epoch in range(args.epochs):
     model.logger = LogCollector()
     model.train_start(opt)
     for i in range(args.steps):
       model.train_emb(opt, *train[i % len(train)])
+      model.logger.tb_log(sink, step=model.Eiters)        # train.py:215
     meters = {k: m.val for k, m in model.logger.meters.items()}
     assert all(np.isfinite(v) for v in meters.values()), meters
     model.val_start(opt)
@@ -63,7 +78,10 @@ def main():
     print('epoch %d: %d steps, Le_vid %.4f, r1 i2t %.2f t2i %.2f, alloc %.0f MB, %.1f s'
           % (epoch, args.steps, meters.get('Le_vid', float('nan')), float(reports[0][0].get('r1', float('nan'))), float(reports[0][1].get('r1', float('nan'))),
              torch.cuda.memory_allocated() / 2 ** 20, time.time() - t0))
-  print('soak ok')
+  from cmhse_amd import ops
+  assert ops.async_status() == 0, 'a resident kernel timed out'
+  assert sink.bad == 0 and sink.n >= args.epochs * args.steps * 9, (sink.n, sink.bad)
+  print('soak ok (%d tensorboard values, all finite)' % sink.n)
 
 
 if __name__ == '__main__':
