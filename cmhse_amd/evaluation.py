@@ -177,6 +177,19 @@ def _host_scalars(n):
   return torch.empty(max(n, 1024), dtype=torch.float32).pin_memory()
 
 
+_HOST_ROWS, _HOST_ROW_EVENTS = [], []
+
+
+def _hold_host_rows(stream, tensors, keep=3):
+  while _HOST_ROWS and (_HOST_ROWS[0][0].query() or len(_HOST_ROWS) >= keep):
+    if not _HOST_ROWS[0][0].query():
+      _HOST_ROWS[0][0].synchronize()
+    _HOST_ROW_EVENTS.append(_HOST_ROWS.pop(0)[0])
+  ev = _HOST_ROW_EVENTS.pop() if _HOST_ROW_EVENTS else torch.cuda.Event()
+  ev.record(stream)
+  _HOST_ROWS.append((ev, tensors))
+
+
 def _pinned_f32(t):
   return (isinstance(t, (torch.Tensor, ops.Ragged)) and not t.is_cuda and t.dtype == torch.float32
           and t.is_contiguous() and t.is_pinned())
@@ -263,6 +276,11 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
           x_ptrs=ops.seq_row_ptrs_many(clips_l + vids_l),
           src_ptrs=ops.seq_row_ptrs_many([b[0] for b in group] + [b[2] for b in group]))
       v_events = ops.pull_steps(v_sched, int(group[0][0].shape[2]), copy, UPLOAD_CHUNK[0])
+      # the pull kernels read the pinned tensors by address, possibly after this function has
+      # returned: they stay referenced here until an event behind the last chunk has completed (a
+      # caller that drops its loader batches right away would otherwise hand the blocks back to
+      # torch's pinned-memory allocator while they are still being read)
+      _hold_host_rows(copy, [b[0] for b in group] + [b[2] for b in group])
     for t in clips_l + vids_l:
       t.record_stream(copy)        # allocated on the caller's stream, written on the copy stream
     v_sched.meta.record_stream(main)   # the other way round

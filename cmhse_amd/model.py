@@ -233,6 +233,7 @@ class VSE(object):
     # host-fed steps (HOST_FEED): the device slots of the batch hand-over, the slot this step reads,
     # and an event behind every step's last launch (is the GPU still busy when the next is queued?)
     self._stager, self._stage_slot, self._step_done, self._step_done_pool = None, None, None, []
+    self._host_rows, self._host_ev_pool = [], []    # (event behind the last pull chunk, the pinned tensors the pulls read)
 
   # -- checkpoint contract: a LIST of 4 / 6 / 8 state-dicts (model.py:166-191) ------------------
   def _modules(self):
@@ -419,6 +420,14 @@ class VSE(object):
     self._stage_slot = slot
     return staged
 
+  def _release_host_rows(self, keep=6):
+    """Drop the host tensors whose pulls have run (see _pull_visual); never hold more than `keep`."""
+    rows = self._host_rows
+    while rows and (rows[0][0].query() or len(rows) > keep):
+      if not rows[0][0].query():
+        rows[0][0].synchronize()
+      self._host_ev_pool.append(rows.pop(0)[0])
+
   def _pull_visual(self, clips, videos, lengths_clip, lengths_video):
     """The hand-over of a host-fed training step (HOST_PULL): when `clips` and `videos` are the
     loader's pinned float32 host tensors (padded, or the ops.Ragged members of collate_packed),
@@ -440,11 +449,19 @@ class VSE(object):
     # and the rows of step k + 1 start crossing PCIe while step k's backward pass still computes.
     # (A block of that pool is reused only when the streams that read it have passed its release:
     # record_stream below; the towers' streams are joined into the caller's before the step ends.)
+    self._release_host_rows()
     with torch.cuda.stream(copy):
       cd, vd = _empty_like_on(clips, device), _empty_like_on(videos, device)
       sched = ops.SeqSchedule(lens, device, x_ptrs=ops.seq_row_ptrs_many([cd, vd]),
                               src_ptrs=ops.seq_row_ptrs_many([clips, videos]))
       events = ops.pull_steps(sched, int(clips.shape[2]), copy, HOST_PULL_CHUNK[0])
+    # The pull kernels read the loader's pinned tensors by ADDRESS, possibly after this call has
+    # returned (the host runs ahead of the GPU) — torch's pinned-memory allocator knows nothing of
+    # them and would hand the blocks to the loader's next batch as soon as the loop drops this one.
+    # Keep the tensors until an event recorded behind the last chunk has completed.
+    ev = self._host_ev_pool.pop() if self._host_ev_pool else torch.cuda.Event()
+    ev.record(copy)
+    self._host_rows.append((ev, clips, videos))
     for t in (cd, vd, sched.meta):
       t.record_stream(main)          # allocated on the copy stream, consumed on the caller's (and its forks)
     self._pull_on_s3 = copy.cuda_stream == ops.stream_set(device)[3].cuda_stream
@@ -684,6 +701,7 @@ class VSE(object):
     ev = self._step_done_pool[self.Eiters % 2] if len(self._step_done_pool) == 2 else self._step_done_pool[-1]
     ev.record()
     self._step_done = ev
+    self._release_host_rows()
     if self._stage_slot is not None:
       from .collate import DeviceStager
       DeviceStager.done(self._stage_slot, torch.cuda.current_stream())

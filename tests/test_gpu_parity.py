@@ -2329,3 +2329,84 @@ def test_host_fed_train_step_is_bit_identical(dev, monkeypatch):
         assert float((g[key] - w).abs().max()) <= 1e-6 * max(1.0, float(w.abs().max())), (feed, key)
       else:
         assert torch.equal(g[key], w), (feed, key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('feed', ['pull', 'ahead'])
+def test_host_fed_batch_may_be_dropped_right_after_the_call(dev, monkeypatch, feed):
+  """A DataLoader's pinned batch is released by the loop as soon as train_emb returns, and torch's
+  pinned-memory allocator hands the block to the next batch — while the GPU, a step behind the
+  host, may not have read it yet.  The hand-overs must keep what they read alive themselves: the
+  DMA copies ('ahead') through torch's own bookkeeping, the pull kernels ('pull'), which read the
+  tensors by address, through VSE's (model._host_rows).  Here, after a warm-up step, the copy
+  stream is kept busy for a few hundred ms so that the hand-over runs LATE, the batch is dropped,
+  and same-sized pinned blocks full of garbage are allocated at once (they reuse a freed block);
+  the step's losses must still be those of the resident step (checked to FAIL without the
+  keep-alive: round 4)."""
+  import copy
+  import gc
+  from cmhse_amd import model as model_mod, ops, synthetic
+  from cmhse_amd.model import VSE
+  opt = golden_opt('attention', low_level_loss=True, norm=True, img_dim=64, embed_size=64,
+                   img_first_size=64, cap_first_size=64)
+  spec = synthetic.anet_like_spec(64, seed=8)
+  batches = synthetic.make_batches(spec, 32, opt.img_dim, opt.vocab_size, seed=9)
+  on_dev = lambda b: [t.to(dev) if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)]
+  pinned = lambda b: [t.pin_memory() if isinstance(t, torch.Tensor) and i < 4 else t for i, t in enumerate(b)]
+  torch.manual_seed(6)
+  ref = VSE(opt)
+  sd0 = copy.deepcopy(ref.state_dict(opt))
+  ref.logger = MeterLog()
+  ref.train_start(opt)
+  for b in batches:
+    ref.train_emb(opt, *on_dev(b))
+  torch.cuda.synchronize()
+  want = [c for c in ref.logger.calls if c[0].startswith('Le')]
+  want = want[len(want) // 2:]                     # the second step
+
+  class LateLog(MeterLog):       # takes the values late, like evaluation.LogCollector: train_emb does not wait
+    def __init__(self):
+      MeterLog.__init__(self)
+      self.pending = []
+
+    def defer(self, thunk):
+      self.pending.append(thunk)
+
+    def settle(self):
+      while self.pending:
+        self.pending.pop(0)()
+
+    def _update(self, k, v, n=0):
+      self.update(k, v, n)
+
+  model = VSE(opt)
+  model.load_state_dict(copy.deepcopy(sd0), opt)
+  model.logger = LateLog()
+  model.train_start(opt)
+  monkeypatch.setattr(model_mod, 'HOST_FEED', [feed])
+  model.train_emb(opt, *pinned(batches[0]))        # warm-up: arenas, streams, allocator pools
+  torch.cuda.synchronize()
+  model.logger.settle()
+  model.logger.calls = []
+  shapes = [(t.shape, t.dtype) for t in batches[1][:4]]
+  host = pinned(batches[1])
+  ptrs = {t.data_ptr() for t in host[:4]}
+  with torch.cuda.stream(ops.copy_stream(dev)):    # ~0.3 s of work in front of whatever is queued there next
+    a = torch.randn(8192, 8192, device=dev)
+    for _ in range(30):
+      a = (a @ a) * 1e-4
+  model.train_emb(opt, *host)
+  busy = not model._step_done.query()
+  del host
+  gc.collect()
+  junk = [torch.full(s, 7 if d == torch.int64 else 1e30, dtype=d).pin_memory() for s, d in shapes for _ in range(2)]
+  reused = any(t.data_ptr() in ptrs for t in junk)
+  torch.cuda.synchronize()
+  model.logger.settle()
+  got = [c for c in model.logger.calls if c[0].startswith('Le')]
+  assert [c[0] for c in got] == [c[0] for c in want]
+  for g, w in zip(got, want):
+    assert loss_close(g[1], w[1]), (feed, g, w, 'GPU still busy when the batch was dropped: %s, a pinned '
+                                    'block was reused: %s' % (busy, reused))
+  assert busy, 'the hand-over was not late: the test did not exercise what it is for'
+  del junk, a
