@@ -70,6 +70,7 @@ class StepLosses(ctypes.Structure):
 SIGNATURES = {
     'cmhse_gru_pool_workspace': (c_size_t, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32]),
     'cmhse_async_status': (ctypes.c_int, [c_int32]),
+    'cmhse_selftest_grid_sync': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'cmhse_gru_pool_ws_region': (ctypes.c_int, [c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
                                                 ctypes.c_char_p, ctypes.POINTER(c_size_t),
                                                 ctypes.POINTER(c_size_t)]),

@@ -2146,6 +2146,38 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
 
 extern "C" int cmhse_async_status(int32_t clear) { return resident_status(clear != 0); }
 
+namespace cmhse {
+// Self-test of the grid barrier (grid_sync.hpp): every workgroup arrives `rounds` times, but each
+// barrier expects `missing` more arrivals than there are workgroups.  missing == 0: the ordinary
+// path; missing > 0: nobody ever completes the barrier — the wall-time bound must end the kernel,
+// raise the abort word and the device's status word.
+__global__ __launch_bounds__(64) void grid_sync_selftest_kernel(GridSync g, unsigned* out, int missing, int rounds) {
+  unsigned arrivals = 0;
+  for (int r = 0; r < rounds; ++r) {
+    __builtin_amdgcn_s_waitcnt(0);
+    arrivals += gridDim.x + static_cast<unsigned>(missing);
+    if (!grid_sync_wait(g, arrivals)) {
+      if (threadIdx.x == 0) atomicAdd(out + 1, 1u);      // workgroups that left through the abort path
+      return;
+    }
+  }
+  if (threadIdx.x == 0) atomicAdd(out, 1u);              // workgroups that passed every barrier
+}
+}  // namespace cmhse
+
+extern "C" int cmhse_selftest_grid_sync(void* workspace, int32_t workgroups, int32_t missing,
+                                        int32_t rounds, void* stream_) {
+  if (!workspace || workgroups <= 0 || workgroups > 1024 || missing < 0 || rounds <= 0) return CMHSE_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return CMHSE_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (hipMemsetAsync(workspace, 0, 256, stream) != hipSuccess) return CMHSE_ERR_LAUNCH;
+  unsigned* words = static_cast<unsigned*>(workspace);
+  const GridSync g = make_grid_sync(words, words + 1);
+  hipLaunchKernelGGL(grid_sync_selftest_kernel, dim3(static_cast<unsigned>(workgroups)), dim3(64), 0, stream,
+                     g, words + 2, missing, rounds);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
 extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_jobs, void* stream_) {
   if (!reqs || n_jobs <= 0 || n_jobs > kMaxJobs) return CMHSE_ERR_ARG;
   if (resident_check() != CMHSE_OK) return CMHSE_ERR_TIMEOUT;

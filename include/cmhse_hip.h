@@ -468,6 +468,15 @@ int cmhse_tune(const char* name, int32_t value, int32_t* old_value);
  * that have RUN, so poll it after a stream synchronisation (or once per step, one step late). */
 int cmhse_async_status(int32_t clear);
 
+/* Self-test of that barrier and of its failure path (tests): launches `workgroups` (<= 1024)
+ * single-wave workgroups that each arrive at `rounds` grid barriers, every barrier expecting
+ * `missing` more arrivals than there are workgroups.  workspace: 256 bytes, 256-byte aligned
+ * (zeroed by the call); on completion uint32 word [2] = workgroups that passed every barrier, word
+ * [3] = workgroups that left through the abort path.  missing = 0 never times out; missing > 0 always
+ * does, after "resident_timeout_ms", and raises the status cmhse_async_status reports. */
+int cmhse_selftest_grid_sync(void* workspace, int32_t workgroups, int32_t missing, int32_t rounds,
+                             void* stream);
+
 /* Text for an error code returned by the functions above (static storage). */
 const char* cmhse_strerror(int code);
 

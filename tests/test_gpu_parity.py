@@ -2410,3 +2410,42 @@ def test_host_fed_batch_may_be_dropped_right_after_the_call(dev, monkeypatch, fe
                                     'block was reused: %s' % (busy, reused))
   assert busy, 'the hand-over was not late: the test did not exercise what it is for'
   del junk, a
+
+
+@pytest.mark.gpu
+def test_grid_barrier_timeout_is_an_error_not_a_trap(dev, tune):
+  """csrc/grid_sync.hpp: the grid barrier of the resident kernels.  With every workgroup
+  present the barriers complete (256 workgroups x 50 rounds); with one arrival missing nobody can
+  complete them — the wall-time bound (resident_timeout_ms) must end the kernel through the abort
+  path (no trap, no hang), raise the device's status word, make the next gru forward / backward
+  call return CMHSE_ERR_TIMEOUT (RuntimeError) without launching, and everything works again once
+  the status is cleared."""
+  import ctypes
+  from cmhse_amd import _lib, layers, ops
+  lib = _lib.load()
+  stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  ws = torch.zeros(64, dtype=torch.int32, device=dev)
+  assert ops.async_status() == 0
+  assert lib.cmhse_selftest_grid_sync(ws.data_ptr(), 256, 0, 50, stream) == 0
+  torch.cuda.synchronize()
+  assert ws[2].item() == 256 and ws[3].item() == 0 and ops.async_status() == 0
+  layer = layers.Seq2Seq(8, 32).to(dev)
+  x, lens = torch.randn(3, 4, 8, device=dev), torch.tensor([4, 2, 1])
+  tune(resident_timeout_ms=30)
+  try:
+    import time
+    t0 = time.time()
+    assert lib.cmhse_selftest_grid_sync(ws.data_ptr(), 64, 1, 3, stream) == 0
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0                      # bounded: ~30 ms, not the default 5 s, not forever
+    assert ws[2].item() == 0 and ws[3].item() == 64    # every workgroup left through the abort path
+    assert ops.async_status() == _lib.load().cmhse_async_status(0) == -5
+    with pytest.raises(RuntimeError, match='grid barrier'):
+      with torch.no_grad():
+        layer(x, lens)
+    assert ops.async_status(clear=True) == -5 and ops.async_status() == 0
+    with torch.no_grad():
+      y = layer(x, lens)
+    assert torch.isfinite(y).all()
+  finally:
+    ops.async_status(clear=True)
