@@ -1671,14 +1671,9 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
     // many sequences: 64 per workgroup, so that the step is ONE round of workgroups (H / 16 x
     // ceil(S_t / 64) <= 256 up to 256 sequences at H = 1024) instead of two of 32-sequence ones
     const int tall = tunables().mid_tall_min_seqs.load(std::memory_order_relaxed);
-    if (tall > 0 && S_t >= tall && bu == 16 && alone && j.save) {   // (training calls: the validation pass keeps its shapes)
-      // ... and 48 per workgroup where three row blocks give that one round (129-192 sequences at
-      // H = 1024: 192 or 256 workgroups of 74 KB of LDS, two of which fit a CU, against 192 of the
-      // 64-sequence shape whose 98 KB let the two towers' workgroups exclude each other)
-      const int mid3 = tunables().mid_tall_rows48.load(std::memory_order_relaxed);
-      if (mid3 > 0 && ((j.b->H + 15) / 16) * ((S_t + 47) / 48) <= kChipCUs) return 3 | 512 | 16384;
-      return 3 | 512 | 8192;
-    }
+    // (a 48-sequence tile for 129-192 sequences — one round of 192 / 256 workgroups instead of 192 of
+    // this shape — was built in round 4, bit-identical, and changed nothing: profiles/r04_train_ab.txt)
+    if (tall > 0 && S_t >= tall && bu == 16 && alone && j.save) return 3 | 512 | 8192;   // (training calls: the validation pass keeps its shapes)
     return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0) |
            (alone ? 512 : 0);
   }
@@ -1732,8 +1727,6 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
   } while (0)
       if ((kind & 8192) != 0) {       // 64 sequences per workgroup (only with 16 units, 8 waves)
         hipLaunchKernelGGL((gru_step_mid_kernel<4, 16, 8>), dim3(grid), dim3(512), 0, stream, g);
-      } else if ((kind & 16384) != 0) {   // 48 sequences per workgroup (likewise)
-        hipLaunchKernelGGL((gru_step_mid_kernel<3, 16, 8>), dim3(grid), dim3(512), 0, stream, g);
       } else if ((kind & 32) != 0) {
         if (bu == 4) MID_LAUNCH_(1, 4);
         else if (bu == 8) MID_LAUNCH_(1, 8);
@@ -1779,7 +1772,7 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
 unsigned step_grid(const FwdJob& j, int kind, int S_t) {
   const int H = j.b->H;
   if ((kind & 3) == 3) {
-    const int bm = (kind & 8192) != 0 ? 64 : ((kind & 16384) != 0 ? 48 : ((kind & 32) != 0 ? 16 : 32));
+    const int bm = (kind & 8192) != 0 ? 64 : ((kind & 32) != 0 ? 16 : 32);
     const int bu = (kind & 256) != 0 ? 4 : ((kind & 128) != 0 ? 8 : 16);
     return static_cast<unsigned>((H + bu - 1) / bu) * ((S_t + bm - 1) / bm);
   }
@@ -2311,7 +2304,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs}, {"mid_tall_rows48", &t.mid_tall_rows48},
+      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
       {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"xproj_chunk_rows", &t.xproj_chunk_rows},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)

@@ -61,7 +61,6 @@ struct Tunables {
   std::atomic<int> bwd_split_min_seqs{33};   // ... and from which (up to bwd_mid_max_seqs) it runs as two launches with K split over the grid (0 = never)
   std::atomic<int> bwd_tail_min_steps{4};    // steps with <= 32 active sequences at the end of a chain from which its BPTT runs them in one resident kernel (0 = never)
   std::atomic<int> mid_tall_min_seqs{129};   // active sequences from which the mid-size forward step takes 64 sequences per workgroup (0 = never)
-  std::atomic<int> mid_tall_rows48{1};       // 1: ... 48 per workgroup where that gives one round of workgroups (0 = only the 64-sequence shape)
   // training-size BPTT steps (33-256 active sequences) from which one request of a call runs them in
   // resident chain kernels (gru_bwd_chain_kernel); 0 = never — the DEFAULT: measured slower than the
   // two launches per step it replaces (profiles/r04_chain_resident.txt: 39 against 22 us per step

@@ -83,7 +83,7 @@ def _f32c(t, name):
 def tune(name, value=-1):
   """cmhse_tune: set (value >= 0) or read (value < 0) one kernel-shape crossover of the library;
   returns its previous value.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
-  tall_tile_min_wgs, mid_tall_min_seqs, mid_tall_rows48, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
+  tall_tile_min_wgs, mid_tall_min_seqs, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
   fwd_tail_min_steps, bwd_chunk_rows, bwd_chain_min_steps, resident_timeout_ms
   (include/cmhse_hip.h)."""
   old = ctypes.c_int32(0)

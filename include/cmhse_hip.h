@@ -428,8 +428,6 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *   "mid_waves"            0  4 | 8 forces its waves per workgroup
  *   "mid_tall_min_seqs"  129  active sequences from which the mid-size step of a training call
  *                             takes 64 sequences per workgroup instead of 32 (bit-identical)
- *   "mid_tall_rows48"      1  1: of those steps, the ones whose grid then fits one round (up to 192
- *                             sequences at H = 1024) take 48 sequences per workgroup (bit-identical)
  *   "tall_tile_min_wgs" 2048  64-row workgroups from which an LDS-tiled launch uses 128-row tiles
  *   "bwd_mid_max_seqs"   512  active sequences at or below which a BPTT step runs on the mid-size
  *                             backward kernel
