@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, 'libcmhse_hip.so')
 SOURCES = ['gru.hip', 'sim.hip', 'bwd.hip']
 HEADERS = [os.path.join(CSRC, 'nt_core.hpp'), os.path.join(CSRC, 'tn_core.hpp'),
            os.path.join(CSRC, 'tn_rows.hpp'), os.path.join(CSRC, 'step_loss.hpp'),
-           os.path.join(CSRC, 'gru_ws.hpp'),
+           os.path.join(CSRC, 'gru_ws.hpp'), os.path.join(CSRC, 'grid_sync.hpp'),
            os.path.join(os.path.dirname(HERE), 'include', 'cmhse_hip.h')]
 
 

@@ -1536,14 +1536,28 @@ struct TnRowsLaunch {
     TnRowsProblem& q = g.q[g.n];
     q.a = a; q.lda = lda; q.b_addr = b_addr; q.c = c; q.ldc = ldc;
     q.bias = bias; q.M = M; q.N = N; q.n_tiles = (N + 127) / 128;
-    g.start[g.n] = grid;
-    grid += static_cast<unsigned>(q.n_tiles) * ((M + 127) / 128);
     ++g.n;
+  }
+  // Tile height of this launch (Tunables::tn_rows_bm; 0 = by shape): the tall tile when every
+  // product's M is a whole number of them (3H = 3072 is), else the small one
+  int tile_bm() const {
+    const int want = tunables().tn_rows_bm.load(std::memory_order_relaxed);
+    if (want == kTnRowsBmSmall || want == kTnRowsBmTall) return want;
+    for (int k = 0; k < g.n; ++k)
+      if (g.q[k].M % kTnRowsBmTall != 0) return kTnRowsBmSmall;
+    return kTnRowsBmTall;
   }
   // `part`: scratch of `part_floats` floats for the row split's parts (nullptr = never split)
   void launch(int64_t p0, int64_t p1, bool accumulate, hipStream_t st, float* part = nullptr,
               int64_t part_floats = 0, bool beside = false) {
     if (g.n == 0 || p1 <= p0) return;
+    const int bm = tile_bm();
+    constexpr int resident = 3;   // workgroups a CU holds at once (either tile)
+    grid = 0;
+    for (int k = 0; k < g.n; ++k) {
+      g.start[k] = grid;
+      grid += static_cast<unsigned>(g.q[k].n_tiles) * ((g.q[k].M + bm - 1) / bm);
+    }
     for (int k = g.n; k < kTnRowsMaxProblems; ++k) g.start[k] = 0xffffffffu;
     // the kernel addresses A rows with 32-bit byte offsets from the first row of the range
     int64_t max_lda = 1, per_split = 0;
@@ -1553,7 +1567,8 @@ struct TnRowsLaunch {
       per_split += static_cast<int64_t>(g.q[k].M) * g.q[k].N + g.q[k].M;
     }
     const int64_t max_rows = (0x7fffffffLL / (max_lda * 4)) / kBK * kBK;
-    const size_t smem = TileSmem<128, 128>::kBytes;
+    const size_t smem = (bm == kTnRowsBmTall) ? TileSmem<kTnRowsBmTall, 128>::kBytes
+                                              : TileSmem<kTnRowsBmSmall, 128>::kBytes;
     for (int64_t a = p0; a < p1; a += max_rows) {
       g.p0 = a;
       g.p1 = (a + max_rows < p1) ? a + max_rows : p1;
@@ -1568,14 +1583,14 @@ struct TnRowsLaunch {
       // on whether a side stream is used: results are bit-identical with and without one.)
       const int64_t rows = g.p1 - g.p0;
       int best = 1;
-      if (part != nullptr && grid < (beside ? 512u : 1024u)) {
+      if (part != nullptr && grid * static_cast<unsigned>(bm / 64) < (beside ? 1024u : 2048u)) {
         double best_cost = 1e30;
         for (int sp = 1; sp <= 8 && (sp == 1 || (rows / sp >= 256 && per_split * sp <= part_floats)); ++sp) {
           const double wgs = static_cast<double>(grid) * sp;
           const double per_cu = wgs / 256.0;
           const double busiest = static_cast<double>((static_cast<int64_t>(wgs) + 255) / 256);
           // time ~ the busiest CU's share of the work; co-residents below three leave latency exposed
-          const double fill = per_cu >= 3.0 ? 1.0 : (per_cu >= 2.0 ? 1.15 : 1.6);
+          const double fill = per_cu >= resident ? 1.0 : (per_cu >= 2.0 ? 1.15 : 1.6);
           const double cost = busiest / sp * fill * (1.0 + 0.03 * (sp - 1));
           if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
         }
@@ -1590,7 +1605,10 @@ struct TnRowsLaunch {
         g.part = part;
         g.part_stride = per_split;
       }
-      hipLaunchKernelGGL(gemm_tn_rows_kernel, dim3(grid, splits), dim3(kThreads), smem, st, g);
+      if (bm == kTnRowsBmTall)
+        hipLaunchKernelGGL(gemm_tn_rows_kernel<3>, dim3(grid, splits), dim3(kThreads), smem, st, g);
+      else
+        hipLaunchKernelGGL(gemm_tn_rows_kernel<2>, dim3(grid, splits), dim3(kThreads), smem, st, g);
       if (splits > 1)
         for (int k = 0; k < g.n; ++k) {
           TnRowsReduce r;

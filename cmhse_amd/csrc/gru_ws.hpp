@@ -69,6 +69,7 @@ struct Tunables {
   std::atomic<int> bwd_chain_min_steps{0};
   std::atomic<int> resident_timeout_ms{5000};  // wall time one grid barrier of a resident kernel may take before the launch gives up (grid_sync.hpp)
   std::atomic<int> xproj_chunk_rows{1536};   // packed rows per chunk of a training chain's hoisted input projection beside the chain (0 = one launch in front of it)
+  std::atomic<int> tn_rows_bm{0};            // tile height of the weight-gradient products: 128, 192, or 0 = 192 where 3H is a whole number of them (tn_rows.hpp)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };
 Tunables& tunables();

@@ -42,6 +42,12 @@ struct TnRowsProblem {
   int32_t M, N, n_tiles;   // n_tiles = ceil(N / 128)
 };
 
+// Tile heights (columns of A = rows of C per workgroup) the kernel is built for.
+//   128: each wave 64 x 64 of C, 32 MFMAs per barrier;
+//   192: each wave 96 x 64, 48 MFMAs per barrier.  3H = 3072 is a whole number of either.
+// Three workgroups per CU both.
+constexpr int kTnRowsBmSmall = 128, kTnRowsBmTall = 192;
+
 constexpr int kTnRowsMaxProblems = 4;
 
 struct TnRowsGroup {
@@ -62,11 +68,19 @@ struct TnRowsGroup {
   int64_t part_off[kTnRowsMaxProblems];
 };
 
-// three waves per SIMD (168 registers): three workgroups share a CU and hide each other's barrier
-// and load latencies — 115 TFLOP/s on a launch of exactly three tiles per CU, against 66 with two
+// Three waves per SIMD (<= 168 registers) either way: three workgroups share a CU and hide each
+// other's barrier and load latencies (128-row tile: 115-119 TFLOP/s on a launch of exactly three
+// tiles per CU against 66 with two; four per CU — 128 registers, 2 spilled — 94).
+// MS = 2: BM = 128.  MS = 3: BM = 192, 96 accumulator registers; with the two fragment sets of the
+// rotated pipeline it needs 184 registers (two waves per SIMD: 115 TFLOP/s at an exact fill, no
+// better than the small tile), with ONE fragment set 166: 122-125 TFLOP/s (K = 9600; I = 5120 /
+// 2048, H = 1024; profiles/r04_wgrad_rate.txt) — the barrier is amortised over 48 MFMAs per wave
+// instead of 32, the ratio of the validation pass's step kernel.
+template <int MS>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3)))
 void gemm_tn_rows_kernel(const TnRowsGroup g) {
-  constexpr int BM = 128, BN = 128, MSUB = 2, NSUB = 2;
+  constexpr int BM = 64 * MS, BN = 128, MSUB = MS, NSUB = 2;
+  constexpr bool TALL = (MS == 3);
   using SM = TileSmem<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int qi = 0;
@@ -80,10 +94,15 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int c = tid & 127;
   const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);   // waves 0,1: rows 0..7; waves 2,3: rows 8..15
+  // TALL: columns 128..191 of the A tile — thread (c2 = 128 + lane, kq = wave) loads column c2 of
+  // the 4 packed rows kq*4 .. kq*4+3 of the chunk
+  const int c2 = 128 + lane;
+  const int kq = __builtin_amdgcn_readfirstlane(wave);
   // this thread's column of the A tile / B tile, clamped into the matrix (columns past the edge
   // compute on a valid column's data and are never stored)
   const unsigned am = static_cast<unsigned>((m0 + c < q.M) ? (m0 + c) : (q.M - 1));
   const unsigned bn = static_cast<unsigned>((n0 + c < q.N) ? (n0 + c) : (q.N - 1));
+  const unsigned am2 = static_cast<unsigned>((m0 + c2 < q.M) ? (m0 + c2) : (q.M - 1));
   int64_t p0 = g.p0, p1 = g.p1;
   if (g.seg > 0) {
     p0 += static_cast<int64_t>(blockIdx.y) * g.seg;
@@ -105,9 +124,11 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(q.a + p0 * q.lda), 0, 0x7fffffff, kRsrcFlags);
   cptr_u64 const b_tab = (cptr_u64)(reinterpret_cast<uintptr_t>(q.b_addr + p0));
-  const unsigned a_off = am * 4u, b_off = bn * 4u;
+  const unsigned a_off = am * 4u, b_off = bn * 4u, a2_off = am2 * 4u;
 
   float ra[8], rb[8];
+  float ra2[TALL ? 4 : 1];
+  float bsum2 = 0.f;
   rowaddr_t nb[8];          // B row bases of the next chunk to load (scalar)
   float bsum = 0.f;
   f32x16 acc[MSUB][NSUB];
@@ -120,6 +141,10 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
   // re-reads the last row; write_lds masks it)
   auto row_of = [&](int ch, int j) {
     const int r = ch * kBK + kg * 8 + j;
+    return (r < nrows) ? r : (nrows - 1);
+  };
+  auto row2_of = [&](int ch, int j) {
+    const int r = ch * kBK + kq * 4 + j;
     return (r < nrows) ? r : (nrows - 1);
   };
   auto fetch_rows = [&](int ch) {
@@ -135,6 +160,11 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
           reinterpret_cast<void*>(nb[j]), 0, 0x7fffffff, kRsrcFlags);
       rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off, 0, 0));
     }
+    if (TALL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ra2[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, a2_off, row2_of(ch, j) * lda_b, 0));
+    }
   };
   auto write_lds = [&](int buf, int ch, auto maskedc) {
     constexpr bool MASKED = decltype(maskedc)::value;
@@ -143,10 +173,20 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (rk + j >= nrows) ra[j] = 0.f;    // A = 0 removes the row from C and from the bias
+      if (TALL) {
+        const int rq = ch * kBK + kq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (rq + j >= nrows) ra2[j] = 0.f;
+      }
     }
     if (want_bias) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) bsum += ra[j];
+      if (TALL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bsum2 += ra2[j];
+      }
     }
     float* ap = SM::a(smem, buf) + c * kLdsLd + kg * 8;
     float* bp = SM::b(smem, buf) + c * kLdsLd + kg * 8;
@@ -154,9 +194,12 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
     *reinterpret_cast<float4*>(ap + 4) = make_float4(ra[4], ra[5], ra[6], ra[7]);
     *reinterpret_cast<float4*>(bp) = make_float4(rb[0], rb[1], rb[2], rb[3]);
     *reinterpret_cast<float4*>(bp + 4) = make_float4(rb[4], rb[5], rb[6], rb[7]);
+    if (TALL)
+      *reinterpret_cast<float4*>(SM::a(smem, buf) + c2 * kLdsLd + kq * 4) =
+          make_float4(ra2[0], ra2[1], ra2[2], ra2[3]);
   };
   const int frow = lane & 31, fk = (lane >> 5) * 4;
-  const int a_row0 = wm * 64;
+  const int a_row0 = wm * (BM / 2);
   const int b_row0[NSUB] = {wn * 64, wn * 64 + 32};
   float4 f0a[MSUB], f0b[NSUB], f1a[MSUB], f1b[NSUB];
   auto read_frags = [&](int buf, int kb, float4(&fa)[MSUB], float4(&fb)[NSUB]) {
@@ -192,51 +235,83 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
   // chunk ch lies wholly inside the range?
   auto full = [&](int ch) { return (ch + 1) * kBK <= nrows; };
 
-  // the rotated software pipeline of nt_phase (see there): only the barrier is exposed
-  fetch_rows(0);
-  issue_global(0);
-  if (nchunks > 1) fetch_rows(1);
-  if (full(0)) write_lds(0, 0, Plain{}); else write_lds(0, 0, Masked{});
-  __syncthreads();
-  read_frags(0, 0, f0a, f0b);
-  if (nchunks > 1) {
-    issue_global(1);
-    if (nchunks > 2) fetch_rows(2);
-  }
-  read_frags(0, 1, f1a, f1b);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_block(f0a, f0b, I0{}, I3{});
-  __builtin_amdgcn_sched_barrier(0);
-  if (nchunks > 1) {
-    if (full(1)) write_lds(1, 1, Plain{}); else write_lds(1, 1, Masked{});
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_block(f0a, f0b, I3{}, I4{});
-  for (int ch = 1; ch < nchunks; ++ch) {
-    const int cur = ch & 1;
-    const bool more = ch + 1 < nchunks;      // uniform
-    __syncthreads();
-    read_frags(cur, 0, f0a, f0b);
-    if (more) {
-      issue_global(ch + 1);
-      if (ch + 2 < nchunks) fetch_rows(ch + 2);
+  if constexpr (TALL) {
+    // One fragment set (the second would not fit three waves per SIMD beside 96 accumulators): the
+    // fragments of the chunk's second half are requested once the MFMAs of its first half have
+    // issued; the other two workgroups of the CU cover that latency.  Same k order as below.
+    using I0_ = std::integral_constant<int, 0>;
+    using I4_ = std::integral_constant<int, 4>;
+    fetch_rows(0);
+    issue_global(0);
+    if (nchunks > 1) fetch_rows(1);
+    if (full(0)) write_lds(0, 0, Plain{}); else write_lds(0, 0, Masked{});
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int cur = ch & 1;
+      const bool more = ch + 1 < nchunks;      // uniform
+      __syncthreads();
+      read_frags(cur, 0, f0a, f0b);
+      if (more) {
+        issue_global(ch + 1);
+        if (ch + 2 < nchunks) fetch_rows(ch + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f0a, f0b, I0_{}, I4_{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(cur, 1, f0a, f0b);
+      if (more) {
+        if (full(ch + 1)) write_lds(cur ^ 1, ch + 1, Plain{}); else write_lds(cur ^ 1, ch + 1, Masked{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f0a, f0b, I0_{}, I4_{});
     }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(f1a, f1b, I0{}, I4{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(cur, 1, f1a, f1b);
+    __syncthreads();
+  } else {
+    // the rotated software pipeline of nt_phase (see there): only the barrier is exposed
+    fetch_rows(0);
+    issue_global(0);
+    if (nchunks > 1) fetch_rows(1);
+    if (full(0)) write_lds(0, 0, Plain{}); else write_lds(0, 0, Masked{});
+    __syncthreads();
+    read_frags(0, 0, f0a, f0b);
+    if (nchunks > 1) {
+      issue_global(1);
+      if (nchunks > 2) fetch_rows(2);
+    }
+    read_frags(0, 1, f1a, f1b);
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f0a, f0b, I0{}, I3{});
     __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      if (full(ch + 1)) write_lds(cur ^ 1, ch + 1, Plain{}); else write_lds(cur ^ 1, ch + 1, Masked{});
+    if (nchunks > 1) {
+      if (full(1)) write_lds(1, 1, Plain{}); else write_lds(1, 1, Masked{});
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(f0a, f0b, I3{}, I4{});
+    for (int ch = 1; ch < nchunks; ++ch) {
+      const int cur = ch & 1;
+      const bool more = ch + 1 < nchunks;      // uniform
+      __syncthreads();
+      read_frags(cur, 0, f0a, f0b);
+      if (more) {
+        issue_global(ch + 1);
+        if (ch + 2 < nchunks) fetch_rows(ch + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f1a, f1b, I0{}, I4{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(cur, 1, f1a, f1b);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f0a, f0b, I0{}, I3{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        if (full(ch + 1)) write_lds(cur ^ 1, ch + 1, Plain{}); else write_lds(cur ^ 1, ch + 1, Masked{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(f0a, f0b, I3{}, I4{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(f1a, f1b, I0{}, I4{});
+    __syncthreads();
   }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_block(f1a, f1b, I0{}, I4{});
-  __syncthreads();
 
   // ---- epilogue ----
   const bool accum = g.accumulate != 0 && g.seg == 0;    // (a split's part is always stored)
@@ -258,12 +333,23 @@ void gemm_tn_rows_kernel(const TnRowsGroup g) {
       float* dst = bias + m0 + c;
       *dst = accum ? (*dst + s) : s;
     }
+    if (TALL) {
+      // columns 128..191: the four row quarters (kq) of a column, added in the order of kq
+      float* red2 = smem + 128;
+      if (kq > 0) red2[(kq - 1) * 64 + lane] = bsum2;
+      __syncthreads();
+      if (kq == 0 && m0 + c2 < q.M) {
+        const float s = ((bsum2 + red2[lane]) + red2[64 + lane]) + red2[128 + lane];
+        float* dst = bias + m0 + c2;
+        *dst = accum ? (*dst + s) : s;
+      }
+    }
   }
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
+      const int m = m0 + a_row0 + ms * 32 + acc_row(r, lane);
       if (m >= q.M) continue;
       float* crow = cbase + static_cast<int64_t>(m) * ldc;
 #pragma unroll

@@ -450,6 +450,12 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *   "bwd_chunk_rows"    2048  packed rows a weight-gradient chunk spans before its products are
  *                             issued beside the chain (changes the order in which chunks are
  *                             accumulated, i.e. the gradients to fp32 rounding)
+ *   "xproj_chunk_rows"  1536  packed rows per chunk of a training chain's hoisted input projection
+ *                             beside the chain; 0 = one launch in front of it
+ *   "tn_rows_bm"           0  tile height of the weight-gradient products: 128 | 192; 0 = 192 where
+ *                             every product's row count (3H, H) is a whole number of them, else 128
+ *                             (the row split into parts follows the tile count, i.e. the gradients
+ *                             to fp32 rounding; profiles/r04_wgrad_rate.txt)
  * Process-wide (atomics): set them between calls, not while calls that size workspaces with them
  * (`*_workspace` reads mid_max_seqs) are in flight on other threads.  Unknown name: CMHSE_ERR_ARG. */
 int cmhse_tune(const char* name, int32_t value, int32_t* old_value);

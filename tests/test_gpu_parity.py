@@ -828,6 +828,53 @@ def test_bptt_training_size_steps_as_resident_chain_kernel(dev, oracle, pool, cl
       grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
 
 
+@pytest.mark.parametrize('cls,pool,I,H,S,T', [
+    ('Seq2Seq', 'seq2seq', 24, 64, 37, 9),        # 3H = 192: one tall tile, N < 128
+    ('Attention', 'attention', 200, 128, 150, 7),   # 3H = 384: two tall tiles; rows split into parts
+    ('Maxout', 'maxout', 36, 40, 21, 5),          # 3H = 120: a tall tile forced onto a ragged M
+    ('Seq2Seq', 'seq2seq', 130, 192, 300, 4),     # N = 130: a second column tile of 2; > 1024 rows
+])
+def test_weight_gradient_tall_tile_vs_small_tile(dev, oracle, tune, cls, pool, I, H, S, T):
+  """The weight-gradient products (gemm_tn_rows_kernel, tn_rows.hpp) on their 192-row tile (each
+  wave 96 x 64 of C, two workgroups per CU) against the 128-row tile: every gradient equal to fp32
+  rounding (the row split into parts is chosen per tile count, so the order of the partial sums may
+  differ), each bitwise reproducible, and against the float64 oracle.  Ragged M (3H = 120 on a
+  192-row tile), N below and just above a column tile, row counts that are not a multiple of 16."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(5 + H + S)
+  torch.manual_seed(9)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[0] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  w = rng.standard_normal((S, H)).astype(np.float32)
+
+  def run(bm):
+    tune(tn_rows_bm=bm)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    (layer(xt, torch.from_numpy(lens)) * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return [xt.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  small, tall, again = run(128), run(192), run(192)
+  for a, b, c in zip(small, tall, again):
+    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max()))
+    assert torch.equal(b, c), 'not reproducible from run to run'
+  _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, None)
+  grads, dx, _ = oracle.pooled_gru_backward(cache, w.astype(np.float64))
+  grad_close(tall[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
+  for (pn, _), got in zip(layer.named_parameters(), tall[1:]):
+    grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
 @pytest.mark.parametrize('pool,cls', [('attention', 'Attention'), ('maxout', 'Maxout')])
 def test_weight_gradients_in_time_chunks_beside_the_chain(dev, oracle, pool, cls, monkeypatch, tune):
   """The weight-gradient products (gemm_tn_rows_kernel) of a batch long enough to be taken in

@@ -15,7 +15,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-from cmhse_amd import layers  # noqa: E402
+from cmhse_amd import layers, ops  # noqa: E402
 
 
 def main():
@@ -26,8 +26,10 @@ def main():
   ap.add_argument('--H', type=int, default=1024)
   ap.add_argument('--pool', default='seq2seq', choices=['seq2seq', 'attention', 'maxout'])
   ap.add_argument('--reps', type=int, default=5)
+  ap.add_argument('--tn_rows_bm', type=int, default=0, help='tile height of the products: 128, 192, 0 = by shape')
   args = ap.parse_args()
   dev = torch.device('cuda', 0)
+  ops.tune('tn_rows_bm', args.tn_rows_bm)
   cls = {'seq2seq': layers.Seq2Seq, 'attention': layers.Attention, 'maxout': layers.Maxout}[args.pool]
   torch.manual_seed(0)
   layer = cls(args.I, args.H).to(dev)
