@@ -201,6 +201,8 @@ def main():
 
   debug = os.environ.get('CMHSE_BENCH_DEBUG', '0') == '1'   # host-side marks of every pass on stderr
 
+  host_queue_ms = []     # per pass: host ms until the encoders / the ranking were queued
+
   def step(plan=None, src=None):
     """One validation pass, scored: the embeddings are encoded, both directions ranked, the
     per-batch meters replayed, and the ranks brought to the host and turned into the Recall@K /
@@ -216,6 +218,7 @@ def main():
       r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
       packed = torch.stack([r_i, t_i, r_t, t_t])
       h2 = time.perf_counter()
+      host_queue_ms.append(((h1 - h0) * 1e3, (h2 - h1) * 1e3))
       finish_log()     # the per-batch 'Letest' meters (evaluation.py:129), after the ranking is queued
       host = packed.cpu().numpy().astype(np.float64)     # ONE device-to-host copy for both directions
       last['rep_i'], last['rep_t'] = report_from_ranks(host[0]), report_from_ranks(host[2])
@@ -255,10 +258,25 @@ def main():
     gc.freeze()
   t0 = time.perf_counter()
   with ops.StepTimers() as timers, ops.SimTimers() as sim_timers:
+    pass_marks = [t0]
+    del host_queue_ms[:]
+    gc_spans = []
+    def _gc_cb(phase, info, _t=[0.0]):
+      if phase == 'start':
+        _t[0] = time.perf_counter()
+      else:
+        gc_spans.append(((time.perf_counter() - _t[0]) * 1e3, info.get('generation')))
+    import gc as _gc
+    _gc.callbacks.append(_gc_cb)
     for _ in range(args.steps):
       ranks_i, ranks_t = step()
+      pass_marks.append(time.perf_counter())   # (a pass ends with its ranks on the host)
     sync()
   elapsed = time.perf_counter() - t0
+  _gc.callbacks.remove(_gc_cb)
+  timed_host_queue = list(host_queue_ms)
+  pass_list = [(b - a) * 1e3 for a, b in zip(pass_marks[:-1], pass_marks[1:])]
+  pass_ms = sorted((b - a) * 1e3 for a, b in zip(pass_marks[:-1], pass_marks[1:]))
   my_elapsed = elapsed
   if world > 1:
     t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
@@ -325,6 +343,12 @@ def main():
                                 'gloo, %d ranks sharing %d GPU(s): functional run of the N-rank '
                                 'path, not a scaling measurement' % (world, torch.cuda.device_count())))},
         'videos_per_s': N * args.steps / elapsed, 'r1_i2t_random_init': r1,
+        # spread of the timed passes on rank 0 (`ms_per_step` is their mean, whatever the spread)
+        'pass_ms': {'min': pass_ms[0], 'median': pass_ms[len(pass_ms) // 2], 'max': pass_ms[-1],
+                    'slowest_pass': int(np.argmax(pass_list)),
+                    'host_ms_until_encoders_queued': ([round(x[0], 2) for x in timed_host_queue] or None),
+                    'python_gc_ms': round(sum(x[0] for x in gc_spans), 2),
+                    'python_gc_full_collections': sum(1 for x in gc_spans if x[1] == 2)},
         'report_i2t_random_init': {k: float(v) for k, v in last['rep_i'].items()},
         'report_t2i_random_init': {k: float(v) for k, v in last['rep_t'].items()},
         # identity of the integer ranks of both directions (partition-independent by construction:

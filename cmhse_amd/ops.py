@@ -26,19 +26,22 @@ def _stream():
 # The arena is allocated once, at the first upload (model set-up / warm-up).
 _SLOT_BYTES = 2 << 20
 _N_SLOTS = 64
-_ARENA = {'buf': None, 'events': None, 'next': 0}
+_ARENA = {'buf': None, 'np': None, 'events': None, 'next': 0}
 
 
 def _staging_slot(nbytes):
-  """(pinned uint8 view of >= nbytes, event to record after the copy)."""
+  """((pinned uint8 tensor view of >= nbytes, the same bytes as a NumPy array), event to record
+  after the copy)."""
   if nbytes > _SLOT_BYTES:    # larger than any schedule array of this path: a block of its own
-    return torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.cuda.Event()
+    block = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    return (block, block.numpy()), torch.cuda.Event()
   if _ARENA['buf'] is None:
     # everything that can stall later is paid here, once: page-locking, the first touch of every
     # page (a fresh slot's first copy ran at 0.1 GB/s), and the creation of the slots' events
     # (torch creates an event at its first record; one such creation was seen to take 65 ms)
     _ARENA['buf'] = torch.empty(_SLOT_BYTES * _N_SLOTS, dtype=torch.uint8).pin_memory()
     _ARENA['buf'].zero_()
+    _ARENA['np'] = _ARENA['buf'].numpy()      # the same pinned bytes as a NumPy array (upload())
     _ARENA['events'] = [torch.cuda.Event() for _ in range(_N_SLOTS)]
     for ev in _ARENA['events']:
       ev.record()
@@ -46,7 +49,8 @@ def _staging_slot(nbytes):
   _ARENA['next'] = (i + 1) % _N_SLOTS
   ev = _ARENA['events'][i]
   ev.synchronize()            # 63 uploads ago: complete unless the host is far ahead of the GPU
-  return _ARENA['buf'][i * _SLOT_BYTES:(i + 1) * _SLOT_BYTES], ev
+  return (_ARENA['buf'][i * _SLOT_BYTES:(i + 1) * _SLOT_BYTES],
+          _ARENA['np'][i * _SLOT_BYTES:(i + 1) * _SLOT_BYTES]), ev
 
 
 def upload(arr, device):
@@ -58,10 +62,13 @@ def upload(arr, device):
   n = arr.nbytes
   if n == 0:
     return torch.from_numpy(arr).to(device)
-  buf, ev = _staging_slot(n)
-  src = torch.from_numpy(arr)
-  view = buf[:n].view(src.dtype).view(arr.shape)
-  view.copy_(src)
+  (buf, buf_np), ev = _staging_slot(n)
+  # host -> pinned staging with NumPy (one memcpy on this thread).  torch's CPU copy_ splits a
+  # copy of this size (a 22 k-sequence schedule is 0.5 MB) over its intra-op thread pool, and
+  # waking that pool on a many-core host took 60-190 ms once in ~20 validation passes — with the
+  # GPU idle behind it (tools/pass_jitter.py: stack samples of the slow passes).
+  buf_np[:n] = arr.reshape(-1).view(np.uint8)
+  view = buf[:n].view(torch.from_numpy(arr.reshape(-1)[:0]).dtype).view(arr.shape)
   dev = view.to(device, non_blocking=True)
   ev.record(torch.cuda.current_stream(dev.device))
   return dev
