@@ -14,6 +14,8 @@ MI355X-first differences in HOW (not WHAT) things are computed:
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import hashlib
 import os
 import time
@@ -432,6 +434,21 @@ def _encode_group_planned(model, group, contextual_model, device, plan):
               batch_sizes=plan['batch_sizes'])
 
 
+@contextlib.contextmanager
+def _no_gc_pause():
+  """No cyclic garbage collection while a pass's launches are being queued: the GPU has nothing
+  to do until the first of them arrives, and a full collection over a training process's objects
+  was measured at 70-90 ms in that spot (tools/pass_jitter.py; a pass is 281).  The collector is
+  switched back on right after (the pass allocates a few thousand short-lived objects)."""
+  was = gc.isenabled()
+  gc.disable()
+  try:
+    yield
+  finally:
+    if was:
+      gc.enable()
+
+
 def _group_batches(batches, max_bytes):
   """Split the loader's batches into super-batches of at most `max_bytes` of padded features."""
   groups, cur, cur_bytes = [], [], 0
@@ -486,7 +503,7 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
                   .format(state['i'], n_loader, batch_time=batch_time, e_log=str(val_logger)))
         state['i'] += 1
 
-  with torch.no_grad():
+  with torch.no_grad(), _no_gc_pause():
     for gi, group in enumerate(_group_batches(batches, superbatch_bytes)):
       model.logger = val_logger                     # evaluation.py:99
       enc = encode_group(model, group, contextual_model,

@@ -42,7 +42,7 @@ def main():
   ops.gru_pool_fwd_multi = wrapped
   from cmhse_amd import evaluation
   evaluation.ops.gru_pool_fwd_multi = wrapped
-  for i in range(3):
+  for i in range(5):
     torch.cuda.synchronize()
     marks.clear()
     t0 = time.perf_counter()
@@ -61,7 +61,7 @@ def main():
   pr.disable()
   torch.cuda.synchronize()
   fin()
-  pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+  pstats.Stats(pr).sort_stats('tottime').print_stats(28)
 
 
 if __name__ == '__main__':
