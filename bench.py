@@ -24,7 +24,8 @@ and exits with the worst child's return code.  On a box with fewer GPUs than ran
 share the GPUs over a gloo group (a functional run of the N-rank path, flagged in the JSON).
 
 The JSON line also carries
-  roofline      for the dominant kernel (gru_step_kernel): algorithmic FLOPs of the timed launches
+  roofline      for the dominant kernel (the LDS-tiled GRU step: gru_step_chain_kernel, one launch per
+                chain of time steps, and gru_step_kernel): algorithmic FLOPs of the timed launches
                 (2*3H*I + 2*3H*H + 14H per sequence-step) / their HIP-event time,
                 against the exact-fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
   roofline_sim  the similarity GEMM (sim_kernel<Rank>): 2*nrows*M*D FLOP per direction over the
@@ -283,9 +284,9 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  # Roofline of the dominant kernel (gru_step_kernel, the LDS-tiled GRU step): every one of its
-  # launches in the timed region sits between its own HIP event pair (cmhse_timer_tiled), priced
-  # with its algorithmic FLOPs.  `all_step_kernels` adds the small-batch step kernel (the ragged
+  # Roofline of the dominant kernel (the LDS-tiled GRU step: gru_step_chain_kernel — the tiled steps
+  # of a call in one launch — and gru_step_kernel): every one of its launches in the timed region
+  # sits between its own HIP event pair (cmhse_timer_tiled), priced with its algorithmic FLOPs.  `all_step_kernels` adds the small-batch step kernel (the ragged
   # tails), from the event spans around each encoder call's whole step sequence.
   spans = timers.collect()
   sims = sim_timers.collect()
@@ -318,7 +319,7 @@ def main():
   pairs = float(N) * float(N)
 
   clk = measured_clock_ghz()
-  traffic = measured_traffic('gru_step_kernel<')
+  traffic = measured_traffic(('gru_step_kernel<', 'gru_step_chain_kernel<'))
   if rank == 0:
     r1 = 100.0 * float((np.asarray(ranks_i) < 1).mean())
     out = {
@@ -356,7 +357,9 @@ def main():
         'ranks_crc32': zlib.crc32(np.asarray(ranks_i, dtype=np.int64).tobytes() +
                                   np.asarray(ranks_t, dtype=np.int64).tobytes()),
         'per_rank': per_rank,
-        'roofline': {'kernel': 'gru_step_kernel', 'bound': 'mfma', 'achieved': achieved,
+        'roofline': {'kernel': 'gru_step_chain_kernel / gru_step_kernel (the LDS-tiled GRU step: one launch per '
+                               'chain of time steps, or per step where a chain cannot be used)',
+                     'bound': 'mfma', 'achieved': achieved,
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                      'traffic': traffic,

@@ -77,6 +77,46 @@ __device__ __forceinline__ bool grid_sync_wait(const GridSync& g, unsigned targe
   return s_ok != 0;
 }
 
+// One-sided wait of the step-chain kernel (gru_step_chain_kernel, gru.hip): every thread of the
+// workgroup returns once `*flag` has reached `need` (other workgroups add to it with
+// flag_signal() after their write-through stores have left the CU), or false when the wait was
+// abandoned — the same wall-time bound, abort word and host status word as grid_sync_wait.
+__device__ __forceinline__ bool flag_wait(const GridSync& g, const unsigned* flag, unsigned need) {
+  __shared__ int s_flag_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    uint64_t t0 = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) != 0) continue;
+      if (__hip_atomic_load(g.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        ok = 0;
+        break;
+      }
+      const uint64_t now = wall_clock64();
+      if (t0 == 0) {
+        t0 = now;
+      } else if (now - t0 > g.timeout_ticks) {
+        __hip_atomic_store(g.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g.status_host != nullptr)
+          __hip_atomic_store(g.status_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok = 0;
+        break;
+      }
+    }
+    s_flag_ok = ok;
+  }
+  __syncthreads();
+  return s_flag_ok != 0;
+}
+
+// All waves must have drained their stores (s_waitcnt) before calling.
+__device__ __forceinline__ void flag_signal(unsigned* flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Host side (gru.hip): the device's status word and the GridSync of a launch.
 unsigned* resident_status_word();                 // pinned, device-visible; NULL if it cannot be allocated
 GridSync make_grid_sync(unsigned* counter, unsigned* abort_word);

@@ -120,15 +120,29 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 
 constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
 
-template <bool VEC, int MSUB, bool BF3>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
-void gru_step_kernel(const GruStepGroup grp) {
+// What a tile of the step-CHAIN kernel (gru_step_chain_kernel below) waits for and signals: the
+// counter of the same row tile one step earlier must have reached `need` (all its column tiles)
+// before the h phase starts, and `done` is bumped once this tile's state rows have left the CU.
+struct ChainDep {
+  const unsigned* wait;   // NULL: nothing to wait for (the chain's first step)
+  unsigned need;
+  unsigned* done;
+  GridSync sync;          // abort word / status word / timeout of the launch (counter unused)
+};
+
+// One tile of the LDS-tiled GRU step: sequences [m0, m0 + BM) x hidden units [u0, u0 + BU) of step
+// `t`.  CHAIN = false: the body of gru_step_kernel (one launch per time step).  CHAIN = true: the
+// same arithmetic inside gru_step_chain_kernel — the x phase (which does not depend on the
+// previous step) first, then the wait for the previous step's rows, the h phase, and the new state
+// written THROUGH the non-coherent L2 (agent-scope stores) before `done` is signalled.
+template <bool VEC, int MSUB, bool BF3, bool CHAIN>
+__device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsigned wg, const int t,
+                                              const int S_t, const int64_t off_prev,
+                                              const int64_t off_cur, const ChainDep& dep) {
   constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
 #ifdef TILE_TRACE_BUILD
   const uint64_t t_first = wall_clock64();
 #endif
-  unsigned wg;
-  const GruStepParams& p = grp.j[group_job(grp, &wg)];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -156,20 +170,20 @@ void gru_step_kernel(const GruStepGroup grp) {
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i) {
     const int m = m0 + srow + 64 * i;
-    av[i] = m < p.S_t;
-    const int mc = av[i] ? m : (p.S_t - 1);
+    av[i] = m < S_t;
+    const int mc = av[i] ? m : (S_t - 1);
     if (BF3) {
-      ax[i] = row_addr(p.xs + (p.off_cur + mc) * split_ld(I));   // (token lookups included)
+      ax[i] = row_addr(p.xs + (off_cur + mc) * split_ld(I));   // (token lookups included)
     } else if (p.tok_rows != nullptr) {
-      long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
+      long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[t];
       tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
       ax[i] = row_addr(p.emb + tok * I);
     } else {
-      ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * p.x_step * 4u;
+      ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(t) * p.x_step * 4u;
     }
-    if (p.t > 0)
-      ah[i] = BF3 ? row_addr(p.hs_s + (p.off_prev + mc) * split_ld(H))
-                  : row_addr(p.hs + (p.off_prev + mc) * H);
+    if (t > 0)
+      ah[i] = BF3 ? row_addr(p.hs_s + (off_prev + mc) * split_ld(H))
+                  : row_addr(p.hs + (off_prev + mc) * H);
     else if (p.h0_rows != nullptr)
       ah[i] = BF3 ? row_addr(p.h0_s + static_cast<int64_t>(mc) * split_ld(H)) : p.h0_rows[mc];
     else
@@ -202,10 +216,9 @@ void gru_step_kernel(const GruStepGroup grp) {
 
   const int a_row0 = wm * 32 * MSUB;
   const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
-  const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
+  const bool have_h = (t > 0) || (p.h0_rows != nullptr);
 
-  const int S_t = p.S_t, t = p.t, pool_mode = p.pool_mode;
-  const int64_t off_prev = p.off_prev, off_cur = p.off_cur;
+  const int pool_mode = p.pool_mode;
   float* const hs = p.hs;
   float* const gates = p.gates;
   float* const out = p.out;
@@ -223,6 +236,10 @@ void gru_step_kernel(const GruStepGroup grp) {
     if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   } else {
     nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
+    if (CHAIN) {
+      // the previous step's rows of this row tile: complete (written through by their tiles)?
+      if (dep.wait != nullptr && !flag_wait(dep.sync, dep.wait, dep.need)) return;
+    }
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
   }
   TRACE_MARK(3);
@@ -308,7 +325,10 @@ void gru_step_kernel(const GruStepGroup grp) {
         }
       }
       if (uv && m < S_t) {
-        hs[(off_cur + m) * H + u] = hn[r];
+        if (CHAIN)   // read by the next step's tiles on other XCDs: past this XCD's L2 (sc1)
+          __hip_atomic_store(&hs[(off_cur + m) * H + u], hn[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          hs[(off_cur + m) * H + u] = hn[r];
         if (gates != nullptr) {
           float* gp = gates + (off_cur + m) * 4 * H + u;
           gp[0] = rg;
@@ -340,8 +360,13 @@ void gru_step_kernel(const GruStepGroup grp) {
         len[i] = (pool_mode == CMHSE_POOL_LAST) ? lens[mc] : 0;
       }
       if (pool_mode == CMHSE_POOL_MAX && t > 0) {
+        // (CHAIN: the running maximum was written by the previous step's tile, on another CU — an
+        // agent-scope load, which neither this CU's L1 nor a non-coherent L2 serves)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] = out[static_cast<int64_t>(orow[i]) * H + uc];
+        for (int i = 0; i < 4; ++i)
+          cur[i] = CHAIN ? __hip_atomic_load(&out[static_cast<int64_t>(orow[i]) * H + uc], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)
+                         : out[static_cast<int64_t>(orow[i]) * H + uc];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -350,7 +375,10 @@ void gru_step_kernel(const GruStepGroup grp) {
         const float v = hn[r4 + i];
         if (pool_mode == CMHSE_POOL_MAX) {
           if (t == 0 || v > cur[i]) {  // strict '>': the first maximum wins, like max_pool1d
-            out[static_cast<int64_t>(orow[i]) * H + u] = v;
+            if (CHAIN)
+              __hip_atomic_store(&out[static_cast<int64_t>(orow[i]) * H + u], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+              out[static_cast<int64_t>(orow[i]) * H + u] = v;
             if (argmax != nullptr) argmax[static_cast<int64_t>(m) * H + u] = t;
           }
         } else if (pool_mode == CMHSE_POOL_LAST) {
@@ -361,6 +389,120 @@ void gru_step_kernel(const GruStepGroup grp) {
       }
     }
   }
+  if (CHAIN) {
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's write-through state stores have been performed
+    flag_signal(dep.done);
+  }
+}
+
+template <bool VEC, int MSUB, bool BF3>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
+void gru_step_kernel(const GruStepGroup grp) {
+  unsigned wg;
+  const GruStepParams& p = grp.j[group_job(grp, &wg)];
+  ChainDep none;
+  none.wait = nullptr;
+  none.need = 0;
+  none.done = nullptr;
+  gru_step_tile<VEC, MSUB, BF3, false>(p, wg, p.t, p.S_t, p.off_prev, p.off_cur, none);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step CHAIN: the LDS-tiled steps t0 .. t0 + nsteps - 1 of up to kMaxJobs encoders in ONE launch.
+//
+// Per-step launches drain the chip at every time step: the last round of a step's workgroups runs
+// on a partly empty chip (a full split: ~2 % of the kernel's time; a rank's 615-video share, whose
+// steps are one or two rounds each: 15 %), although row tile r of step t + 1 needs nothing but row
+// tile r of step t — the sequences are sorted by length, so the active set of a step is a prefix
+// of the previous one's — and two thirds of its work (the x phase, K = I) nothing at all.  Here
+// every (step, request, row tile, column tile) is a TASK; a workgroup takes the next task of its
+// XCD's queue (tasks in step order; column tile c belongs to XCD c % 8, so an XCD's L2 keeps
+// re-serving the same weight rows exactly as with the per-step launches' block order), runs the
+// tile's x phase, waits until the counter of (request, step - 1, row tile) has reached the number
+// of column tiles, runs the h phase and the epilogue, writes the new state rows through to memory
+// (agent-scope stores: the next step's tiles run on other XCDs, whose L2s are not coherent with
+// this one; nobody has read those addresses before they were written, so the readers' plain
+// loads miss their L2 and are served from memory) and bumps its own counter.  Results are
+// bit-identical to the per-step launches (same tiles, same k order).
+//
+// Progress: a workgroup takes its task when it starts, tasks are numbered in step order, and a task
+// depends only on tasks of the previous step — so the lowest-numbered unfinished task of every
+// queue is always held by a running workgroup whose own dependencies have lower numbers.  No
+// co-residency requirement (the grid is one workgroup per task, dispatched as slots free up); an
+// XCD that was handed more workgroups than its queue holds takes tasks of the other queues.  The
+// wait is bounded like the resident kernels' barrier (grid_sync.hpp): CMHSE_ERR_TIMEOUT, not a hang.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChainMaxSteps = kChainMaxStepsWs;
+constexpr int kXcds = 8;
+struct GruChainGroup {
+  GruStepParams j[kMaxJobs];            // (t, S_t, off_prev, off_cur unused: derived per task)
+  const int32_t* step_off[kMaxJobs];    // device: first packed row of every step of request k
+  unsigned* done[kMaxJobs];             // zeroed counters [nsteps][rt_stride[k]] of request k
+  int32_t rt_stride[kMaxJobs];          // row tiles of request k at step t0 (its maximum)
+  uint32_t cum[kChainMaxSteps + 1];     // row tiles (all requests) in front of step t0 + s
+  unsigned* ticket;                     // [kXcds] zeroed: next task of every XCD's queue
+  GridSync sync;
+  int32_t n, t0, nsteps, n_tiles;
+};
+
+__device__ __forceinline__ int chain_cols_of(int n_tiles, int x) {
+  return (n_tiles > x) ? (n_tiles - x + kXcds - 1) / kXcds : 0;
+}
+
+template <bool VEC, int MSUB>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
+void gru_step_chain_kernel(const GruChainGroup g) {
+  constexpr int BM = 64 * MSUB;
+  __shared__ unsigned s_task[2];
+  const unsigned units = g.cum[g.nsteps];
+  if (threadIdx.x == 0) {
+    const unsigned x = static_cast<unsigned>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) & (kXcds - 1);   // XCC_ID
+    unsigned got = 0xffffffffu, queue = 0xffffffffu;
+    for (unsigned d = 0; d < kXcds; ++d) {
+      const unsigned y = (x + d) & (kXcds - 1);
+      const unsigned cols = static_cast<unsigned>(chain_cols_of(g.n_tiles, static_cast<int>(y)));
+      if (cols == 0) continue;
+      const unsigned tk = __hip_atomic_fetch_add(g.ticket + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk < units * cols) {
+        got = tk;
+        queue = y;
+        break;
+      }
+    }
+    s_task[0] = got;
+    s_task[1] = queue;
+  }
+  __syncthreads();
+  const unsigned queue = __builtin_amdgcn_readfirstlane(s_task[1]);
+  if (queue == 0xffffffffu) return;      // every queue is empty (cannot happen with one workgroup per task)
+  const unsigned tk = __builtin_amdgcn_readfirstlane(s_task[0]);
+  const unsigned cols = static_cast<unsigned>(chain_cols_of(g.n_tiles, static_cast<int>(queue)));
+  const unsigned unit = tk / cols;
+  const int c = static_cast<int>(queue + kXcds * (tk % cols));
+  int lo = 0, hi = g.nsteps - 1;         // the last step whose first unit is <= unit
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (g.cum[mid] <= unit) lo = mid; else hi = mid - 1;
+  }
+  const int s = lo, t = g.t0 + s;
+  unsigned rem = unit - g.cum[s];
+  int k = 0, S_t = 0;
+  for (; k < g.n; ++k) {
+    S_t = g.step_off[k][t + 1] - g.step_off[k][t];
+    const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
+    if (rem < rt || k == g.n - 1) break;
+    rem -= rt;
+  }
+  const GruStepParams& p = g.j[k];
+  const int64_t off_cur = g.step_off[k][t];
+  const int64_t off_prev = (t > 0) ? g.step_off[k][t - 1] : 0;
+  ChainDep dep;
+  dep.sync = g.sync;
+  dep.need = static_cast<unsigned>(g.n_tiles);
+  dep.done = g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rem;
+  dep.wait = (s > 0) ? g.done[k] + static_cast<size_t>(s - 1) * g.rt_stride[k] + rem : nullptr;
+  gru_step_tile<VEC, MSUB, false, true>(p, rem * static_cast<unsigned>(g.n_tiles) + static_cast<unsigned>(c), t, S_t,
+                                        off_prev, off_cur, dep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1495,6 +1637,7 @@ struct FwdJob {
   bool pooled;               // attention already launched (early, beside the others' tail)
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
   int32_t tail_lo;           // steps >= tail_lo run inside ONE resident kernel (gru_fwd_tail_kernel); -1 = none
+  int32_t chain_until;       // steps < chain_until are inside a queued gru_step_chain_kernel launch
 };
 
 // 128-row tiles (2 workgroups per CU, 230 registers per lane) halve the weight bytes and cut the
@@ -1847,6 +1990,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   for (int k = 0; k < n; ++k) {
     FwdJob& j = jobs[k];
     j.tail_lo = -1;
+    j.chain_until = 0;
     const cmhse_seq_batch* b = j.b;
     const int min_steps = tunables().fwd_tail_min_steps.load(std::memory_order_relaxed);
     if (min_steps <= 0 || !j.save || j.bf3 || !j.vec || js[k] == main_stream || j.t_mid != 0 ||
@@ -1890,6 +2034,66 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       j.p.t = t;
       kind[k] = step_kind(j, j.b->step_count_host[t], mid_blocks, alone, tiled_wgs);
       any_tiled = any_tiled || (kind[k] & 3) == 1 || (kind[k] & 3) == 2;
+    }
+    // Step chain (gru_step_chain_kernel): when the requests that run an fp32 LDS-tiled step now go
+    // on doing so together for at least chain_min_steps steps, those steps are ONE launch, queued
+    // here; the requests are skipped by the per-step launches below until the chain's last step.
+    bool in_chain[kMaxJobs] = {};
+    int chain_end = 0, chain_kind = -1;
+    hipStream_t chain_stream = nullptr;
+    {
+      const int min_steps = tunables().chain_min_steps.load(std::memory_order_relaxed);
+      int n_c = 0, tiles_c = -1;
+      bool ok = min_steps > 0;
+      for (int k = 0; k < n && ok; ++k) {
+        if (done[k] || (kind[k] & 3) != 1) continue;
+        const FwdJob& j = jobs[k];
+        if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0 ||
+            j.b->step_events_host != nullptr) {
+          ok = false;
+        } else if (n_c == 0) {
+          chain_kind = kind[k];
+          tiles_c = j.p.n_tiles;
+          chain_stream = js[k];
+        } else if (kind[k] != chain_kind || j.p.n_tiles != tiles_c || js[k] != chain_stream) {
+          ok = false;
+        }
+        in_chain[k] = true;
+        ++n_c;
+      }
+      if (ok && n_c > 0) {
+        // tile height of a chain: the 128-row tile already from chain_tall_min_wgs 64-row workgroups
+        // per step (nothing drains between steps here, so what decides is the tile's own efficiency)
+        const int tall = tunables().chain_tall_min_wgs.load(std::memory_order_relaxed);
+        chain_kind = (chain_kind & ~2048) | ((tall > 0 && tiled_wgs >= tall) ? 2048 : 0);
+        chain_end = t + 1;
+        while (chain_end - t < kChainMaxSteps) {
+          bool same = true;
+          for (int k = 0; k < n && same; ++k) {
+            const FwdJob& j = jobs[k];
+            const bool tiled_next = chain_end < j.b->Tmax && chain_end < j.t_mid && !j.bf3 &&
+                                    j.b->step_count_host[chain_end] > tiny_max_seqs();
+            same = tiled_next == in_chain[k];
+          }
+          if (!same) break;
+          ++chain_end;
+        }
+        // one workgroup per task: the grid must stay below 2^31 (halve the chain until it does)
+        for (;;) {
+          const int bm_c = (chain_kind & 2048) != 0 ? 128 : 64;
+          uint64_t units_c = 0;
+          for (int q = t; q < chain_end; ++q)
+            for (int k = 0; k < n; ++k)
+              if (in_chain[k]) units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c);
+          if (units_c * static_cast<uint64_t>(tiles_c) <= 0x7fffffffULL || chain_end - t <= 1) break;
+          chain_end = t + (chain_end - t) / 2;
+        }
+        ok = chain_end - t >= min_steps;
+      }
+      if (!ok || n_c == 0) {
+        chain_end = 0;
+        for (int k = 0; k < kMaxJobs; ++k) in_chain[k] = false;
+      }
     }
     for (int k = 0; k < n; ++k) {
       if (done[k]) continue;
@@ -1978,6 +2182,86 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       j.p.off_cur = j.off;
       j.off += S_t;
     }
+    if (chain_end > t) {
+      GruChainGroup cg;
+      cg.n = 0;
+      cg.t0 = t;
+      cg.nsteps = chain_end - t;
+      cg.ticket = nullptr;
+      unsigned* abort_word = nullptr;
+      const int bm = (chain_kind & 2048) != 0 ? 128 : 64;
+      for (int k = 0; k < n; ++k) {
+        if (!in_chain[k]) continue;
+        FwdJob& j = jobs[k];
+        const int q = cg.n++;
+        cg.j[q] = j.p;
+        cg.n_tiles = j.p.n_tiles;
+        cg.step_off[q] = j.b->step_off;
+        cg.rt_stride[q] = (j.b->step_count_host[t] + bm - 1) / bm;
+        unsigned* words = reinterpret_cast<unsigned*>(j.wsb + j.L.chain_sync);
+        cg.done[q] = words + 64;
+        (void)hipMemsetAsync(words, 0, 256 + sizeof(unsigned) * static_cast<size_t>(cg.nsteps) * cg.rt_stride[q],
+                             chain_stream);
+        if (q == 0) {
+          cg.ticket = words;
+          abort_word = words + kXcds;
+        }
+        j.chain_until = chain_end;
+        done[k] = true;
+      }
+      for (int q = cg.n; q < kMaxJobs; ++q) {
+        cg.step_off[q] = nullptr;
+        cg.done[q] = nullptr;
+        cg.rt_stride[q] = 0;
+      }
+      uint64_t units = 0;
+      double flops = 0.0, bytes = 0.0;
+      for (int sidx = 0; sidx <= cg.nsteps; ++sidx) {
+        cg.cum[sidx] = static_cast<uint32_t>(units);
+        if (sidx == cg.nsteps) break;
+        for (int k = 0; k < n; ++k) {
+          if (!in_chain[k]) continue;
+          const int S_k = jobs[k].b->step_count_host[t + sidx];
+          units += static_cast<uint64_t>((S_k + bm - 1) / bm);
+          const double I = jobs[k].p.I, H = jobs[k].p.H;
+          flops += S_k * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
+          bytes += S_k * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
+        }
+      }
+      for (int sidx = cg.nsteps + 1; sidx <= kChainMaxSteps; ++sidx) cg.cum[sidx] = static_cast<uint32_t>(units);
+      cg.sync = make_grid_sync(nullptr, abort_word);
+      const unsigned cgrid = static_cast<unsigned>(units * static_cast<uint64_t>(cg.n_tiles));
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timer != nullptr) {
+        e0 = event_get(true);
+        e1 = e0 ? event_get(true) : nullptr;
+        if (e0 && !e1) {
+          event_put(e0, true);
+          e0 = nullptr;
+        }
+        if (e0 && e1) (void)hipEventRecord(e0, chain_stream);
+      }
+      const bool cvec = (chain_kind & 4) == 0;
+      if (bm == 128) {
+        const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
+        if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 2>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
+        else hipLaunchKernelGGL((gru_step_chain_kernel<false, 2>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
+      } else {
+        const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
+        if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 1>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
+        else hipLaunchKernelGGL((gru_step_chain_kernel<false, 1>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
+      }
+      if (e0 && e1) {
+        (void)hipEventRecord(e1, chain_stream);
+        timer->tiled_events.push_back(e0);
+        timer->tiled_events.push_back(e1);
+        timer->tiled_flops += flops;
+        timer->tiled_bytes += bytes;
+      }
+      ++launches;
+    }
+    for (int k = 0; k < n; ++k)
+      if (!done[k] && t < jobs[k].chain_until) done[k] = true;   // inside a chain launch queued at an earlier step
     for (int k = 0; k < n; ++k) {
       if (done[k]) continue;
       GruStepGroup g;
@@ -2305,7 +2589,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
       {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

@@ -37,10 +37,11 @@
 
 namespace cmhse {
 
+constexpr int kChainMaxStepsWs = 96;   // steps one launch of gru_step_chain_kernel covers at most (gru.hip: kChainMaxSteps)
 constexpr int kAttBN = 256;  // columns of W_lin per attention-energy workgroup
 
 struct GruWs {
-  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, tail_sync, total;
+  size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, tail_sync, chain_sync, total;
 };
 
 // Kernel-shape crossovers a caller may move (cmhse_tune, include/cmhse_hip.h): values, never
@@ -70,6 +71,8 @@ struct Tunables {
   std::atomic<int> resident_timeout_ms{5000};  // wall time one grid barrier of a resident kernel may take before the launch gives up (grid_sync.hpp)
   std::atomic<int> xproj_chunk_rows{1536};   // packed rows per chunk of a training chain's hoisted input projection beside the chain (0 = one launch in front of it)
   std::atomic<int> tn_rows_bm{0};            // tile height of the weight-gradient products: 128, 192, or 0 = 192 where 3H is a whole number of them (tn_rows.hpp)
+  std::atomic<int> chain_min_steps{2};       // consecutive LDS-tiled steps (inference calls) from which they run as ONE launch of gru_step_chain_kernel; 0 = never
+  std::atomic<int> chain_tall_min_wgs{256};  // 64-row workgroups per step from which a step chain uses 128-row tiles (per-step launches: tall_tile_min_wgs)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };
 Tunables& tunables();
@@ -128,6 +131,12 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
     off += ws_align(static_cast<size_t>(gx_rows_bound(S, Tmax, sum_T)) * 3 * H * sizeof(float));
   L.tail_sync = off;   // barrier counter of gru_fwd_tail_kernel (training calls)
   if (save) off += 256;
+  // step-chain kernel (inference calls): 8 task tickets + the abort word, then one counter per
+  // (step of a chain launch, 64-row tile)
+  L.chain_sync = off;
+  if (!save && Tmax > 0)
+    off += ws_align(256 + sizeof(unsigned) * static_cast<size_t>(Tmax < kChainMaxStepsWs ? Tmax : kChainMaxStepsWs) *
+                              static_cast<size_t>((S + 63) / 64));
   L.total = off;
   return L;
 }

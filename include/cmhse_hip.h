@@ -452,6 +452,10 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             accumulated, i.e. the gradients to fp32 rounding)
  *   "xproj_chunk_rows"  1536  packed rows per chunk of a training chain's hoisted input projection
  *                             beside the chain; 0 = one launch in front of it
+ *   "chain_min_steps"      2  consecutive LDS-tiled steps of an inference call from which they run as
+ *                             ONE launch (gru_step_chain_kernel: per-row-tile dependencies instead
+ *                             of a launch per time step; bit-identical); 0 = never
+ *   "chain_tall_min_wgs" 256  64-row workgroups per step from which such a chain uses 128-row tiles
  *   "tn_rows_bm"           0  tile height of the weight-gradient products: 128 | 192; 0 = 192 where
  *                             every product's row count (3H, H) is a whole number of them, else 128
  *                             (the row split into parts follows the tile count, i.e. the gradients

@@ -1275,6 +1275,86 @@ def test_gru_pool_fwd_multi_equals_separate_calls(dev):
   assert lib.cmhse_gru_pool_fwd_multi(None, 1, None) == -1
 
 
+@pytest.mark.parametrize('shape', ['one_xcd_queue', 'two_requests', 'full_width', 'scalar_loads', 'long_chain'])
+def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shape):
+  """The LDS-tiled steps of a call as ONE launch (gru_step_chain_kernel: a workgroup per (step,
+  request, row tile, column tile) task, per-XCD task queues, the previous step's rows awaited
+  between the x phase and the h phase, state rows written through the non-coherent L2s) against one
+  launch per time step (chain_min_steps = 0): outputs and every hidden state equal bit for bit,
+  repeated (a missing dependency shows up as a flaky mismatch), and no timeout recorded.
+    one_xcd_queue  H = 64: one column tile, so seven XCDs' workgroups take tasks of another queue
+    two_requests   attention, last-state, all-states and max-pooling requests of different lengths in
+                   one call; the chain is cut where one of them ends; initial states; tokens + table
+    full_width     H = 1024 (16 column tiles: two per XCD queue), 3000 sequences, 128-row tiles
+    scalar_loads   I, H not multiples of 4 (the scalar-load variant of the tile loop)
+    long_chain     more steps than one launch covers (96): the chain is cut and resumed"""
+  from cmhse_amd import _lib, ops
+  rng = np.random.RandomState(3)
+  g = torch.Generator().manual_seed(8)
+  keep = []
+
+  def weights(I, H, attn):
+    w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.2), w_hh=torch.randn(3 * H, H, generator=g).mul_(0.1),
+             b_ih=torch.randn(3 * H, generator=g).mul_(0.1), b_hh=torch.randn(3 * H, generator=g).mul_(0.1))
+    if attn:
+      w.update(w_lin=torch.randn(H, H, generator=g).mul_(0.1), b_lin=torch.randn(H, generator=g).mul_(0.1),
+               w_att=torch.randn(1, H, generator=g).mul_(0.2))
+    return {k: v.to(dev) for k, v in w.items()}
+
+  def request(S, T, I, H, mode, h0=False, tokens=False, full=0):
+    lens = rng.randint(1, T + 1, size=S).astype(np.int64)
+    lens[:max(1, full)] = T
+    r = dict(weights=weights(I, H, mode == ops.POOL_ATTN), pool_mode=mode, lens=lens, I=I, H=H, device=dev)
+    if tokens:
+      tok = torch.randint(0, 40, (S, T), generator=g).to(dev)
+      table = torch.randn(40, I, generator=g).to(dev)
+      keep.extend([tok, table])
+      r.update(tok_ptrs=ops.padded_row_ptrs(tok), emb_table=table)
+    else:
+      x = torch.randn(S, T, I, generator=g).to(dev)
+      keep.append(x)
+      r.update(x_ptrs=ops.padded_row_ptrs(x))
+    if h0:
+      h = torch.randn(S, H, generator=g).to(dev)
+      keep.append(h)
+      r.update(h0_ptrs=ops.padded_row_ptrs(h))
+    return r
+
+  tune(tiny_max_seqs=0, mid_max_seqs=0)       # every step on the LDS-tiled kernel
+  if shape == 'one_xcd_queue':
+    reqs = [request(300, 9, 24, 64, ops.POOL_ATTN)]
+  elif shape == 'two_requests':
+    reqs = [request(700, 11, 36, 128, ops.POOL_ATTN, h0=True), request(450, 5, 20, 128, ops.POOL_LAST, tokens=True),
+            request(90, 7, 16, 128, ops.POOL_ALL), request(520, 9, 24, 128, ops.POOL_MAX)]
+  elif shape == 'full_width':
+    tune(tall_tile_min_wgs=64)                # 128-row tiles
+    reqs = [request(3000, 6, 64, 1024, ops.POOL_ATTN, full=1500), request(2100, 4, 32, 1024, ops.POOL_LAST)]
+  elif shape == 'scalar_loads':
+    reqs = [request(200, 6, 10, 33, ops.POOL_LAST, h0=True), request(150, 8, 10, 33, ops.POOL_ATTN)]
+  else:
+    reqs = [request(70, 130, 8, 32, ops.POOL_ATTN, full=3)]
+
+  def run(min_steps):
+    tune(chain_min_steps=min_steps)
+    res = ops.gru_pool_fwd_multi(reqs)
+    torch.cuda.synchronize()
+    assert _lib.load().cmhse_async_status(0) == 0
+    out = []
+    for o, c in res:
+      out.append((o.clone(), c['ws'][:c['sched'].sum_T * c['H'] * 4].clone()))
+    return out
+
+  per_step = run(0)
+  for _ in range(3):
+    for (o1, h1), (o2, h2) in zip(per_step, run(2)):
+      assert torch.equal(o1, o2)
+      assert torch.equal(h1, h2)
+  with ops.StepTimers() as timers:            # the timed form (an event pair around the launch)
+    timed = run(2)
+  spans = timers.collect()
+  assert spans and all(torch.equal(a[0], b[0]) for a, b in zip(per_step, timed))
+
+
 def test_abi_error_codes_on_device(dev):
   """Error behaviour of the C ABI with real device buffers: too-small / misaligned workspace,
   bad stripe, bad pooling mode -> negative codes, nothing launched, no exception across the ABI."""

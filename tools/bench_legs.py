@@ -416,8 +416,9 @@ def measured_traffic(kernel='gru_step'):
     return None
   d = json.load(open(paths[-1]))
   tot, n = 0.0, 0
+  names = (kernel,) if isinstance(kernel, str) else tuple(kernel)
   for k, v in d.items():
-    if kernel in k:
+    if any(nm in k for nm in names):
       tot += v['launches'] * (v['hbm_read_bytes_per_launch_corrected'] +
                               v['hbm_write_bytes_per_launch'])
       n += v['launches']

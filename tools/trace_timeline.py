@@ -14,7 +14,7 @@ from collections import OrderedDict
 
 
 def short(name):
-  for key in ['gru_step_tiny_kernel', 'gru_step_mid_kernel', 'gru_step_kernel', 'attn_energy_kernel',
+  for key in ['gru_step_tiny_kernel', 'gru_step_mid_kernel', 'gru_step_chain_kernel', 'gru_step_kernel', 'attn_energy_kernel',
               'attn_pool_kernel', 'sim_kernel<1', 'sim_kernel<0', 'sim_kernel<2', 'l2norm_rows',
               'contrastive', 'xproj_kernel', 'top1_finalize', 'copyBuffer', 'fillBuffer']:
     if key in name:
