@@ -1275,7 +1275,8 @@ def test_gru_pool_fwd_multi_equals_separate_calls(dev):
   assert lib.cmhse_gru_pool_fwd_multi(None, 1, None) == -1
 
 
-@pytest.mark.parametrize('shape', ['one_xcd_queue', 'two_requests', 'full_width', 'scalar_loads', 'long_chain'])
+@pytest.mark.parametrize('shape', ['one_xcd_queue', 'two_requests', 'full_width', 'scalar_loads', 'long_chain',
+                                   'many_rounds'])
 def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shape):
   """The LDS-tiled steps of a call as ONE launch (gru_step_chain_kernel: a workgroup per (step,
   request, row tile, column tile) task, per-XCD task queues, the previous step's rows awaited
@@ -1287,11 +1288,14 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
                    one call; the chain is cut where one of them ends; initial states; tokens + table
     full_width     H = 1024 (16 column tiles: two per XCD queue), 3000 sequences, 128-row tiles
     scalar_loads   I, H not multiples of 4 (the scalar-load variant of the tile loop)
-    long_chain     more steps than one launch covers (96): the chain is cut and resumed"""
+    long_chain     more steps than one launch covers (96): the chain is cut and resumed
+    many_rounds    H = 1024, 6000 + 5000 sequences: ~15 rounds of workgroups per launch, so tasks wait
+                   for tiles that run later on other XCDs (the validation pass's regime)"""
   from cmhse_amd import _lib, ops
   rng = np.random.RandomState(3)
   g = torch.Generator().manual_seed(8)
-  keep = []
+  g_dev = torch.Generator(device=dev).manual_seed(9)
+  keep, fresh = [], []          # fresh: the input tensors whose values are redrawn between rounds
 
   def weights(I, H, attn):
     w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.2), w_hh=torch.randn(3 * H, H, generator=g).mul_(0.1),
@@ -1309,14 +1313,17 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
       tok = torch.randint(0, 40, (S, T), generator=g).to(dev)
       table = torch.randn(40, I, generator=g).to(dev)
       keep.extend([tok, table])
+      fresh.extend([tok, table])
       r.update(tok_ptrs=ops.padded_row_ptrs(tok), emb_table=table)
     else:
       x = torch.randn(S, T, I, generator=g).to(dev)
       keep.append(x)
+      fresh.append(x)
       r.update(x_ptrs=ops.padded_row_ptrs(x))
     if h0:
       h = torch.randn(S, H, generator=g).to(dev)
       keep.append(h)
+      fresh.append(h)
       r.update(h0_ptrs=ops.padded_row_ptrs(h))
     return r
 
@@ -1331,6 +1338,8 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     reqs = [request(3000, 6, 64, 1024, ops.POOL_ATTN, full=1500), request(2100, 4, 32, 1024, ops.POOL_LAST)]
   elif shape == 'scalar_loads':
     reqs = [request(200, 6, 10, 33, ops.POOL_LAST, h0=True), request(150, 8, 10, 33, ops.POOL_ATTN)]
+  elif shape == 'many_rounds':
+    reqs = [request(6000, 10, 256, 1024, ops.POOL_ATTN, full=3000), request(5000, 7, 64, 1024, ops.POOL_LAST, full=1200)]
   else:
     reqs = [request(70, 130, 8, 32, ops.POOL_ATTN, full=3)]
 
@@ -1353,6 +1362,17 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     timed = run(2)
   spans = timers.collect()
   assert spans and all(torch.equal(a[0], b[0]) for a, b in zip(per_step, timed))
+  # New input VALUES in the same tensors, the chained run FIRST: the workspace blocks come back from
+  # the allocator with the previous round's states in them, so a tile that read a state row before
+  # its producer's store had reached memory (or from a stale cache line) would see the old round's
+  # value and differ from the per-step run that follows.
+  for _ in range(4):
+    for t_ in fresh:
+      t_.normal_(generator=g_dev) if t_.dtype == torch.float32 else t_.random_(0, 40, generator=g_dev)
+    chained = run(2)
+    for (o1, h1), (o2, h2) in zip(run(0), chained):
+      assert torch.equal(o1, o2)
+      assert torch.equal(h1, h2)
 
 
 def test_abi_error_codes_on_device(dev):
