@@ -2048,8 +2048,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       for (int k = 0; k < n && ok; ++k) {
         if (done[k] || (kind[k] & 3) != 1) continue;
         const FwdJob& j = jobs[k];
-        if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0 ||
-            j.b->step_events_host != nullptr) {
+        if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0) {
           ok = false;
         } else if (n_c == 0) {
           chain_kind = kind[k];
@@ -2074,6 +2073,10 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
             const bool tiled_next = chain_end < j.b->Tmax && chain_end < j.t_mid && !j.bf3 &&
                                     j.b->step_count_host[chain_end] > tiny_max_seqs();
             same = tiled_next == in_chain[k];
+            // a step whose inputs are still crossing PCIe (cmhse_pull_steps: an event per chunk of
+            // time steps) starts a new chain, launched behind that event
+            if (same && in_chain[k] && j.b->step_events_host != nullptr && j.b->step_events_host[chain_end] != nullptr)
+              same = false;
           }
           if (!same) break;
           ++chain_end;

@@ -155,7 +155,7 @@ def _side_streams(device):
 
 
 PIPELINE_UPLOAD = [True]      # pinned host batches are pulled chunk by chunk under the step pipeline
-UPLOAD_CHUNK = [8]             # time steps per pull chunk once the pipeline is full
+UPLOAD_CHUNK = [int(os.environ.get('CMHSE_UPLOAD_CHUNK', '8'))]   # time steps per pull chunk once the pipeline is full
 
 
 def _copy_stream(device):
