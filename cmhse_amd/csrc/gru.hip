@@ -416,7 +416,7 @@ void gru_step_kernel(const GruStepGroup grp) {
 // tile r of step t — the sequences are sorted by length, so the active set of a step is a prefix
 // of the previous one's — and two thirds of its work (the x phase, K = I) nothing at all.  Here
 // every (step, request, row tile, column tile) is a TASK; a workgroup takes the next task of its
-// XCD's queue (tasks in step order; column tile c belongs to XCD c % 8, so an XCD's L2 keeps
+// XCD's queue (tasks in step order; column tile c belongs to queue c % 8, so an XCD's L2 keeps
 // re-serving the same weight rows exactly as with the per-step launches' block order), runs the
 // tile's x phase, waits until the counter of (request, step - 1, row tile) has reached the number
 // of column tiles, runs the h phase and the epilogue, writes the new state rows through to memory
@@ -425,12 +425,15 @@ void gru_step_kernel(const GruStepGroup grp) {
 // loads miss their L2 and are served from memory) and bumps its own counter.  Results are
 // bit-identical to the per-step launches (same tiles, same k order).
 //
-// Progress: a workgroup takes its task when it starts, tasks are numbered in step order, and a task
-// depends only on tasks of the previous step — so the lowest-numbered unfinished task of every
-// queue is always held by a running workgroup whose own dependencies have lower numbers.  No
-// co-residency requirement (the grid is one workgroup per task, dispatched as slots free up); an
-// XCD that was handed more workgroups than its queue holds takes tasks of the other queues.  The
-// wait is bounded like the resident kernels' barrier (grid_sync.hpp): CMHSE_ERR_TIMEOUT, not a hang.
+// Progress: a workgroup takes its task when it starts (queue = its index modulo 8), workgroups
+// start in index order, every queue lists its tasks in step order, and a task depends only on
+// tasks of the previous step.  So the queues advance in step with each other, and the earliest
+// unfinished task overall is either running (everything it waits for is earlier, hence done) or
+// the next one its queue hands out, with every task that is already held at most a step ahead of
+// it — some held task can always run.  No co-residency requirement (the grid is one workgroup per
+// task, dispatched as slots free up); a workgroup whose queue is exhausted takes a task of another
+// queue.  The wait is bounded like the resident kernels' barrier (grid_sync.hpp):
+// CMHSE_ERR_TIMEOUT, not a hang.
 // ---------------------------------------------------------------------------------------------
 constexpr int kChainMaxSteps = kChainMaxStepsWs;
 constexpr int kXcds = 8;
@@ -456,7 +459,11 @@ void gru_step_chain_kernel(const GruChainGroup g) {
   __shared__ unsigned s_task[2];
   const unsigned units = g.cum[g.nsteps];
   if (threadIdx.x == 0) {
-    const unsigned x = static_cast<unsigned>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) & (kXcds - 1);   // XCC_ID
+    // home queue: workgroups are dealt to the XCDs round-robin by their index (b and b + 8 share an
+    // XCD — what the per-step kernels' block order relies on too), so this IS the workgroup's XCD on
+    // an unpartitioned MI355X; derived from the index rather than read from XCC_ID so that the
+    // queues advance in step with the dispatch order whatever the partition mode
+    const unsigned x = blockIdx.x & (kXcds - 1);
     unsigned got = 0xffffffffu, queue = 0xffffffffu;
     for (unsigned d = 0; d < kXcds; ++d) {
       const unsigned y = (x + d) & (kXcds - 1);
