@@ -151,8 +151,10 @@ int cmhse_gru_pool_fwd(const cmhse_seq_batch* seqs, const cmhse_gru_weights* w, 
  * to the separate calls; step t of every request shares one launch, so two encoders that do not
  * depend on each other — the clip and sentence encoders of VSE.forward_emb (model.py:222-236), the
  * video and paragraph encoders of structure_emb (model.py:238-255) — pay one launch latency and one
- * partially filled last wave of workgroups per time step instead of two.  The first request's
- * step_timer (if set) brackets the step launches of the whole group. */
+ * partially filled last wave of workgroups per time step instead of two — and, for inference calls,
+ * the LDS-tiled steps of all requests that run them together are ONE launch altogether (the step
+ * chain, "chain_min_steps" below: per-row-tile dependencies instead of a launch per time step).
+ * The first request's step_timer (if set) brackets the step launches of the whole group. */
 typedef struct cmhse_gru_job {
   const cmhse_seq_batch* seqs;
   const cmhse_gru_weights* weights;
