@@ -155,7 +155,7 @@ def _side_streams(device):
 
 
 PIPELINE_UPLOAD = [True]      # pinned host batches are pulled chunk by chunk under the step pipeline
-UPLOAD_CHUNK = [int(os.environ.get('CMHSE_UPLOAD_CHUNK', '8'))]   # time steps per pull chunk once the pipeline is full
+UPLOAD_CHUNK = [8]             # time steps per pull chunk once the pipeline is full (4 and 8 level, 12+ slower: DESIGN §7b)
 
 
 def _copy_stream(device):
@@ -202,6 +202,14 @@ def _empty_like_on(t, device):
   if isinstance(t, ops.Ragged):
     return ops.Ragged(torch.empty(t.data.shape, dtype=torch.float32, device=device), t.lens)
   return torch.empty(t.shape, dtype=torch.float32, device=device)
+
+
+def _lens_i64(x):
+  """A batch's length member (host int64 tensor from the loader, list, or array) as int64 NumPy;
+  the tensor case without the detour through `__array__` (616 of these per pass of the full split)."""
+  if type(x) is torch.Tensor and x.dtype == torch.int64 and not x.is_cuda:
+    return x.numpy()
+  return np.asarray(x, dtype=np.int64)
 
 
 def _dev_seq(t, device, dtype):
@@ -273,8 +281,7 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
     copy.wait_stream(main)         # the fresh device buffers may recycle blocks still in use
     with torch.cuda.stream(copy):
       v_sched = ops.SeqSchedule(
-          np.concatenate([np.asarray(b[4], dtype=np.int64) for b in group] +
-                         [np.asarray(b[6], dtype=np.int64) for b in group]), device,
+          np.concatenate([_lens_i64(b[4]) for b in group] + [_lens_i64(b[6]) for b in group]), device,
           x_ptrs=ops.seq_row_ptrs_many(clips_l + vids_l),
           src_ptrs=ops.seq_row_ptrs_many([b[0] for b in group] + [b[2] for b in group]))
       v_events = ops.pull_steps(v_sched, int(group[0][0].shape[2]), copy, UPLOAD_CHUNK[0])
@@ -292,10 +299,10 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
       vids_l.append(_dev_seq(b[2], device, torch.float32))
     caps_l.append(_dev_seq(b[1], device, torch.int64))
     pars_l.append(_dev_seq(b[3], device, torch.int64))
-    len_clip.append(np.asarray(b[4], dtype=np.int64))
-    len_cap.append(np.asarray(b[5], dtype=np.int64))
-    len_vid.append(np.asarray(b[6], dtype=np.int64))
-    len_par.append(np.asarray(b[7], dtype=np.int64))
+    len_clip.append(_lens_i64(b[4]))
+    len_cap.append(_lens_i64(b[5]))
+    len_vid.append(_lens_i64(b[6]))
+    len_par.append(_lens_i64(b[7]))
     num_clips.extend(b[8])
     num_caps.extend(b[9])
   n_clip = int(sum(len(l) for l in len_clip))
