@@ -2068,9 +2068,19 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
         ++n_c;
       }
       if (ok && n_c > 0) {
-        // tile height of a chain: the 128-row tile already from chain_tall_min_wgs 64-row workgroups
-        // per step (nothing drains between steps here, so what decides is the tile's own efficiency)
-        const int tall = tunables().chain_tall_min_wgs.load(std::memory_order_relaxed);
+        // Tile height of a chain.  Nothing drains between steps here, so the 128-row tile (the more
+        // efficient one) pays from far fewer workgroups per step than with per-step launches:
+        // chain_tall_min_wgs (256) 64-row workgroups when every request's x phase is at least as long
+        // as its h phase (I >= H: a tile has that much work in front of its wait), four times that
+        // otherwise — a chain of h-dominated tiles is a latency chain, and half as many, twice as
+        // long tiles lengthen it (one tower alone, I = 300, 1100-2048 sequences: 185-194 us per
+        // step with 128 rows against 128-147 with 64; I = 2048: level; profiles/r04_step_chain.txt).
+        int tall = tunables().chain_tall_min_wgs.load(std::memory_order_relaxed);
+        for (int k = 0; k < n; ++k)
+          if (in_chain[k] && jobs[k].b->I < jobs[k].b->H) {
+            tall *= 4;
+            break;
+          }
         chain_kind = (chain_kind & ~2048) | ((tall > 0 && tiled_wgs >= tall) ? 2048 : 0);
         chain_end = t + 1;
         while (chain_end - t < kChainMaxSteps) {

@@ -458,6 +458,7 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             ONE launch (gru_step_chain_kernel: per-row-tile dependencies instead
  *                             of a launch per time step; bit-identical); 0 = never
  *   "chain_tall_min_wgs" 256  64-row workgroups per step from which such a chain uses 128-row tiles
+ *                             (four times that when a request of the chain has I < H)
  *   "tn_rows_bm"           0  tile height of the weight-gradient products: 128 | 192; 0 = 192 where
  *                             every product's row count (3H, H) is a whole number of them, else 128
  *                             (the row split into parts follows the tile count, i.e. the gradients
