@@ -421,8 +421,9 @@ void gru_step_kernel(const GruStepGroup grp) {
 // tile's x phase, waits until the counter of (request, step - 1, row tile) has reached the number
 // of column tiles, runs the h phase and the epilogue, writes the new state rows through to memory
 // (agent-scope stores: the next step's tiles run on other XCDs, whose L2s are not coherent with
-// this one; nobody has read those addresses before they were written, so the readers' plain
-// loads miss their L2 and are served from memory) and bumps its own counter.  Results are
+// this one; nobody has read those addresses — whole cache lines: H % 32 == 0 is a condition of the
+// chain — before they were written, so the readers' plain loads miss their L2 and are served
+// from memory) and bumps its own counter.  Results are
 // bit-identical to the per-step launches (same tiles, same k order).
 //
 // Progress: a workgroup takes its task when it starts (queue = its index modulo 8), workgroups
@@ -2055,7 +2056,10 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       for (int k = 0; k < n && ok; ++k) {
         if (done[k] || (kind[k] & 3) != 1) continue;
         const FwdJob& j = jobs[k];
-        if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0) {
+        // (H % 32: a state row must be whole 128-byte cache lines — a reader that pulled a line
+        // shared with the NEXT row tile's first row into its L2 before that row was written would
+        // leave a stale copy there for the tile that needs it)
+        if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0 || j.b->H % 32 != 0) {
           ok = false;
         } else if (n_c == 0) {
           chain_kind = kind[k];

@@ -1287,7 +1287,8 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     two_requests   attention, last-state, all-states and max-pooling requests of different lengths in
                    one call; the chain is cut where one of them ends; initial states; tokens + table
     full_width     H = 1024 (16 column tiles: two per XCD queue), 3000 sequences, 128-row tiles
-    scalar_loads   I, H not multiples of 4 (the scalar-load variant of the tile loop)
+    scalar_loads   I not a multiple of 4 (the scalar-load variant of the tile loop; H = 96: a chain needs
+                   state rows of whole cache lines, H % 32 == 0 — other widths keep per-step launches)
     long_chain     more steps than one launch covers (96): the chain is cut and resumed
     many_rounds    H = 1024, 6000 + 5000 sequences: ~15 rounds of workgroups per launch, so tasks wait
                    for tiles that run later on other XCDs (the validation pass's regime)"""
@@ -1337,7 +1338,7 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     tune(tall_tile_min_wgs=64)                # 128-row tiles
     reqs = [request(3000, 6, 64, 1024, ops.POOL_ATTN, full=1500), request(2100, 4, 32, 1024, ops.POOL_LAST)]
   elif shape == 'scalar_loads':
-    reqs = [request(200, 6, 10, 33, ops.POOL_LAST, h0=True), request(150, 8, 10, 33, ops.POOL_ATTN)]
+    reqs = [request(200, 6, 10, 96, ops.POOL_LAST, h0=True), request(150, 8, 10, 96, ops.POOL_ATTN)]
   elif shape == 'many_rounds':
     reqs = [request(6000, 10, 256, 1024, ops.POOL_ATTN, full=3000), request(5000, 7, 64, 1024, ops.POOL_LAST, full=1200)]
   else:
