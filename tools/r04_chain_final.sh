@@ -32,4 +32,4 @@ for a, b in (('w8_shared_gpu.json', 'w1_ref.json'), ('w8_shared_gpu_pinned.json'
         '| reports equal:', x.get('report_i2t_random_init') == y.get('report_i2t_random_init'), x.get('error', ''), y.get('error', ''))
   if 'per_rank' in x: print('   per-rank videos', [r.get('videos') for r in x['per_rank']])
 PY
-tail -2 $D/w8.err $D/w8p.err
+tail -n 2 $D/w8.err; tail -n 2 $D/w8p.err
