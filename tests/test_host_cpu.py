@@ -64,6 +64,46 @@ def test_seq_schedule_matches_pack_padded_sequence():
     SeqSchedule(np.array([2, 0]), 'cpu', x_ptrs=ptrs[:2])
 
 
+def test_seq_schedule_order_is_the_stable_descending_sort():
+  """The schedule's order is torch.sort(lengths, 0, True)'s for the reference (layers.py:94) up to
+  ties, and among equal lengths the input order (stable) — with the 16-bit radix keys used for
+  ordinary lengths and with the comparison sort used for lengths >= 65536 alike."""
+  from cmhse_amd.ops import SeqSchedule
+  rng = np.random.RandomState(4)
+  for hi in (7, 435, 70000):
+    lens = rng.randint(1, hi + 1, size=5000).astype(np.int64)
+    lens[17] = hi
+    if hi > 65535:
+      lens[:4000] = rng.randint(1, 50, size=4000)     # keep the packed batch below 2^31 rows
+    s = SeqSchedule(lens, 'cpu', x_ptrs=np.arange(len(lens), dtype=np.uint64))
+    assert s.order.tolist() == np.argsort(-lens, kind='stable').tolist()
+    assert s.lens_sorted.tolist() == sorted(lens.tolist(), reverse=True)
+    for t in range(0, s.Tmax, max(1, s.Tmax // 50)):
+      assert int(s.step_count_host[t]) == int((lens > t).sum())
+
+
+def test_validation_pass_switches_the_cyclic_collector_off_and_back_on():
+  """evaluation._no_gc_pause: no cyclic collection while a pass's launches are queued; the
+  collector's state is what it was afterwards, also after an exception, also when it was off."""
+  import gc
+  from cmhse_amd.evaluation import _no_gc_pause
+  assert gc.isenabled()
+  with _no_gc_pause():
+    assert not gc.isenabled()
+  assert gc.isenabled()
+  with pytest.raises(RuntimeError):
+    with _no_gc_pause():
+      raise RuntimeError('x')
+  assert gc.isenabled()
+  gc.disable()
+  try:
+    with _no_gc_pause():
+      assert not gc.isenabled()
+    assert not gc.isenabled()
+  finally:
+    gc.enable()
+
+
 def test_meters_follow_reference_quirks():
   from cmhse_amd.evaluation import AverageMeter, LogCollector
   m = AverageMeter()
