@@ -1666,6 +1666,23 @@ def test_didemo_recon_train_step_full_dims_vs_oracle(dev, oracle, monkeypatch, r
   print('configs[3] %s: %d of %d (sequence, unit) pairs routed at a near-tie' % (rnn_type, flipped, pairs))
 
 
+@pytest.mark.parametrize('argv', [['--rounds', '2'], ['--rounds', '2', '--n_videos', '615'],
+                                  ['--rounds', '1', '--rnn_type', 'maxout', '--workload', 'anet_c3d_val']])
+def test_step_chain_at_full_size_on_new_inputs_every_round(dev, monkeypatch, argv):
+  """tools/chain_stress.py: the validation pass at bench.py's sizes (the full split, a rank's
+  615-video share of it, the C3D split with max pooling) with the LDS-tiled steps as step chains
+  against per-step launches, new input values every round and the chained pass first — all six
+  embedding tensors bit-identical, no timeout recorded."""
+  import importlib
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  mod = importlib.import_module('chain_stress')
+  monkeypatch.setattr(sys, 'argv', ['chain_stress.py'] + argv)
+  with pytest.raises(SystemExit) as e:
+    mod.main()
+  assert e.value.code == 0
+
+
 def test_full_val_split_icep_encode_sample_vs_oracle(dev, oracle):
   """configs[4], encode half at full size: the whole N = 4917 ActivityNet-val-shaped split at
   img_dim 2048 through encode_data_device as ONE super-batch (what bench.py times), then the six
