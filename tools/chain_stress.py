@@ -29,6 +29,7 @@ def main():
   ap.add_argument('--n_videos', type=int, default=0)
   ap.add_argument('--workload', default='anet_icep_val')
   ap.add_argument('--rnn_type', default='attention')
+  ap.add_argument('--sizes', default='', help='comma-separated n_videos to run one after the other (overrides --n_videos)')
   args = ap.parse_args()
   dev = torch.device('cuda', 0)
   torch.cuda.set_device(0)
@@ -36,7 +37,16 @@ def main():
   opt = bench.make_opt(wl, args.rnn_type, 1024)
   torch.manual_seed(1)
   model = VSE(opt)
-  spec = synthetic.anet_like_spec(args.n_videos or wl['n_videos'], seed=0, dataset=wl['dataset'])
+  sizes = [int(x) for x in args.sizes.split(',') if x] or [args.n_videos or wl['n_videos']]
+  bad = 0
+  for i, nv in enumerate(sizes):
+    bad += one_size(args, wl, opt, model, dev, nv, seed=i)
+  ops.tune('chain_min_steps', 2)
+  sys.exit(1 if bad else 0)
+
+
+def one_size(args, wl, opt, model, dev, n_videos, seed):
+  spec = synthetic.anet_like_spec(n_videos, seed=seed, dataset=wl['dataset'])
   batches = bench.build_loader(spec, wl, dev, 0, (spec.n_videos + 31) // 32)
   g = torch.Generator(device=dev).manual_seed(5)
   quiet = lambda *a, **k: None
@@ -62,10 +72,9 @@ def main():
     diffs = {k: float((chained[k] - per_step[k]).abs().max()) for k in keys}
     same = all(torch.equal(chained[k], per_step[k]) for k in keys)
     bad += 0 if same else 1
-    print('round %d: %s  max |diff| %s' % (r, 'bit-identical' if same else 'MISMATCH',
-                                            ' '.join('%s %.2g' % kv for kv in diffs.items())))
-  ops.tune('chain_min_steps', 2)
-  sys.exit(1 if bad else 0)
+    print('%5d videos, round %d: %s  max |diff| %s' % (n_videos, r, 'bit-identical' if same else 'MISMATCH',
+                                                        ' '.join('%s %.2g' % kv for kv in diffs.items())))
+  return bad
 
 
 if __name__ == '__main__':
