@@ -250,10 +250,10 @@ def main():
     wst.collect()
   sync()
   phase_sum.clear()      # the per-rank phase times below are those of the timed passes only
-  if os.environ.get('CMHSE_BENCH_GC_FREEZE', '1') == '1':
-    # the loader batches, schedules and modules built so far are ~10^6 long-lived Python objects;
-    # an unlucky full collection walks them all in the middle of a pass (tens of ms of host stall
-    # before the next launch).  Park them in the permanent generation.
+  if os.environ.get('CMHSE_BENCH_GC_FREEZE', '0') == '1':
+    # (opt-in since late round 4: encode_data_device itself keeps Python's cyclic collector out of
+    # the stretch in which a pass's launches are queued — what this used to be for — so the timed
+    # region runs as a caller's would; `pass_ms.python_gc_ms` reports what the collector took)
     import gc
     gc.collect()
     gc.freeze()
