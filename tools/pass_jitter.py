@@ -2,7 +2,7 @@
 """Per-pass wall time of the validation pass against the time the host spends inside the level-1
 call (cmhse_gru_pool_fwd_multi): does a pass whose launches block the host run slower?
 
-  python tools/pass_jitter.py [--passes 16] [--plan] [--no_freeze]   (default: gc.freeze() after pass 2, as bench.py does)
+  python tools/pass_jitter.py [--passes 16] [--plan] [--no_freeze]   (default: gc.freeze() after pass 2, as bench.py did until late round 4)
 """
 import os
 import sys
