@@ -1968,6 +1968,173 @@ struct XprojPlan {
   std::vector<hipEvent_t> ev;   // recorded behind chunk c's launch on the side stream
 };
 
+// The requests of a call that run an fp32 LDS-tiled step at time step t and will go on doing so
+// TOGETHER: which of them (in_chain), up to which step (end, exclusive; 0 = no chain here), with
+// which tile height (kind, bit 2048 = 128 rows) and on which stream.
+struct ChainPlan {
+  bool in_chain[kMaxJobs];
+  int end, kind;
+  hipStream_t stream;
+};
+
+static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, const bool* done,
+                            const hipStream_t* js, int tiled_wgs) {
+  ChainPlan c;
+  for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = false;
+  c.end = 0;
+  c.kind = -1;
+  c.stream = nullptr;
+
+  const int min_steps = tunables().chain_min_steps.load(std::memory_order_relaxed);
+  int n_c = 0, tiles_c = -1;
+  bool ok = min_steps > 0;
+  for (int k = 0; k < n && ok; ++k) {
+    if (done[k] || (kind[k] & 3) != 1) continue;
+    const FwdJob& j = jobs[k];
+    // (H % 32: a state row must be whole 128-byte cache lines — a reader that pulled a line
+    // shared with the NEXT row tile's first row into its L2 before that row was written would
+    // leave a stale copy there for the tile that needs it)
+    if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0 || j.b->H % 32 != 0) {
+      ok = false;
+    } else if (n_c == 0) {
+      c.kind = kind[k];
+      tiles_c = j.p.n_tiles;
+      c.stream = js[k];
+    } else if (kind[k] != c.kind || j.p.n_tiles != tiles_c || js[k] != c.stream) {
+      ok = false;
+    }
+    c.in_chain[k] = true;
+    ++n_c;
+  }
+  if (ok && n_c > 0) {
+    // Tile height of a chain.  Nothing drains between steps here, so the 128-row tile (the more
+    // efficient one) pays from far fewer workgroups per step than with per-step launches:
+    // chain_tall_min_wgs (256) 64-row workgroups when every request's x phase is at least as long
+    // as its h phase (I >= H: a tile has that much work in front of its wait), four times that
+    // otherwise — a chain of h-dominated tiles is a latency chain, and half as many, twice as
+    // long tiles lengthen it (one tower alone, I = 300, 1100-2048 sequences: 185-194 us per
+    // step with 128 rows against 128-147 with 64; I = 2048: level; profiles/r04_step_chain.txt).
+    int tall = tunables().chain_tall_min_wgs.load(std::memory_order_relaxed);
+    for (int k = 0; k < n; ++k)
+      if (c.in_chain[k] && jobs[k].b->I < jobs[k].b->H) {
+        tall *= 4;
+        break;
+      }
+    c.kind = (c.kind & ~2048) | ((tall > 0 && tiled_wgs >= tall) ? 2048 : 0);
+    c.end = t + 1;
+    while (c.end - t < kChainMaxSteps) {
+      bool same = true;
+      for (int k = 0; k < n && same; ++k) {
+        const FwdJob& j = jobs[k];
+        const bool tiled_next = c.end < j.b->Tmax && c.end < j.t_mid && !j.bf3 &&
+                                j.b->step_count_host[c.end] > tiny_max_seqs();
+        same = tiled_next == c.in_chain[k];
+        // a step whose inputs are still crossing PCIe (cmhse_pull_steps: an event per chunk of
+        // time steps) starts a new chain, launched behind that event
+        if (same && c.in_chain[k] && j.b->step_events_host != nullptr && j.b->step_events_host[c.end] != nullptr)
+          same = false;
+      }
+      if (!same) break;
+      ++c.end;
+    }
+    // one workgroup per task: the grid must stay below 2^31 (halve the chain until it does)
+    for (;;) {
+      const int bm_c = (c.kind & 2048) != 0 ? 128 : 64;
+      uint64_t units_c = 0;
+      for (int q = t; q < c.end; ++q)
+        for (int k = 0; k < n; ++k)
+          if (c.in_chain[k]) units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c);
+      if (units_c * static_cast<uint64_t>(tiles_c) <= 0x7fffffffULL || c.end - t <= 1) break;
+      c.end = t + (c.end - t) / 2;
+    }
+    ok = c.end - t >= min_steps;
+  }
+  if (!ok || n_c == 0) {
+    c.end = 0;
+    for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = false;
+  }
+  return c;
+}
+
+// Queue ONE gru_step_chain_kernel launch for steps [t, c.end) of the requests in `c` (counters and
+// tickets zeroed on the chain's stream in front of it; with `timer`, an event pair around it).
+static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* timer) {
+  GruChainGroup cg;
+  cg.n = 0;
+  cg.t0 = t;
+  cg.nsteps = c.end - t;
+  cg.ticket = nullptr;
+  unsigned* abort_word = nullptr;
+  const int bm = (c.kind & 2048) != 0 ? 128 : 64;
+  for (int k = 0; k < n; ++k) {
+    if (!c.in_chain[k]) continue;
+    FwdJob& j = jobs[k];
+    const int q = cg.n++;
+    cg.j[q] = j.p;
+    cg.n_tiles = j.p.n_tiles;
+    cg.step_off[q] = j.b->step_off;
+    cg.rt_stride[q] = (j.b->step_count_host[t] + bm - 1) / bm;
+    unsigned* words = reinterpret_cast<unsigned*>(j.wsb + j.L.chain_sync);
+    cg.done[q] = words + 64;
+    (void)hipMemsetAsync(words, 0, 256 + sizeof(unsigned) * static_cast<size_t>(cg.nsteps) * cg.rt_stride[q],
+                         c.stream);
+    if (q == 0) {
+      cg.ticket = words;
+      abort_word = words + kXcds;
+    }
+    j.chain_until = c.end;
+  }
+  for (int q = cg.n; q < kMaxJobs; ++q) {
+    cg.step_off[q] = nullptr;
+    cg.done[q] = nullptr;
+    cg.rt_stride[q] = 0;
+  }
+  uint64_t units = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int sidx = 0; sidx <= cg.nsteps; ++sidx) {
+    cg.cum[sidx] = static_cast<uint32_t>(units);
+    if (sidx == cg.nsteps) break;
+    for (int k = 0; k < n; ++k) {
+      if (!c.in_chain[k]) continue;
+      const int S_k = jobs[k].b->step_count_host[t + sidx];
+      units += static_cast<uint64_t>((S_k + bm - 1) / bm);
+      const double I = jobs[k].p.I, H = jobs[k].p.H;
+      flops += S_k * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
+      bytes += S_k * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
+    }
+  }
+  for (int sidx = cg.nsteps + 1; sidx <= kChainMaxSteps; ++sidx) cg.cum[sidx] = static_cast<uint32_t>(units);
+  cg.sync = make_grid_sync(nullptr, abort_word);
+  const unsigned cgrid = static_cast<unsigned>(units * static_cast<uint64_t>(cg.n_tiles));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timer != nullptr) {
+    e0 = event_get(true);
+    e1 = e0 ? event_get(true) : nullptr;
+    if (e0 && !e1) {
+      event_put(e0, true);
+      e0 = nullptr;
+    }
+    if (e0 && e1) (void)hipEventRecord(e0, c.stream);
+  }
+  const bool cvec = (c.kind & 4) == 0;
+  if (bm == 128) {
+    const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
+    if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 2>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
+    else hipLaunchKernelGGL((gru_step_chain_kernel<false, 2>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
+  } else {
+    const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
+    if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 1>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
+    else hipLaunchKernelGGL((gru_step_chain_kernel<false, 1>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
+  }
+  if (e0 && e1) {
+    (void)hipEventRecord(e1, c.stream);
+    timer->tiled_events.push_back(e0);
+    timer->tiled_events.push_back(e1);
+    timer->tiled_flops += flops;
+    timer->tiled_bytes += bytes;
+  }
+}
+
 int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;
   XprojPlan plan[kMaxJobs];
@@ -2045,80 +2212,8 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     }
     // Step chain (gru_step_chain_kernel): when the requests that run an fp32 LDS-tiled step now go
     // on doing so together for at least chain_min_steps steps, those steps are ONE launch, queued
-    // here; the requests are skipped by the per-step launches below until the chain's last step.
-    bool in_chain[kMaxJobs] = {};
-    int chain_end = 0, chain_kind = -1;
-    hipStream_t chain_stream = nullptr;
-    {
-      const int min_steps = tunables().chain_min_steps.load(std::memory_order_relaxed);
-      int n_c = 0, tiles_c = -1;
-      bool ok = min_steps > 0;
-      for (int k = 0; k < n && ok; ++k) {
-        if (done[k] || (kind[k] & 3) != 1) continue;
-        const FwdJob& j = jobs[k];
-        // (H % 32: a state row must be whole 128-byte cache lines — a reader that pulled a line
-        // shared with the NEXT row tile's first row into its L2 before that row was written would
-        // leave a stale copy there for the tile that needs it)
-        if (t < j.chain_until || j.save || j.bf3 || j.tail_lo >= 0 || j.b->H % 32 != 0) {
-          ok = false;
-        } else if (n_c == 0) {
-          chain_kind = kind[k];
-          tiles_c = j.p.n_tiles;
-          chain_stream = js[k];
-        } else if (kind[k] != chain_kind || j.p.n_tiles != tiles_c || js[k] != chain_stream) {
-          ok = false;
-        }
-        in_chain[k] = true;
-        ++n_c;
-      }
-      if (ok && n_c > 0) {
-        // Tile height of a chain.  Nothing drains between steps here, so the 128-row tile (the more
-        // efficient one) pays from far fewer workgroups per step than with per-step launches:
-        // chain_tall_min_wgs (256) 64-row workgroups when every request's x phase is at least as long
-        // as its h phase (I >= H: a tile has that much work in front of its wait), four times that
-        // otherwise — a chain of h-dominated tiles is a latency chain, and half as many, twice as
-        // long tiles lengthen it (one tower alone, I = 300, 1100-2048 sequences: 185-194 us per
-        // step with 128 rows against 128-147 with 64; I = 2048: level; profiles/r04_step_chain.txt).
-        int tall = tunables().chain_tall_min_wgs.load(std::memory_order_relaxed);
-        for (int k = 0; k < n; ++k)
-          if (in_chain[k] && jobs[k].b->I < jobs[k].b->H) {
-            tall *= 4;
-            break;
-          }
-        chain_kind = (chain_kind & ~2048) | ((tall > 0 && tiled_wgs >= tall) ? 2048 : 0);
-        chain_end = t + 1;
-        while (chain_end - t < kChainMaxSteps) {
-          bool same = true;
-          for (int k = 0; k < n && same; ++k) {
-            const FwdJob& j = jobs[k];
-            const bool tiled_next = chain_end < j.b->Tmax && chain_end < j.t_mid && !j.bf3 &&
-                                    j.b->step_count_host[chain_end] > tiny_max_seqs();
-            same = tiled_next == in_chain[k];
-            // a step whose inputs are still crossing PCIe (cmhse_pull_steps: an event per chunk of
-            // time steps) starts a new chain, launched behind that event
-            if (same && in_chain[k] && j.b->step_events_host != nullptr && j.b->step_events_host[chain_end] != nullptr)
-              same = false;
-          }
-          if (!same) break;
-          ++chain_end;
-        }
-        // one workgroup per task: the grid must stay below 2^31 (halve the chain until it does)
-        for (;;) {
-          const int bm_c = (chain_kind & 2048) != 0 ? 128 : 64;
-          uint64_t units_c = 0;
-          for (int q = t; q < chain_end; ++q)
-            for (int k = 0; k < n; ++k)
-              if (in_chain[k]) units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c);
-          if (units_c * static_cast<uint64_t>(tiles_c) <= 0x7fffffffULL || chain_end - t <= 1) break;
-          chain_end = t + (chain_end - t) / 2;
-        }
-        ok = chain_end - t >= min_steps;
-      }
-      if (!ok || n_c == 0) {
-        chain_end = 0;
-        for (int k = 0; k < kMaxJobs; ++k) in_chain[k] = false;
-      }
-    }
+    // below; the requests are skipped by the per-step launches until the chain's last step.
+    const ChainPlan chain = plan_chain(jobs, n, t, kind, done, js, tiled_wgs);
     for (int k = 0; k < n; ++k) {
       if (done[k]) continue;
       FwdJob& j = jobs[k];
@@ -2206,82 +2301,10 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       j.p.off_cur = j.off;
       j.off += S_t;
     }
-    if (chain_end > t) {
-      GruChainGroup cg;
-      cg.n = 0;
-      cg.t0 = t;
-      cg.nsteps = chain_end - t;
-      cg.ticket = nullptr;
-      unsigned* abort_word = nullptr;
-      const int bm = (chain_kind & 2048) != 0 ? 128 : 64;
-      for (int k = 0; k < n; ++k) {
-        if (!in_chain[k]) continue;
-        FwdJob& j = jobs[k];
-        const int q = cg.n++;
-        cg.j[q] = j.p;
-        cg.n_tiles = j.p.n_tiles;
-        cg.step_off[q] = j.b->step_off;
-        cg.rt_stride[q] = (j.b->step_count_host[t] + bm - 1) / bm;
-        unsigned* words = reinterpret_cast<unsigned*>(j.wsb + j.L.chain_sync);
-        cg.done[q] = words + 64;
-        (void)hipMemsetAsync(words, 0, 256 + sizeof(unsigned) * static_cast<size_t>(cg.nsteps) * cg.rt_stride[q],
-                             chain_stream);
-        if (q == 0) {
-          cg.ticket = words;
-          abort_word = words + kXcds;
-        }
-        j.chain_until = chain_end;
-        done[k] = true;
-      }
-      for (int q = cg.n; q < kMaxJobs; ++q) {
-        cg.step_off[q] = nullptr;
-        cg.done[q] = nullptr;
-        cg.rt_stride[q] = 0;
-      }
-      uint64_t units = 0;
-      double flops = 0.0, bytes = 0.0;
-      for (int sidx = 0; sidx <= cg.nsteps; ++sidx) {
-        cg.cum[sidx] = static_cast<uint32_t>(units);
-        if (sidx == cg.nsteps) break;
-        for (int k = 0; k < n; ++k) {
-          if (!in_chain[k]) continue;
-          const int S_k = jobs[k].b->step_count_host[t + sidx];
-          units += static_cast<uint64_t>((S_k + bm - 1) / bm);
-          const double I = jobs[k].p.I, H = jobs[k].p.H;
-          flops += S_k * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
-          bytes += S_k * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
-        }
-      }
-      for (int sidx = cg.nsteps + 1; sidx <= kChainMaxSteps; ++sidx) cg.cum[sidx] = static_cast<uint32_t>(units);
-      cg.sync = make_grid_sync(nullptr, abort_word);
-      const unsigned cgrid = static_cast<unsigned>(units * static_cast<uint64_t>(cg.n_tiles));
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timer != nullptr) {
-        e0 = event_get(true);
-        e1 = e0 ? event_get(true) : nullptr;
-        if (e0 && !e1) {
-          event_put(e0, true);
-          e0 = nullptr;
-        }
-        if (e0 && e1) (void)hipEventRecord(e0, chain_stream);
-      }
-      const bool cvec = (chain_kind & 4) == 0;
-      if (bm == 128) {
-        const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
-        if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 2>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
-        else hipLaunchKernelGGL((gru_step_chain_kernel<false, 2>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
-      } else {
-        const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
-        if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 1>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
-        else hipLaunchKernelGGL((gru_step_chain_kernel<false, 1>), dim3(cgrid), dim3(kThreads), smem, chain_stream, cg);
-      }
-      if (e0 && e1) {
-        (void)hipEventRecord(e1, chain_stream);
-        timer->tiled_events.push_back(e0);
-        timer->tiled_events.push_back(e1);
-        timer->tiled_flops += flops;
-        timer->tiled_bytes += bytes;
-      }
+    if (chain.end > t) {
+      launch_chain(jobs, n, t, chain, timer);
+      for (int k = 0; k < n; ++k)
+        if (chain.in_chain[k]) done[k] = true;
       ++launches;
     }
     for (int k = 0; k < n; ++k)
