@@ -37,7 +37,8 @@ class SeqBatch(ctypes.Structure):
               ('emb_table', c_void_p),
               ('vocab', c_int32), ('h0_rows', c_void_p), ('lens', c_void_p),
               ('out_row', c_void_p), ('step_off', c_void_p), ('step_count_host', c_void_p),
-              ('step_timer', c_void_p), ('step_events_host', c_void_p)]
+              ('step_timer', c_void_p), ('step_events_host', c_void_p),
+              ('step_plan_host', c_void_p)]
 
 
 class GruJob(ctypes.Structure):

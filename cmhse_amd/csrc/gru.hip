@@ -433,8 +433,10 @@ void gru_step_kernel(const GruStepGroup grp) {
 // the next one its queue hands out, with every task that is already held at most a step ahead of
 // it — some held task can always run.  No co-residency requirement (the grid is one workgroup per
 // task, dispatched as slots free up); a workgroup whose queue is exhausted takes a task of another
-// queue.  The wait is bounded like the resident kernels' barrier (grid_sync.hpp):
-// CMHSE_ERR_TIMEOUT, not a hang.
+// queue.  That argument needs EQUAL queues: it holds when the column tiles are a whole multiple of
+// the 8 XCDs (H = 512, 1024, 1536 ...); for every other count there is one queue for the whole
+// chip (chain_cols_of), whose tickets are a topological order of the tasks.  The wait is bounded
+// like the resident kernels' barrier (grid_sync.hpp): CMHSE_ERR_TIMEOUT, not a hang.
 // ---------------------------------------------------------------------------------------------
 constexpr int kChainMaxSteps = kChainMaxStepsWs;
 constexpr int kXcds = 8;
@@ -449,8 +451,17 @@ struct GruChainGroup {
   int32_t n, t0, nsteps, n_tiles;
 };
 
+// Column tiles of queue x.  n_tiles % 8 == 0: column tile c belongs to queue c % 8, every queue
+// the same number.  Any other count (H = 128, 192, 256, 320, 768, 1280 ...): ONE queue holds all
+// the tasks in (step, row tile, column tile) order — with uneven queues the workgroups of the XCDs
+// with fewer (or no) columns overflow into the others, those queues run steps ahead of the short
+// ones and can fill every resident slot with workgroups waiting for tasks nobody is left to start
+// (a discrete-event model of the ticket logic deadlocks at n_tiles = 2, 4, 12, 20).
+// With one ticket every held task depends on earlier tickets only, so the earliest unfinished one
+// can always run.
 __device__ __forceinline__ int chain_cols_of(int n_tiles, int x) {
-  return (n_tiles > x) ? (n_tiles - x + kXcds - 1) / kXcds : 0;
+  if (n_tiles % kXcds != 0) return x == 0 ? n_tiles : 0;
+  return n_tiles / kXcds;
 }
 
 template <bool VEC, int MSUB>
@@ -464,7 +475,7 @@ void gru_step_chain_kernel(const GruChainGroup g) {
     // XCD — what the per-step kernels' block order relies on too), so this IS the workgroup's XCD on
     // an unpartitioned MI355X; derived from the index rather than read from XCC_ID so that the
     // queues advance in step with the dispatch order whatever the partition mode
-    const unsigned x = blockIdx.x & (kXcds - 1);
+    const unsigned x = (g.n_tiles % kXcds != 0) ? 0u : (blockIdx.x & (kXcds - 1));
     unsigned got = 0xffffffffu, queue = 0xffffffffu;
     for (unsigned d = 0; d < kXcds; ++d) {
       const unsigned y = (x + d) & (kXcds - 1);
@@ -486,7 +497,8 @@ void gru_step_chain_kernel(const GruChainGroup g) {
   const unsigned tk = __builtin_amdgcn_readfirstlane(s_task[0]);
   const unsigned cols = static_cast<unsigned>(chain_cols_of(g.n_tiles, static_cast<int>(queue)));
   const unsigned unit = tk / cols;
-  const int c = static_cast<int>(queue + kXcds * (tk % cols));
+  const int c = (g.n_tiles % kXcds != 0) ? static_cast<int>(tk % cols)
+                                         : static_cast<int>(queue + kXcds * (tk % cols));
   int lo = 0, hi = g.nsteps - 1;         // the last step whose first unit is <= unit
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1644,6 +1656,8 @@ struct FwdJob {
   hipStream_t side_stream;   // optional stream for throughput work beside a small-batch chain (projection chunks, attention)
   bool pooled;               // attention already launched (early, beside the others' tail)
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
+  const int32_t* kind_count; // HOST [Tmax]: active sequences the KIND of step t's kernel is chosen from — the batch's own
+                             // step counts, or the caller's step_plan_host (the counts of the whole split this batch is a share of)
   int32_t tail_lo;           // steps >= tail_lo run inside ONE resident kernel (gru_fwd_tail_kernel); -1 = none
   int32_t chain_until;       // steps < chain_until are inside a queued gru_step_chain_kernel launch
 };
@@ -1684,6 +1698,10 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
     sum_T += c;
   }
   if (b->step_count_host[0] != b->S) return CMHSE_ERR_ARG;
+  if (b->step_plan_host != nullptr)   // a share cannot have more active sequences than the whole
+    for (int t = 0; t < b->Tmax; ++t)
+      if (b->step_plan_host[t] < b->step_count_host[t] || (t > 0 && b->step_plan_host[t] > b->step_plan_host[t - 1]))
+        return CMHSE_ERR_ARG;
   if (sum_T * b->H >= (int64_t(1) << 40)) return CMHSE_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0 ||
       workspace_bytes < cmhse_gru_pool_workspace(b->S, b->Tmax, sum_T, b->I, b->H, mode_flags))
@@ -1691,6 +1709,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   job->b = b;
   job->w = w;
   job->out = out;
+  job->kind_count = b->step_plan_host != nullptr ? b->step_plan_host : b->step_count_host;
   job->L = gru_ws_layout(b->S, sum_T, b->H, mode_flags, b->I, b->Tmax);
   job->wsb = static_cast<char*>(workspace);
   job->sum_T = sum_T;
@@ -1724,7 +1743,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
   job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
-  job->bf3 = bf3 && job->vec && (b->S > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
+  job->bf3 = bf3 && job->vec && (job->kind_count[0] > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
   // steps with few active sequences: mid-size kernel on a hoisted input projection
   job->t_mid = b->Tmax;
   p.gx = nullptr;
@@ -1733,7 +1752,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   if (job->vec && mid_max_seqs() > 0) {
     int64_t p0 = 0;
     for (int t = 0; t < b->Tmax; ++t) {
-      if (b->step_count_host[t] <= mid_max_seqs()) {
+      if (job->kind_count[t] <= mid_max_seqs()) {
         job->t_mid = t;
         break;
       }
@@ -1757,7 +1776,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
     p.w_ih_s = wih_s;
     p.w_hh_s = whh_s;
     // the steps the tiled bf16x3 kernel serves are a prefix (S_t is non-increasing)
-    for (int t = 0; t < b->Tmax && t < job->t_mid && b->step_count_host[t] > tiny_max_seqs(); ++t)
+    for (int t = 0; t < b->Tmax && t < job->t_mid && job->kind_count[t] > tiny_max_seqs(); ++t)
       job->rows_split += b->step_count_host[t];
     p.xs = reinterpret_cast<float*>(wsb + L.xs);
     p.hs_s = reinterpret_cast<float*>(wsb + L.hs_s);
@@ -1828,7 +1847,10 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
     return 3 | (S_t <= 16 ? 32 : 0) | (bu == 8 ? 128 : 0) | (bu == 4 ? 256 : 0) |
            (alone ? 512 : 0);
   }
-  int k = (S_t <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
+  // (WHICH of the differently-ordered sums serves the step comes from kind_count — the whole
+  // split's active count when the batch is a share of one — so that a sequence sees the same
+  // arithmetic whatever else is in its batch; shapes within a kind are bit-identical)
+  int k = (j.kind_count[j.p.t] <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 1 && gru_msub_for(tiled_wgs) == 2) k |= 2048;
   return k | (j.vec ? 0 : 4);
 }
@@ -2027,7 +2049,7 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
       for (int k = 0; k < n && same; ++k) {
         const FwdJob& j = jobs[k];
         const bool tiled_next = c.end < j.b->Tmax && c.end < j.t_mid && !j.bf3 &&
-                                j.b->step_count_host[c.end] > tiny_max_seqs();
+                                j.kind_count[c.end] > tiny_max_seqs();
         same = tiled_next == c.in_chain[k];
         // a step whose inputs are still crossing PCIe (cmhse_pull_steps: an event per chunk of
         // time steps) starts a new chain, launched behind that event
@@ -2037,14 +2059,15 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
       if (!same) break;
       ++c.end;
     }
-    // one workgroup per task: the grid must stay below 2^31 (halve the chain until it does)
+    // one workgroup per task: HIP rejects a launch of more than 2^32 - 1 threads, i.e. 2^24 - 1
+    // workgroups of 256 (halve the chain until it fits)
     for (;;) {
       const int bm_c = (c.kind & 2048) != 0 ? 128 : 64;
       uint64_t units_c = 0;
       for (int q = t; q < c.end; ++q)
         for (int k = 0; k < n; ++k)
           if (c.in_chain[k]) units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c);
-      if (units_c * static_cast<uint64_t>(tiles_c) <= 0x7fffffffULL || c.end - t <= 1) break;
+      if (units_c * static_cast<uint64_t>(tiles_c) * kThreads <= 0xffffffffULL || c.end - t <= 1) break;
       c.end = t + (c.end - t) / 2;
     }
     ok = c.end - t >= min_steps;
@@ -2199,7 +2222,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (t < jobs[k].b->Tmax && t < jobs[k].t_mid) {
         alone = false;   // a tiled / tiny step runs too
         const int S_k = jobs[k].b->step_count_host[t];
-        if (S_k > tiny_max_seqs() && !jobs[k].bf3)
+        if (jobs[k].kind_count[t] > tiny_max_seqs() && !jobs[k].bf3)
           tiled_wgs += jobs[k].p.n_tiles * ((S_k + 63) / 64);
       }
     for (int k = 0; k < n; ++k) {

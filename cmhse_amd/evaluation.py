@@ -248,7 +248,41 @@ def _base_ptr(t):
   return t.data.data_ptr() if isinstance(t, ops.Ragged) else t.data_ptr()
 
 
-def encode_group(model, group, contextual_model=True, device=None, plan=None):
+TOWERS = ('v1', 't1', 'v2', 't2')   # clips + whole videos | sentences + paragraphs | clips per video | sentences per paragraph
+
+
+def length_histograms(batches):
+  """{tower: np.bincount of the sequence lengths} of the four encoders over `batches` (12-tuples
+  with their length members; a stub batch contributes nothing).  Histograms add over any partition
+  of a split, which is how ranks that hold different batches agree on split_step_plan."""
+  acc = {k: [] for k in TOWERS}
+  for b in batches:
+    if b[4] is None:
+      continue
+    acc['v1'] += [_lens_i64(b[4]), _lens_i64(b[6])]
+    acc['t1'] += [_lens_i64(b[5]), _lens_i64(b[7])]
+    acc['v2'].append(np.asarray(b[8], dtype=np.int64))
+    acc['t2'].append(np.asarray(b[9] if b[9] is not None else b[8], dtype=np.int64))
+  return {k: (np.bincount(np.concatenate(v)) if v else np.zeros(1, dtype=np.int64)).astype(np.int64)
+          for k, v in acc.items()}
+
+
+def plan_from_histograms(hists):
+  """{tower: #{s : len_s > t} for t = 0 .. Tmax - 1} from length histograms."""
+  return {k: (int(h.sum()) - np.cumsum(h)[:-1]).astype(np.int64) for k, h in hists.items()}
+
+
+def split_step_plan(batches):
+  """The step plan of a validation split: for each of the four encoders the number of sequences of
+  the WHOLE split still active at time step t.  Handed to every encoder call that encodes a share
+  of that split (one super-batch of several, one rank's batches: cmhse_seq_batch.step_plan_host), it
+  pins which kernel serves each time step, so every sequence is encoded bit for bit as in a
+  single call over the whole split — and the integer ranks do not depend on how the split was cut
+  ("ranks must be identical for G in {1,2,4,8}")."""
+  return plan_from_histograms(length_histograms(batches))
+
+
+def encode_group(model, group, contextual_model=True, device=None, plan=None, step_plan=None):
   """Encode a list of loader batches (12-tuples) as ONE super-batch.  Returns a dict of device
   tensors: the six un-normalised embedding matrices plus their L2-normalised versions, rows in
   loader order.  Arithmetic per sequence is identical to per-batch encoding (sequences are
@@ -258,8 +292,9 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
   pointer tables) are built on the first pass and reused afterwards — 2 ms of host work in front
   of the first launch, 5 % of a rank's 45 ms share of the split."""
   device = device or torch.device('cuda', torch.cuda.current_device())
+  sp = step_plan or {}
   if plan is not None and plan.get('key') == _plan_key(group) and GROUP_TOWERS[0] and not TWO_STREAMS[0]:
-    return _encode_group_planned(model, group, contextual_model, device, plan)
+    return _encode_group_planned(model, group, contextual_model, device, plan, sp)
   clips_l, caps_l, vids_l, pars_l = [], [], [], []
   len_clip, len_cap, len_vid, len_par = [], [], [], []
   num_clips, num_caps = [], []
@@ -317,12 +352,12 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
   img_dim = clips_l[0].shape[2]
   table = model.txt_enc.embed.weight.detach()
 
-  def level2(enc, rows, counts, ctx_rows, Hin):
+  def level2(enc, rows, counts, ctx_rows, Hin, tower):
     counts = np.asarray(counts, dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
     x_ptrs = np.uint64(rows.data_ptr()) + starts * np.uint64(Hin * 4)
     h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
-    return enc.rnn.forward_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
+    return enc.rnn.forward_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0, step_plan=sp.get(tower))
 
   n = ops.l2norm_rows
 
@@ -330,19 +365,20 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
     # level 1: clips of all batches, then whole-video streams of all batches (same weights)
     ptrs = ops.seq_row_ptrs_many(clips_l + vids_l)
     lens = np.concatenate(len_clip + len_vid)
-    vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs)
+    vis = clip_rnn.forward_ptrs(lens, img_dim, device, x_ptrs=ptrs, step_plan=sp.get('v1'))
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
     # level 2: each video's clips are consecutive rows of clip_emb -> addressed in place
-    vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v)
+    vid_emb = level2(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v, 'v2')
     return n(vid_emb), n(clip_emb), n(vid_ctx)
 
   def text_tower():
     # level 1: sentences, then paragraphs (embedding lookup fused into the operand load)
     ptrs = ops.seq_row_ptrs_many(caps_l + pars_l)
     lens = np.concatenate(len_cap + len_par)
-    txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table)
+    txt = txt_rnn.forward_ptrs(lens, table.shape[1], device, tok_ptrs=ptrs, table=table,
+                               step_plan=sp.get('t1'))
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
-    para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)
+    para_emb = level2(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t, 't2')
     return n(para_emb), n(cap_emb), n(para_ctx)
 
   if TWO_STREAMS[0]:
@@ -383,22 +419,24 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
                   batch_sizes=[len(b[8]) for b in group], keep=(clips_l, vids_l, caps_l, pars_l))
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
         clip_rnn.request_ptrs(v_lens, img_dim, device, x_ptrs=v_ptrs,
-                              sched=v_sched, step_events=v_events),
+                              sched=v_sched, step_events=v_events, step_plan=sp.get('v1')),
         txt_rnn.request_ptrs(t_lens, table.shape[1], device,
-                             tok_ptrs=t_ptrs, table=table, sched=t_sched)], tail_stream=tail)
+                             tok_ptrs=t_ptrs, table=table, sched=t_sched,
+                             step_plan=sp.get('t1'))], tail_stream=tail)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
 
-    def level2_request(enc, rows, counts, ctx_rows, Hin):
+    def level2_request(enc, rows, counts, ctx_rows, Hin, tower):
       counts = np.asarray(counts, dtype=np.int64)
       starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
       x_ptrs = np.uint64(rows.data_ptr()) + starts * np.uint64(Hin * 4)
       h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
-      return enc.rnn.request_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
+      return enc.rnn.request_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0,
+                                  step_plan=sp.get(tower))
 
     (vid_emb, _), (para_emb, _) = ops.gru_pool_fwd_multi([
-        level2_request(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v),
-        level2_request(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t)])
+        level2_request(model.vid_seq_enc, clip_emb, num_clips, vid_ctx, H1v, 'v2'),
+        level2_request(model.txt_seq_enc, cap_emb, num_caps, para_ctx, H1t, 't2')])
     out_vis = (n(vid_emb), n(clip_emb), n(vid_ctx))
     out_txt = (n(para_emb), n(cap_emb), n(para_ctx))
   else:
@@ -409,7 +447,7 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None):
               batch_sizes=[len(b[8]) for b in group])
 
 
-def _encode_group_planned(model, group, contextual_model, device, plan):
+def _encode_group_planned(model, group, contextual_model, device, plan, sp):
   """encode_group's grouped schedule with the level-1 schedules of an earlier pass over the same
   batches (encode_group(plan=...)): same launches, same values."""
   clip_rnn, txt_rnn = model.clip_enc.rnn, model.txt_enc.rnn
@@ -420,21 +458,23 @@ def _encode_group_planned(model, group, contextual_model, device, plan):
   tail = _tail_stream(device) if EARLY_POOL[0] else None
   (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
       clip_rnn.request_ptrs(plan['v_lens'], plan['img_dim'], device, x_ptrs=plan['v_ptrs'],
-                            sched=plan['v_sched']),
+                            sched=plan['v_sched'], step_plan=sp.get('v1')),
       txt_rnn.request_ptrs(plan['t_lens'], table.shape[1], device, tok_ptrs=plan['t_ptrs'],
-                           table=table, sched=plan['t_sched'])], tail_stream=tail)
+                           table=table, sched=plan['t_sched'], step_plan=sp.get('t1'))],
+      tail_stream=tail)
   clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
   cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
 
-  def level2_request(enc, rows, counts, ctx_rows, Hin):
+  def level2_request(enc, rows, counts, ctx_rows, Hin, tower):
     starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
     x_ptrs = np.uint64(rows.data_ptr()) + starts * np.uint64(Hin * 4)
     h0 = ops.padded_row_ptrs(ctx_rows) if contextual_model else None
-    return enc.rnn.request_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0)
+    return enc.rnn.request_ptrs(counts, Hin, device, x_ptrs=x_ptrs, h0_ptrs=h0,
+                                step_plan=sp.get(tower))
 
   (vid_emb, _), (para_emb, _) = ops.gru_pool_fwd_multi([
-      level2_request(model.vid_seq_enc, clip_emb, plan['num_clips'], vid_ctx, H1v),
-      level2_request(model.txt_seq_enc, cap_emb, plan['num_caps'], para_ctx, H1t)])
+      level2_request(model.vid_seq_enc, clip_emb, plan['num_clips'], vid_ctx, H1v, 'v2'),
+      level2_request(model.txt_seq_enc, cap_emb, plan['num_caps'], para_ctx, H1t, 't2')])
   n = ops.l2norm_rows
   return dict(vid_emb=n(vid_emb), para_emb=n(para_emb), clip_emb=n(clip_emb), cap_emb=n(cap_emb),
               vid_ctx=n(vid_ctx), para_ctx=n(para_ctx), n_vid=plan['n_vid'],
@@ -472,14 +512,17 @@ def _group_batches(batches, max_bytes):
 
 
 def encode_data_device(opt, model, data_loader, log_step=10, logging=print, contextual_model=True,
-                       superbatch_bytes=48 << 30, defer_logging=False, plan=None):
+                       superbatch_bytes=48 << 30, defer_logging=False, plan=None, step_plan=None):
   """Device-resident core of encode_data: returns (dict of six [N,*] normalised embedding tensors
   on the GPU, num_clips_total, cur_vid_total).  With `defer_logging` the per-batch 'Letest' values
   travel to the host asynchronously and a fourth return value, `finish()`, replays the logger
   updates: a caller that scores the embeddings right away (bench.py, parallel_eval) queues its
   ranking kernels first and calls finish() afterwards, so the GPU does not idle through that
   device-to-host round trip.  `plan`: a dict kept by a caller that encodes the SAME resident
-  batches again and again (encode_group): schedules built once."""
+  batches again and again (encode_group): schedules built once.  `step_plan`: split_step_plan() of
+  the whole split when `data_loader` is only a share of it (parallel_eval passes the one all ranks
+  agree on); by default the plan of `data_loader` itself, so that cutting it into several
+  super-batches (`superbatch_bytes`) does not change a bit of any embedding."""
   batch_time = AverageMeter()
   val_logger = LogCollector()
   model.val_start(opt)
@@ -511,10 +554,13 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
         state['i'] += 1
 
   with torch.no_grad(), _no_gc_pause():
-    for gi, group in enumerate(_group_batches(batches, superbatch_bytes)):
+    groups = _group_batches(batches, superbatch_bytes)
+    if step_plan is None and len(groups) > 1:       # (one group: its own step counts ARE the split's)
+      step_plan = split_step_plan(batches)
+    for gi, group in enumerate(groups):
       model.logger = val_logger                     # evaluation.py:99
       enc = encode_group(model, group, contextual_model,
-                         plan=None if plan is None else plan.setdefault(gi, {}))
+                         plan=None if plan is None else plan.setdefault(gi, {}), step_plan=step_plan)
       for k in outs:
         outs[k].append(enc[k])
       # per-loader-batch 'Letest' loss (evaluation.py:129), all on device, one sync per group

@@ -455,22 +455,22 @@ class _GRUPoolBase(nn.Module):
                      table)
 
   def forward_ptrs(self, lens, in_dim, device, x_ptrs=None, tok_ptrs=None, table=None,
-                   h0_ptrs=None, out=None):
+                   h0_ptrs=None, out=None, step_plan=None):
     """Inference-only entry used by the fused paths (EncoderText, structure_emb, encode_data):
     sequences are given by base address (numpy uint64, input order), so padded batches, several
     loader batches at once and consecutive-row level-2 inputs are consumed in place."""
     out, _ = ops.gru_pool_fwd(**self.request_ptrs(lens, in_dim, device, x_ptrs, tok_ptrs, table,
-                                                  h0_ptrs, out))
+                                                  h0_ptrs, out, step_plan=step_plan))
     return out
 
   def request_ptrs(self, lens, in_dim, device, x_ptrs=None, tok_ptrs=None, table=None,
-                   h0_ptrs=None, out=None, sched=None, step_events=None):
+                   h0_ptrs=None, out=None, sched=None, step_events=None, step_plan=None):
     """The arguments of forward_ptrs as one request of ops.gru_pool_fwd_multi, which runs
     independent encoders (the visual and the text tower) in shared per-step launches."""
     return dict(weights=self._weights(), pool_mode=self.POOL, lens=lens, I=in_dim,
                 H=self.rnn.weight_hh_l0.shape[1], device=device, x_ptrs=x_ptrs,
                 tok_ptrs=tok_ptrs, emb_table=table, h0_ptrs=h0_ptrs, out=out, sched=sched,
-                step_events=step_events)
+                step_events=step_events, step_plan=step_plan)
 
   def forward_tokens(self, tokens, q_len, table):
     """Fused embedding-lookup + encoder (model.EncoderText.forward, model.py:92-99): the word

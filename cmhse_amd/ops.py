@@ -207,6 +207,16 @@ class SeqSchedule(object):
     self.is_tokens = x_ptrs is None
 
 
+def step_counts(lens):
+  """#{s : lens[s] > t} for t = 0 .. max(lens) - 1 (int64): the active sequences per time step of a
+  length-sorted packed batch — SeqSchedule.step_count_host, without the schedule."""
+  lens = np.asarray(lens, dtype=np.int64).reshape(-1)
+  if lens.size == 0:
+    return np.zeros(0, dtype=np.int64)
+  hist = np.bincount(lens, minlength=int(lens.max()) + 1)
+  return (lens.size - np.cumsum(hist)[:-1]).astype(np.int64)
+
+
 def padded_row_ptrs(t):
   """Base address of every sequence of a contiguous padded batch [S, T, ...]."""
   S = t.shape[0]
@@ -404,10 +414,13 @@ def pull_steps(sched, row_floats, copy_stream, chunk=8):
 
 def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
-                 constant_input=False, sched=None, step_events=None, side=True):
+                 constant_input=False, sched=None, step_events=None, side=True, step_plan=None):
   """Build the ctypes request of one cmhse_gru_pool_fwd call.  Returns (job dict, timer meta).
   `sched`: a prebuilt SeqSchedule for these sequences (else built here); `step_events`:
-  {step: torch.cuda.Event} the step's launch must wait for (chunked upload, pull_steps)."""
+  {step: torch.cuda.Event} the step's launch must wait for (chunked upload, pull_steps);
+  `step_plan`: active sequences per time step of the WHOLE set these sequences are a share of
+  (step_counts() of all its lengths; cmhse_seq_batch.step_plan_host) — the kernel kind of every step
+  is then chosen from it, so a sequence is encoded bit for bit the same in any share."""
   lib = _lib.load()
   if sched is None:
     sched = SeqSchedule(lens, device, x_ptrs, tok_ptrs, h0_ptrs,
@@ -447,6 +460,14 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
   b.h0_rows = sched.p_h0
   b.lens, b.out_row, b.step_off = sched.p_lens, sched.p_out_row, sched.p_step_off
   b.step_count_host = sched.step_count_host.ctypes.data
+  if step_plan is not None and not save_for_backward:
+    plan = np.zeros(sched.Tmax, dtype=np.int32)
+    sp = np.asarray(step_plan, dtype=np.int32)[:sched.Tmax]
+    plan[:len(sp)] = sp
+    # (a share's own counts are a lower bound: a caller whose plan was built from other lengths gets
+    # CMHSE_ERR_ARG from the library rather than a silently different schedule)
+    b.step_plan_host = plan.ctypes.data
+    keep.append(plan)
   ev_arr = None
   if step_events:
     ev_arr = (ctypes.c_void_p * sched.Tmax)()

@@ -16,9 +16,13 @@ data-parallel sharding the path offers: videos/paragraphs are independent units.
   4. all-gather of the int32 ranks / top-1 (a few KB), un-permuted to loader order, and the
      Recall@K report on every rank, computed exactly as evaluation.py:173-184.
 
-Ranks do not depend on the partition (each row is computed independently, and a common permutation
-of videos and paragraphs keeps every diagonal pair together), so the result is identical for any
-world size.  `encode_fn` / `rank_fn` exist so the partition/merge logic can be exercised on CPU
+Ranks do not depend on the partition: each score row is computed independently, a common
+permutation of videos and paragraphs keeps every diagonal pair together, and every rank encodes
+its share with the kernel kinds the WHOLE split selects per time step (`global_step_plan`: a
+share's own, smaller active counts would otherwise move some steps from the LDS-tiled kernel to the
+small-batch one, whose sums are ordered differently — embeddings equal to fp32 rounding only, a
+handful of the 9834 rank rows flipped at N = 4917 in round 4).  So the result is identical, bit for
+bit, for any world size.  `encode_fn` / `rank_fn` exist so the partition/merge logic can be exercised on CPU
 with gloo in tests; the defaults are the HIP path and have no fallback.
 """
 from __future__ import annotations
@@ -78,15 +82,44 @@ def costs_of(batches, img_dim=None):
   return out
 
 
-def _default_encode(opt, model, batches, plan=None):
+def _default_encode(opt, model, batches, plan=None, step_plan=None):
   """(video embeddings, paragraph embeddings, finish): `finish()` replays the per-batch 'Letest'
   meters (evaluation.py:129); validate_sharded calls it after the exchange and the ranking kernels
   are queued, so no host sync stands in front of them."""
   if not batches:
     return None
   cat, _, _, finish = evaluation.encode_data_device(opt, model, batches, logging=lambda *a: None,
-                                                    defer_logging=True, plan=plan)
+                                                    defer_logging=True, plan=plan, step_plan=step_plan)
   return cat['vid_emb'], cat['para_emb'], finish
+
+
+def global_step_plan(own_batches, group=None, device=None):
+  """evaluation.split_step_plan of the WHOLE split, agreed on by all ranks, from each rank's own
+  batches: the length histograms of the four encoders add over the ranks (two small control
+  collectives: the longest length per encoder, then the histograms — a few hundred integers).  A
+  rank never needs the lengths of batches it does not encode, so loaders that materialise only
+  their own batches work.  With it every rank picks, for every time step, the kernel the single
+  process would pick for the whole split, and a sequence's embedding is the same bit pattern on
+  any number of ranks."""
+  hists = evaluation.length_histograms(own_batches)
+  if dist.get_world_size(group) > 1:
+    dev = _collective_device(group, device)
+    sizes = torch.tensor([len(hists[k]) for k in evaluation.TOWERS], dtype=torch.int64, device=dev)
+    dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=group)
+    sizes = [int(v) for v in sizes.cpu().tolist()]
+    flat = np.zeros(sum(sizes), dtype=np.int64)
+    pos = 0
+    for k, n in zip(evaluation.TOWERS, sizes):
+      flat[pos:pos + len(hists[k])] = hists[k]
+      pos += n
+    t = torch.from_numpy(flat).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    flat = t.cpu().numpy()
+    pos = 0
+    for k, n in zip(evaluation.TOWERS, sizes):
+      hists[k] = flat[pos:pos + n].copy()
+      pos += n
+  return evaluation.plan_from_histograms(hists)
 
 
 def _default_rank(queries, gallery, row0, nrows):
@@ -199,7 +232,7 @@ class _Phases(object):
 
 
 def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_fn=None,
-                     device=None, dim=None, assignment=None, timings=None, plan=None):
+                     device=None, dim=None, assignment=None, timings=None, plan=None, step_plan=None):
   """Sharded counterpart of train.validate's encode_data + i2t + t2i (train.py:223-236).
   Returns (report_i2t, report_t2i, ranks_i2t, ranks_t2i, top1_i2t, top1_t2i) on every rank, rows in
   loader order.  `assignment`: per-rank batch-index lists (default: assign_batches on the loader's
@@ -208,9 +241,10 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   `timings`: a dict that receives this rank's encode_ms / exchange_ms / score_ms — on a GPU from
   HIP events on the current stream (device time between the marks; the pass is not synchronised
   for them) — measurement only.  `plan`: a dict the caller keeps between passes over the SAME
-  resident batches (evaluation.encode_group): this rank's schedules are built once."""
-  if encode_fn is None:
-    encode_fn = (lambda o, m, b: _default_encode(o, m, b, plan)) if plan is not None else _default_encode
+  resident batches (evaluation.encode_group): this rank's schedules are built once.  `step_plan`:
+  evaluation.split_step_plan of the whole split if the caller has it; by default the ranks agree on
+  it themselves (global_step_plan) — it is what makes the integer ranks independent of the world
+  size bit for bit (each rank encodes its share with the kernels the whole split selects)."""
   rank_fn = rank_fn or _default_rank
   world = dist.get_world_size(group)
   me = dist.get_rank(group)
@@ -218,6 +252,10 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   if assignment is None:
     assignment = assign_batches(costs_of(batches), world)
     _same_on_all_ranks(assignment, group, device)
+  if encode_fn is None:
+    if step_plan is None:
+      step_plan = global_step_plan([batches[i] for i in assignment[me]], group, device)
+    encode_fn = lambda o, m, b: _default_encode(o, m, b, plan, step_plan)
   sizes = [len(b[8]) for b in batches]
   starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
   # global (loader-order) video index of every row of the gathered matrices, rank after rank

@@ -121,6 +121,15 @@ typedef struct cmhse_seq_batch {
                                NULL: before step t's kernel is launched, its stream waits on entry t.
                                Lets the caller feed x rows chunk by chunk (cmhse_pull_steps on a copy
                                stream) while earlier steps compute */
+  const int32_t* step_plan_host; /* optional HOST [Tmax], or NULL: #{s : lens[s] > t} over the WHOLE set of
+                               sequences this batch is a share of (one rank's part of a validation
+                               split, one super-batch of several: >= step_count_host[t], non-increasing).
+                               Which kernel serves step t — the LDS-tiled one (one k-ordered sum over
+                               [x_t | h_{t-1}]) or the small-batch one (hoisted input projection + K in
+                               8 slices) — is then chosen from THIS count instead of the batch's own, so
+                               a sequence is encoded bit for bit the same whatever share of the split
+                               it is encoded with (parallel_eval: integer ranks identical for any
+                               number of ranks).  NULL = the batch's own counts */
 } cmhse_seq_batch;
 
 /* Bytes of workspace cmhse_gru_pool_fwd needs for this batch: the time-major packed hidden states

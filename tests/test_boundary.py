@@ -198,12 +198,15 @@ def test_bench_starts_its_own_ranks_and_matches_the_single_process_ranks():
   """`python bench.py --gpus 2` from a bare shell (no torchrun, no WORLD_SIZE): the parent starts
   two rank processes (sharing this box's GPU over gloo when it has only one), ONE JSON line comes
   out with two per_rank entries, and the integer ranks of both directions at ICEP width are those
-  of the single-process run (train.py:223-236's validate, sharded)."""
-  one = _run_bench(['--gpus', '1', '--n_videos', '600'])
-  two = _run_bench(['--gpus', '2', '--n_videos', '600'])
+  of the single-process run (train.py:223-236's validate, sharded) — at 1500 videos, where a rank's
+  share and the whole split sit on different sides of the 1024-sequence kernel crossover for many
+  time steps (level 2: 750 against 1500 videos): the ranks agree on the whole split's step plan
+  (parallel_eval.global_step_plan, two small control collectives) and encode their shares with it."""
+  one = _run_bench(['--gpus', '1', '--n_videos', '1500'])
+  two = _run_bench(['--gpus', '2', '--n_videos', '1500'])
   assert one['n_gpus'] == 1 and two['n_gpus'] == 2
   assert len(two['per_rank']) == 2
-  assert sum(r['videos'] for r in two['per_rank']) == 600
+  assert sum(r['videos'] for r in two['per_rank']) == 1500
   assert all(r['encode_ms'] > 0 and r['score_ms'] > 0 for r in two['per_rank'])
   assert two['ranks_crc32'] == one['ranks_crc32']
   assert two['report_i2t_random_init'] == one['report_i2t_random_init']

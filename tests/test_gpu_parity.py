@@ -397,6 +397,89 @@ def test_superbatch_equals_per_batch(dev):
       pos += B
 
 
+def _plan_setup(dev, n_videos=1500, H=256, img_dim=64, rnn_type='attention'):
+  from cmhse_amd import synthetic
+  from cmhse_amd.model import VSE
+  opt = argparse.Namespace(
+      margin=0.2, word_dim=300, embed_size=H, grad_clip=0.0, learning_rate=0.001, max_violation=False,
+      img_dim=img_dim, measure='cosine', rnn_type=rnn_type, img_first_size=H, cap_first_size=H,
+      low_level_loss=False, weak_low_level_loss=False, reconstruct_loss=False,
+      lowest_reconstruct_loss=False, norm=False, data_name='anet_precomp', vocab_size=300)
+  torch.manual_seed(4)
+  model = VSE(opt)
+  spec = synthetic.anet_like_spec(n_videos, seed=2)
+  batches = synthetic.make_batches(spec, 32, img_dim, opt.vocab_size, seed=3)
+  batches = [tuple(x.to(dev) if isinstance(x, torch.Tensor) and i < 4 else x for i, x in enumerate(b))
+             for b in batches]
+  return opt, model, batches
+
+
+KEYS6 = ['vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx']
+
+
+@pytest.mark.parametrize('rnn_type', ['attention', 'maxout'])
+def test_step_plan_makes_every_share_of_a_split_bit_identical(dev, rnn_type):
+  """"ranks must be identical for G in {1,2,4,8}".  A 1500-video split whose shares
+  straddle the 1024-sequence crossover between the LDS-tiled step kernel and the small-batch one
+  (level 2: 1500 videos against 750 / 500; level 1: the whole split's active count passes 1024 many
+  steps after a share's): every share encoded with the WHOLE split's step plan
+  (evaluation.split_step_plan -> cmhse_seq_batch.step_plan_host) gives all six embedding matrices
+  bit for bit as the single call over the split does — and without the plan it does not (the test
+  has teeth: the two kernels order their sums differently)."""
+  from cmhse_amd import evaluation
+  opt, model, batches = _plan_setup(dev, rnn_type=rnn_type)
+  quiet = lambda *a: None
+  whole, _, _ = evaluation.encode_data_device(opt, model, batches, logging=quiet)
+  plan = evaluation.split_step_plan(batches)
+  assert plan['v2'][0] == 1500 and plan['v1'][0] > 1024 and plan['t1'][-1] <= 1024
+  sizes = np.cumsum([0] + [len(b[8]) for b in batches])
+  csizes = np.cumsum([0] + [sum(b[8]) for b in batches])
+  differs_without = False
+  for world in (2, 3):
+    for r in range(world):
+      own = [i for i in range(len(batches)) if i % world == r]        # a scrambled deal
+      mine = [batches[i] for i in own]
+      got, _, _ = evaluation.encode_data_device(opt, model, mine, logging=quiet, step_plan=plan)
+      bare, _, _ = evaluation.encode_data_device(opt, model, mine, logging=quiet)
+      vid_rows = np.concatenate([np.arange(sizes[i], sizes[i + 1]) for i in own])
+      clip_rows = np.concatenate([np.arange(csizes[i], csizes[i + 1]) for i in own])
+      for k in KEYS6:
+        rows = torch.from_numpy(clip_rows if k in ('clip_emb', 'cap_emb') else vid_rows).to(dev)
+        assert torch.equal(got[k], whole[k][rows]), (world, r, k)
+        differs_without = differs_without or not torch.equal(bare[k], whole[k][rows])
+  assert differs_without, 'no share crossed a kernel crossover: the test does not test the plan'
+  # the same holds for a single process that cuts its loader into several super-batches: the plan
+  # of the whole loader is the default there
+  cut, _, _ = evaluation.encode_data_device(opt, model, batches, logging=quiet,
+                                            superbatch_bytes=int(batches[0][0].numel() * 4 * 9))
+  for k in KEYS6:
+    assert torch.equal(cut[k], whole[k]), k
+
+
+def test_step_plan_is_validated_by_the_library(dev):
+  """A plan below the batch's own counts (built from other lengths) is an argument error, not a
+  silently different schedule."""
+  from cmhse_amd import ops
+  H, I, S, T = 64, 16, 40, 5
+  x = torch.randn(S, T, I, device=dev)
+  w = dict(w_ih=torch.randn(3 * H, I, device=dev), w_hh=torch.randn(3 * H, H, device=dev),
+           b_ih=torch.zeros(3 * H, device=dev), b_hh=torch.zeros(3 * H, device=dev))
+  lens = np.full(S, T, dtype=np.int64)
+  ok, _ = ops.gru_pool_fwd(w, ops.POOL_LAST, lens, I, H, dev, x_ptrs=ops.padded_row_ptrs(x),
+                           step_plan=np.full(T + 3, 5000))
+  ref, _ = ops.gru_pool_fwd(w, ops.POOL_LAST, lens, I, H, dev, x_ptrs=ops.padded_row_ptrs(x))
+  with ops.tuned(tiny_max_seqs=0, mid_max_seqs=0):
+    tiled, _ = ops.gru_pool_fwd(w, ops.POOL_LAST, lens, I, H, dev, x_ptrs=ops.padded_row_ptrs(x))
+  assert torch.equal(ok, tiled)                 # a plan above 1024 selects the LDS-tiled kernel
+  assert torch.allclose(ok, ref, atol=1e-5)
+  with pytest.raises(RuntimeError):
+    ops.gru_pool_fwd(w, ops.POOL_LAST, lens, I, H, dev, x_ptrs=ops.padded_row_ptrs(x),
+                     step_plan=np.full(T, S - 1))
+  with pytest.raises(RuntimeError):
+    ops.gru_pool_fwd(w, ops.POOL_LAST, lens, I, H, dev, x_ptrs=ops.padded_row_ptrs(x),
+                     step_plan=np.array([50, 60, 60, 60, 60]))
+
+
 def test_stream_schedules_are_bit_identical(dev):
   """The side-stream schedule of encode_group (the two towers on two streams), the grouped launches
   of cmhse_gru_pool_fwd_multi and the early attention pass of the shorter chain on a side stream
@@ -1276,7 +1359,7 @@ def test_gru_pool_fwd_multi_equals_separate_calls(dev):
 
 
 @pytest.mark.parametrize('shape', ['one_xcd_queue', 'two_requests', 'full_width', 'scalar_loads', 'long_chain',
-                                   'many_rounds'])
+                                   'many_rounds', 'uneven_256', 'uneven_768', 'uneven_128_long'])
 def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shape):
   """The LDS-tiled steps of a call as ONE launch (gru_step_chain_kernel: a workgroup per (step,
   request, row tile, column tile) task, per-XCD task queues, the previous step's rows awaited
@@ -1291,7 +1374,12 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
                    state rows of whole cache lines, H % 32 == 0 — other widths keep per-step launches)
     long_chain     more steps than one launch covers (96): the chain is cut and resumed
     many_rounds    H = 1024, 6000 + 5000 sequences: ~15 rounds of workgroups per launch, so tasks wait
-                   for tiles that run later on other XCDs (the validation pass's regime)"""
+                   for tiles that run later on other XCDs (the validation pass's regime)
+    uneven_256 / uneven_768 / uneven_128_long   4, 12 and 2 column tiles — not a whole multiple of the 8
+                   XCD queues — at sizes far beyond what the chip holds at once (47-94 row tiles x 12-20
+                   steps): with per-XCD queues of unequal length the long queues ran ahead and could fill
+                   every slot with waiting workgroups (deadlock in a model of the ticket
+                   logic); these counts now share ONE queue whose tickets are a topological order"""
   from cmhse_amd import _lib, ops
   rng = np.random.RandomState(3)
   g = torch.Generator().manual_seed(8)
@@ -1341,6 +1429,12 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     reqs = [request(200, 6, 10, 96, ops.POOL_LAST, h0=True), request(150, 8, 10, 96, ops.POOL_ATTN)]
   elif shape == 'many_rounds':
     reqs = [request(6000, 10, 256, 1024, ops.POOL_ATTN, full=3000), request(5000, 7, 64, 1024, ops.POOL_LAST, full=1200)]
+  elif shape == 'uneven_256':
+    reqs = [request(3000, 12, 48, 256, ops.POOL_ATTN, full=2000)]
+  elif shape == 'uneven_768':
+    reqs = [request(3000, 12, 32, 768, ops.POOL_MAX, full=2500), request(1500, 10, 32, 768, ops.POOL_ATTN, full=700)]
+  elif shape == 'uneven_128_long':
+    reqs = [request(6000, 20, 16, 128, ops.POOL_LAST, full=5000)]
   else:
     reqs = [request(70, 130, 8, 32, ops.POOL_ATTN, full=3)]
 

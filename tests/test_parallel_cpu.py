@@ -206,3 +206,70 @@ def test_batch_lengths_match_the_materialised_batches():
   for (lc, lv, lw, lp), b in zip(lens, batches):
     assert list(lc) == b[4].tolist() and list(lw) == b[5].tolist()
     assert list(lv) == b[6].tolist() and list(lp) == b[7].tolist()
+
+
+def _plan_worker(rank, world, port, out_dir):
+  sys.path.insert(0, REPO)
+  from cmhse_amd import evaluation, parallel_eval, synthetic
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  spec = synthetic.ragged_spec(41, seed=9, max_clips=6, max_frames=17, max_words=11, max_video=23)
+  batches = synthetic.make_batches(spec, 4, 8, 50, seed=0)
+  own = [i for i in range(len(batches)) if (i * 5 + 1) % world == rank]
+  if rank == world - 1:
+    own = []                       # a rank with no batches at all still takes part
+  # this rank's loader: its own batches materialised, stubs (num_clips only) for the others
+  mine = []
+  for i, b in enumerate(batches):
+    if i in own:
+      mine.append(b)
+    else:
+      stub = [None] * 12
+      stub[8] = b[8]
+      mine.append(tuple(stub))
+  plan = parallel_eval.global_step_plan([mine[i] for i in own], None, 'cpu')
+  np.savez(os.path.join(out_dir, 'p%d.npz' % rank), **plan)
+  dist.destroy_process_group()
+
+
+def test_global_step_plan_is_the_whole_splits_on_every_rank(tmp_path):
+  """parallel_eval.global_step_plan: ranks that hold different batches (and one that holds none)
+  agree on evaluation.split_step_plan of the union of the ranks' batches — the per-time-step active
+  counts of the four encoders from which every rank picks its kernels."""
+  from cmhse_amd import evaluation, synthetic
+  world = 3
+  mp.spawn(_plan_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  spec = synthetic.ragged_spec(41, seed=9, max_clips=6, max_frames=17, max_words=11, max_video=23)
+  batches = synthetic.make_batches(spec, 4, 8, 50, seed=0)
+  held = [b for i, b in enumerate(batches) if (i * 5 + 1) % world != world - 1]
+  want = evaluation.split_step_plan(held)
+  for r in range(world):
+    got = np.load(os.path.join(str(tmp_path), 'p%d.npz' % r))
+    assert sorted(got.files) == sorted(evaluation.TOWERS)
+    for k in evaluation.TOWERS:
+      np.testing.assert_array_equal(got[k], want[k])
+
+
+def test_split_step_plan_counts_active_sequences_per_step():
+  from cmhse_amd import evaluation, ops, synthetic
+  spec = synthetic.ragged_spec(13, seed=2)
+  batches = synthetic.make_batches(spec, 5, 8, 50, seed=0)
+  plan = evaluation.split_step_plan(batches)
+  v1 = np.concatenate([np.asarray(b[4]) for b in batches] + [np.asarray(b[6]) for b in batches])
+  t1 = np.concatenate([np.asarray(b[5]) for b in batches] + [np.asarray(b[7]) for b in batches])
+  v2 = np.concatenate([np.asarray(b[8]) for b in batches])
+  for k, lens in (('v1', v1), ('t1', t1), ('v2', v2), ('t2', v2)):
+    want = [int((lens > t).sum()) for t in range(int(lens.max()))]
+    assert plan[k].tolist() == want
+    assert ops.step_counts(lens).tolist() == want
+    # ... exactly what a schedule over all of them hands to the library as its own counts
+  # histograms add over any cut of the split
+  a = evaluation.length_histograms(batches[:1])
+  b = evaluation.length_histograms(batches[1:])
+  for k in evaluation.TOWERS:
+    n = max(len(a[k]), len(b[k]))
+    tot = np.zeros(n, dtype=np.int64)
+    tot[:len(a[k])] += a[k]
+    tot[:len(b[k])] += b[k]
+    np.testing.assert_array_equal(tot, evaluation.length_histograms(batches)[k])
