@@ -789,16 +789,18 @@ struct RecPartParams {
   int32_t S_next, H, K, k_slice, m_pad, n_tiles;
 };
 
+constexpr int kRecFusedMaxTiles = 1024;   // arrival words of bwd_step_fused_kernel (column tiles x row blocks of a step)
 constexpr int kRecThreads = 512;   // 8 waves: two per SIMD, so one wave's chunk barrier and LDS round trip hide under the other's MFMAs
 
-__global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPartParams q) {
-  CHAIN_WAVE_PRIORITY();
-  __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
+// The product of one (32-row block, 128-column tile, K slice): acc[mb][reg] = element (row 16 mb +
+// 4 kq + reg, column 16 wave + r16) of the slice's partial tile.  Ends with a workgroup barrier
+// (the LDS buffers may be reused).
+typedef float (*RecLds)[(kRecBM + kRecBN) * kRecLd];
+__device__ __forceinline__ void rec_part_tile(const RecPartParams& q, RecLds lds, const int m0, const int n0,
+                                              const int y, f32x4v (&acc)[2]) {
   constexpr int ROWS = kRecBM + kRecBN, PIECES = ROWS * (kRecBK / 4), NP = (PIECES + kRecThreads - 1) / kRecThreads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
-  const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
-  const int k0 = static_cast<int>(blockIdx.y) * q.k_slice;
+  const int k0 = y * q.k_slice;
   const int k1 = (k0 + q.k_slice < q.K) ? (k0 + q.k_slice) : q.K;
   const int nchunks = (k1 - k0 + kRecBK - 1) / kRecBK;
   // staging: a row of a chunk is 32 floats = 8 x 16 B: piece p = tid + 512 i -> staged row p >> 3
@@ -836,7 +838,8 @@ __global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPart
   };
   // wave w owns the 16 columns 16 w .. 16 w + 15 of the 32 x 128 tile, both 16-row blocks:
   // v_mfma_f32_16x16x4_f32, lane (r16 = lane & 15, kq = lane >> 4) feeds k = 4 kq + j of a 16-k block
-  f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int r16 = lane & 15, kq = lane >> 4;
   auto compute = [&](int cur) {
     const float* A = &lds[cur][0] + r16 * kRecLd + 4 * kq;
@@ -867,6 +870,17 @@ __global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPart
     if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPartParams q) {
+  CHAIN_WAVE_PRIORITY();
+  __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
+  const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
+  f32x4v acc[2];
+  rec_part_tile(q, lds, m0, n0, static_cast<int>(blockIdx.y), acc);
   // the slice's partial tile (element (row r, col c) of a 16 x 16 block: lane (r >> 2) * 16 + c,
   // register r & 3); rows past S_next hold a clamped row's garbage and are never read
   float* P = q.part + (static_cast<int64_t>(blockIdx.y) * q.m_pad + m0) * q.H;
@@ -943,6 +957,172 @@ __global__ __launch_bounds__(kThreads) void bwd_gates_kernel(const GatesBwdParam
   *reinterpret_cast<float4*>(gh + H) = dzp;
   *reinterpret_cast<float4*>(gh + 2 * H) = dnr;
   *reinterpret_cast<float4*>(q.carry + static_cast<int64_t>(m) * H + u) = car;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same step as ONE launch (round 5; opt-in, Tunables::bwd_fused_step): split-K with a
+// last-arriver epilogue.  Grid = (column tiles x row blocks of S_t, K slices).  A slice workgroup
+// computes its partial tile exactly as bwd_rec_part_kernel does (rec_part_tile), writes it THROUGH
+// the non-coherent L2s (16-byte sc1 stores from an LDS transpose of the accumulators — a dword
+// sc1 store is one fabric write each), drains its stores (s_waitcnt vmcnt(0) by every wave, then
+// the workgroup barrier) and bumps the tile's arrival word (one agent-scope atomic add).  The
+// workgroup whose add returns splits - 1 is the last: it puts the word back to 0 for the next
+// step's launch, re-reads the `splits` partial tiles IN SLICE ORDER with sc1 loads (so the sum is
+// bitwise the one bwd_gates_kernel forms) and evaluates bwd_gates_kernel's arithmetic for the
+// tile's 32 x 128 elements.  No spinning, no co-residency requirement, no grid barrier: the
+// dependency between steps stays a kernel boundary, one per step instead of two.  Row blocks past
+// S_next (sequences whose last step is t: no continuing gradient) have no product: their slice-0
+// workgroup runs the gates alone.  Bit-identical to the two launches
+// (test_bptt_step_as_one_launch_with_a_last_arriver_epilogue) and SLOWER, hence opt-in: 23.4 us per
+// launch against 16.3 + 5.4 at 152 sequences — the epilogue (arrival's return, then the partials'
+// round trip past the L2s, then the stores) sits on the launch's critical path behind its SLOWEST
+// slice and runs on one workgroup per tile, which costs as much as the second launch's gap plus a
+// gates kernel spread over the whole chip: +0.9 ... +1.9 us per step stand-alone, +0.08 ... +0.28 ms
+// per training step (profiles/r05_bptt_one_launch.txt; round 3 measured the same sign).
+// ---------------------------------------------------------------------------------------------
+struct RecFusedParams {
+  RecPartParams r;
+  BwdStepParams s;
+  unsigned* arrive;    // [tiles] arrival words: zero between launches
+  int32_t splits;
+};
+
+__global__ __launch_bounds__(kRecThreads) void bwd_step_fused_kernel(const RecFusedParams f) {
+  CHAIN_WAVE_PRIORITY();
+  __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
+  __shared__ int s_last;
+  const RecPartParams& q = f.r;
+  const BwdStepParams& g = f.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int H = q.H, K = q.K;
+  const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
+  const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
+  const int y = static_cast<int>(blockIdx.y);
+  const bool product = m0 < q.S_next;
+  if (!product && y != 0) return;
+  typedef int i32x4v __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(q.part, 0, 0x7fffffff, 0x00020000);
+  constexpr int TLd = kRecBN + 4;
+  if (product) {
+    f32x4v acc[2];
+    rec_part_tile(q, lds, m0, n0, y, acc);
+    // accumulators -> LDS tile [32][132] -> 16-byte write-through stores
+    float* T = &lds[0][0];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) T[(16 * mb + 4 * kq + reg) * TLd + 16 * wave + r16] = acc[mb][reg];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = tid + kRecThreads * i, row = pc >> 5, c4 = pc & 31;
+      if (m0 + row < q.S_next && n0 + 4 * c4 < H) {
+        const float4 tv = *reinterpret_cast<const float4*>(&T[row * TLd + 4 * c4]);
+        const i32x4v v = {__builtin_bit_cast(int, tv.x), __builtin_bit_cast(int, tv.y),
+                          __builtin_bit_cast(int, tv.z), __builtin_bit_cast(int, tv.w)};
+        const int64_t off = ((static_cast<int64_t>(y) * q.m_pad + m0 + row) * H + n0 + 4 * c4) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(v, part_rs, static_cast<int>(off), 0, 16);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);     // this wave's write-through stores have been performed
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(f.arrive + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == static_cast<unsigned>(f.splits - 1);
+      if (last) __hip_atomic_store(f.arrive + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+  }
+  // ---- the tile's gates (bwd_gates_kernel's arithmetic), by the last slice to arrive ----
+  // Two (sequence, 4 units) elements per thread.  Everything an element needs is requested before
+  // anything is used — the operands that do not depend on the product first, then the partials
+  // eight slices at a time — so the epilogue is two or three memory round trips, not one per slice.
+  bool live[2], cont[2];
+  int mm[2], uu[2];
+  float4 e_car[2], e_dp[2], e_g[2][4], e_hp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pc = tid + kRecThreads * i, row = pc >> 5, c4 = pc & 31;
+    const int m = m0 + row, u = n0 + 4 * c4;
+    mm[i] = m; uu[i] = u;
+    live[i] = m < g.S_t && u < H;
+    cont[i] = live[i] && m < g.S_next;
+    const int mc = live[i] ? m : 0, uc = live[i] ? u : 0;
+    const int64_t p = g.off_cur + mc;
+    e_car[i] = *reinterpret_cast<const float4*>(g.carry + static_cast<int64_t>(mc) * H + uc);
+    e_dp[i] = *reinterpret_cast<const float4*>(g.dpool + p * H + uc);
+    const float* gp = g.gates + p * 4 * H + uc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e_g[i][c] = *reinterpret_cast<const float4*>(gp + static_cast<int64_t>(c) * H);
+    e_hp[i] = zero4();
+    if (g.t > 0)
+      e_hp[i] = *reinterpret_cast<const float4*>(g.hs + (g.off_prev + mc) * H + uc);
+    else if (g.h0_rows != nullptr)
+      e_hp[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.h0_rows[mc]) + uc);
+  }
+  float4 sum[2] = {zero4(), zero4()};
+  if (product) {
+    const int stride = q.m_pad * H * 4;      // bytes between consecutive slices' partial tiles
+    for (int y0 = 0; y0 < f.splits; y0 += 8) {
+      i32x4v pv[2][8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int base = ((cont[i] ? mm[i] : 0) * H + (cont[i] ? uu[i] : 0)) * 4;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int yy = (y0 + jj < f.splits) ? (y0 + jj) : (f.splits - 1);
+          pv[i][jj] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, base + yy * stride, 0, 16);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          if (y0 + jj < f.splits) {   // slice order: the sum bwd_gates_kernel forms
+            // (__int_as_float, not __builtin_bit_cast: the latter applied to an element of an ext
+            // vector reads the vector's FIRST element for .y/.z/.w too — clang 19 / ROCm 7.2)
+            sum[i].x += __int_as_float(pv[i][jj].x); sum[i].y += __int_as_float(pv[i][jj].y);
+            sum[i].z += __int_as_float(pv[i][jj].z); sum[i].w += __int_as_float(pv[i][jj].w);
+          }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!live[i]) continue;
+    const int m = mm[i], u = uu[i];
+    float4 rec = zero4();
+    if (cont[i]) {
+      rec = e_car[i];
+      rec.x += sum[i].x; rec.y += sum[i].y; rec.z += sum[i].z; rec.w += sum[i].w;
+    }
+    const int64_t p = g.off_cur + m;
+    const float4 dp = e_dp[i], rg = e_g[i][0], zg = e_g[i][1], ng = e_g[i][2], ghn = e_g[i][3], hp = e_hp[i];
+    float4 drp, dzp, dnp, dnr, car;
+#define GATE_LANE_(c)                                            \
+  {                                                                   \
+    const float dh = rec.c + dp.c;                                    \
+    const float dn_pre = dh * (1.0f - zg.c) * (1.0f - ng.c * ng.c);   \
+    dzp.c = dh * (hp.c - ng.c) * zg.c * (1.0f - zg.c);                \
+    drp.c = dn_pre * ghn.c * rg.c * (1.0f - rg.c);                    \
+    dnp.c = dn_pre;                                                   \
+    dnr.c = dn_pre * rg.c;                                            \
+    car.c = dh * zg.c;                                                \
+  }
+    GATE_LANE_(x) GATE_LANE_(y) GATE_LANE_(z) GATE_LANE_(w)
+#undef GATE_LANE_
+    float* gx = g.dgx + p * K + u;
+    float* gh = g.dgh + p * K + u;
+    *reinterpret_cast<float4*>(gx) = drp;
+    *reinterpret_cast<float4*>(gx + H) = dzp;
+    *reinterpret_cast<float4*>(gx + 2 * H) = dnp;
+    *reinterpret_cast<float4*>(gh) = drp;
+    *reinterpret_cast<float4*>(gh + H) = dzp;
+    *reinterpret_cast<float4*>(gh + 2 * H) = dnr;
+    *reinterpret_cast<float4*>(g.carry + static_cast<int64_t>(m) * H + u) = car;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1649,7 +1829,7 @@ static size_t wg_part_floats(int64_t sum_T, int I, int H) {
 
 struct BwdWs {
   size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, dxaddr, hsaddr, p_t, zero_row,
-      tail_sync, colsum, dx_part, wg_part, rec_part, total;
+      tail_sync, rec_cnt, colsum, dx_part, wg_part, rec_part, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -1672,6 +1852,7 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.p_t = take(static_cast<size_t>(sum_T) * 4);
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
   L.tail_sync = take(256);      // (right behind zero_row: one memset clears both)
+  L.rec_cnt = take(kRecFusedMaxTiles * sizeof(unsigned));   // ... and the fused BPTT step's arrival words
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
   L.dx_part = take(det_split_scratch_bytes(sum_T, I > H ? I : H));   // (also the attention backward's dpool product: N = H)
   L.wg_part = take(wg_part_floats(sum_T, I, H) * sizeof(float));
@@ -1781,7 +1962,7 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   const int pool_mode = j.pool_mode;
   const bool beside = j.side != st;
 
-  (void)hipMemsetAsync(zero_row, 0, L.tail_sync + 256 - L.zero_row, st);   // zero_row and the tail kernel's barrier counter
+  (void)hipMemsetAsync(zero_row, 0, L.rec_cnt + kRecFusedMaxTiles * sizeof(unsigned) - L.zero_row, st);   // zero_row, the tail kernel's barrier counter, the fused step's arrival words
   (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
   if (beside) stream_after(j.side, st);     // fork: the caller's inputs (and zero_row) are ready
   // per packed row: address of x_{t,s} and of h_{t-1,s} — the B operands of dW_ih / dW_hh
@@ -2087,6 +2268,16 @@ void bwd_steps(BwdJob* jobs, int n) {
         rp.k_slice = ((K + splits - 1) / splits + kRecBK - 1) / kRecBK * kRecBK;
         splits = (K + rp.k_slice - 1) / rp.k_slice;
         rp.m_pad = m_tiles * kRecBM;
+        const int all_tiles = rp.n_tiles * ((sp.S_t + kRecBM - 1) / kRecBM);
+        if (sp.t >= 0 && all_tiles <= kRecFusedMaxTiles &&
+            tunables().bwd_fused_step.load(std::memory_order_relaxed) != 0) {
+          RecFusedParams fp;      // ONE launch: the last K slice of a tile to arrive runs its gates
+          fp.r = rp; fp.s = sp; fp.splits = splits;
+          fp.arrive = reinterpret_cast<unsigned*>(j.ws + j.L.rec_cnt);
+          hipLaunchKernelGGL(bwd_step_fused_kernel, dim3(all_tiles, splits), dim3(kRecThreads), 0, j.st, fp);
+          kind[k] = 0;
+          continue;
+        }
         hipLaunchKernelGGL(bwd_rec_part_kernel, dim3(tiles, splits), dim3(kRecThreads), 0, j.st, rp);
         gp.part = rp.part; gp.splits = splits; gp.m_pad = rp.m_pad;
       }

@@ -2659,7 +2659,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
       {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

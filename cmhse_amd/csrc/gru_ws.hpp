@@ -68,6 +68,9 @@ struct Tunables {
   // stand-alone at 152 sequences, +0.4 ... +1.0 ms per training step): every exchange between
   // workgroups is a round trip past the non-coherent L2s plus a grid barrier, twice per step
   std::atomic<int> bwd_chain_min_steps{0};
+  // the two-launch BPTT step (bwd_split_min_seqs) as ONE launch: split-K whose last-arriving slice adds
+  // the partials in slice order and runs the gate derivatives (bwd_step_fused_kernel); 0 = two launches
+  std::atomic<int> bwd_fused_step{0};
   std::atomic<int> resident_timeout_ms{5000};  // wall time one grid barrier of a resident kernel may take before the launch gives up (grid_sync.hpp)
   std::atomic<int> xproj_chunk_rows{1536};   // packed rows per chunk of a training chain's hoisted input projection beside the chain (0 = one launch in front of it)
   std::atomic<int> tn_rows_bm{0};            // tile height of the weight-gradient products: 128, 192, or 0 = 192 where 3H is a whole number of them (tn_rows.hpp)

@@ -911,6 +911,61 @@ def test_bptt_training_size_steps_as_resident_chain_kernel(dev, oracle, pool, cl
       grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
 
 
+@pytest.mark.parametrize('pool,cls,H,S,T', [('attention', 'Attention', 128, 70, 21), ('maxout', 'Maxout', 256, 150, 17),
+                                            ('seq2seq', 'Seq2Seq', 1024, 152, 9), ('attention', 'Attention', 96, 300, 12)])
+def test_bptt_step_as_one_launch_with_a_last_arriver_epilogue(dev, oracle, pool, cls, H, S, T, tune):
+  """The two-launch BPTT step (K split over the grid + ordered gate kernel) as ONE launch
+  (bwd_step_fused_kernel, tunable bwd_fused_step): the slice workgroup whose arrival completes a
+  tile re-reads the partials in slice order and runs the gate derivatives.  Same slices, same
+  order, same arithmetic: every gradient equals the two-launch path's to the last bits the
+  compiler's contraction may move (held to 1e-6 relative; bit-identity is reported), is bitwise
+  reproducible run after run, and matches the float64 oracle.  Shapes: ragged lengths so that the
+  active count grows through the step range (row blocks past S_next run their gates alone),
+  H = 96 (a partial column tile), H = 1024 (8 column tiles, 6 slices)."""
+  from cmhse_amd import layers
+  rng = np.random.RandomState(23 + H + S)
+  I = 24 if H < 1024 else 64
+  torch.manual_seed(6)
+  layer = getattr(layers, cls)(I, H)
+  with torch.no_grad():
+    layer.rnn.bias_ih_l0.normal_(0, 0.1)
+    layer.rnn.bias_hh_l0.normal_(0, 0.1)
+  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+  layer = layer.to(dev)
+  lens = rng.randint(1, T + 1, size=S)
+  lens[:40] = T
+  x = np.zeros((S, T, I), dtype=np.float32)
+  for i, l in enumerate(lens):
+    x[i, :l] = rng.standard_normal((l, I))
+  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
+  w = rng.standard_normal((S, H)).astype(np.float32)
+  tune(bwd_tail_min_steps=0, fwd_tail_min_steps=0)
+
+  def run(fused):
+    tune(bwd_fused_step=fused)
+    layer.zero_grad()
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
+    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    return [xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+
+  two, one, again = run(0), run(1), run(1)
+  exact = True
+  for a, b, c in zip(two, one, again):
+    assert float((a - b).abs().max()) <= 1e-6 * max(1e-6, float(a.abs().max()))
+    assert torch.equal(b, c), 'not reproducible from run to run'
+    exact = exact and torch.equal(a, b)
+  print('one-launch BPTT step bit-identical to the two-launch step:', exact)
+  if H <= 256:
+    _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
+    grads, dx, dh0 = oracle.pooled_gru_backward(cache, w.astype(np.float64))
+    grad_close(one[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
+    grad_close(one[1].cpu().numpy(), dh0, pool + ' dh0')
+    for (pn, _), got in zip(layer.named_parameters(), one[2:]):
+      grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
+
+
 @pytest.mark.parametrize('cls,pool,I,H,S,T', [
     ('Seq2Seq', 'seq2seq', 24, 64, 37, 9),        # 3H = 192: one tall tile, N < 128
     ('Attention', 'attention', 200, 128, 150, 7),   # 3H = 384: two tall tiles; rows split into parts
