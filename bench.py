@@ -40,7 +40,12 @@ The JSON line also carries
                 pack_padded_sequence, kind "torch-cpu") timed on this host's cores on a bounded
                 sample of the same workload, extrapolated to the full split (encode ~ N,
                 scoring ~ N^2) — a reported baseline, never the thing measured as `value`;
-                cpu_baseline_numpy: the NumPy oracle ("port") the same way;
+                cpu_baseline_numpy (--cpu_numpy 1): the NumPy oracle ("port") the same way;
+  rank_noise_floor  the HIP path against that oracle on the SAME sample, end to end: largest embedding
+                difference, rank rows on which the two runs differ (random-init encoders: every score
+                within ~1e-3 of every other, so this is the floor any fp32 evaluation order has), and the
+                rows the same deviation moves on separable (correlated) embeddings — the ruler
+                every optional math mode is held to;
   cached_schedule_pass  the pass for a resident, unchanged split with the level-1 schedules kept
                 between passes (opt-in; the headline pass rebuilds them like the reference).
 """
@@ -67,8 +72,8 @@ from cmhse_amd.model import VSE  # noqa: E402
 from bench_common import (BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS, WORKLOADS, build_loader,  # noqa: E402,F401
                           device_batch, gru_flops_per_step, make_opt)
 from bench_legs import (TRAIN_CONFIGS, cpu_baseline, fast_mode_bench, measured_clock_ghz,  # noqa: E402,F401
-                        measured_step_latency_us, measured_traffic, rank_check, train_bench,
-                        train_step_work)
+                        measured_step_latency_us, measured_traffic, rank_check, rank_noise_floor,
+                        train_bench, train_step_work)
 
 def costs_sum(costs, idx):
   return float(sum(costs[i][0] for i in idx))
@@ -138,16 +143,16 @@ def main():
                        '(PCIe-inclusive rate; never the headline value)')
   ap.add_argument('--rank_check', type=int, default=1,
                   help='check HIP ranks on correlated embeddings against fp64 NumPy (0 = skip)')
-  ap.add_argument('--cpu_batches', type=int, default=8,
-                  help='loader batches in the sample of the two CPU baselines (default 8 x 32 = 256 videos, so '
-                       'that the default run stays near a minute; 16 = the 512-video subset of BASELINE.md '
-                       'section 3; 0 = skip)')
+  ap.add_argument('--cpu_batches', type=int, default=16,
+                  help='loader batches in the sample of the CPU baseline (default 16 x 32 = the 512-video subset '
+                       'BASELINE.md section 3 names; 0 = skip)')
+  ap.add_argument('--cpu_numpy', type=int, default=0,
+                  help='1: also time the NumPy oracle ("port", rounds 1-3\'s baseline) on the same sample')
   ap.add_argument('--pin_shapes', type=int, default=0,
                   help='1: every GRU step on the LDS-tiled kernel whatever its active count (tiny_max_seqs = '
-                       'mid_max_seqs = 0) — the encoders are then bit-identical for ANY partition of the split, '
-                       'so ranks_crc32 of an N-rank run equals the single-process one exactly (by default a '
-                       "rank's share runs more of its steps on the small-batch kernels, whose sums are ordered "
-                       'differently: embeddings equal to fp32 rounding)')
+                       'mid_max_seqs = 0).  An A/B switch only since round 5: the DEFAULT run is partition-'
+                       'independent bit for bit (every rank picks its kernels from the whole split\'s step plan, '
+                       'parallel_eval.global_step_plan), so ranks_crc32 is the same for any --gpus without it')
   ap.add_argument('--cached_steps', type=int, default=5,
                   help='also time this many passes that reuse the level-1 schedules of a resident '
                        'split (evaluation.encode_group(plan=)); 0 = skip')
@@ -471,7 +476,10 @@ def main():
       # north_star's baseline: "the reference PyTorch CPU path" -> the torch-CPU restatement; the NumPy
       # port (rounds 1-3's cpu_baseline) beside it on the same sample
       leg('cpu_baseline', lambda: cpu_baseline('torch-cpu', wl, opt, model, spec, args.cpu_batches, N))
-      leg('cpu_baseline_numpy', lambda: cpu_baseline('port', wl, opt, model, spec, args.cpu_batches, N))
+      if args.cpu_numpy:
+        leg('cpu_baseline_numpy', lambda: cpu_baseline('port', wl, opt, model, spec, args.cpu_batches, N))
+      # the exact path's own distance from the oracle on the same sample, rank by rank
+      leg('rank_noise_floor', lambda: rank_noise_floor(wl, opt, model, spec, args.cpu_batches, N))
     print(json.dumps(out))
     sys.stdout.flush()
   if world > 1:

@@ -1965,6 +1965,21 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   (void)hipMemsetAsync(zero_row, 0, L.rec_cnt + kRecFusedMaxTiles * sizeof(unsigned) - L.zero_row, st);   // zero_row, the tail kernel's barrier counter, the fused step's arrival words
   (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
   if (beside) stream_after(j.side, st);     // fork: the caller's inputs (and zero_row) are ready
+  // W_hh^T for the chain depends on the weights only: with a side stream it is the FIRST thing
+  // there, beside the pooling backward on `st` (it stood 50 us in front of the chain's first
+  // launch), and the chain's stream waits for just that launch's event further down
+  hipEvent_t whh_ev = nullptr;
+  if (beside) {
+    launch_transpose(w->w_hh, whh_t, 3 * H, H, j.side);
+    whh_ev = event_get(false);
+    if (whh_ev != nullptr && hipEventRecord(whh_ev, j.side) != hipSuccess) {
+      (void)hipGetLastError();
+      event_put(whh_ev, false);
+      whh_ev = nullptr;
+      (void)hipStreamSynchronize(j.side);      // no event: host-side ordering, then nothing to wait for
+    }
+    if (whh_ev == nullptr) (void)hipStreamSynchronize(j.side);
+  }
   // per packed row: address of x_{t,s} and of h_{t-1,s} — the B operands of dW_ih / dW_hh
   RowAddrParams rp;
   rp.x_rows = b->x_rows; rp.tok_rows = b->tok_rows; rp.emb = b->emb_table; rp.h0_rows = b->h0_rows;
@@ -2013,7 +2028,15 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
     hipLaunchKernelGGL(pool_scatter_bwd_kernel, dim3(S), dim3(kThreads), 0, st, pp);
   }
 
-  launch_transpose(w->w_hh, whh_t, 3 * H, H, st);
+  // W_hh^T for the chain: depends on the weights only, so with a side stream it runs there beside
+  // the pooling backward (it stood 50 us in front of the chain's first launch) and the chain's
+  // stream waits for it
+  if (whh_ev != nullptr) {
+    (void)hipStreamWaitEvent(st, whh_ev, 0);   // (the wait captures the record: the event may be reused)
+    event_put(whh_ev, false);
+  } else if (!beside) {
+    launch_transpose(w->w_hh, whh_t, 3 * H, H, st);
+  }
   if (j.dx_rows || j.d_emb_table)   // d(input) = dGx . W_ih runs on W_ih^T (NT)
     launch_transpose(w->w_ih, reinterpret_cast<float*>(ws + L.wih_t), 3 * H, I, j.side);
   if (j.dx_rows || j.d_emb_table) {

@@ -1572,7 +1572,9 @@ GridSync make_grid_sync(unsigned* counter, unsigned* abort_word) {
   g.abort_word = abort_word;
   g.status_host = resident_status_word();
   const int ms = tunables().resident_timeout_ms.load(std::memory_order_relaxed);
-  g.timeout_ticks = static_cast<uint64_t>(ms > 0 ? ms : 1) * 100000ull;   // s_memrealtime: 100 MHz
+  // s_memrealtime: 100 MHz.  0 = a wait gives up at its second clock check (~512 polls, tens of
+  // microseconds): the value tests use to walk the abort path of a chain for real
+  g.timeout_ticks = static_cast<uint64_t>(ms > 0 ? ms : 0) * 100000ull;
   return g;
 }
 
@@ -1582,7 +1584,18 @@ static int resident_status(bool clear) {
   std::lock_guard<std::mutex> lock(g_status_mutex);
   volatile unsigned* w = g_status_host[dev];
   if (w == nullptr || *w == 0) return CMHSE_OK;
-  if (clear) *w = 0;
+  if (clear) {
+    *w = 0;
+    // A timeout means this device does not give the multi-step kernels what they need (workgroups
+    // started in index order / all resident: a CU mask, another tenant).  The caller has been told
+    // (this status); from here on the process uses one launch per time step, which needs neither —
+    // cmhse_tune() re-enables the kernels explicitly.
+    Tunables& t = tunables();
+    t.chain_min_steps.store(0, std::memory_order_relaxed);
+    t.fwd_tail_min_steps.store(0, std::memory_order_relaxed);
+    t.bwd_tail_min_steps.store(0, std::memory_order_relaxed);
+    t.bwd_chain_min_steps.store(0, std::memory_order_relaxed);
+  }
   return CMHSE_ERR_TIMEOUT;
 }
 

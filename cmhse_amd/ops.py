@@ -92,7 +92,7 @@ def tune(name, value=-1):
   returns its previous value.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
   tall_tile_min_wgs, mid_tall_min_seqs, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
   fwd_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, bwd_chain_min_steps,
-  chain_min_steps, chain_tall_min_wgs,
+  bwd_fused_step, chain_min_steps, chain_tall_min_wgs,
   resident_timeout_ms
   (include/cmhse_hip.h)."""
   old = ctypes.c_int32(0)
@@ -104,7 +104,9 @@ def async_status(clear=False):
   """cmhse_async_status: 0, or CMHSE_ERR_TIMEOUT (-5) once a resident-kernel launch on the current
   device has given up at a grid barrier (its workgroups were not all on the chip: a shared GPU, a CU
   mask).  The status is asynchronous — it reflects launches that have run — and sticky until
-  cleared; the gru forward / backward entry points check it themselves and raise."""
+  cleared; the gru forward / backward entry points check it themselves and raise.  Clearing a
+  raised status also turns the multi-step kernels off for the process (one launch per time step
+  from then on; ops.tune('chain_min_steps', 2) etc. turn them back on)."""
   return int(_lib.load().cmhse_async_status(1 if clear else 0))
 
 

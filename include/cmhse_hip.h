@@ -456,8 +456,13 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             (3H / 128) workgroups that keep their W_hh^T slice in LDS, two grid
  *                             barriers per step instead of two launches; H % 128 == 0; 0 = never.
  *                             Gradients equal the per-step path's to fp32 rounding
- *   "resident_timeout_ms" 5000  wall time a grid barrier of a resident kernel may take before the
- *                             launch gives up (cmhse_async_status)
+ *   "resident_timeout_ms" 5000  wall time a grid barrier of a resident kernel / a dependency wait of
+ *                             the step chain may take before the launch gives up (cmhse_async_status);
+ *                             0 = give up at the second clock check of a wait (tests: walks the
+ *                             abort path)
+ *   "bwd_fused_step"       0  (opt-in; measured slower, profiles/r05_bptt_one_launch.txt) the two-launch
+ *                             BPTT step as ONE: split-K whose last-arriving slice adds the partials in
+ *                             slice order and runs the gate derivatives; bit-identical
  *   "bwd_chunk_rows"    2048  packed rows a weight-gradient chunk spans before its products are
  *                             issued beside the chain (changes the order in which chunks are
  *                             accumulated, i.e. the gradients to fp32 rounding)
@@ -484,7 +489,10 @@ int cmhse_tune(const char* name, int32_t value, int32_t* old_value);
  * invalid, and a word in pinned host memory is raised.  This function returns CMHSE_ERR_TIMEOUT
  * while that word is set for the calling thread's current device (CMHSE_OK otherwise) and clears
  * it when `clear` != 0; cmhse_gru_pool_fwd[_multi] / cmhse_gru_pool_bwd[_multi] check it on entry
- * and return CMHSE_ERR_TIMEOUT without launching.  The status is asynchronous: it reflects launches
+ * and return CMHSE_ERR_TIMEOUT without launching.  Clearing a raised status also switches the
+ * multi-step kernels off for the rest of the process ("chain_min_steps", "*_tail_min_steps",
+ * "bwd_chain_min_steps" = 0: one launch per time step, which needs neither co-residency nor
+ * in-order workgroup starts); cmhse_tune() switches them back on.  The status is asynchronous: it reflects launches
  * that have RUN, so poll it after a stream synchronisation (or once per step, one step late). */
 int cmhse_async_status(int32_t clear);
 
