@@ -408,6 +408,111 @@ void gru_step_kernel(const GruStepGroup grp) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
+// ---------------------------------------------------------------------------------------------
+struct AttnEnergyParams {
+  const float* hs_s;   // bf16x3: pre-split hidden states (rows of split_ld(H) units) or NULL
+  const float* hs;     // [rows, H]
+  const float* w_lin;  // [H, H]
+  const float* w_lin_s;  // bf16x3 pre-split copy or NULL
+  const float* b_lin;
+  const float* w_att;
+  float* e_part;  // [n_tiles, rows]
+  float* v;       // [rows, H] tanh(W_lin h + b) kept for the backward pass, or NULL
+  int64_t rows;   // all packed rows (stride of e_part)
+  int64_t row_begin, row_end;   // the rows this launch computes
+  int32_t H, n_tiles;
+};
+
+
+// One tile: packed rows [m0, m0 + 64 MSUB) (those below row_end) x columns [256 nt, 256 nt + 256).
+// The body of attn_energy_kernel, and a task of the step chain (gru_step_chain_kernel).  A row's
+// result does not depend on the tile height or on which rows share its tile.
+template <bool VEC, int MSUB, bool BF3, bool ASPLIT>
+__device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, const int nt, const int64_t m0,
+                                                 const int64_t row_end) {
+  constexpr int BM = 64 * MSUB, BN = kAttBN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = nt * BN;
+  const int srow = tid >> 2;
+  const int H = p.H;
+
+  rowaddr_t ar[BM / 64];
+  rowaddr_t br[BN / 64];
+  bool av[BM / 64], bv[BN / 64];
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i) {
+    const int64_t m = m0 + srow + 64 * i;
+    av[i] = m < row_end;
+    ar[i] = ASPLIT ? row_addr(p.hs_s + (av[i] ? m : (row_end - 1)) * split_ld(H))
+                   : row_addr(p.hs + (av[i] ? m : (row_end - 1)) * H);
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 64; ++i) {
+    const int n = n0 + srow + 64 * i;
+    bv[i] = n < H;
+    br[i] = BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
+                : row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
+  }
+  constexpr int NS = BN / 64;   // 32-column sub-tiles per wave
+  f32x16 acc[MSUB][NS];
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+    for (int a = 0; a < NS; ++a) acc[ms][a] = zero16();
+  int b_row0[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
+  if (BF3)
+    nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1, ASPLIT>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+  else
+    nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
+
+  // epilogue: per-row partial dot over this wave's BN/2 columns, then the two N-waves via LDS
+  float wa[NS], bl[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int n = n0 + b_row0[ns] + acc_col(lane);
+    wa[ns] = (n < H) ? p.w_att[n] : 0.f;
+    bl[ns] = (n < H) ? p.b_lin[n] : 0.f;
+  }
+  float* red = smem;  // [2 (wn)][BM]; main loop ended with a barrier
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s = 0.f;
+      const int64_t vm = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const float tv = tanhf_(acc[ms][ns][r] + bl[ns]);
+        s += wa[ns] * tv;
+        const int n = n0 + b_row0[ns] + acc_col(lane);
+        if (p.v != nullptr && vm < row_end && n < H) p.v[vm * H + n] = tv;
+      }
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+      if ((lane & 31) == 0) red[wn * BM + wm * 32 * MSUB + ms * 32 + acc_row(r, lane)] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < BM) {
+    const int64_t m = m0 + tid;
+    if (m < row_end) p.e_part[static_cast<int64_t>(nt) * p.rows + m] = red[tid] + red[BM + tid];
+  }
+}
+
+template <bool VEC, int MSUB, bool BF3, bool ASPLIT = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
+void attn_energy_kernel(const AttnEnergyParams p) {
+  attn_energy_tile<VEC, MSUB, BF3, ASPLIT>(p, static_cast<int>(blockIdx.x % p.n_tiles),
+                                           p.row_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * (64 * MSUB),
+                                           p.row_end);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Step CHAIN: the LDS-tiled steps t0 .. t0 + nsteps - 1 of up to kMaxJobs encoders in ONE launch.
 //
 // Per-step launches drain the chip at every time step: the last round of a step's workgroups runs
@@ -435,54 +540,67 @@ void gru_step_kernel(const GruStepGroup grp) {
 // task, dispatched as slots free up); a workgroup whose queue is exhausted takes a task of another
 // queue.  That argument needs EQUAL queues: it holds when the column tiles are a whole multiple of
 // the 8 XCDs (H = 512, 1024, 1536 ...); for every other count there is one queue for the whole
-// chip (chain_cols_of), whose tickets are a topological order of the tasks.  The wait is bounded
+// chip (chain_queues), whose tickets are a topological order of the tasks.  The wait is bounded
 // like the resident kernels' barrier (grid_sync.hpp): CMHSE_ERR_TIMEOUT, not a hang.
 // ---------------------------------------------------------------------------------------------
 constexpr int kChainMaxSteps = kChainMaxStepsWs;
 constexpr int kXcds = 8;
+// Tasks of a queue come in PHASES, the same number of tickets in every queue:
+//   phase 2 s      (s < nsteps)  the GRU tiles of step t0 + s: (request, row tile) x the queue's column tiles;
+//   phase 2 s + 3                the attention-energy tiles (attn_energy_tile: e = w_att . tanh(W_lin h + b), the
+//                                first half of layers.py:105-106's pooling) of the rows step t0 + s produced —
+//                                handed out after the GRU tiles of step s + 1, whose x phases need nothing, so
+//                                that by then the rows they read are (almost always) complete; they fill the
+//                                slots the recurrence leaves empty (a rank's share of the split: steps of one
+//                                round of workgroups or less; the ragged end of any chain) instead of running
+//                                as a launch of their own behind the chain.
+// (phases 1 and 2 nsteps are empty.)  tick[p] = tickets of a queue in front of phase p.
+constexpr int kChainPhases = 2 * kChainMaxSteps + 2;
 struct GruChainGroup {
   GruStepParams j[kMaxJobs];            // (t, S_t, off_prev, off_cur unused: derived per task)
+  AttnEnergyParams att[kMaxJobs];       // attention-pooled requests whose energies are tasks of this launch (att_on)
   const int32_t* step_off[kMaxJobs];    // device: first packed row of every step of request k
   unsigned* done[kMaxJobs];             // zeroed counters [nsteps][rt_stride[k]] of request k
   int32_t rt_stride[kMaxJobs];          // row tiles of request k at step t0 (its maximum)
-  uint32_t cum[kChainMaxSteps + 1];     // row tiles (all requests) in front of step t0 + s
-  unsigned* ticket;                     // [kXcds] zeroed: next task of every XCD's queue
+  int32_t att_on[kMaxJobs];
+  uint32_t tick[kChainPhases + 1];
+  unsigned* ticket;                     // [kXcds] zeroed: next task of every queue
   GridSync sync;
   int32_t n, t0, nsteps, n_tiles;
+  int32_t att_tiles;                    // 256-column tiles of W_lin (4 or 8 when any att_on)
 };
 
-// Column tiles of queue x.  n_tiles % 8 == 0: column tile c belongs to queue c % 8, every queue
-// the same number.  Any other count (H = 128, 192, 256, 320, 768, 1280 ...): ONE queue holds all
+// Queues.  n_tiles % 8 == 0: eight, column tile c of the GRU step in queue c % 8 (an XCD's L2 keeps
+// re-serving the same weight rows, as with the per-step launches' block order), every queue the same
+// number of tickets.  Any other count (H = 128, 192, 256, 320, 768, 1280 ...): ONE queue holds all
 // the tasks in (step, row tile, column tile) order — with uneven queues the workgroups of the XCDs
 // with fewer (or no) columns overflow into the others, those queues run steps ahead of the short
 // ones and can fill every resident slot with workgroups waiting for tasks nobody is left to start
 // (a discrete-event model of the ticket logic deadlocks at n_tiles = 2, 4, 12, 20).
 // With one ticket every held task depends on earlier tickets only, so the earliest unfinished one
 // can always run.
-__device__ __forceinline__ int chain_cols_of(int n_tiles, int x) {
-  if (n_tiles % kXcds != 0) return x == 0 ? n_tiles : 0;
-  return n_tiles / kXcds;
-}
+__device__ __host__ __forceinline__ int chain_queues(int n_tiles) { return (n_tiles % kXcds == 0) ? kXcds : 1; }
 
 template <bool VEC, int MSUB>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_chain_kernel(const GruChainGroup g) {
   constexpr int BM = 64 * MSUB;
   __shared__ unsigned s_task[2];
-  const unsigned units = g.cum[g.nsteps];
+  const unsigned nq = static_cast<unsigned>(chain_queues(g.n_tiles));
+  const unsigned cols = static_cast<unsigned>(g.n_tiles) / nq;
+  const int n_phases = 2 * g.nsteps + 2;
+  const unsigned per_queue = g.tick[n_phases];
   if (threadIdx.x == 0) {
     // home queue: workgroups are dealt to the XCDs round-robin by their index (b and b + 8 share an
     // XCD — what the per-step kernels' block order relies on too), so this IS the workgroup's XCD on
     // an unpartitioned MI355X; derived from the index rather than read from XCC_ID so that the
     // queues advance in step with the dispatch order whatever the partition mode
-    const unsigned x = (g.n_tiles % kXcds != 0) ? 0u : (blockIdx.x & (kXcds - 1));
+    const unsigned x = blockIdx.x & (nq - 1);
     unsigned got = 0xffffffffu, queue = 0xffffffffu;
-    for (unsigned d = 0; d < kXcds; ++d) {
-      const unsigned y = (x + d) & (kXcds - 1);
-      const unsigned cols = static_cast<unsigned>(chain_cols_of(g.n_tiles, static_cast<int>(y)));
-      if (cols == 0) continue;
+    for (unsigned d = 0; d < nq; ++d) {
+      const unsigned y = (x + d) & (nq - 1);
       const unsigned tk = __hip_atomic_fetch_add(g.ticket + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk < units * cols) {
+      if (tk < per_queue) {
         got = tk;
         queue = y;
         break;
@@ -493,36 +611,69 @@ void gru_step_chain_kernel(const GruChainGroup g) {
   }
   __syncthreads();
   const unsigned queue = __builtin_amdgcn_readfirstlane(s_task[1]);
-  if (queue == 0xffffffffu) return;      // every queue is empty (cannot happen with one workgroup per task)
+  if (queue == 0xffffffffu) return;      // every queue is empty (cannot happen: one workgroup per ticket)
   const unsigned tk = __builtin_amdgcn_readfirstlane(s_task[0]);
-  const unsigned cols = static_cast<unsigned>(chain_cols_of(g.n_tiles, static_cast<int>(queue)));
-  const unsigned unit = tk / cols;
-  const int c = (g.n_tiles % kXcds != 0) ? static_cast<int>(tk % cols)
-                                         : static_cast<int>(queue + kXcds * (tk % cols));
-  int lo = 0, hi = g.nsteps - 1;         // the last step whose first unit is <= unit
+  int lo = 0, hi = n_phases - 1;         // the last phase whose first ticket is <= tk
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (g.cum[mid] <= unit) lo = mid; else hi = mid - 1;
+    if (g.tick[mid] <= tk) lo = mid; else hi = mid - 1;
   }
-  const int s = lo, t = g.t0 + s;
-  unsigned rem = unit - g.cum[s];
+  const int ph = lo;
+  const unsigned local = tk - g.tick[ph];
+  if ((ph & 1) == 0) {
+    // ---- a GRU tile of step s ----
+    const int s = ph >> 1, t = g.t0 + s;
+    unsigned rem = local / cols;
+    const int c = static_cast<int>(queue + nq * (local % cols));
+    int k = 0, S_t = 0;
+    for (; k < g.n; ++k) {
+      S_t = g.step_off[k][t + 1] - g.step_off[k][t];
+      const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
+      if (rem < rt || k == g.n - 1) break;
+      rem -= rt;
+    }
+    const GruStepParams& p = g.j[k];
+    const int64_t off_cur = g.step_off[k][t];
+    const int64_t off_prev = (t > 0) ? g.step_off[k][t - 1] : 0;
+    ChainDep dep;
+    dep.sync = g.sync;
+    dep.need = static_cast<unsigned>(g.n_tiles);
+    dep.done = g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rem;
+    dep.wait = (s > 0) ? g.done[k] + static_cast<size_t>(s - 1) * g.rt_stride[k] + rem : nullptr;
+    gru_step_tile<VEC, MSUB, false, true>(p, rem * static_cast<unsigned>(g.n_tiles) + static_cast<unsigned>(c), t, S_t,
+                                          off_prev, off_cur, dep);
+    return;
+  }
+  // ---- an attention-energy tile of the rows step s produced ----
+  // 8 column tiles (H = 2048): tile a in queue a, every row tile.  4 (H = 1024): tile a in queues a
+  // and a + 4, the even row tiles in the first, the odd ones in the second (an XCD's L2 then serves one
+  // 1 MB slice of W_lin); a queue's ticket whose row tile does not exist (odd count) is a no-op — the
+  // price of equal queues.
+  const int s = (ph - 3) >> 1, t = g.t0 + s;
+  const unsigned par = static_cast<unsigned>(kXcds / g.att_tiles);    // 1 or 2
+  const int a = static_cast<int>(queue % static_cast<unsigned>(g.att_tiles));
+  unsigned rem = local;
   int k = 0, S_t = 0;
+  unsigned rt_n = 0;
+  bool found = false;
   for (; k < g.n; ++k) {
+    if (!g.att_on[k]) continue;
     S_t = g.step_off[k][t + 1] - g.step_off[k][t];
-    const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
-    if (rem < rt || k == g.n - 1) break;
-    rem -= rt;
+    rt_n = static_cast<unsigned>((S_t + BM - 1) / BM);
+    const unsigned cnt = (rt_n + par - 1) / par;
+    if (rem < cnt) {
+      found = true;
+      break;
+    }
+    rem -= cnt;
   }
-  const GruStepParams& p = g.j[k];
-  const int64_t off_cur = g.step_off[k][t];
-  const int64_t off_prev = (t > 0) ? g.step_off[k][t - 1] : 0;
-  ChainDep dep;
-  dep.sync = g.sync;
-  dep.need = static_cast<unsigned>(g.n_tiles);
-  dep.done = g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rem;
-  dep.wait = (s > 0) ? g.done[k] + static_cast<size_t>(s - 1) * g.rt_stride[k] + rem : nullptr;
-  gru_step_tile<VEC, MSUB, false, true>(p, rem * static_cast<unsigned>(g.n_tiles) + static_cast<unsigned>(c), t, S_t,
-                                        off_prev, off_cur, dep);
+  if (!found) return;
+  const unsigned rt = par * rem + (par == 2 ? queue / static_cast<unsigned>(g.att_tiles) : 0u);
+  if (rt >= rt_n) return;
+  if (!flag_wait(g.sync, g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rt, static_cast<unsigned>(g.n_tiles)))
+    return;
+  const int64_t row0 = g.step_off[k][t];
+  attn_energy_tile<VEC, MSUB, false, false>(g.att[k], a, row0 + static_cast<int64_t>(rt) * BM, row0 + S_t);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1092,102 +1243,6 @@ void xproj_kernel(const XprojParams p) {
       }
     }
     __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
-// ---------------------------------------------------------------------------------------------
-struct AttnEnergyParams {
-  const float* hs_s;   // bf16x3: pre-split hidden states (rows of split_ld(H) units) or NULL
-  const float* hs;     // [rows, H]
-  const float* w_lin;  // [H, H]
-  const float* w_lin_s;  // bf16x3 pre-split copy or NULL
-  const float* b_lin;
-  const float* w_att;
-  float* e_part;  // [n_tiles, rows]
-  float* v;       // [rows, H] tanh(W_lin h + b) kept for the backward pass, or NULL
-  int64_t rows;   // all packed rows (stride of e_part)
-  int64_t row_begin, row_end;   // the rows this launch computes
-  int32_t H, n_tiles;
-};
-
-
-template <bool VEC, int MSUB, bool BF3, bool ASPLIT = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
-void attn_energy_kernel(const AttnEnergyParams p) {
-  constexpr int BM = 64 * MSUB, BN = kAttBN;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nt = blockIdx.x % p.n_tiles;
-  const int n0 = nt * BN;
-  const int64_t m0 = p.row_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
-  const int srow = tid >> 2;
-  const int H = p.H;
-
-  rowaddr_t ar[BM / 64];
-  rowaddr_t br[BN / 64];
-  bool av[BM / 64], bv[BN / 64];
-#pragma unroll
-  for (int i = 0; i < BM / 64; ++i) {
-    const int64_t m = m0 + srow + 64 * i;
-    av[i] = m < p.row_end;
-    ar[i] = ASPLIT ? row_addr(p.hs_s + (av[i] ? m : (p.row_end - 1)) * split_ld(H))
-                   : row_addr(p.hs + (av[i] ? m : (p.row_end - 1)) * H);
-  }
-#pragma unroll
-  for (int i = 0; i < BN / 64; ++i) {
-    const int n = n0 + srow + 64 * i;
-    bv[i] = n < H;
-    br[i] = BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
-                : row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
-  }
-  constexpr int NS = BN / 64;   // 32-column sub-tiles per wave
-  f32x16 acc[MSUB][NS];
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-    for (int a = 0; a < NS; ++a) acc[ms][a] = zero16();
-  int b_row0[NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
-  if (BF3)
-    nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1, ASPLIT>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-  else
-    nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-
-  // epilogue: per-row partial dot over this wave's BN/2 columns, then the two N-waves via LDS
-  float wa[NS], bl[NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns) {
-    const int n = n0 + b_row0[ns] + acc_col(lane);
-    wa[ns] = (n < H) ? p.w_att[n] : 0.f;
-    bl[ns] = (n < H) ? p.b_lin[n] : 0.f;
-  }
-  float* red = smem;  // [2 (wn)][BM]; main loop ended with a barrier
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float s = 0.f;
-      const int64_t vm = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
-#pragma unroll
-      for (int ns = 0; ns < NS; ++ns) {
-        const float tv = tanhf_(acc[ms][ns][r] + bl[ns]);
-        s += wa[ns] * tv;
-        const int n = n0 + b_row0[ns] + acc_col(lane);
-        if (p.v != nullptr && vm < p.row_end && n < H) p.v[vm * H + n] = tv;
-      }
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-      if ((lane & 31) == 0) red[wn * BM + wm * 32 * MSUB + ms * 32 + acc_row(r, lane)] = s;
-    }
-  }
-  __syncthreads();
-  if (tid < BM) {
-    const int64_t m = m0 + tid;
-    if (m < p.row_end) p.e_part[static_cast<int64_t>(nt) * p.rows + m] = red[tid] + red[BM + tid];
   }
 }
 
@@ -2008,6 +2063,7 @@ struct XprojPlan {
 // which tile height (kind, bit 2048 = 128 rows) and on which stream.
 struct ChainPlan {
   bool in_chain[kMaxJobs];
+  bool att[kMaxJobs];      // the request's attention energies of these steps are tasks of the launch
   int end, kind;
   hipStream_t stream;
 };
@@ -2015,7 +2071,7 @@ struct ChainPlan {
 static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, const bool* done,
                             const hipStream_t* js, int tiled_wgs) {
   ChainPlan c;
-  for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = false;
+  for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = c.att[k] = false;
   c.end = 0;
   c.kind = -1;
   c.stream = nullptr;
@@ -2072,6 +2128,21 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
       if (!same) break;
       ++c.end;
     }
+    // Attention energies as tasks of the chain (chain_attention): an attention-pooled request whose
+    // rows in front of step t are all projected already (so that the rows this launch projects
+    // extend that prefix), at widths whose 256-column tiles of W_lin deal evenly onto the eight
+    // queues (H = 1024: 4 tiles x 2 row-tile parities; H = 2048: 8 tiles).
+    const int att_tiles_c = tiles_c > 0 ? (jobs[0].b->H + kAttBN - 1) / kAttBN : 0;
+    if (tunables().chain_attention.load(std::memory_order_relaxed) != 0 && chain_queues(tiles_c) == kXcds)
+      for (int k = 0; k < n; ++k) {
+        const FwdJob& j = jobs[k];
+        if (!c.in_chain[k] || j.pool_mode != CMHSE_POOL_ATTN || j.pooled) continue;
+        const int at = (j.b->H + kAttBN - 1) / kAttBN;
+        int64_t rows_before = 0;
+        for (int q = 0; q < t; ++q) rows_before += j.b->step_count_host[q];
+        c.att[k] = (at == 4 || at == 8) && j.b->H % kAttBN == 0 && j.att_rows_done == rows_before;
+      }
+    (void)att_tiles_c;
     // one workgroup per task: HIP rejects a launch of more than 2^32 - 1 threads, i.e. 2^24 - 1
     // workgroups of 256 (halve the chain until it fits)
     for (;;) {
@@ -2079,7 +2150,8 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
       uint64_t units_c = 0;
       for (int q = t; q < c.end; ++q)
         for (int k = 0; k < n; ++k)
-          if (c.in_chain[k]) units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c);
+          if (c.in_chain[k])
+            units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c) * (c.att[k] ? 2 : 1);
       if (units_c * static_cast<uint64_t>(tiles_c) * kThreads <= 0xffffffffULL || c.end - t <= 1) break;
       c.end = t + (c.end - t) / 2;
     }
@@ -2087,7 +2159,7 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
   }
   if (!ok || n_c == 0) {
     c.end = 0;
-    for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = false;
+    for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = c.att[k] = false;
   }
   return c;
 }
@@ -2100,12 +2172,17 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
   cg.t0 = t;
   cg.nsteps = c.end - t;
   cg.ticket = nullptr;
+  cg.att_tiles = 4;
   unsigned* abort_word = nullptr;
   const int bm = (c.kind & 2048) != 0 ? 128 : 64;
+  bool any_att = false;
+  int slot_of[kMaxJobs];
   for (int k = 0; k < n; ++k) {
+    slot_of[k] = -1;
     if (!c.in_chain[k]) continue;
     FwdJob& j = jobs[k];
     const int q = cg.n++;
+    slot_of[k] = q;
     cg.j[q] = j.p;
     cg.n_tiles = j.p.n_tiles;
     cg.step_off[q] = j.b->step_off;
@@ -2118,30 +2195,57 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
       cg.ticket = words;
       abort_word = words + kXcds;
     }
+    cg.att_on[q] = c.att[k] ? 1 : 0;
+    AttnEnergyParams& ep = cg.att[q];
+    ep.hs_s = nullptr; ep.hs = j.p.hs; ep.w_lin = j.w->w_lin; ep.w_lin_s = nullptr;
+    ep.b_lin = j.w->b_lin; ep.w_att = j.w->w_att;
+    ep.e_part = reinterpret_cast<float*>(j.wsb + j.L.e_part);
+    ep.v = nullptr;
+    ep.rows = j.sum_T; ep.row_begin = 0; ep.row_end = 0;
+    ep.H = j.b->H; ep.n_tiles = (j.b->H + kAttBN - 1) / kAttBN;
+    if (c.att[k]) {
+      any_att = true;
+      cg.att_tiles = ep.n_tiles;
+    }
     j.chain_until = c.end;
   }
   for (int q = cg.n; q < kMaxJobs; ++q) {
     cg.step_off[q] = nullptr;
     cg.done[q] = nullptr;
     cg.rt_stride[q] = 0;
+    cg.att_on[q] = 0;
   }
-  uint64_t units = 0;
+  // per-queue tickets, phase by phase (GruChainGroup): G(s) at phase 2 s, A(s) at phase 2 s + 3
+  const int nq = chain_queues(cg.n_tiles);
+  const unsigned cols = static_cast<unsigned>(cg.n_tiles / nq);
+  const unsigned par = static_cast<unsigned>(kXcds / cg.att_tiles);
+  const int n_phases = 2 * cg.nsteps + 2;
+  uint32_t count[kChainPhases];
+  for (int p = 0; p < kChainPhases; ++p) count[p] = 0;
   double flops = 0.0, bytes = 0.0;
-  for (int sidx = 0; sidx <= cg.nsteps; ++sidx) {
-    cg.cum[sidx] = static_cast<uint32_t>(units);
-    if (sidx == cg.nsteps) break;
+  for (int sidx = 0; sidx < cg.nsteps; ++sidx) {
     for (int k = 0; k < n; ++k) {
       if (!c.in_chain[k]) continue;
       const int S_k = jobs[k].b->step_count_host[t + sidx];
-      units += static_cast<uint64_t>((S_k + bm - 1) / bm);
+      const unsigned rt = static_cast<unsigned>((S_k + bm - 1) / bm);
+      count[2 * sidx] += rt * cols;
       const double I = jobs[k].p.I, H = jobs[k].p.H;
       flops += S_k * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
       bytes += S_k * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
+      if (c.att[k]) {
+        count[2 * sidx + 3] += (rt + par - 1) / par;
+        flops += S_k * (2.0 * H * H + 6.0 * H);       // attention pooling, per time step
+        bytes += 4.0 * H * H;                          // (h_t is read again from cache; W_lin once per step)
+      }
     }
   }
-  for (int sidx = cg.nsteps + 1; sidx <= kChainMaxSteps; ++sidx) cg.cum[sidx] = static_cast<uint32_t>(units);
+  uint64_t total = 0;
+  for (int p = 0; p <= kChainPhases; ++p) {
+    cg.tick[p] = static_cast<uint32_t>(total);
+    if (p < n_phases) total += count[p];
+  }
   cg.sync = make_grid_sync(nullptr, abort_word);
-  const unsigned cgrid = static_cast<unsigned>(units * static_cast<uint64_t>(cg.n_tiles));
+  const unsigned cgrid = static_cast<unsigned>(total * static_cast<uint64_t>(nq));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timer != nullptr) {
     e0 = event_get(true);
@@ -2154,14 +2258,21 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
   }
   const bool cvec = (c.kind & 4) == 0;
   if (bm == 128) {
-    const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
+    const size_t smem = any_att ? TileSmem<128, kAttBN>::kBytes : TileSmem<128, 3 * kGruBU>::kBytes;
     if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 2>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
     else hipLaunchKernelGGL((gru_step_chain_kernel<false, 2>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
   } else {
-    const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
+    const size_t smem = any_att ? TileSmem<64, kAttBN>::kBytes : TileSmem<64, 3 * kGruBU>::kBytes;
     if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 1>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
     else hipLaunchKernelGGL((gru_step_chain_kernel<false, 1>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
   }
+  // the rows these steps produce are projected: the attention pass behind the steps starts after them
+  for (int k = 0; k < n; ++k)
+    if (c.att[k]) {
+      int64_t rows = 0;
+      for (int q = 0; q < c.end; ++q) rows += jobs[k].b->step_count_host[q];
+      jobs[k].att_rows_done = rows;
+    }
   if (e0 && e1) {
     (void)hipEventRecord(e1, c.stream);
     timer->tiled_events.push_back(e0);
@@ -2451,6 +2562,9 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   ep.n_tiles = att_tiles;
   const bool att_bf3 = job.bf3 && sum_T > tiny_max_seqs();
   const int att_bm = att_bf3 ? 128 : 64 * msub;
+  // (a step chain may already have projected rows beyond the ones asked for: its attention tasks)
+  if (row_end < job.att_rows_done) row_end = job.att_rows_done;
+  ep.row_end = row_end;
   const int64_t m_tiles = (row_end - job.att_rows_done + att_bm - 1) / att_bm;
   job.att_rows_done = row_end;
   if (m_tiles * att_tiles > 0x7fffffffLL) return CMHSE_ERR_UNSUPPORTED;
@@ -2672,7 +2786,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
       {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

@@ -75,6 +75,12 @@ struct Tunables {
   std::atomic<int> xproj_chunk_rows{1536};   // packed rows per chunk of a training chain's hoisted input projection beside the chain (0 = one launch in front of it)
   std::atomic<int> tn_rows_bm{0};            // tile height of the weight-gradient products: 128, 192, or 0 = 192 where 3H is a whole number of them (tn_rows.hpp)
   std::atomic<int> chain_min_steps{2};       // consecutive LDS-tiled steps (inference calls) from which they run as ONE launch of gru_step_chain_kernel; 0 = never
+  // 1: the attention energies of a chain's steps are tasks of the chain launch (H = 1024 / 2048); 0
+  // (default): a launch of their own behind the steps.  Bit-identical; measured 0.9 % (full split)
+  // to 2.2 % (a 615-video share) SLOWER as tasks: the projection is throughput work that the old
+  // schedule already runs beside the text tower's latency-bound tail — inside the chain it lengthens
+  // the launch that tail has to wait for (profiles/r05_chain_attention.txt)
+  std::atomic<int> chain_attention{0};
   std::atomic<int> chain_tall_min_wgs{256};  // 64-row workgroups per step from which a step chain uses 128-row tiles (per-step launches: tall_tile_min_wgs)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };

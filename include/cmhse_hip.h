@@ -471,6 +471,10 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *   "chain_min_steps"      2  consecutive LDS-tiled steps of an inference call from which they run as
  *                             ONE launch (gru_step_chain_kernel: per-row-tile dependencies instead
  *                             of a launch per time step; bit-identical); 0 = never
+ *   "chain_attention"      0  (opt-in; measured 0.9-2.2 % slower, profiles/r05_chain_attention.txt) 1: the
+ *                             attention energies e = w_att . tanh(W_lin h + b) of a chain's steps are
+ *                             tasks of the same launch (H = 1024 / 2048), handed out one step behind the
+ *                             GRU tiles that produce their rows; bit-identical
  *   "chain_tall_min_wgs" 256  64-row workgroups per step from which such a chain uses 128-row tiles
  *                             (four times that when a request of the chain has I < H)
  *   "tn_rows_bm"           0  tile height of the weight-gradient products: 128 | 192; 0 = 192 where

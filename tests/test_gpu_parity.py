@@ -1414,7 +1414,8 @@ def test_gru_pool_fwd_multi_equals_separate_calls(dev):
 
 
 @pytest.mark.parametrize('shape', ['one_xcd_queue', 'two_requests', 'full_width', 'scalar_loads', 'long_chain',
-                                   'many_rounds', 'uneven_256', 'uneven_768', 'uneven_128_long'])
+                                   'many_rounds', 'uneven_256', 'uneven_768', 'uneven_128_long',
+                                   'attention_2048', 'attention_share'])
 def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shape):
   """The LDS-tiled steps of a call as ONE launch (gru_step_chain_kernel: a workgroup per (step,
   request, row tile, column tile) task, per-XCD task queues, the previous step's rows awaited
@@ -1430,6 +1431,10 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     long_chain     more steps than one launch covers (96): the chain is cut and resumed
     many_rounds    H = 1024, 6000 + 5000 sequences: ~15 rounds of workgroups per launch, so tasks wait
                    for tiles that run later on other XCDs (the validation pass's regime)
+    attention_2048 / attention_share   the attention energies of a chain's steps as tasks of the same launch
+                   (phase 2 s + 3 of every queue: H = 2048, one column tile of W_lin per queue; H = 1024, two
+                   queues per column tile by row-tile parity, odd counts padded with no-op tickets); also
+                   exercised by full_width and many_rounds, whose first request is attention-pooled
     uneven_256 / uneven_768 / uneven_128_long   4, 12 and 2 column tiles — not a whole multiple of the 8
                    XCD queues — at sizes far beyond what the chip holds at once (47-94 row tiles x 12-20
                    steps): with per-XCD queues of unequal length the long queues ran ahead and could fill
@@ -1472,6 +1477,7 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     return r
 
   tune(tiny_max_seqs=0, mid_max_seqs=0)       # every step on the LDS-tiled kernel
+  tune(chain_attention=1)                     # (opt-in) attention energies as tasks of the chain launch
   if shape == 'one_xcd_queue':
     reqs = [request(300, 9, 24, 64, ops.POOL_ATTN)]
   elif shape == 'two_requests':
@@ -1484,6 +1490,13 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     reqs = [request(200, 6, 10, 96, ops.POOL_LAST, h0=True), request(150, 8, 10, 96, ops.POOL_ATTN)]
   elif shape == 'many_rounds':
     reqs = [request(6000, 10, 256, 1024, ops.POOL_ATTN, full=3000), request(5000, 7, 64, 1024, ops.POOL_LAST, full=1200)]
+  elif shape == 'attention_2048':
+    # H = 2048: 8 attention column tiles, one per queue; 4 GRU column tiles per queue
+    reqs = [request(1500, 5, 64, 2048, ops.POOL_ATTN, full=900)]
+  elif shape == 'attention_share':
+    # a rank's share: steps of one round of workgroups or less, where the attention tasks of the
+    # previous step fill the slots the recurrence leaves empty; odd row-tile counts (no-op tickets)
+    reqs = [request(700, 14, 96, 1024, ops.POOL_ATTN, h0=True, full=200), request(330, 9, 40, 1024, ops.POOL_ATTN, tokens=True)]
   elif shape == 'uneven_256':
     reqs = [request(3000, 12, 48, 256, ops.POOL_ATTN, full=2000)]
   elif shape == 'uneven_768':
@@ -1508,6 +1521,10 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     for (o1, h1), (o2, h2) in zip(per_step, run(2)):
       assert torch.equal(o1, o2)
       assert torch.equal(h1, h2)
+  tune(chain_attention=0)                     # (the default) the attention projection as a launch of its own behind the chain
+  for (o1, h1), (o2, h2) in zip(per_step, run(2)):
+    assert torch.equal(o1, o2) and torch.equal(h1, h2)
+  tune(chain_attention=1)
   with ops.StepTimers() as timers:            # the timed form (an event pair around the launch)
     timed = run(2)
   spans = timers.collect()
