@@ -568,6 +568,11 @@ struct GruChainGroup {
   GridSync sync;
   int32_t n, t0, nsteps, n_tiles;
   int32_t att_tiles;                    // 256-column tiles of W_lin (4 or 8 when any att_on)
+  int32_t col_map;                      // 0: queue x serves column tiles x, x + 8, ... of EVERY row tile;
+                                        // 1 (n_tiles = 16, experiment chain_col_map): queue x serves column tiles
+                                        //   x % 4 + {0, 4, 8, 12} of the row tiles of parity x / 4 — an XCD then
+                                        //   pulls HALF the A rows (4x instead of 8x over the chip) and four weight
+                                        //   slices instead of two
 };
 
 // Queues.  n_tiles % 8 == 0: eight, column tile c of the GRU step in queue c % 8 (an XCD's L2 keeps
@@ -623,14 +628,35 @@ void gru_step_chain_kernel(const GruChainGroup g) {
   if ((ph & 1) == 0) {
     // ---- a GRU tile of step s ----
     const int s = ph >> 1, t = g.t0 + s;
-    unsigned rem = local / cols;
-    const int c = static_cast<int>(queue + nq * (local % cols));
-    int k = 0, S_t = 0;
-    for (; k < g.n; ++k) {
-      S_t = g.step_off[k][t + 1] - g.step_off[k][t];
-      const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
-      if (rem < rt || k == g.n - 1) break;
-      rem -= rt;
+    unsigned rem;
+    int c, k = 0, S_t = 0;
+    if (g.col_map == 0) {
+      rem = local / cols;
+      c = static_cast<int>(queue + nq * (local % cols));
+      for (; k < g.n; ++k) {
+        S_t = g.step_off[k][t + 1] - g.step_off[k][t];
+        const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
+        if (rem < rt || k == g.n - 1) break;
+        rem -= rt;
+      }
+    } else {
+      unsigned j = local >> 2;                          // (row tile of this queue's parity, 4 column tiles each)
+      c = static_cast<int>((queue & 3u) + 4u * (local & 3u));
+      unsigned rt_n = 0;
+      bool found = false;
+      for (; k < g.n; ++k) {
+        S_t = g.step_off[k][t + 1] - g.step_off[k][t];
+        rt_n = static_cast<unsigned>((S_t + BM - 1) / BM);
+        const unsigned cnt = (rt_n + 1) >> 1;
+        if (j < cnt) {
+          found = true;
+          break;
+        }
+        j -= cnt;
+      }
+      if (!found) return;
+      rem = 2 * j + (queue >> 2);
+      if (rem >= rt_n) return;                          // (odd count: the padding ticket of the odd-parity queues)
     }
     const GruStepParams& p = g.j[k];
     const int64_t off_cur = g.step_off[k][t];
@@ -2173,6 +2199,7 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
   cg.nsteps = c.end - t;
   cg.ticket = nullptr;
   cg.att_tiles = 4;
+  cg.col_map = 0;
   unsigned* abort_word = nullptr;
   const int bm = (c.kind & 2048) != 0 ? 128 : 64;
   bool any_att = false;
@@ -2218,6 +2245,7 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
   // per-queue tickets, phase by phase (GruChainGroup): G(s) at phase 2 s, A(s) at phase 2 s + 3
   const int nq = chain_queues(cg.n_tiles);
   const unsigned cols = static_cast<unsigned>(cg.n_tiles / nq);
+  if (cg.n_tiles == 16 && tunables().chain_col_map.load(std::memory_order_relaxed) == 1) cg.col_map = 1;
   const unsigned par = static_cast<unsigned>(kXcds / cg.att_tiles);
   const int n_phases = 2 * cg.nsteps + 2;
   uint32_t count[kChainPhases];
@@ -2228,7 +2256,7 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
       if (!c.in_chain[k]) continue;
       const int S_k = jobs[k].b->step_count_host[t + sidx];
       const unsigned rt = static_cast<unsigned>((S_k + bm - 1) / bm);
-      count[2 * sidx] += rt * cols;
+      count[2 * sidx] += cg.col_map == 1 ? ((rt + 1) / 2) * 4 : rt * cols;
       const double I = jobs[k].p.I, H = jobs[k].p.H;
       flops += S_k * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
       bytes += S_k * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
@@ -2786,7 +2814,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
       {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_col_map", &t.chain_col_map}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {

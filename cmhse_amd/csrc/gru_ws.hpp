@@ -81,6 +81,10 @@ struct Tunables {
   // schedule already runs beside the text tower's latency-bound tail — inside the chain it lengthens
   // the launch that tail has to wait for (profiles/r05_chain_attention.txt)
   std::atomic<int> chain_attention{0};
+  // experiment (H = 1024): 1 = an XCD's queue serves FOUR column tiles of the row tiles of one parity
+  // instead of two column tiles of every row tile: half the A-row traffic over the fabric, twice the
+  // weight slices per L2 (profiles/r05_dual_column_tile.txt)
+  std::atomic<int> chain_col_map{0};
   std::atomic<int> chain_tall_min_wgs{256};  // 64-row workgroups per step from which a step chain uses 128-row tiles (per-step launches: tall_tile_min_wgs)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };
