@@ -147,6 +147,10 @@ SIGNATURES = {
                                          ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(c_int32)]),
     'cmhse_tune': (ctypes.c_int, [ctypes.c_char_p, c_int32, ctypes.POINTER(c_int32)]),
+    'cmhse_ctx_create': (c_void_p, []),
+    'cmhse_ctx_destroy': (None, [c_void_p]),
+    'cmhse_ctx_tune': (ctypes.c_int, [c_void_p, ctypes.c_char_p, c_int32, ctypes.POINTER(c_int32)]),
+    'cmhse_ctx_enter': (c_void_p, [c_void_p]),
     'cmhse_strerror': (ctypes.c_char_p, [ctypes.c_int]),
     'cmhse_version': (ctypes.c_char_p, []),
 }

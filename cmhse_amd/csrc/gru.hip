@@ -1659,6 +1659,8 @@ GridSync make_grid_sync(unsigned* counter, unsigned* abort_word) {
   return g;
 }
 
+static Tunables& global_tunables();
+
 static int resident_status(bool clear) {
   const int dev = event_device();
   if (dev < 0) return CMHSE_OK;
@@ -1671,11 +1673,13 @@ static int resident_status(bool clear) {
     // started in index order / all resident: a CU mask, another tenant).  The caller has been told
     // (this status); from here on the process uses one launch per time step, which needs neither —
     // cmhse_tune() re-enables the kernels explicitly.
-    Tunables& t = tunables();
-    t.chain_min_steps.store(0, std::memory_order_relaxed);
-    t.fwd_tail_min_steps.store(0, std::memory_order_relaxed);
-    t.bwd_tail_min_steps.store(0, std::memory_order_relaxed);
-    t.bwd_chain_min_steps.store(0, std::memory_order_relaxed);
+    Tunables* both[2] = {&tunables(), &global_tunables()};    // the caller's context and the process defaults
+    for (Tunables* t : both) {
+      t->chain_min_steps.store(0, std::memory_order_relaxed);
+      t->fwd_tail_min_steps.store(0, std::memory_order_relaxed);
+      t->bwd_tail_min_steps.store(0, std::memory_order_relaxed);
+      t->bwd_chain_min_steps.store(0, std::memory_order_relaxed);
+    }
   }
   return CMHSE_ERR_TIMEOUT;
 }
@@ -1696,10 +1700,18 @@ void stream_after(hipStream_t waiter, hipStream_t signal) {
   }
 }
 
-Tunables& tunables() {
+// The process-wide defaults (cmhse_tune) and, while a thread is inside cmhse_ctx_enter ...
+// cmhse_ctx_leave, that thread's CONTEXT: a private copy of the crossovers (cmhse_ctx_create).  Every
+// read of a crossover anywhere in the library goes through tunables(), so a call made inside a
+// context — workspace sizing included — sees that context's values and nothing another thread or
+// another context does to its own.
+static Tunables& global_tunables() {
   static Tunables t;
   return t;
 }
+static thread_local Tunables* tl_ctx = nullptr;
+
+Tunables& tunables() { return tl_ctx != nullptr ? *tl_ctx : global_tunables(); }
 
 }  // namespace cmhse
 
@@ -2353,6 +2365,37 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     j.tail_lo = lo;
     (void)hipMemsetAsync(j.wsb + j.L.tail_sync, 0, 256, js[k]);   // the barrier counter, off the chain's path
   }
+  // The hoisted input projection of an inference chain's small-batch steps (x W_ih^T of the rows of
+  // the steps >= t_mid) depends on the inputs only.  With a side stream it is launched THERE, now,
+  // beside the tiled steps, instead of on the chain's stream when the chain reaches t_mid, where it
+  // stood in front of the text tower's few-sequence tail — the end of a rank's share of the split is
+  // that tail, 1.7 of its 41 ms were this GEMM (profiles/r05_rank_share.txt).  Step t_mid waits for
+  // the event.  (Inputs still crossing PCIe — step_events_host — keep the in-order form.)
+  hipEvent_t early_xproj[kMaxJobs];
+  for (int k = 0; k < kMaxJobs; ++k) early_xproj[k] = nullptr;
+  if (side != nullptr && tunables().early_xproj.load(std::memory_order_relaxed) != 0) {
+    bool side_ready = false;
+    for (int k = 0; k < n; ++k) {
+      const FwdJob& j = jobs[k];
+      if (j.save || j.t_mid <= 0 || j.t_mid >= j.b->Tmax || j.b->step_events_host != nullptr ||
+          j.own_stream != nullptr)
+        continue;
+      if (!side_ready) {
+        stream_after(side, main_stream);     // the caller's inputs are ready
+        side_ready = true;
+      }
+      launch_xproj(j, side);
+      hipEvent_t ev = event_get(false);
+      if (ev != nullptr && hipEventRecord(ev, side) == hipSuccess) {
+        early_xproj[k] = ev;
+      } else {                               // no event: order the whole stream instead
+        event_put(ev, false);
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(side);
+        early_xproj[k] = reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(1));   // done, nothing to wait for
+      }
+    }
+  }
   bool forked = false;
   auto fork = [&](int k) {
     if (side == nullptr || js[k] != main_stream) return;
@@ -2431,7 +2474,13 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
             if (j.b->step_events_host[q] != nullptr)
               (void)hipStreamWaitEvent(st, static_cast<hipEvent_t>(const_cast<void*>(j.b->step_events_host[q])), 0);
         };
-        if (!chunked) {
+        if (early_xproj[k] != nullptr) {          // launched on the side stream before the first step
+          if (early_xproj[k] != reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(1))) {
+            (void)hipStreamWaitEvent(stream, early_xproj[k], 0);
+            event_put(early_xproj[k], false);
+          }
+          early_xproj[k] = nullptr;
+        } else if (!chunked) {
           wait_uploads(stream, t + 1, j.b->Tmax);
           launch_xproj(j, stream);
         } else {
@@ -2806,15 +2855,59 @@ extern "C" int cmhse_gather_rows(const float* table, const int64_t* ids, int64_t
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
+namespace {
+struct TuneEntry { const char* name; std::atomic<int>* v; };
+int tune_in(Tunables& t, const char* name, int32_t value, int32_t* old_value);
+}  // namespace
+
 extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
   if (!name) return CMHSE_ERR_ARG;
-  Tunables& t = tunables();
-  struct { const char* name; std::atomic<int>* v; } table[] = {
+  return tune_in(global_tunables(), name, value, old_value);
+}
+
+extern "C" void* cmhse_ctx_create(void) {
+  Tunables* c = new (std::nothrow) Tunables;
+  if (c == nullptr) return nullptr;
+  // a copy of the process defaults as they are now, name by name
+  Tunables& g = global_tunables();
+  static const char* const names[] = {
+      "tiny_max_seqs", "mid_max_seqs", "mid_units", "mid_waves", "tall_tile_min_wgs", "bwd_mid_max_seqs",
+      "bwd_split_min_seqs", "bwd_tail_min_steps", "fwd_tail_min_steps", "mid_tall_min_seqs", "bwd_chunk_rows",
+      "bwd_chain_min_steps", "bwd_fused_step", "xproj_chunk_rows", "tn_rows_bm", "chain_min_steps", "chain_attention",
+      "chain_col_map", "early_xproj", "chain_tall_min_wgs", "resident_timeout_ms"};
+  for (const char* n : names) {
+    int32_t v = 0;
+    (void)tune_in(g, n, -1, &v);
+    (void)tune_in(*c, n, v, nullptr);
+  }
+  return c;
+}
+
+extern "C" void cmhse_ctx_destroy(void* ctx) {
+  Tunables* c = static_cast<Tunables*>(ctx);
+  if (c != nullptr && tl_ctx == c) tl_ctx = nullptr;
+  delete c;
+}
+
+extern "C" int cmhse_ctx_tune(void* ctx, const char* name, int32_t value, int32_t* old_value) {
+  if (!ctx || !name) return CMHSE_ERR_ARG;
+  return tune_in(*static_cast<Tunables*>(ctx), name, value, old_value);
+}
+
+extern "C" void* cmhse_ctx_enter(void* ctx) {
+  Tunables* prev = tl_ctx;
+  tl_ctx = static_cast<Tunables*>(ctx);
+  return prev;
+}
+
+namespace {
+int tune_in(Tunables& t, const char* name, int32_t value, int32_t* old_value) {
+  TuneEntry table[] = {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
       {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_col_map", &t.chain_col_map}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
+      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_col_map", &t.chain_col_map}, {"early_xproj", &t.early_xproj}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {
@@ -2824,6 +2917,7 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
     }
   return CMHSE_ERR_ARG;
 }
+}  // namespace
 
 extern "C" void* cmhse_timer_create(void) {
   Timer* t = new (std::nothrow) Timer;

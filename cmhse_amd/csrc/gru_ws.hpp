@@ -85,6 +85,10 @@ struct Tunables {
   // instead of two column tiles of every row tile: half the A-row traffic over the fabric, twice the
   // weight slices per L2 (profiles/r05_dual_column_tile.txt)
   std::atomic<int> chain_col_map{0};
+  // 1: the hoisted input projection of an inference call's small-batch steps is launched on the
+  // call's side stream before the first step (beside the tiled steps) instead of in front of the
+  // few-sequence tail; 0: in order on the chain's stream.  Results do not depend on it.
+  std::atomic<int> early_xproj{1};
   std::atomic<int> chain_tall_min_wgs{256};  // 64-row workgroups per step from which a step chain uses 128-row tiles (per-step launches: tall_tile_min_wgs)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
 };

@@ -89,8 +89,16 @@ class LogCollector(object):
 
   @meters.setter
   def meters(self, value):      # `collector.meters = OrderedDict()`: a reset
-    self._deferred = []
+    # what is still queued belongs to the meters being replaced: deliver it first (the reference's
+    # tb_log would already have emitted those rows), then reset
+    self.settle()
     self._meters = value
+
+  def flush(self):
+    """Deliver everything still queued (late loss values, tb_log rows): call after the LAST step of
+    a loop that no reader follows (a reader — `meters`, str(), train_start / val_start — does it
+    implicitly)."""
+    self.settle()
 
   def __str__(self):
     return '  '.join('%s %s' % (k, m) for k, m in self.meters.items())

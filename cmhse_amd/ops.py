@@ -5,6 +5,7 @@ fallback — tensors must live on the MI355X.
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -92,7 +93,7 @@ def tune(name, value=-1):
   returns its previous value.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
   tall_tile_min_wgs, mid_tall_min_seqs, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
   fwd_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, bwd_chain_min_steps,
-  bwd_fused_step, chain_min_steps, chain_attention, chain_tall_min_wgs,
+  bwd_fused_step, chain_min_steps, chain_attention, chain_col_map, early_xproj, chain_tall_min_wgs,
   resident_timeout_ms
   (include/cmhse_hip.h)."""
   old = ctypes.c_int32(0)
@@ -125,6 +126,69 @@ class tuned(object):
   def __exit__(self, *a):
     for k, v in self.old.items():
       tune(k, v)
+
+
+class TuneContext(object):
+  """A private copy of the library's kernel-shape crossovers (cmhse_ctx_*): `with ctx: ...` makes it
+  the calling thread's current context for every library call in the block — workspace sizing and
+  launches — whatever cmhse_tune, other threads or other contexts do meanwhile.  Two models tuned
+  differently can live in one process, each running inside its own context.  A forward pass made
+  inside a context remembers it, and its backward pass (which autograd runs on another thread)
+  re-enters it.  Initialised from the process defaults (ops.tune) at creation."""
+  _current = threading.local()
+
+  def __init__(self, **kw):
+    self._lib = _lib.load()
+    self.handle = self._lib.cmhse_ctx_create()
+    if not self.handle:
+      raise MemoryError('cmhse_ctx_create failed')
+    self._prev = []
+    for k, v in kw.items():
+      self.tune(k, v)
+
+  def tune(self, name, value=-1):
+    old = ctypes.c_int32(0)
+    _lib.check(self._lib.cmhse_ctx_tune(self.handle, name.encode(), int(value), ctypes.byref(old)),
+               'cmhse_ctx_tune(%s)' % name)
+    return int(old.value)
+
+  def __enter__(self):
+    self._prev.append((self._lib.cmhse_ctx_enter(self.handle), getattr(TuneContext._current, 'ctx', None)))
+    TuneContext._current.ctx = self
+    return self
+
+  def __exit__(self, *a):
+    prev_handle, prev_obj = self._prev.pop()
+    self._lib.cmhse_ctx_enter(prev_handle)
+    TuneContext._current.ctx = prev_obj
+
+  def __del__(self):
+    try:
+      if self.handle and not self._prev:
+        self._lib.cmhse_ctx_destroy(self.handle)
+        self.handle = None
+    except Exception:      # noqa: BLE001  (interpreter shutdown)
+      pass
+
+  @staticmethod
+  def current():
+    """The TuneContext the calling thread is inside of, or None."""
+    return getattr(TuneContext._current, 'ctx', None)
+
+
+class _in_ctx(object):
+  """`with _in_ctx(ctx):` enters `ctx` unless it is None or already current (backward passes)."""
+
+  def __init__(self, ctx):
+    self.ctx = ctx if (ctx is not None and TuneContext.current() is not ctx) else None
+
+  def __enter__(self):
+    if self.ctx is not None:
+      self.ctx.__enter__()
+
+  def __exit__(self, *a):
+    if self.ctx is not None:
+      self.ctx.__exit__(*a)
 
 
 _MATH_MODE = ['fp32']
@@ -478,7 +542,7 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
     b.step_events_host = ctypes.cast(ev_arr, ctypes.c_void_p)
     keep.append((ev_arr, step_events))
   ctx = dict(sched=sched, ws=ws, keep=keep, H=H, I=I, batch=b, weights=w, pool_mode=pool_mode,
-             device=device, mode_flags=mode_flags)
+             device=device, mode_flags=mode_flags, tune_ctx=TuneContext.current())
   job = dict(b=b, w=w, mode_flags=mode_flags, out=out, ws=ws, ws_bytes=ws_bytes, ctx=ctx, side=side)
   meta = (sched.Tmax, sched.sum_T, I, H, h0_ptrs is not None, S)
   return job, meta
@@ -872,7 +936,13 @@ def gru_pool_bwd_multi(requests, job_streams=None, join=True, hold=None, prepare
   """cmhse_gru_pool_bwd_multi: `requests` = keyword dicts of gru_pool_bwd for INDEPENDENT encoders
   (the two towers of a training step); their BPTT steps share launches — or, with `job_streams`
   (one torch stream per request), run as separate chains on those streams with their launches
-  interleaved step by step.  Returns [(grads, dh0)].  join / hold: as in gru_pool_fwd_multi."""
+  interleaved step by step.  Returns [(grads, dh0)].  join / hold: as in gru_pool_fwd_multi.
+  Runs inside the TuneContext the forward pass was made in (autograd calls this on its own thread)."""
+  with _in_ctx(requests[0]['fctx'].get('tune_ctx') if requests else None):
+    return _gru_pool_bwd_multi(requests, job_streams, join, hold, prepared)
+
+
+def _gru_pool_bwd_multi(requests, job_streams, join, hold, prepared):
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_bwd_multi takes 1..%d requests' % MAX_JOBS)

@@ -23,8 +23,9 @@
  *     lists of those HIP events (creating an event while the GPU is busy can stall the host for
  *     tens of milliseconds, so events are recycled; an event returns to the list of the device
  *     that is current in the calling thread — use one device per thread across a call); (ii) the
- *     kernel-shape crossovers of cmhse_tune() below.  Nothing else: no cached device memory, no
- *     cached streams, no environment variables;
+ *     DEFAULT kernel-shape crossovers of cmhse_tune() below (a caller that must not share them
+ *     enters a tuning context, cmhse_ctx_*: its own copy, current per thread).  Nothing else: no
+ *     cached device memory, no cached streams, no environment variables;
  *   - return value: 0 = success, negative = error code (cmhse_strerror); no exceptions or aborts
  *     cross the ABI.
  */
@@ -475,15 +476,34 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             attention energies e = w_att . tanh(W_lin h + b) of a chain's steps are
  *                             tasks of the same launch (H = 1024 / 2048), handed out one step behind the
  *                             GRU tiles that produce their rows; bit-identical
+ *   "early_xproj"          1  the hoisted input projection of an inference call's small-batch steps on
+ *                             the call's side stream (tail_stream) before the first step, beside the
+ *                             tiled steps; 0 = in order in front of those steps (results identical)
+ *   "chain_col_map"        0  (experiment, H = 1024) 1: an XCD's queue serves four column tiles of the row
+ *                             tiles of one parity (profiles/r05_dual_column_tile.txt); bit-identical
  *   "chain_tall_min_wgs" 256  64-row workgroups per step from which such a chain uses 128-row tiles
  *                             (four times that when a request of the chain has I < H)
  *   "tn_rows_bm"           0  tile height of the weight-gradient products: 128 | 192; 0 = 192 where
  *                             every product's row count (3H, H) is a whole number of them, else 128
  *                             (the row split into parts follows the tile count, i.e. the gradients
  *                             to fp32 rounding; profiles/r04_wgrad_rate.txt)
- * Process-wide (atomics): set them between calls, not while calls that size workspaces with them
- * (`*_workspace` reads mid_max_seqs) are in flight on other threads.  Unknown name: CMHSE_ERR_ARG. */
+ * These are the PROCESS DEFAULTS (atomics): set them between calls, not while calls that size
+ * workspaces with them (`*_workspace` reads mid_max_seqs) are in flight on other threads.  A caller
+ * that wants its own values — two models tuned differently in one process, a library that must not
+ * disturb its host's settings — uses a context instead (below).  Unknown name: CMHSE_ERR_ARG. */
 int cmhse_tune(const char* name, int32_t value, int32_t* old_value);
+
+/* Tuning contexts (round 5; SURVEY 8b "re-entrant, no global state").  A context is a private copy
+ * of the crossovers above, initialised from the process defaults at creation.  cmhse_ctx_enter(ctx)
+ * makes it the CALLING THREAD's current context and returns the previous one (NULL = none): every
+ * library call that thread makes until it enters another one (cmhse_ctx_enter(prev) to leave) —
+ * workspace sizing and launches alike — reads its crossovers from the context, and cmhse_tune /
+ * other threads / other contexts do not affect it.  The context must outlive the calls made inside
+ * it; host-side only (a few hundred bytes).  cmhse_ctx_tune: cmhse_tune on a context. */
+void* cmhse_ctx_create(void);
+void cmhse_ctx_destroy(void* ctx);
+int cmhse_ctx_tune(void* ctx, const char* name, int32_t value, int32_t* old_value);
+void* cmhse_ctx_enter(void* ctx);
 
 /* The kernels that stay resident over several time steps of a chain (the few-sequence tails and
  * the training-size BPTT runs: "*_tail_min_steps", "bwd_chain_min_steps") synchronise their

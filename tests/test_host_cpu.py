@@ -378,6 +378,18 @@ def test_log_collector_replays_late_values_in_order():
   b.defer(lambda: b._update('Le_vid', 10.0, 4))
   d = pickle.loads(pickle.dumps(b))
   assert d.meters['Le_vid'].val == 10.0 and str(d) == str(b)
+  # a reset (`collector.meters = OrderedDict()`) delivers what was queued for the OLD meters first:
+  # the tensorboard rows of the last step are not dropped
+  from collections import OrderedDict
+  b.defer(lambda: b._update('Le_vid', 11.0, 4))
+  b.tb_log(tb, prefix='t/', step=10)
+  n_before = len(tb.got)
+  b.meters = OrderedDict()
+  assert len(tb.got) > n_before and ('t/Le_vid', 11.0, 10) in tb.got
+  assert len(b.meters) == 0
+  b.defer(lambda: b._update('Le_vid', 12.0, 4))
+  b.flush()
+  assert b.meters['Le_vid'].val == 12.0
 
 
 def test_plan_key_sees_every_batch():

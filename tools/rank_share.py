@@ -49,7 +49,11 @@ def main():
   ap.add_argument('--workload', default='anet_icep_val', choices=sorted(WORKLOADS))
   ap.add_argument('--rnn_type', default='attention')
   ap.add_argument('--embed', type=int, default=1024)
+  ap.add_argument('--tune', default='', help='crossovers to move for the run: name=value,name=value (ops.tune)')
   args = ap.parse_args()
+  for kv in [x for x in args.tune.split(',') if x]:
+    k, v = kv.split('=')
+    ops.tune(k, int(v))
   torch.cuda.set_device(0)
   dev = torch.device('cuda', 0)
   wl = dict(WORKLOADS[args.workload])
@@ -97,7 +101,7 @@ def main():
   print(json.dumps({'world': args.world, 'rank': args.rank, 'plan': bool(args.plan), 'videos': n_own,
                     'stripe': '%d x %d' % (n_own, N), 'ms_per_pass': ms, 'pass_ms_min': per[0],
                     'pass_ms_median': per[len(per) // 2], 'pass_ms_max': per[-1], 'steps': args.steps,
-                    'workload': args.workload, 'rnn_type': args.rnn_type,
+                    'workload': args.workload, 'rnn_type': args.rnn_type, 'tune': args.tune,
                     'gru_tflop': float(sum(costs[i][0] for i in own)) / 1e12}))
 
 
