@@ -1,7 +1,9 @@
 #!/bin/bash
-# Round 4: rocprofv3 kernel stats + trace of the default bench pass, PMC fabric traffic (two separate
-# passes, as MI355X_MICROARCH.md prescribes), SQ MFMA-busy counters, in-kernel clock of the tiled step.
-OUT=${1:-r04_final}
+# rocprofv3 kernel stats + trace of the default bench pass, PMC fabric traffic (two separate passes, as
+# MI355X_MICROARCH.md prescribes), SQ MFMA-busy counters, in-kernel clock of the tiled step.
+#   bash tools/collect_profiles.sh <dir under gpurun_out> <round label>; copy the results to profiles/rNN_*
+OUT=${1:-r05_final}
+ROUND=${2:-5}
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 D=$R/gpurun_out/$OUT
@@ -17,7 +19,7 @@ cd $R
 python tools/pmc_traffic.py $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE > $D/pmc_hbm_traffic.json
 python tools/pmc_sq.py $D/pmc_SQ > $D/pmc_sq_summary.md 2>&1
 rm -rf $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE $D/pmc_SQ
-python tools/summarize_rocprof.py $D/stats/*/*kernel_stats.csv "round 4, final kernels: rocprofv3 --kernel-trace --stats -- python3 $B (anet_icep_val, exact fp32, every pass rebuilds its schedules)" > $D/kernel_stats.md
+python tools/summarize_rocprof.py $D/stats/*/*kernel_stats.csv "round $ROUND, final kernels: rocprofv3 --kernel-trace --stats -- python3 $B (anet_icep_val, exact fp32, every pass rebuilds its schedules)" > $D/kernel_stats.md
 python tools/trace_timeline.py $D/stats/*/*kernel_trace.csv > $D/pass_timeline.txt
 rm -rf $D/stats
 python tools/tile_trace.py 22419 2048 1024 > $D/tile_trace.txt 2>&1
