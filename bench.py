@@ -46,10 +46,6 @@ The JSON line also carries
                 within ~1e-3 of every other, so this is the floor any fp32 evaluation order has), and the
                 rows the same deviation moves on separable (correlated) embeddings — the ruler
                 every optional math mode is held to;
-  fast_mode_bf16x6  (--fast_steps 5, --fast_modes) the same pass in the opt-in fp32-GRADE math mode (three bf16
-                pieces per operand, six products on the bf16 matrix pipe, fp32 accumulate): its own ms per
-                pass, tiled-step rate, distance from the exact path's embeddings and the rank rows it moves
-                (random-init and on the correlated ruler).  Never `value`: not bit-identical to the fp32 chain;
   cached_schedule_pass  the pass for a resident, unchanged split with the level-1 schedules kept
                 between passes (opt-in; the headline pass rebuilds them like the reference).
 """
@@ -135,11 +131,9 @@ def main():
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
-  ap.add_argument('--fast_steps', type=int, default=5,
-                  help='also time this many passes in the opt-in math modes of --fast_modes (supplementary '
-                       'legs, never `value`: they are outside the bit-identical-ranks contract); 0 = skip')
-  ap.add_argument('--fast_modes', default='bf16x6',
-                  help='which opt-in math modes --fast_steps times (ops.set_math_mode)')
+  ap.add_argument('--fast_steps', type=int, default=0,
+                  help='also time this many passes in the opt-in bf16x3 math mode (default 0 = skip: the '
+                       'mode is outside the bit-identical-ranks contract, DESIGN.md section 9)')
   ap.add_argument('--train_steps', type=int, default=10,
                   help='also time this many VSE.train_emb steps per BASELINE training config (0 = skip)')
   ap.add_argument('--train_configs', default='anet_c3d_tau0,anet_icep_tau0,anet_icep_recon,didemo_icep_recon',
@@ -436,9 +430,7 @@ def main():
         return {'steps': args.cached_steps, 'ms_per_step': dt * 1e3, 'value': pairs / dt, 'unit': 'pairs/s'}
       leg('cached_schedule_pass', cached)
     if world == 1 and args.fast_steps > 0:
-      for fm in [m for m in args.fast_modes.split(',') if m]:
-        leg('fast_mode' if fm == 'bf16x3' else 'fast_mode_' + fm,
-            lambda fm=fm: fast_mode_bench(opt, model, batches, N, args.fast_steps, fm))
+      leg('fast_mode', lambda: fast_mode_bench(opt, model, batches, N, args.fast_steps))
     if world == 1 and args.train_steps > 0:
       # the BASELINE training configurations (configs[1..3]) as driver-timed train_emb steps —
       # timed while the GPU is still at its working clocks (right behind the validation passes:

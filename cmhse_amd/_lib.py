@@ -13,7 +13,6 @@ LIB_PATH = os.environ.get('CMHSE_HIP_LIB') or os.path.join(_HERE, 'libcmhse_hip.
 POOL_LAST, POOL_ATTN, POOL_MAX, POOL_ALL = 0, 1, 2, 3
 SAVE_FOR_BACKWARD = 0x100
 MATH_BF16X3 = 0x200
-MATH_BF16X6 = 0x800
 NO_JOIN = 0x400
 MAX_JOBS = 4            # requests per cmhse_gru_pool_fwd_multi call
 POOL_OF = {'seq2seq': POOL_LAST, 'attention': POOL_ATTN, 'maxout': POOL_MAX}

@@ -135,7 +135,7 @@ struct ChainDep {
 // same arithmetic inside gru_step_chain_kernel — the x phase (which does not depend on the
 // previous step) first, then the wait for the previous step's rows, the h phase, and the new state
 // written THROUGH the non-coherent L2 (agent-scope stores) before `done` is signalled.
-template <bool VEC, int MSUB, bool BF3, bool CHAIN, bool BF6 = false>
+template <bool VEC, int MSUB, bool BF3, bool CHAIN>
 __device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsigned wg, const int t,
                                               const int S_t, const int64_t off_prev,
                                               const int64_t off_cur, const ChainDep& dep) {
@@ -198,10 +198,7 @@ __device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsi
     const int g = br / BU, u = u0 + (br % BU);
     bv[i] = u < H;
     const int uc = bv[i] ? u : (H - 1);
-    if (BF6) {          // weights pre-split into three bf16 pieces (split_bf16x6_kernel); A rows stay fp32
-      bx[i] = row_addr(p.w_ih_s + (static_cast<int64_t>(g) * H + uc) * split_ld6(I));
-      bh[i] = row_addr(p.w_hh_s + (static_cast<int64_t>(g) * H + uc) * split_ld6(H));
-    } else if (BF3) {
+    if (BF3) {
       bx[i] = row_addr(p.w_ih_s + (static_cast<int64_t>(g) * H + uc) * split_ld(I));
       bh[i] = row_addr(p.w_hh_s + (static_cast<int64_t>(g) * H + uc) * split_ld(H));
     } else {
@@ -233,10 +230,7 @@ __device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsi
 #ifdef TILE_TRACE_BUILD
   if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime();
 #endif
-  if (BF6) {
-    nt_phase_bf6<BM, BNR, MSUB, 3, 4, 2>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
-    if (have_h) nt_phase_bf6<BM, BNR, MSUB, 3, 4, 3>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
-  } else if (BF3) {
+  if (BF3) {
     // pre-split A operands: xs, then hs_s of the previous step (or the pre-split initial states)
     nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2, true>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
@@ -401,7 +395,7 @@ __device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsi
   }
 }
 
-template <bool VEC, int MSUB, bool BF3, bool BF6 = false>
+template <bool VEC, int MSUB, bool BF3>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_kernel(const GruStepGroup grp) {
   unsigned wg;
@@ -410,7 +404,7 @@ void gru_step_kernel(const GruStepGroup grp) {
   none.wait = nullptr;
   none.need = 0;
   none.done = nullptr;
-  gru_step_tile<VEC, MSUB, BF3, false, BF6>(p, wg, p.t, p.S_t, p.off_prev, p.off_cur, none);
+  gru_step_tile<VEC, MSUB, BF3, false>(p, wg, p.t, p.S_t, p.off_prev, p.off_cur, none);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -434,7 +428,7 @@ struct AttnEnergyParams {
 // One tile: packed rows [m0, m0 + 64 MSUB) (those below row_end) x columns [256 nt, 256 nt + 256).
 // The body of attn_energy_kernel, and a task of the step chain (gru_step_chain_kernel).  A row's
 // result does not depend on the tile height or on which rows share its tile.
-template <bool VEC, int MSUB, bool BF3, bool ASPLIT, bool BF6 = false>
+template <bool VEC, int MSUB, bool BF3, bool ASPLIT>
 __device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, const int nt, const int64_t m0,
                                                  const int64_t row_end) {
   constexpr int BM = 64 * MSUB, BN = kAttBN;
@@ -459,8 +453,7 @@ __device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, cons
   for (int i = 0; i < BN / 64; ++i) {
     const int n = n0 + srow + 64 * i;
     bv[i] = n < H;
-    br[i] = BF6 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld6(H))
-          : BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
+    br[i] = BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
                 : row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
   }
   constexpr int NS = BN / 64;   // 32-column sub-tiles per wave
@@ -472,9 +465,7 @@ __device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, cons
   int b_row0[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
-  if (BF6)
-    nt_phase_bf6<BM, BN, MSUB, NS, NS, NS - 1>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-  else if (BF3)
+  if (BF3)
     nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1, ASPLIT>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
   else
     nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
@@ -513,10 +504,10 @@ __device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, cons
   }
 }
 
-template <bool VEC, int MSUB, bool BF3, bool ASPLIT = false, bool BF6 = false>
+template <bool VEC, int MSUB, bool BF3, bool ASPLIT = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void attn_energy_kernel(const AttnEnergyParams p) {
-  attn_energy_tile<VEC, MSUB, BF3, ASPLIT, BF6>(p, static_cast<int>(blockIdx.x % p.n_tiles),
+  attn_energy_tile<VEC, MSUB, BF3, ASPLIT>(p, static_cast<int>(blockIdx.x % p.n_tiles),
                                            p.row_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * (64 * MSUB),
                                            p.row_end);
 }
@@ -595,7 +586,9 @@ struct GruChainGroup {
 // can always run.
 __device__ __host__ __forceinline__ int chain_queues(int n_tiles) { return (n_tiles % kXcds == 0) ? kXcds : 1; }
 
-template <bool VEC, int MSUB>
+// ATT: the instantiation that also serves attention-energy tasks (chain_attention); the default one
+// does not contain that tile, whose live ranges would cost it registers (256 + spills against 230).
+template <bool VEC, int MSUB, bool ATT = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_chain_kernel(const GruChainGroup g) {
   constexpr int BM = 64 * MSUB;
@@ -679,6 +672,7 @@ void gru_step_chain_kernel(const GruChainGroup g) {
                                           off_prev, off_cur, dep);
     return;
   }
+  if (!ATT) return;   // (no attention tickets are handed out to this instantiation)
   // ---- an attention-energy tile of the rows step s produced ----
   // 8 column tiles (H = 2048): tile a in queue a, every row tile.  4 (H = 1024): tile a in queues a
   // and a + 4, the even row tiles in the first, the odd ones in the second (an XCD's L2 then serves one
@@ -1485,36 +1479,6 @@ __global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __r
   o[8 + q] = lo;
 }
 
-// bf16x6 pre-split of a weight matrix: row r of `out` has split_ld6(K) float units; per 16-k chunk 8
-// dwords of h pairs, 8 of m pairs, 8 of l pairs (x = h + m + l exactly; k beyond K zero-filled).
-__global__ __launch_bounds__(kThreads) void split_bf16x6_kernel(const float* __restrict__ W,
-                                                                uint32_t* __restrict__ out, int R,
-                                                                int K) {
-  const int64_t ld = split_ld6(K);
-  const int64_t pairs = ld / 3;  // one thread per (row, k pair): 8 pairs per 24-unit chunk
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (idx >= static_cast<int64_t>(R) * pairs) return;
-  const int r = static_cast<int>(idx / pairs);
-  const int pp = static_cast<int>(idx % pairs);
-  const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
-  const float x0 = (k < K) ? W[static_cast<int64_t>(r) * K + k] : 0.f;
-  const float x1 = (k + 1 < K) ? W[static_cast<int64_t>(r) * K + k + 1] : 0.f;
-  const uint32_t h = pack_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  const uint32_t m = pack_bf16(r0, r1);
-  const uint32_t l = pack_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
-  uint32_t* o = out + static_cast<int64_t>(r) * ld + c * 24;
-  o[q] = h;
-  o[8 + q] = m;
-  o[16 + q] = l;
-}
-
-static void launch_split6(const float* W, float* out, int R, int K, hipStream_t st) {
-  const int64_t n = static_cast<int64_t>(R) * (split_ld6(K) / 3);
-  hipLaunchKernelGGL(split_bf16x6_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)),
-                     dim3(kThreads), 0, st, W, reinterpret_cast<uint32_t*>(out), R, K);
-}
-
 static void launch_split(const float* W, float* out, int R, int K, hipStream_t st) {
   const int64_t n = static_cast<int64_t>(R) * (split_ld(K) / 2);
   hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)),
@@ -1794,7 +1758,6 @@ struct FwdJob {
   int64_t sum_T, off;
   int32_t pool_mode;
   bool vec, bf3, save;
-  bool bf6;                  // (with bf3, which stands for "a split math mode is on" in the schedule) the 6-product form
   int32_t t_mid;             // first step served by the mid-size kernel (Tmax: none)
   int64_t rows_split;        // bf16x3: packed rows of the steps the tiled bf16x3 kernel serves
   hipStream_t tail_stream;   // optional stream the call's remaining steps move to when this chain ends early
@@ -1830,8 +1793,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   if (!w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh) return CMHSE_ERR_ARG;
   const int32_t mode_flags = pool_mode;
   const bool save = (pool_mode & CMHSE_SAVE_FOR_BACKWARD) != 0;
-  const bool bf6 = (pool_mode & CMHSE_MATH_BF16X6) != 0;
-  bool bf3 = bf6 || (pool_mode & CMHSE_MATH_BF16X3) != 0;
+  bool bf3 = (pool_mode & CMHSE_MATH_BF16X3) != 0;
   pool_mode &= kModeMask;
   if (pool_mode != CMHSE_POOL_LAST && pool_mode != CMHSE_POOL_ATTN && pool_mode != CMHSE_POOL_MAX &&
       pool_mode != CMHSE_POOL_ALL)
@@ -1891,7 +1853,6 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
   // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
   job->bf3 = bf3 && job->vec && (job->kind_count[0] > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
-  job->bf6 = job->bf3 && bf6;
   // steps with few active sequences: mid-size kernel on a hoisted input projection
   job->t_mid = b->Tmax;
   p.gx = nullptr;
@@ -1916,15 +1877,7 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   p.hs_s = nullptr;
   p.h0_s = nullptr;
   job->rows_split = 0;
-  if (job->bf6) {
-    // three-piece weights; the A operands (inputs, hidden states) stay fp32 and are split in registers
-    float* wih_s = reinterpret_cast<float*>(wsb + L.wih_s);
-    float* whh_s = reinterpret_cast<float*>(wsb + L.whh_s);
-    launch_split6(w->w_ih, wih_s, 3 * b->H, b->I, stream);
-    launch_split6(w->w_hh, whh_s, 3 * b->H, b->H, stream);
-    p.w_ih_s = wih_s;
-    p.w_hh_s = whh_s;
-  } else if (job->bf3) {
+  if (job->bf3) {
     float* wih_s = reinterpret_cast<float*>(wsb + L.wih_s);
     float* whh_s = reinterpret_cast<float*>(wsb + L.whh_s);
     launch_split(w->w_ih, wih_s, 3 * b->H, b->I, stream);
@@ -2006,7 +1959,7 @@ int step_kind(const FwdJob& j, int S_t, int mid_blocks, bool alone, int tiled_wg
   // (WHICH of the differently-ordered sums serves the step comes from kind_count — the whole
   // split's active count when the batch is a share of one — so that a sequence sees the same
   // arithmetic whatever else is in its batch; shapes within a kind are bit-identical)
-  int k = (j.kind_count[j.p.t] <= tiny_max_seqs()) ? 0 : (j.bf3 ? (j.bf6 ? (2 | 16384) : 2) : 1);
+  int k = (j.kind_count[j.p.t] <= tiny_max_seqs()) ? 0 : (j.bf3 ? 2 : 1);
   if (k == 1 && gru_msub_for(tiled_wgs) == 2) k |= 2048;
   return k | (j.vec ? 0 : 4);
 }
@@ -2076,11 +2029,6 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
       }
       break;
     case 2: {
-      if ((kind & 16384) != 0) {   // bf16x6: fp32 A tiles, three-piece weight tiles
-        const size_t smem6 = TileSmem6<128, 3 * kGruBU>::kBytes;
-        hipLaunchKernelGGL((gru_step_kernel<true, 2, false, true>), dim3(grid), dim3(kThreads), smem6, stream, g);
-        break;
-      }
       // staging-bound loop: the 128-row tile halves the weight bytes per MFMA
       const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
       hipLaunchKernelGGL((gru_step_kernel<true, 2, true>), dim3(grid), dim3(kThreads), smem, stream, g);
@@ -2352,15 +2300,26 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
     if (e0 && e1) (void)hipEventRecord(e0, c.stream);
   }
   const bool cvec = (c.kind & 4) == 0;
+#define CHAIN_LAUNCH_(V, M, A, SMEM) \
+  hipLaunchKernelGGL((gru_step_chain_kernel<V, M, A>), dim3(cgrid), dim3(kThreads), SMEM, c.stream, cg)
   if (bm == 128) {
-    const size_t smem = any_att ? TileSmem<128, kAttBN>::kBytes : TileSmem<128, 3 * kGruBU>::kBytes;
-    if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 2>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
-    else hipLaunchKernelGGL((gru_step_chain_kernel<false, 2>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
+    if (any_att) {
+      if (cvec) CHAIN_LAUNCH_(true, 2, true, (TileSmem<128, kAttBN>::kBytes));
+      else CHAIN_LAUNCH_(false, 2, true, (TileSmem<128, kAttBN>::kBytes));
+    } else {
+      if (cvec) CHAIN_LAUNCH_(true, 2, false, (TileSmem<128, 3 * kGruBU>::kBytes));
+      else CHAIN_LAUNCH_(false, 2, false, (TileSmem<128, 3 * kGruBU>::kBytes));
+    }
   } else {
-    const size_t smem = any_att ? TileSmem<64, kAttBN>::kBytes : TileSmem<64, 3 * kGruBU>::kBytes;
-    if (cvec) hipLaunchKernelGGL((gru_step_chain_kernel<true, 1>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
-    else hipLaunchKernelGGL((gru_step_chain_kernel<false, 1>), dim3(cgrid), dim3(kThreads), smem, c.stream, cg);
+    if (any_att) {
+      if (cvec) CHAIN_LAUNCH_(true, 1, true, (TileSmem<64, kAttBN>::kBytes));
+      else CHAIN_LAUNCH_(false, 1, true, (TileSmem<64, kAttBN>::kBytes));
+    } else {
+      if (cvec) CHAIN_LAUNCH_(true, 1, false, (TileSmem<64, 3 * kGruBU>::kBytes));
+      else CHAIN_LAUNCH_(false, 1, false, (TileSmem<64, 3 * kGruBU>::kBytes));
+    }
   }
+#undef CHAIN_LAUNCH_
   // the rows these steps produce are projected: the attention pass behind the steps starts after them
   for (int k = 0; k < n; ++k)
     if (c.att[k]) {
@@ -2704,13 +2663,6 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   ep.w_lin_s = nullptr;
   if (att_grid == 0) {
     // nothing left to project (every row was served by an earlier partial launch)
-  } else if (att_bf3 && job.bf6) {
-    float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
-    if (ep.row_begin == 0) launch_split6(w->w_lin, wlin_s, b->H, b->H, stream);
-    ep.w_lin_s = wlin_s;
-    const size_t att_smem6 = TileSmem6<128, kAttBN>::kBytes;
-    hipLaunchKernelGGL((attn_energy_kernel<true, 2, false, false, true>), dim3(att_grid), dim3(kThreads), att_smem6,
-                       stream, ep);
   } else if (att_bf3) {
     float* wlin_s = reinterpret_cast<float*>(wsb + L.wlin_s);
     if (ep.row_begin == 0) launch_split(w->w_lin, wlin_s, b->H, b->H, stream);

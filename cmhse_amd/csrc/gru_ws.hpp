@@ -105,20 +105,17 @@ static inline int64_t gx_rows_bound(int32_t S, int32_t Tmax, int64_t sum_T) {
   return b < sum_T ? b : sum_T;
 }
 
-constexpr int32_t kModeMask = ~(CMHSE_SAVE_FOR_BACKWARD | CMHSE_MATH_BF16X3 | CMHSE_MATH_BF16X6 | CMHSE_NO_JOIN);
+constexpr int32_t kModeMask = ~(CMHSE_SAVE_FOR_BACKWARD | CMHSE_MATH_BF16X3 | CMHSE_NO_JOIN);
 
 // row length (in float units) of a bf16x3 pre-split weight row: K rounded up to whole 16-k chunks
 __host__ __device__ static inline int64_t split_ld(int K) { return (static_cast<int64_t>(K) + 15) / 16 * 16; }
-// ... and of a bf16x6 (three-piece) one: 24 units per 16-k chunk (nt_core.hpp: split_ld6)
-static inline int64_t split_ld6_ws(int K) { return (static_cast<int64_t>(K) + 15) / 16 * 24; }
 
 static inline size_t ws_align(size_t v) { return (v + 255) / 256 * 256; }
 
 static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t mode_flags,
                                   int32_t I = 0, int32_t Tmax = 0) {
   const bool save = (mode_flags & CMHSE_SAVE_FOR_BACKWARD) != 0;
-  const bool bf6 = (mode_flags & CMHSE_MATH_BF16X6) != 0;   // weights in three pieces; activations stay fp32
-  const bool bf3 = !bf6 && (mode_flags & CMHSE_MATH_BF16X3) != 0;
+  const bool bf3 = (mode_flags & CMHSE_MATH_BF16X3) != 0;
   const int mode = mode_flags & kModeMask;
   GruWs L;
   size_t off = 0;
@@ -135,13 +132,10 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   if (save && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(sum_T) * H * sizeof(float));
   L.wih_s = off;
   if (bf3) off += ws_align(static_cast<size_t>(3) * H * split_ld(I) * sizeof(float));
-  if (bf6) off += ws_align(static_cast<size_t>(3) * H * split_ld6_ws(I) * sizeof(float));
   L.whh_s = off;
   if (bf3) off += ws_align(static_cast<size_t>(3) * H * split_ld(H) * sizeof(float));
-  if (bf6) off += ws_align(static_cast<size_t>(3) * H * split_ld6_ws(H) * sizeof(float));
   L.wlin_s = off;
   if (bf3 && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(H) * split_ld(H) * sizeof(float));
-  if (bf6 && mode == CMHSE_POOL_ATTN) off += ws_align(static_cast<size_t>(H) * split_ld6_ws(H) * sizeof(float));
   // bf16x3: the inputs and the hidden states of the LDS-tiled steps in pre-split (hi | lo) rows
   L.xs = off;
   if (bf3) off += ws_align(static_cast<size_t>(sum_T) * split_ld(I) * sizeof(float));

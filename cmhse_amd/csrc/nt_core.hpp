@@ -470,170 +470,6 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
   __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------------
-// bf16x6 variant ("CMHSE_MATH_BF16X6", round 5): fp32-GRADE products on the bf16 matrix pipe.
-//   x = x_h + x_m + x_l exactly (three bf16 pieces, 8 + 8 + 8 significand bits), and
-//   a*b ~= a_l*b_h + a_h*b_l + a_m*b_m + a_m*b_h + a_h*b_m + a_h*b_h      (smallest terms first)
-// drops only the three products below 2^-24 of a*b; every kept product of two 8-bit pieces is exact
-// in the fp32 accumulator.  Six v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 k) replace eight
-// v_mfma_f32_32x32x2_f32 (64 cycles each): 2.05x the matrix rate at the clock the chip holds
-// (profiles/r05_bf16x6_rate.txt).  NOT bit-identical to the fp32 chain: an opt-in, held to the rank
-// noise floor of the exact path (tests/test_gpu_parity.py).
-//   * A stays fp32 in HBM and LDS (the tiles and staging of nt_phase); each lane splits its 8-k
-//     fragment into three pieces in registers.
-//   * B (weights) is pre-split once per call by split_bf16x6_kernel: per 16-k chunk 32 B of h, 32 B
-//     of m, 32 B of l = 24 float units (split_ld6); LDS rows of 28 floats (112 B: odd in 16-byte
-//     units, conflict-free for the b128 fragment reads).
-// ---------------------------------------------------------------------------------------------
-constexpr int kLdsLd6 = 28;
-__host__ __device__ static inline int64_t split_ld6(int K) { return (static_cast<int64_t>(K) + 15) / 16 * 24; }
-
-template <int BM, int BNR>
-struct TileSmem6 {
-  static constexpr int kAFloats = BM * kLdsLd;
-  static constexpr int kBFloats = BNR * kLdsLd6;
-  static constexpr int kFloats = 2 * (kAFloats + kBFloats);
-  static constexpr size_t kBytes = sizeof(float) * kFloats;
-  __device__ static float* a(float* base, int buf) { return base + buf * kAFloats; }
-  __device__ static float* b(float* base, int buf) { return base + 2 * kAFloats + buf * kBFloats; }
-};
-
-__device__ __forceinline__ void split8x3(const float4& lo4, const float4& hi4, uint4& h, uint4& m, uint4& l) {
-  const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-  uint32_t hh[4], mm[4], ll[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hh[i] = pack_bf16(x[2 * i], x[2 * i + 1]);
-    const float r0 = x[2 * i] - __uint_as_float(hh[i] << 16);
-    const float r1 = x[2 * i + 1] - __uint_as_float(hh[i] & 0xffff0000u);
-    mm[i] = pack_bf16(r0, r1);
-    ll[i] = pack_bf16(r0 - __uint_as_float(mm[i] << 16), r1 - __uint_as_float(mm[i] & 0xffff0000u));
-  }
-  h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-  m = make_uint4(mm[0], mm[1], mm[2], mm[3]);
-  l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-}
-
-// arow: fp32 rows (K floats); brow: pre-split rows (split_ld6(K) float units).  VEC shapes only
-// (K % 4 == 0).
-template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST>
-__device__ __forceinline__ void nt_phase_bf6(float* smem, const rowaddr_t (&arow)[BM / 64],
-                                             const bool (&aval)[BM / 64],
-                                             const rowaddr_t (&brow)[BNR / 64],
-                                             const bool (&bval)[BNR / 64], int K, int a_row0,
-                                             const int (&b_row0)[NSUB], f32x16 (&acc)[MSUB][NACC]) {
-  using SM = TileSmem6<BM, BNR>;
-  constexpr int AP = BM / 64, BP = BNR / 64;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int srow = tid >> 2;
-  const int part = tid & 3;
-  const int sk = part * 4;
-  const int nchunks = (K + kBK - 1) / kBK;
-  if (nchunks == 0) return;
-  const int Kb = nchunks * 24;      // float units of a pre-split row
-  const int frow = lane & 31;
-  const int fk = (lane >> 5) * 8;   // this lane-half's 8 k inside the 16-k chunk
-  float4 ra[AP], rb[BP], rb2[BP];   // rb: float units [4 part, 4 part + 4) of the chunk's 24; rb2 (part < 2): [16 + 4 part, ...)
-  float4 xa[MSUB][2];
-  uint4 ah[MSUB], am[MSUB], al[MSUB], bh[NSUB], bm[NSUB], bl[NSUB];
-
-  auto issue_global = [&](int c) {   // chunk index
-#pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = issue_row4<true>(arow[i], c * kBK + sk, K);
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      rb[i] = issue_row4<true>(brow[i], c * 24 + sk, Kb);
-      rb2[i] = issue_row4<true>(brow[i], c * 24 + 16 + 4 * (part & 1), Kb);
-    }
-  };
-  auto write_lds = [&](int buf, int c) {
-#pragma unroll
-    for (int i = 0; i < AP; ++i)
-      *reinterpret_cast<float4*>(SM::a(smem, buf) + (srow + 64 * i) * kLdsLd + sk) =
-          finish_row4<true>(ra[i], aval[i], c * kBK + sk, K);
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      float* row = SM::b(smem, buf) + (srow + 64 * i) * kLdsLd6;
-      *reinterpret_cast<float4*>(row + sk) = finish_row4<true>(rb[i], bval[i], c * 24 + sk, Kb);
-      if (part < 2)
-        *reinterpret_cast<float4*>(row + 16 + 4 * part) = finish_row4<true>(rb2[i], bval[i], c * 24 + 16 + 4 * part, Kb);
-    }
-  };
-  auto read_a = [&](int buf) {
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) {
-      const float* p = SM::a(smem, buf) + (a_row0 + ms * 32 + frow) * kLdsLd + fk;
-      xa[ms][0] = *reinterpret_cast<const float4*>(p);
-      xa[ms][1] = *reinterpret_cast<const float4*>(p + 4);
-    }
-  };
-  auto read_b = [&](int buf) {
-#pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns) {
-      const float* p = SM::b(smem, buf) + (b_row0[ns] + frow) * kLdsLd6 + (fk >> 1);
-      bh[ns] = *reinterpret_cast<const uint4*>(p);
-      bm[ns] = *reinterpret_cast<const uint4*>(p + 8);
-      bl[ns] = *reinterpret_cast<const uint4*>(p + 16);
-    }
-  };
-  auto convert_a = [&]() {
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) split8x3(xa[ms][0], xa[ms][1], ah[ms], am[ms], al[ms]);
-  };
-  auto mfma_chunk = [&]() {
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) {
-      const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[ms]);
-      const bf16x8 a_m = __builtin_bit_cast(bf16x8, am[ms]);
-      const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[ms]);
-#pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) {
-        const bf16x8 b_h = __builtin_bit_cast(bf16x8, bh[ns]);
-        const bf16x8 b_m = __builtin_bit_cast(bf16x8, bm[ns]);
-        const bf16x8 b_l = __builtin_bit_cast(bf16x8, bl[ns]);
-        constexpr int kLast = LAST;
-        const int ai = (ns == NSUB - 1) ? kLast : ns;
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_m, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, b_h, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_m, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[ms][ai], 0, 0, 0);
-      }
-    }
-  };
-
-  // the software pipeline of nt_phase_bf3: chunk c's fragments are read and converted while chunk
-  // c - 1's MFMAs issue; chunk c + 1 is on its way from memory
-  issue_global(0);
-  __syncthreads();
-  write_lds(0, 0);
-  __syncthreads();
-  read_a(0);
-  read_b(0);
-  issue_global(1);
-  convert_a();
-  __builtin_amdgcn_sched_barrier(0);
-  write_lds(1, 1);
-  for (int c = 1; c < nchunks; ++c) {
-    const int cur = c & 1;
-    __syncthreads();
-    read_a(cur);
-    issue_global(c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk();                    // chunk c - 1
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(cur);
-    convert_a();
-    __builtin_amdgcn_sched_barrier(0);
-    write_lds(cur ^ 1, c + 1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_chunk();                      // last chunk
-  __syncthreads();
-}
-
 // Split-K building block of the latency-shaped kernels (gru_step_tiny_kernel, gru_bwd_step_kernel):
 // one 32x32 accumulator; NW (4 or 8) waves split K, this wave takes the 8-k blocks wave, wave+NW, ...; the A and B
 // fragments (row = lane&31, k = 8*kb + 4*(lane>>5) .. +3) go global -> registers directly in MFMA

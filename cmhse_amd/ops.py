@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (MATH_BF16X3, MATH_BF16X6, MAX_JOBS, POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
+from ._lib import (MATH_BF16X3, MAX_JOBS, POOL_ALL, POOL_ATTN, POOL_LAST, POOL_MAX, POOL_OF,  # noqa: F401
                    SAVE_FOR_BACKWARD)
 
 
@@ -195,16 +195,14 @@ _MATH_MODE = ['fp32']
 
 
 def math_mode():
-  """'fp32' (exact, default), 'bf16x3' (3-term bf16 split on the matrix pipe for the large inference
-  GEMMs; ~2^-17 per product, ~1e-6 on the embeddings) or 'bf16x6' (3-way split, six products: ~2^-24
-  per product, fp32-grade — at the exact path's own rank noise floor — but not bit-identical to the
-  fp32 chain).  Both are opt-ins outside the bit-identical-ranks contract.  Set with set_math_mode()."""
+  """'fp32' (exact, default) or 'bf16x3' (3-term bf16 split on the matrix pipe for the large
+  inference GEMMs; ~1e-6 on the embeddings).  Set with set_math_mode()."""
   return _MATH_MODE[0]
 
 
 def set_math_mode(mode):
-  if mode not in ('fp32', 'bf16x3', 'bf16x6'):
-    raise ValueError("math mode must be 'fp32', 'bf16x3' or 'bf16x6'")
+  if mode not in ('fp32', 'bf16x3'):
+    raise ValueError("math mode must be 'fp32' or 'bf16x3'")
   _MATH_MODE[0] = mode
 
 
@@ -500,8 +498,6 @@ def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=N
   mode_flags = pool_mode | (SAVE_FOR_BACKWARD if save_for_backward else 0)
   if math_mode() == 'bf16x3' and not save_for_backward:
     mode_flags |= MATH_BF16X3
-  elif math_mode() == 'bf16x6' and not save_for_backward:
-    mode_flags |= MATH_BF16X6
   ws_bytes = lib.cmhse_gru_pool_workspace(S, sched.Tmax, sched.sum_T, I, H, mode_flags)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
 

@@ -65,12 +65,6 @@ enum {
    * product, ~1e-6 on the embeddings (parity bar 1e-4), ~5x the matrix rate of exact fp32.
    * Default (flag clear) is exact fp32. */
   CMHSE_MATH_BF16X3 = 0x200,
-  /* OR-ed into pool_mode (round 5): the same GEMMs with a 3-way split, x = x_h + x_m + x_l exactly
-   * (8 + 8 + 8 significand bits), six products per term (hh, hm, mh, hl, lh, mm), fp32 accumulate:
-   * ~2^-24 per product — fp32-GRADE, not bit-identical to the fp32 chain — at ~2x the matrix rate of
-   * exact fp32 (profiles/r05_bf16x6_rate.txt).  Inference only.  Wins over CMHSE_MATH_BF16X3 when
-   * both are set. */
-  CMHSE_MATH_BF16X6 = 0x800,
   /* OR-ed into the pool_mode of a cmhse_gru_job / cmhse_gru_bwd_job that has its own `stream`: the
    * call does NOT order its own stream argument behind that stream when it returns.  The job's
    * results are then ready on the job's stream only; a later job on the same stream may consume

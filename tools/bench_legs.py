@@ -214,7 +214,7 @@ def rank_noise_floor(wl, opt, model, spec, n_sample_batches, n_full):
   }
 
 
-def fast_mode_bench(opt, model, batches, N, n_steps, mode='bf16x3'):
+def fast_mode_bench(opt, model, batches, N, n_steps):
   """Supplementary: the same validation pass with CMHSE_MATH_BF16X3 (3-term bf16 hi/lo split on
   the bf16 matrix pipe, fp32 accumulate, for the large encoder GEMMs; ranking stays exact fp32),
   with its measured deviation from the exact-fp32 embeddings and ranks, and its own roofline: the
@@ -230,7 +230,7 @@ def fast_mode_bench(opt, model, batches, N, n_steps, mode='bf16x3'):
 
   ref_cat, ref_i, ref_t = one_pass()          # exact fp32
   try:
-    ops.set_math_mode(mode)
+    ops.set_math_mode('bf16x3')
     with ops.StepTimers() as wt:
       one_pass()
       torch.cuda.synchronize()
@@ -248,8 +248,7 @@ def fast_mode_bench(opt, model, batches, N, n_steps, mode='bf16x3'):
   flops = sum(s[3][1] for s in spans)
   launches = sum(s[3][3] for s in spans)
   achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-  products = 6 if mode == 'bf16x6' else 3
-  peak = BF16_MFMA_PEAK_TFLOPS / products
+  peak = BF16_MFMA_PEAK_TFLOPS / 3.0
   diff = max(float((cat[k] - ref_cat[k]).abs().max()) for k in ['vid_emb', 'para_emb', 'clip_emb',
                                                                  'cap_emb', 'vid_ctx', 'para_ctx'])
   moved = int((r_i != ref_i).sum()) + int((r_t != ref_t).sum())
@@ -266,21 +265,19 @@ def fast_mode_bench(opt, model, batches, N, n_steps, mode='bf16x3'):
   pert_i, _ = ops.sim_rank(ops.l2norm_rows(ad + dev_v), ops.l2norm_rows(bd + dev_p))
   pert_t, _ = ops.sim_rank(ops.l2norm_rows(bd + dev_p), ops.l2norm_rows(ad + dev_v))
   moved_corr = int((pert_i != base_i).sum()) + int((pert_t != base_t).sum())
-  what = ('bf16x6: x = x_h + x_m + x_l (three bf16 pieces), products hh + hm + mh + hl + lh + mm'
-          if mode == 'bf16x6' else 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi')
-  return {'math': what + ' on v_mfma_f32_32x32x16_bf16, fp32 '
+  return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
                   'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
                   'attention projection); ranking kernel exact fp32',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
           'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
           'rank_rows_moved_vs_fp32_random_init': moved, 'rank_rows_total': 2 * N,
           'rank_rows_moved_on_correlated_embeddings': moved_corr,
-          'roofline': {'kernel': 'gru_step_kernel<%s>' % mode, 'bound': 'mfma', 'achieved': achieved,
+          'roofline': {'kernel': 'gru_step_kernel<bf16x3>', 'bound': 'mfma', 'achieved': achieved,
                        'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent products)',
                        'frac': achieved / peak, 'launches': launches,
                        'avg_launch_us': (ms * 1e3 / launches) if launches else None,
                        'kernel_time_share': (ms * 1e-3) / (dt * n_steps) if dt > 0 else None,
-                       'note': 'peak = dense bf16 MFMA 2500 TFLOP/s / %d MFMAs per product' % products}}
+                       'note': 'peak = dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product'}}
 
 
 def rank_check(N, D, n_sample=256, seed=0):
