@@ -417,3 +417,41 @@ def test_plan_key_sees_every_batch():
   replaced[2] = (mid[0].clone(),) + tuple(mid[1:])      # same values, new storage
   assert evaluation._plan_key(replaced) != k0
   assert evaluation._plan_key(batches[:-1] ) != k0
+
+
+def test_tuning_contexts_at_the_abi_without_gpu():
+  """cmhse_ctx_* (include/cmhse_hip.h): a context is a private copy of the crossovers taken at
+  creation; tuning it or the process defaults does not touch the other; cmhse_ctx_enter makes it the
+  calling thread's current context (what every crossover read inside the library then uses) and
+  returns the previous one; other threads keep the defaults.  No GPU involved."""
+  import ctypes
+  import threading
+  from cmhse_amd import _lib
+  lib = _lib.load()
+  old = ctypes.c_int32(0)
+  assert lib.cmhse_tune(b'mid_units', -1, ctypes.byref(old)) == 0
+  default = old.value
+  ctx = lib.cmhse_ctx_create()
+  assert ctx
+  try:
+    assert lib.cmhse_ctx_tune(ctx, b'mid_units', 8, ctypes.byref(old)) == 0 and old.value == default
+    assert lib.cmhse_ctx_tune(ctx, b'mid_units', -1, ctypes.byref(old)) == 0 and old.value == 8
+    assert lib.cmhse_tune(b'mid_units', -1, ctypes.byref(old)) == 0 and old.value == default   # defaults untouched
+    assert lib.cmhse_ctx_tune(ctx, b'no_such_knob', 1, None) == -1
+    assert lib.cmhse_ctx_tune(None, b'mid_units', 1, None) == -1
+    # workspace sizing reads the CURRENT context: mid_max_seqs bounds the hoisted-projection region
+    size = lambda: lib.cmhse_gru_pool_workspace(5000, 40, 100000, 512, 256, 0)
+    outside = size()
+    assert lib.cmhse_ctx_tune(ctx, b'mid_max_seqs', 0, None) == 0
+    prev = lib.cmhse_ctx_enter(ctx)
+    assert not prev
+    try:
+      inside = size()
+      seen = []
+      t = threading.Thread(target=lambda: seen.append(size()))     # another thread: no context
+      t.start(); t.join()
+    finally:
+      assert lib.cmhse_ctx_enter(prev) == ctx
+    assert inside < outside and seen == [outside] and size() == outside
+  finally:
+    lib.cmhse_ctx_destroy(ctx)

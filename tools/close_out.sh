@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5 close-out: full GPU test suite, the default bench line, profiles
+# round close-out: full GPU test suite, the default bench line, profiles (tools/collect_profiles.sh); copy the results to profiles/rNN_*
 out=gpurun_out/r05_final
 mkdir -p $out
 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1
