@@ -1668,6 +1668,20 @@ def test_tuning_contexts_do_not_share_state(dev):
     assert torch.equal(a, b)
 
 
+def test_concurrent_calls_do_not_disturb_each_other(dev):
+  """tools/bystander_check.py: a complete attention-pooled encoder call (step chain, attention
+  projection, pooling) stays bit-identical while another encoder's per-step launches run on a second
+  stream, in every math mode that ships.  (An abandoned bf16x6 mode failed exactly this in 2 of 3
+  repetitions, profiles/r05_bf16x6_rate.txt; any new kernel of the library should pass it.)"""
+  import subprocess
+  import sys
+  from conftest import REPO
+  res = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'bystander_check.py'), '--reps', '12'],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-2000:]
+  assert res.stdout.count('0 of 12 repetitions') == 2, res.stdout[-2000:]
+
+
 def test_abi_error_codes_on_device(dev):
   """Error behaviour of the C ABI with real device buffers: too-small / misaligned workspace,
   bad stripe, bad pooling mode -> negative codes, nothing launched, no exception across the ABI."""
