@@ -312,9 +312,10 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
 // bf16x3 variant of nt_phase ("CMHSE_MATH_BF16X3"): fp32-grade products on the bf16 matrix pipe.
 //   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,  x_hi = bf16(x), x_lo = bf16(x - x_hi)
 // (relative error ~2^-17 per product, fp32 accumulation; measured 1e-6 on the normalised
-// embeddings after 80 GRU steps, against the 1e-4 parity bar).  Three v_mfma_f32_32x32x16_bf16
-// (32 cycles each, 16 k) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each): 5.3x less matrix
-// time per chunk, so this loop is paced by operand staging, not by the MFMAs.
+// embeddings after 80 GRU steps, against the 1e-4 parity bar).  Six v_mfma_f32_32x32x8_bf16_1k
+// (32 cycles each, 8 k: mfma_bf16_16k below, and why it is not three v_mfma_f32_32x32x16_bf16) replace
+// eight v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x less matrix time per chunk; the loop is paced
+// by operand staging and the in-register split of A as much as by its MFMAs.
 //   * A stays fp32 in HBM and LDS; each lane splits its 8-k fragment in registers (v_cvt_pk).
 //   * B (weights) is pre-split once per call by split_bf16x3_kernel into rows of the SAME byte
 //     length: per 16-k chunk 32 B of hi (16 bf16) then 32 B of lo, so the global->LDS staging code
@@ -324,6 +325,28 @@ __device__ __forceinline__ void nt_phase(float* smem, const rowaddr_t (&arow)[BM
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// One 32 x 32 x 16 bf16 product step: lane l holds A[l & 31][8 (l >> 5) + 0..7] and the matching B.
+// gfx950's v_mfma_f32_32x32x16_bf16 does it in one instruction (8 passes) — and is NOT used: while waves
+// of a kernel issue the double-rate matrix instructions gfx950 added (32x32x16 bf16/f16, 16x16x32 bf16,
+// 32x32x32 i8: 128-bit A/B operands), a v_pk_fma_f32 of ANOTHER wave on the same SIMD now and then loses
+// the write of lanes 48-63 of one of its two result registers (tools/microbench/pkfma_lost_update.hip:
+// up to 3 % of a bystander's sums wrong; profiles/r05_bf16_mfma_bystander.txt).  The two-instruction
+// form on v_mfma_f32_32x32x8_bf16_1k (each lane's first four k, then its last four; the k order inside
+// a chunk is free as long as A and B agree) shows no such effect and the loop is paced by operand
+// staging, not by its MFMAs.  CMHSE_BF3_MFMA_32X32X16 restores the single instruction (experiments).
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16_16k(bf16x8_t a, bf16x8_t b, f32x16 c) {
+#ifdef CMHSE_BF3_MFMA_32X32X16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  const bf16x4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+  const bf16x4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+  c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a0, b0, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b1, c, 0, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // round-to-nearest-even pair
   f32x2_t v = {a, b};
@@ -431,9 +454,9 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
         const bf16x8 b_l = __builtin_bit_cast(bf16x8, bl[ns]);
         constexpr int kLast = LAST;
         const int ai = (ns == NSUB - 1) ? kLast : ns;
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_h, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_l, acc[ms][ai], 0, 0, 0);
-        acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, b_h, acc[ms][ai], 0, 0, 0);
+        acc[ms][ai] = mfma_bf16_16k(a_l, b_h, acc[ms][ai]);
+        acc[ms][ai] = mfma_bf16_16k(a_h, b_l, acc[ms][ai]);
+        acc[ms][ai] = mfma_bf16_16k(a_h, b_h, acc[ms][ai]);
       }
     }
   };

@@ -455,3 +455,15 @@ def test_tuning_contexts_at_the_abi_without_gpu():
     assert inside < outside and seen == [outside] and size() == outside
   finally:
     lib.cmhse_ctx_destroy(ctx)
+
+
+def test_device_code_holds_neither_half_of_the_lost_update_pair():
+  """profiles/r05_bf16_mfma_bystander.txt: on gfx950 a v_pk_fma_f32 loses updates while another wave of its SIMD
+  issues the double-rate matrix instructions.  The shipped library contains neither (build.py DEVICE_FLAGS,
+  nt_core.hpp::mfma_bf16_16k): disassemble its three code objects and look."""
+  from cmhse_amd import build
+  lib = build.build()
+  assert len(build.code_objects(lib)) == len(build.SOURCES)
+  assert build.audit_isa(lib) == {}
+  # the audit does see what it is looking for: the matrix instructions the library DOES use
+  assert build.audit_isa(lib, forbidden=('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x8_bf16_1k'))

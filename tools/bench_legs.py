@@ -265,7 +265,7 @@ def fast_mode_bench(opt, model, batches, N, n_steps):
   pert_i, _ = ops.sim_rank(ops.l2norm_rows(ad + dev_v), ops.l2norm_rows(bd + dev_p))
   pert_t, _ = ops.sim_rank(ops.l2norm_rows(bd + dev_p), ops.l2norm_rows(ad + dev_v))
   moved_corr = int((pert_i != base_i).sum()) + int((pert_t != base_t).sum())
-  return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 '
+  return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x8_bf16_1k pairs, fp32 '
                   'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
                   'attention projection); ranking kernel exact fp32',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,

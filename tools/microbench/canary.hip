@@ -96,6 +96,73 @@ __global__ __launch_bounds__(256) void canary_kernel(uint32_t* report, const uin
   if (bad_b) atomicAdd(&report[6], 1u);
 }
 
+// The attention-pooling kernel's inner loop on data whose sums are exact: acc[k] += w[j] * h[row_j][4 tid + k] with
+// w = 1 and h small integers, rows and weights staged in LDS and read back as broadcasts, four 16-byte row loads in
+// flight (the compiler emits v_pk_fma_f32 for the four accumulators, as in attn_pool_kernel).  Every workgroup
+// re-derives the sums in integer arithmetic; a lost update shows up as a deficit that names the step it belongs to.
+// report[0] = workgroup-iterations checked (low word), report[1] = mismatching (thread, component) pairs,
+// report[8 + 8 i ..] = the first 14 mismatches: block, iteration, thread, component, got, want, step count, 0.
+__global__ __launch_bounds__(256) void pkfma_canary_kernel(uint32_t* report, const float* __restrict__ hs, int rows,
+                                                           int len, int iters) {
+  __shared__ float s_w[256];
+  __shared__ long long s_row[256];
+  const int tid = threadIdx.x, u = 4 * tid;
+  uint32_t bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    __syncthreads();
+    if (tid < len) {
+      s_row[tid] = static_cast<long long>((blockIdx.x * 131u + it * 17u + tid * 29u) % static_cast<uint32_t>(rows));
+      s_w[tid] = 1.0f;
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < len; ++j) {
+      const float4 h = *reinterpret_cast<const float4*>(hs + s_row[j] * 1024 + u);
+      const float wgt = s_w[j];
+      a0 += wgt * h.x;
+      a1 += wgt * h.y;
+      a2 += wgt * h.z;
+      a3 += wgt * h.w;
+    }
+    uint32_t e[4] = {0, 0, 0, 0};
+    for (int j = 0; j < len; ++j) {
+      const uint32_t r = static_cast<uint32_t>(s_row[j]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] += (r * 5u + (u + k) * 3u) & 31u;
+    }
+    const float got[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (got[k] != static_cast<float>(e[k])) {
+        ++bad;
+        const uint32_t slot = atomicAdd(&report[2], 1u);
+        if (slot < 14) {
+          uint32_t* q = report + 8 + 8 * slot;
+          q[0] = blockIdx.x; q[1] = it; q[2] = tid; q[3] = k; q[4] = __float_as_uint(got[k]); q[5] = e[k]; q[6] = len;
+        }
+      }
+  }
+  if (tid == 0) atomicAdd(&report[0], static_cast<uint32_t>(iters));
+  if (bad) atomicAdd(&report[1], bad);
+}
+
+__global__ void fill_rows_pattern(float* p, uint32_t n) {      // hs[row][c] = (5 row + 3 c) & 31, 1024 columns
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = static_cast<float>(((i >> 10) * 5u + (i & 1023u) * 3u) & 31u);
+}
+
+extern "C" int pkfma_canary_fill(float* hs, uint32_t rows, void* stream) {
+  const uint32_t n = rows * 1024u;
+  hipLaunchKernelGGL(fill_rows_pattern, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), hs, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int pkfma_canary_launch(uint32_t* report, const float* hs, int rows, int len, int blocks, int iters, void* stream) {
+  hipLaunchKernelGGL(pkfma_canary_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), report, hs, rows, len, iters);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 __global__ void fill_pattern(uint32_t* p, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i * 2654435761u + 7u;
