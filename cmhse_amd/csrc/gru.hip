@@ -1680,6 +1680,7 @@ static int resident_status(bool clear) {
     for (Tunables* t : both) {
       t->chain_min_steps.store(0, std::memory_order_relaxed);
       t->fwd_tail_min_steps.store(0, std::memory_order_relaxed);
+      t->infer_tail_min_steps.store(0, std::memory_order_relaxed);
       t->bwd_tail_min_steps.store(0, std::memory_order_relaxed);
       t->bwd_chain_min_steps.store(0, std::memory_order_relaxed);
     }
@@ -2362,19 +2363,34 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (!seen) stream_after(jobs[k].own_stream, main_stream);
       js[k] = jobs[k].own_stream;
     }
-  // The few-sequence tail of a training chain on its own stream: one resident kernel (below).
+  // The few-sequence tail of a chain as one resident kernel (below): of a training chain on its own
+  // stream, and — opt-in, infer_tail_min_steps — of an inference chain behind its small-batch steps
+  // (the end of a rank's share of the validation split is the text tower's tail, 319 dependent
+  // launches of 7-11 us with at most 32 paragraphs still active).  The tail kernel's arithmetic is the
+  // small-batch kernel's (gru_step_mid_kernel<1, 16, 8>), so the choice follows the LOCAL counts and
+  // leaves the bits alone; it only ever replaces small-batch steps (t > t_mid).  Measured SLOWER for
+  // inference (a share 40.3 -> 42.2 ms, the split 271.6 -> 277.7: 64 resident workgroups at a barrier
+  // per step beside the attention pass lose to 7-us launches that use every CU; profiles/r05_rank_share.txt).
   for (int k = 0; k < n; ++k) {
     FwdJob& j = jobs[k];
     j.tail_lo = -1;
     j.chain_until = 0;
     const cmhse_seq_batch* b = j.b;
-    const int min_steps = tunables().fwd_tail_min_steps.load(std::memory_order_relaxed);
-    if (min_steps <= 0 || !j.save || j.bf3 || !j.vec || js[k] == main_stream || j.t_mid != 0 ||
-        b->H % 16 != 0 || b->H > 1024 || timer != nullptr ||
+    const int min_steps = j.save ? tunables().fwd_tail_min_steps.load(std::memory_order_relaxed)
+                                 : tunables().infer_tail_min_steps.load(std::memory_order_relaxed);
+    if (min_steps <= 0 || j.bf3 || !j.vec || b->H % 16 != 0 || b->H > 1024 || timer != nullptr ||
         !resident_fits(b->H / 16))
       continue;
+    int floor_t = 1;
+    if (j.save) {
+      if (js[k] == main_stream || j.t_mid != 0) continue;
+    } else {
+      // (its hoisted projection is launched or waited for at t_mid: the tail starts behind that step)
+      if (j.own_stream != nullptr || b->step_events_host != nullptr || j.t_mid >= b->Tmax) continue;
+      floor_t = j.t_mid + 1;
+    }
     int lo = b->Tmax;
-    while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= kFwdTailMaxSeqs) --lo;
+    while (lo - 1 >= floor_t && b->step_count_host[lo - 1] <= kFwdTailMaxSeqs) --lo;
     if (b->Tmax - lo < min_steps) continue;
     j.tail_lo = lo;
     (void)hipMemsetAsync(j.wsb + j.L.tail_sync, 0, 256, js[k]);   // the barrier counter, off the chain's path
@@ -2424,7 +2440,8 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     bool any_tiled = false;
     int mid_blocks = 0;
     for (int k = 0; k < n; ++k)
-      if (t < jobs[k].b->Tmax && t >= jobs[k].t_mid) mid_blocks += mid_m_blocks(jobs[k].b->step_count_host[t]);
+      if (t < jobs[k].b->Tmax && t >= jobs[k].t_mid && !(jobs[k].tail_lo >= 0 && t >= jobs[k].tail_lo))
+        mid_blocks += mid_m_blocks(jobs[k].b->step_count_host[t]);
     bool alone = !forked;
     int tiled_wgs = 0;
     for (int k = 0; k < n; ++k)
@@ -2452,6 +2469,7 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       const int S_t = j.b->step_count_host[t];
       if (j.tail_lo >= 0 && t >= j.tail_lo) {      // the resident kernel does this step
         if (t == j.tail_lo) {
+          if (any_tiled) fork(k);                  // (a), as for a small-batch step below
           for (size_t c = 0; c < plan[k].step.size(); ++c)
             if (plan[k].ev[c] != nullptr) {        // its rows' projection chunks, all of them
               (void)hipStreamWaitEvent(js[k], plan[k].ev[c], 0);
@@ -2886,7 +2904,7 @@ extern "C" void* cmhse_ctx_create(void) {
   Tunables& g = global_tunables();
   static const char* const names[] = {
       "tiny_max_seqs", "mid_max_seqs", "mid_units", "mid_waves", "tall_tile_min_wgs", "bwd_mid_max_seqs",
-      "bwd_split_min_seqs", "bwd_tail_min_steps", "fwd_tail_min_steps", "mid_tall_min_seqs", "bwd_chunk_rows",
+      "bwd_split_min_seqs", "bwd_tail_min_steps", "fwd_tail_min_steps", "infer_tail_min_steps", "mid_tall_min_seqs", "bwd_chunk_rows",
       "bwd_chain_min_steps", "bwd_fused_step", "xproj_chunk_rows", "tn_rows_bm", "chain_min_steps", "chain_attention",
       "chain_col_map", "early_xproj", "chain_tall_min_wgs", "resident_timeout_ms"};
   for (const char* n : names) {
@@ -2920,7 +2938,7 @@ int tune_in(Tunables& t, const char* name, int32_t value, int32_t* old_value) {
       {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
       {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
       {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
+      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"infer_tail_min_steps", &t.infer_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
       {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_col_map", &t.chain_col_map}, {"early_xproj", &t.early_xproj}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
       {"resident_timeout_ms", &t.resident_timeout_ms}};
   for (auto& e : table)

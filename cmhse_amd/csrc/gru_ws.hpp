@@ -91,6 +91,7 @@ struct Tunables {
   std::atomic<int> early_xproj{1};
   std::atomic<int> chain_tall_min_wgs{256};  // 64-row workgroups per step from which a step chain uses 128-row tiles (per-step launches: tall_tile_min_wgs)
   std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
+  std::atomic<int> infer_tail_min_steps{0};  // (opt-in; measured slower, profiles/r05_rank_share.txt) the same for the few-sequence tail of an inference chain
 };
 Tunables& tunables();
 static inline int mid_max_seqs() { return tunables().mid_max_seqs.load(std::memory_order_relaxed); }
@@ -146,8 +147,8 @@ static inline GruWs gru_ws_layout(int32_t S, int64_t sum_T, int32_t H, int32_t m
   L.gx = off;   // last region: the backward pass never looks at it (it calls this without Tmax)
   if (I % 4 == 0 && H % 4 == 0)
     off += ws_align(static_cast<size_t>(gx_rows_bound(S, Tmax, sum_T)) * 3 * H * sizeof(float));
-  L.tail_sync = off;   // barrier counter of gru_fwd_tail_kernel (training calls)
-  if (save) off += 256;
+  L.tail_sync = off;   // barrier counter of gru_fwd_tail_kernel
+  off += 256;
   // step-chain kernel (inference calls): 8 task tickets + the abort word, then one counter per
   // (step of a chain launch, 64-row tile)
   L.chain_sync = off;

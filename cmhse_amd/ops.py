@@ -92,7 +92,7 @@ def tune(name, value=-1):
   """cmhse_tune: set (value >= 0) or read (value < 0) one kernel-shape crossover of the library;
   returns its previous value.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
   tall_tile_min_wgs, mid_tall_min_seqs, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
-  fwd_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, bwd_chain_min_steps,
+  fwd_tail_min_steps, infer_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, bwd_chain_min_steps,
   bwd_fused_step, chain_min_steps, chain_attention, chain_col_map, early_xproj, chain_tall_min_wgs,
   resident_timeout_ms
   (include/cmhse_hip.h)."""

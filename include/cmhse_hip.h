@@ -451,6 +451,9 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             workgroups resident (one per CU): at most four such chains at once
  *   "fwd_tail_min_steps"   4  the same for the forward chain of a training call
  *                             (CMHSE_SAVE_FOR_BACKWARD, job on its own stream)
+ *   "infer_tail_min_steps"  0 (opt-in; measured slower than one launch per step) ... and for the
+ *                             few-sequence tail (<= 32 active) of an inference chain behind its
+ *                             small-batch steps; bit-identical to the per-step launches it replaces
  *   "bwd_chain_min_steps"  0  (opt-in; measured slower than the default two launches per step,
  *                             profiles/r04_chain_resident.txt) BPTT steps with 33-256 active sequences from which ONE request of a call
  *                             (the one with the most) runs them inside resident kernels — (H / 128) x

@@ -1551,6 +1551,68 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
       assert torch.equal(h1, h2)
 
 
+@pytest.mark.parametrize('shape', ['text_tower', 'all_small', 'two_towers'])
+def test_inference_tail_as_one_resident_kernel_is_bit_identical(dev, tune, shape):
+  """The few-sequence tail of an INFERENCE chain (the steps behind the last one with more than 32 active
+  sequences: the long paragraphs of the text tower, 319 dependent launches at the end of a rank's share of the
+  validation split) inside ONE resident kernel (gru_fwd_tail_kernel, a grid barrier per step;
+  infer_tail_min_steps, opt-in: measured slower, profiles/r05_rank_share.txt) against one small-batch
+  launch per step (= 0, the default): pooled outputs and every hidden state equal bit for bit, for every
+  pooling, repeated, no timeout recorded.
+    text_tower   2400 short sequences + a few long ones: LDS-tiled steps (a chain), small-batch steps, then the tail
+    all_small    a request that is small-batch from its first step (the level-2 encoders' shape), initial states
+    two_towers   a second, tiled request still running when the first one's tail starts: the tail forks to the
+                 side stream, the attention pass of the request that ends first overlaps it"""
+  from cmhse_amd import _lib, ops
+  rng = np.random.RandomState(5)
+  g = torch.Generator().manual_seed(18)
+  keep = []
+
+  def request(lens, I, H, mode, h0=False):
+    S, T = len(lens), int(max(lens))
+    w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.2), w_hh=torch.randn(3 * H, H, generator=g).mul_(0.1),
+             b_ih=torch.randn(3 * H, generator=g).mul_(0.1), b_hh=torch.randn(3 * H, generator=g).mul_(0.1))
+    if mode == ops.POOL_ATTN:
+      w.update(w_lin=torch.randn(H, H, generator=g).mul_(0.1), b_lin=torch.randn(H, generator=g).mul_(0.1),
+               w_att=torch.randn(1, H, generator=g).mul_(0.2))
+    x = torch.randn(S, T, I, generator=g).to(dev)
+    keep.append(x)
+    r = dict(weights={k: v.to(dev) for k, v in w.items()}, pool_mode=mode, lens=np.asarray(lens, dtype=np.int64),
+             I=I, H=H, device=dev, x_ptrs=ops.padded_row_ptrs(x))
+    if h0:
+      h = torch.randn(S, H, generator=g).to(dev)
+      keep.append(h)
+      r.update(h0_ptrs=ops.padded_row_ptrs(h))
+    return r
+
+  def long_tailed(n_short, t_short, n_long, t_long):
+    return np.concatenate([rng.randint(1, t_short + 1, size=n_short), rng.randint(t_short, t_long + 1, size=n_long)])
+
+  if shape == 'text_tower':
+    reqs = [request(long_tailed(2400, 9, 40, 70), 300, 1024, m) for m in (ops.POOL_ATTN, ops.POOL_MAX)]
+  elif shape == 'all_small':
+    reqs = [request(long_tailed(100, 6, 20, 45), 64, 256, ops.POOL_LAST, h0=True),
+            request(long_tailed(60, 5, 30, 40), 64, 256, ops.POOL_ALL)]
+  else:
+    reqs = [request(long_tailed(1500, 8, 30, 60), 300, 1024, ops.POOL_ATTN),
+            request(np.full(1300, 48), 128, 1024, ops.POOL_ATTN)]
+
+  def run(min_steps):
+    tune(infer_tail_min_steps=min_steps)
+    res = ops.gru_pool_fwd_multi(reqs)
+    torch.cuda.synchronize()
+    assert _lib.load().cmhse_async_status(0) == 0
+    return [(o.clone(), c['ws'][:c['sched'].sum_T * c['H'] * 4].clone()) for o, c in res]
+
+  per_step = run(0)
+  for _ in range(3):
+    for (o1, h1), (o2, h2) in zip(per_step, run(16)):
+      assert torch.equal(o1, o2)
+      assert torch.equal(h1, h2)
+  for (o1, h1), (o2, h2) in zip(per_step, run(1)):      # (a tail of any length)
+    assert torch.equal(o1, o2) and torch.equal(h1, h2)
+
+
 def test_step_chain_failure_modes_are_an_error_or_a_correct_result(dev, tune):
   """the chain's two assumptions, forced.  (a) A chain while another stream
   saturates the chip with GEMMs (the workgroups of the chain start late and far apart, a dependency
