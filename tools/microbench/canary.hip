@@ -1,4 +1,4 @@
-// Bystander canary: small workgroups (256 threads, 3 KB of LDS, ~40 live VGPRs) that fill their LDS and
+// (1) canary_kernel — bystander canary: small workgroups (256 threads, 3 KB of LDS, ~40 live VGPRs) that fill their LDS and
 // registers with patterns and re-check them for a while, re-read a global pattern buffer through the
 // vector L1, and recompute a little floating-point math (expf, division) that must repeat bit for bit.
 // Run on one stream while a suspect kernel runs on another: any mismatch means a CO-RESIDENT
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void canary_kernel(uint32_t* report, const uin
   if (bad_b) atomicAdd(&report[6], 1u);
 }
 
+// (2) pkfma_canary_kernel (tools/pkfma_canary.py) — the one that found it, profiles/r05_bf16_mfma_bystander.txt.
 // The attention-pooling kernel's inner loop on data whose sums are exact: acc[k] += w[j] * h[row_j][4 tid + k] with
 // w = 1 and h small integers, rows and weights staged in LDS and read back as broadcasts, four 16-byte row loads in
 // flight (the compiler emits v_pk_fma_f32 for the four accumulators, as in attn_pool_kernel).  Every workgroup
