@@ -2006,7 +2006,7 @@ def _check_train_step_vs_oracle(model, opt, batch, oracle, rnn_type, recorder, r
     flipped += n_diff
     pairs += n_pairs
   if rnn_type == 'maxout':
-    # measured 0-1 of ~350,000 (sequence, unit) pairs per step (profiles/r05_maxout_route_flips.txt)
+    # measured 0-2 of ~350,000 (sequence, unit) pairs per step (profiles/r05_maxout_route_flips.txt)
     assert pairs > 0 and flipped <= 8, '%d of %d (sequence, unit) pairs routed away from the fp64 arg-max' % (flipped, pairs)
   for i, m in enumerate(model._modules()):
     for pn, pp in m.named_parameters():
