@@ -22,5 +22,5 @@ rm -rf $D/pmc_FETCH_SIZE $D/pmc_WRITE_SIZE $D/pmc_SQ
 python tools/summarize_rocprof.py $D/stats/*/*kernel_stats.csv "round $ROUND, final kernels: rocprofv3 --kernel-trace --stats -- python3 $B (anet_icep_val, exact fp32, every pass rebuilds its schedules)" > $D/kernel_stats.md
 python tools/trace_timeline.py $D/stats/*/*kernel_trace.csv > $D/pass_timeline.txt
 rm -rf $D/stats
-python tools/tile_trace.py 22419 2048 1024 > $D/tile_trace.txt 2>&1
+python tools/tile_trace.py 22419 2048 1024 2> $D/tile_trace.err | grep -v "amdgpu.ids" > $D/tile_trace.txt
 head -30 $D/kernel_stats.md; tail -3 $D/bench_under_rocprof.json | cut -c1-400
