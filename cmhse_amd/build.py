@@ -96,14 +96,16 @@ def is_stale():
 
 
 def build(force=False, verbose=False, extra_flags=(), out=None, device_flags=None):
-  """Build the product library (default) or, with `out` / `extra_flags`, another build of the same
-  sources at another path (tools/: instrumented builds; load it through CMHSE_HIP_LIB)."""
+  """Build the product library (default) or, with `out` / `extra_flags` / `device_flags`, another
+  build of the same sources at another path (tools/: instrumented and A/B builds; load it through
+  CMHSE_HIP_LIB).  The product build is audited (audit_isa) before it replaces the library."""
   global LIB
   if out is None and not extra_flags and device_flags is None and not force and not is_stale():
     return LIB
   target = out or LIB
-  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared'] + list(DEVICE_FLAGS if device_flags is None else device_flags) + [
-      '-o', target + '.tmp'] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
+  cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
+  cmd += list(DEVICE_FLAGS if device_flags is None else device_flags)
+  cmd += ['-o', target + '.tmp'] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
   if verbose:
     cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
   res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

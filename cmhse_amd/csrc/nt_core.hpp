@@ -333,11 +333,11 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // the write of lanes 48-63 of one of its two result registers (tools/microbench/pkfma_lost_update.hip:
 // up to 3 % of a bystander's sums wrong; profiles/r05_bf16_mfma_bystander.txt).  The two-instruction
 // form on v_mfma_f32_32x32x8_bf16_1k (each lane's first four k, then its last four; the k order inside
-// a chunk is free as long as A and B agree) shows no such effect and the loop is paced by operand
-// staging, not by its MFMAs.  CMHSE_BF3_MFMA_32X32X16 restores the single instruction (experiments).
+// a chunk is free as long as A and B agree) shows no such effect; it costs the bf16x3 pass 17 % (the
+// mode is 1.7x the exact path instead of 2.0x).  CMHSE_BF3_MFMA_32X32X16 restores the single
+// instruction (experiments only: build.py::audit_isa refuses such a library).
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_bf16_16k(bf16x8_t a, bf16x8_t b, f32x16 c) {
+__device__ __forceinline__ f32x16 mfma_bf16_16k(bf16x8 a, bf16x8 b, f32x16 c) {
 #ifdef CMHSE_BF3_MFMA_32X32X16
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #else
