@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void tile_offender_kernel(float* sink, const f
 
 // Synthetic mixes in ONE offender wave: four MFMAs (bf16 32x32x16 or fp32 32x32x2, constant or LDS-fed operands) and
 // NV VALU instructions of one kind between them, per loop trip.
-enum { V_NONE, V_PK_ADD, V_CVT_PK, V_FMAC, V_PK_FMA, V_PK_MUL, V_MOV };
+enum { V_NONE, V_PK_ADD, V_CVT_PK, V_FMAC, V_PK_FMA, V_PK_MUL, V_MOV, V_SNOP };
 template <bool BF16, int VALU, int NV, bool LDS_FED, bool BARRIER>
 __global__ __launch_bounds__(256) void combo_offender_kernel(float* sink, int iters) {
   extern __shared__ float4 lds[];
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void combo_offender_kernel(float* sink, int it
         if (VALU == V_CVT_PK) { uint32_t t; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(fx), "v"(fb)); pk += t; }
         if (VALU == V_FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(fx) : "v"(fb), "v"(fa));
         if (VALU == V_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(pk) : "v"(fx));
+        if (VALU == V_SNOP) asm volatile("s_nop 7");                        // 8 idle issue cycles, no instruction at all
       }
     }
     if (BARRIER) __syncthreads();
@@ -516,6 +517,8 @@ int main(int argc, char** argv) {
         {"bf16 MFMA + 2 v_mov_b32", launch_combo<true, V_MOV, 2, false, false>, 150000},
         {"bf16 MFMA + 6 v_fmac_f32", launch_combo<true, V_FMAC, 6, false, false>, 100000},
         {"bf16 MFMA + 6 v_pk_add_f32", launch_combo<true, V_PK_ADD, 6, false, false>, 100000},
+        {"bf16 MFMA + 6 s_nop 7 (idle gaps only)", launch_combo<true, V_SNOP, 6, false, false>, 100000},
+        {"bf16 MFMA + 2 s_nop 7", launch_combo<true, V_SNOP, 2, false, false>, 100000},
         {"fp32 MFMA + 2 v_pk_add_f32", launch_combo<false, V_PK_ADD, 2, false, false>, 40000},
         {"fp32 MFMA + 2 v_fmac_f32", launch_combo<false, V_FMAC, 2, false, false>, 40000},
         {"fp32 MFMA + 6 v_pk_add_f32", launch_combo<false, V_PK_ADD, 6, false, false>, 40000},
