@@ -71,7 +71,8 @@ from cmhse_amd.model import VSE  # noqa: E402
 # (tools/bench_legs.py); re-exported here because the tools and the full-size tests import them from bench
 from bench_common import (BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS, WORKLOADS, build_loader,  # noqa: E402,F401
                           device_batch, gru_flops_per_step, make_opt)
-from bench_legs import (TRAIN_CONFIGS, cpu_baseline, fast_mode_bench, measured_clock_ghz,  # noqa: E402,F401
+from bench_legs import (TRAIN_CONFIGS, cpu_baseline, dropin_validate_bench, fast_mode_bench,  # noqa: E402,F401
+                        measured_clock_ghz,
                         measured_step_latency_us, measured_traffic, rank_check, rank_noise_floor,
                         train_bench, train_step_work)
 
@@ -141,6 +142,9 @@ def main():
   ap.add_argument('--host_steps', type=int, default=10,
                   help='also time this many passes with the loader batches in pinned HOST memory '
                        '(PCIe-inclusive rate; never the headline value)')
+  ap.add_argument('--api_steps', type=int, default=10,
+                  help='also time this many passes through the reference API (train.py:223-236 via cmhse_amd/dropin: '
+                       'encode_data -> NumPy -> i2t -> t2i), resident and host-fed; 0 = skip')
   ap.add_argument('--rank_check', type=int, default=1,
                   help='check HIP ranks on correlated embeddings against fp64 NumPy (0 = skip)')
   ap.add_argument('--cpu_batches', type=int, default=16,
@@ -449,6 +453,7 @@ def main():
         leg_seconds['train_steps.' + name] = round(time.perf_counter() - t_leg, 2)
       if 'anet_icep_tau0' in out['train_steps']:      # round 2's key, same configuration
         out['train_step'] = out['train_steps']['anet_icep_tau0']
+    host_batches = [None]
     if world == 1 and args.host_steps > 0:
       def pcie_leg():
         # the reference's loader contract hands over host tensors (activity_net/data.py:114-150):
@@ -458,6 +463,7 @@ def main():
         host = [tuple(to_pinned(t) if isinstance(t, torch.Tensor) and t.is_cuda else t for t in b)
                 for b in batches]
         torch.cuda.synchronize()
+        host_batches[0] = host
 
         step(src=host)
         torch.cuda.synchronize()
@@ -472,6 +478,22 @@ def main():
                 'note': 'loader batches in pinned host memory, pulled chunk by chunk under the '
                         'step pipeline inside the timed pass; not the headline value'}
       leg('pcie_inclusive', pcie_leg)
+    if world == 1 and args.api_steps > 0:
+      # the pass through the reference's own API: NumPy out of encode_data, NumPy
+      # into i2t / t2i; `vs_device_pass` / `vs_pcie_inclusive` = its time over the corresponding leg above
+      def api_leg():
+        crc = lambda ri, rt: zlib.crc32(np.asarray(ri, dtype=np.int64).tobytes() +
+                                        np.asarray(rt, dtype=np.int64).tobytes())
+        res = dropin_validate_bench(opt, model, {'resident': batches, 'host_fed': host_batches[0]},
+                                    args.api_steps, crc)
+        res['resident']['vs_device_pass'] = res['resident']['ms_per_step'] / ms_per_step
+        res['resident']['ranks_equal_headline'] = res['resident']['ranks_crc32'] == out['ranks_crc32']
+        if 'host_fed' in res and isinstance(out.get('pcie_inclusive'), dict) and 'ms_per_step' in out['pcie_inclusive']:
+          res['host_fed']['vs_pcie_inclusive'] = res['host_fed']['ms_per_step'] / out['pcie_inclusive']['ms_per_step']
+          res['host_fed']['ranks_equal_headline'] = res['host_fed']['ranks_crc32'] == out['ranks_crc32']
+        return res
+      leg('dropin_validate', api_leg)
+      host_batches[0] = None
     if world == 1 and args.cpu_batches > 0:
       # north_star's baseline: "the reference PyTorch CPU path" -> the torch-CPU restatement; the NumPy
       # port (rounds 1-3's cpu_baseline) beside it on the same sample

@@ -522,3 +522,64 @@ def measured_clock_ghz():
         return None
   return None
 
+
+
+def dropin_validate_bench(opt, model, loaders, n_steps, crc_of):
+  """The pass as train.py runs it (train.py:223-236): `from evaluation import encode_data, i2t, t2i`
+  through the drop-in shims (cmhse_amd/dropin first on sys.path), encode_data -> six NumPy matrices
+  -> i2t(vid, para) -> t2i(vid, para) -> currscore, for every loader in `loaders` ({name: list of
+  12-tuples}: the split resident in HBM, and in pinned host memory as the reference's DataLoader
+  hands it over).  Per loader: ms per pass with the package's defaults (page-locked staging under the
+  level-2 encoders, the ranking queued by encode_data and served to i2t / t2i after a content check
+  of the arrays), the same with that reuse switched off ('recompute': i2t / t2i upload the arrays
+  and rank again), and the CRC of the integer ranks, which must equal the headline pass's."""
+  import importlib
+  import logging as pylog
+  from cmhse_amd import evaluation as core
+  dropin = os.path.join(REPO, 'cmhse_amd', 'dropin')
+  sys.path.insert(0, dropin)
+  try:
+    ev = importlib.import_module('evaluation')
+  finally:
+    sys.path.remove(dropin)
+  log = pylog.getLogger('cmhse_bench_validate')
+  log.addHandler(pylog.NullHandler())
+  log.propagate = False
+  log_step = getattr(opt, 'log_step', 10)
+
+  def validate(val_loader):      # train.py:223-236, verbatim in structure
+    vid_seq_embs, para_seq_embs, clip_embs, cap_embs, _, _, num_clips, cur_vid_total = ev.encode_data(
+        opt, model, val_loader, log_step, log.info, contextual_model=True)
+    vid_seq_rep, top1_v2p, rank_vid_v2p = ev.i2t(vid_seq_embs, para_seq_embs, measure=opt.measure)
+    para_seq_rep, top1_p2v, rank_para_p2v = ev.t2i(vid_seq_embs, para_seq_embs, measure=opt.measure)
+    return vid_seq_rep['sum'] + para_seq_rep['sum'], rank_vid_v2p, rank_para_p2v
+
+  def timed(val_loader, steps):
+    validate(val_loader)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      score, ri, rt = validate(val_loader)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, score, crc_of(ri, rt)
+
+  out = {}
+  for name, loader in loaders.items():
+    if loader is None:
+      continue
+    hits0 = dict(core.CACHE_STATS)
+    ms, score, crc = timed(loader, n_steps)
+    hits = core.CACHE_STATS['hits'] - hits0['hits']
+    core.SPECULATE_RANKS[0] = False
+    try:
+      ms_re, score_re, crc_re = timed(loader, max(2, n_steps // 2))
+    finally:
+      core.SPECULATE_RANKS[0] = True
+    out[name] = {'steps': n_steps, 'ms_per_step': ms, 'currscore': float(score), 'ranks_crc32': crc,
+                 'served_from_encode_data': hits, 'calls': 2 * (n_steps + 1),
+                 'recompute': {'ms_per_step': ms_re, 'ranks_crc32': crc_re,
+                               'note': 'SPECULATE_RANKS off: i2t / t2i upload their NumPy arguments '
+                                       'and rank again'}}
+  out['api'] = ('cmhse_amd/dropin: evaluation.encode_data -> NumPy 8-tuple -> evaluation.i2t -> evaluation.t2i '
+                '(the body of train.py:223-236)')
+  return out
