@@ -11,6 +11,23 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 
+# Two bars for every embedding comparison of the HIP path (VERDICT r05 "what's weak" 1):
+#   EMB_TOL     the contract of BASELINE.json's north_star (1e-4, fp32);
+#   GOLDEN_TOL  what the exact-fp32 path actually holds against the reference's outputs and the
+#               oracle, with head-room for evaluation order: ~30x the measured distance (1.5e-7 on
+#               the normalised embeddings at full size).  A kernel that drops a reference quirk — the
+#               0.0001 in the attention softmax's denominator moves a length-1 sequence by ~5e-5 —
+#               passes the contract and fails this one.
+EMB_TOL = 1e-4
+GOLDEN_TOL = 5e-6
+
+
+def assert_emb_close(got, want, err_msg='', tight=GOLDEN_TOL):
+  got, want = np.asarray(got), np.asarray(want)
+  np.testing.assert_allclose(got, want, atol=EMB_TOL, rtol=0, err_msg=err_msg)
+  np.testing.assert_allclose(got, want, atol=tight, rtol=0, err_msg='(tight bar) ' + err_msg)
+
+
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

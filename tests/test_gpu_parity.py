@@ -12,11 +12,10 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, golden_state_dicts, golden_batches
+from conftest import EMB_TOL, assert_emb_close, load_golden, golden_state_dicts, golden_batches
 
 pytestmark = pytest.mark.gpu
 
-EMB_TOL = 1e-4
 
 
 def loss_close(got, want):
@@ -66,8 +65,8 @@ def test_layers_vs_golden(dev, cls, tag):
   with torch.no_grad():
     y = layer(x, lens).cpu().numpy()
     y_h0 = layer(x, lens, h0).cpu().numpy()
-  np.testing.assert_allclose(y, g[key + '.out'], atol=EMB_TOL, rtol=0)
-  np.testing.assert_allclose(y_h0, g[key + '.out_h0'], atol=EMB_TOL, rtol=0)
+  assert_emb_close(y, g[key + '.out'])
+  assert_emb_close(y_h0, g[key + '.out_h0'])
 
 
 @pytest.mark.parametrize('n', [5, 16, 37])
@@ -152,13 +151,13 @@ def test_model_vs_golden(dev, rnn_type):
   for nm, v in [('clip_emb', clip_emb), ('cap_emb', cap_emb), ('word', word),
                 ('vid_context', vid_ctx), ('para_context', para_ctx), ('vid_emb', vid_emb),
                 ('para_emb', para_emb), ('vid_emb_noctx', vid_nc), ('para_emb_noctx', para_nc)]:
-    np.testing.assert_allclose(v.cpu().numpy(), g['fwd.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+    assert_emb_close(v.cpu().numpy(), g['fwd.' + nm], nm)
 
   res = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
   for i, nm in enumerate(['vid_embs', 'para_embs', 'clip_embs', 'cap_embs', 'vid_contexts',
                           'para_contexts']):
     assert res[i].dtype == np.float32
-    np.testing.assert_allclose(res[i], g['enc.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+    assert_emb_close(res[i], g['enc.' + nm], nm)
   assert list(res[6]) == list(g['enc.num_clips_total'])
   # per-batch 'Letest' meter: last value and running average, like the reference's LogCollector
   want = g['enc.test_losses']
@@ -234,8 +233,8 @@ def test_gru_pool_vs_oracle(dev, oracle, pool, S, T, I, H):
                torch.from_numpy(h0).to(dev)).cpu().numpy()
   want = oracle.pooled_gru_forward(pool, x, lens, sd, None, np.float64)
   want0 = oracle.pooled_gru_forward(pool, x, lens, sd, h0, np.float64)
-  np.testing.assert_allclose(y, want, atol=EMB_TOL, rtol=0)
-  np.testing.assert_allclose(y0, want0, atol=EMB_TOL, rtol=0)
+  assert_emb_close(y, want)
+  assert_emb_close(y0, want0)
 
 
 @pytest.mark.parametrize('n,m,d', [(1, 1, 8), (129, 300, 64), (515, 515, 1024), (257, 400, 30)])
@@ -576,7 +575,7 @@ def test_layer_backward_vs_golden(dev, cls, tag):
   h0 = torch.from_numpy(g[key + '.h0']).to(dev).requires_grad_(True)
   w = torch.from_numpy(g[key + '.bwd.w']).to(dev)
   out = layer(x, lens, h0)
-  np.testing.assert_allclose(out.detach().cpu().numpy(), g[key + '.out_h0'], atol=EMB_TOL, rtol=0)
+  assert_emb_close(out.detach().cpu().numpy(), g[key + '.out_h0'])
   (out * w).sum().backward()
   grad_close(x.grad.cpu().numpy(), g[key + '.bwd.dx'], 'dx')
   grad_close(h0.grad.cpu().numpy(), g[key + '.bwd.dh0'], 'dh0')
@@ -1106,7 +1105,7 @@ def test_gru_pool_fuzz_forward_backward_vs_oracle(dev, oracle, seed):
     (y * torch.from_numpy(w).to(dev)).sum().backward()
     want, c = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
     tag = '%s S%d T%d I%d H%d h0=%d' % (pool, S, T, I, H, use_h0)
-    np.testing.assert_allclose(y.detach().cpu().numpy(), want, atol=EMB_TOL, rtol=0, err_msg=tag)
+    assert_emb_close(y.detach().cpu().numpy(), want, tag)
     grads, dx, dh0 = oracle.pooled_gru_backward(c, w.astype(np.float64))
     grad_close(xt.grad.cpu().numpy()[:, :dx.shape[1]], dx, tag + ' dx')
     if use_h0:
@@ -1172,7 +1171,7 @@ def test_decoder_forward_matches_oracle(dev, oracle):
     y = dec(torch.from_numpy(x).to(dev), torch.from_numpy(lens)).cpu().numpy()
   c = oracle.gru_forward_cache(x, lens, sd, None, np.float64)
   want = np.concatenate([c['hs'][i, :l] for i, l in enumerate(lens)], 0)
-  np.testing.assert_allclose(y, want, atol=EMB_TOL, rtol=0)
+  assert_emb_close(y, want)
 
 
 @pytest.mark.parametrize('n', [11, 9])
@@ -1236,7 +1235,7 @@ def test_checkpoint_round_trip_in_reference_format(dev, tmp_path):
   r1 = encode_data(opt, model, synthetic.ListLoader(batches), logging=lambda *a: None)
   r2 = encode_data(opt, model2, synthetic.ListLoader(batches), logging=lambda *a: None)
   np.testing.assert_array_equal(r1[0], r2[0])
-  np.testing.assert_allclose(r2[0], g['enc.vid_embs'], atol=EMB_TOL, rtol=0)
+  assert_emb_close(r2[0], g['enc.vid_embs'])
 
 
 # ------------------------------------------------------------------------------------------
@@ -1310,7 +1309,7 @@ def test_full_size_encoder_properties(dev, oracle, pool):
   yn = ops.l2norm_rows(y).cpu().numpy()
   want = oracle.pooled_gru_forward(pool, x[sample].numpy(), lens[sample], sd, None, np.float64)
   want = want / np.linalg.norm(want, axis=1, keepdims=True)
-  np.testing.assert_allclose(yn[sample], want, atol=EMB_TOL, rtol=0)
+  assert_emb_close(yn[sample], want)
   np.testing.assert_allclose(ops.l2norm_rows(ys).cpu().numpy(), yn[sample], atol=2e-6, rtol=0)
 
 
@@ -1884,7 +1883,7 @@ def test_full_size_encoder_properties_icep(dev, oracle, pool):
     want = oracle.pooled_gru_forward(pool, xd[torch.from_numpy(sample).to(dev)].cpu().numpy(),
                                      lens[sample], sd, None, np.float64)
   want = want / np.linalg.norm(want, axis=1, keepdims=True)
-  np.testing.assert_allclose(yn[sample], want, atol=EMB_TOL, rtol=0)
+  assert_emb_close(yn[sample], want)
   np.testing.assert_allclose(ops.l2norm_rows(ys).cpu().numpy(), yn[sample], atol=2e-6, rtol=0)
 
 
@@ -1919,7 +1918,7 @@ def test_didemo_icep_encode_and_rank_vs_oracle(dev, oracle):
   err = 0.0
   for i in range(6):
     assert res[i].shape == want[i].shape
-    np.testing.assert_allclose(res[i], want[i], atol=EMB_TOL, rtol=0)
+    assert_emb_close(res[i], want[i])
     err = max(err, float(np.abs(res[i] - want[i]).max()))
   assert list(res[6]) == list(want[6])
   v64, p64 = want[0].astype(np.float64), want[1].astype(np.float64)
@@ -2129,8 +2128,7 @@ def test_full_val_split_icep_encode_sample_vs_oracle(dev, oracle, rnn_type):
                                    ('vid_ctx', 4, lo, hi, nv, v0), ('para_ctx', 5, lo, hi, nv, v0),
                                    ('clip_emb', 2, clip_start[lo], clip_start[hi], nc, c0),
                                    ('cap_emb', 3, clip_start[lo], clip_start[hi], nc, c0)]:
-      np.testing.assert_allclose(cat[key][a:b].cpu().numpy(), want[w_idx][o:o + n], atol=EMB_TOL,
-                                 rtol=0, err_msg='%s batch %d' % (key, i))
+      assert_emb_close(cat[key][a:b].cpu().numpy(), want[w_idx][o:o + n], '%s batch %d' % (key, i))
     v0 += nv
     c0 += nc
 
@@ -2382,7 +2380,7 @@ def test_bf16x3_mode_on_the_reference_goldens(dev, rnn_type, tune):
   for i, nm in enumerate(['vid_embs', 'para_embs', 'clip_embs', 'cap_embs', 'vid_contexts',
                           'para_contexts']):
     np.testing.assert_allclose(res[i], g['enc.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
-    np.testing.assert_allclose(exact[i], g['enc.' + nm], atol=EMB_TOL, rtol=0, err_msg=nm)
+    assert_emb_close(exact[i], g['enc.' + nm], nm)
     engaged = engaged or not np.array_equal(res[i], exact[i])
   assert engaged, 'bf16x3 mode did not engage'
   for nm, fn in [('i2t', i2t), ('t2i', t2i)]:

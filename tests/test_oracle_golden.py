@@ -283,3 +283,24 @@ def test_argmax_route_override(oracle):
   bad[s, 0] = lens[s]
   with pytest.raises(ValueError):
     oracle.train_step_grads('maxout', sds, batch, argmax_route={'clip': bad}, **kw)
+
+
+@pytest.mark.parametrize('a', [6, 9, 12])
+def test_attention_epsilon_quirk_cases(oracle, a):
+  """tests/golden/quirks.npz: energies of about -a, where the 0.0001 of layers.py:158-162 is as
+  large as exp(e) itself.  The oracle follows the reference; an oracle WITHOUT the epsilon (the
+  textbook masked softmax) misses the same vectors by more than a thousand tolerances — what makes
+  these cases a detector for the quirk on the HIP side too (tests/test_quirks_tight.py)."""
+  g = load_golden('quirks.npz')
+  tag = 'a%d' % a
+  p = {k[len(tag) + 4:]: g[k] for k in g.files if k.startswith(tag + '.sd.')}
+  x, lens, h0 = g['x'], g['lens'], g['h0']
+  np.testing.assert_allclose(oracle.attention_forward(x, lens, p), g[tag + '.out'], atol=TOL, rtol=0)
+  np.testing.assert_allclose(oracle.attention_forward(x, lens, p, h0), g[tag + '.out_h0'], atol=TOL, rtol=0)
+  # the textbook softmax: weights of a length-1 sequence are exactly 1 -> out = h_1
+  hs = oracle.gru_forward(x, lens, p['rnn.rnn.weight_ih_l0'], p['rnn.rnn.weight_hh_l0'],
+                          p['rnn.rnn.bias_ih_l0'], p['rnn.rnn.bias_hh_l0'])
+  hs = hs[0]
+  one = np.flatnonzero(lens == 1)
+  miss = np.abs(hs[one, 0] - g[tag + '.out'][one]).max()
+  assert miss > 1000 * TOL, miss

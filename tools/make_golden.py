@@ -138,6 +138,49 @@ def golden_layers(ref_layers, out):
   np.savez_compressed(os.path.join(out, 'layers.npz'), **cases)
 
 
+def golden_quirks(ref_layers, out):
+  """Cases in which a reference quirk carries most of the answer, so that an implementation without
+  it misses by far more than fp32 rounding: layers.Attention's softmax adds
+  0.0001 to the denominator and does not subtract the maximum (layers.py:158-162).  With strongly
+  NEGATIVE energies (lin.bias = +3 saturates the tanh, att_w = -a / H gives e ~ -a) exp(e) is of
+  the order of that 0.0001: a length-1 sequence comes out as h * exp(e) / (exp(e) + 1e-4) — 0.96,
+  0.55 and 0.06 of h for a = 6, 9, 12 — where a softmax without the epsilon returns h itself."""
+  gen = torch.Generator().manual_seed(23)
+  I, H = 24, 32
+  cases = {}
+  lens = [1, 1, 2, 3, 1, 5]
+  S, T = len(lens), max(lens)
+  x = torch.zeros(S, T, I)
+  for i, l in enumerate(lens):
+    x[i, :l] = torch.randn(l, I, generator=gen)
+  h0 = 0.5 * torch.randn(S, H, generator=gen)
+  w = torch.randn(S, H, generator=gen)
+  cases['x'] = x.numpy(); cases['lens'] = np.array(lens, dtype=np.int64)
+  cases['h0'] = h0.numpy(); cases['w'] = w.numpy()
+  for a in [6, 9, 12]:
+    torch.manual_seed(40 + a)
+    layer = ref_layers.Attention(I, H)
+    randomize_biases(layer, gen)
+    with torch.no_grad():
+      layer.lin.bias.fill_(3.0)
+      layer.att_w.weight.fill_(-float(a) / H)
+    tag = 'a%d' % a
+    for k, v in sd_np(layer, 'rnn.').items():
+      cases['%s.sd.%s' % (tag, k)] = v
+    with torch.no_grad():
+      cases[tag + '.out'] = layer(x, torch.tensor(lens)).numpy()
+      cases[tag + '.out_h0'] = layer(x, torch.tensor(lens), h0).numpy()
+    xg = x.clone().requires_grad_(True)
+    hg = h0.clone().requires_grad_(True)
+    layer.zero_grad()
+    (layer(xg, torch.tensor(lens), hg) * w).sum().backward()
+    cases[tag + '.bwd.dx'] = xg.grad.numpy()
+    cases[tag + '.bwd.dh0'] = hg.grad.numpy()
+    for pn, pp in layer.named_parameters():
+      cases[tag + '.bwd.grad.rnn.' + pn] = pp.grad.detach().numpy().copy()
+  np.savez_compressed(os.path.join(out, 'quirks.npz'), **cases)
+
+
 def golden_loss(ref_loss, out):
   """loss.ContrastiveLoss x {max_violation} x {norm}, (im,s) and CL(x,x); F.normalize;
   decoder.loss.EuclideanLoss."""
@@ -407,6 +450,7 @@ def main():
   golden_model(ref_model, ref_eval, out)
   golden_recon(ref_model, out)
   golden_collate(out)
+  golden_quirks(ref_layers, out)
   for f in sorted(os.listdir(out)):
     print(f, os.path.getsize(os.path.join(out, f)))
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Mutation check of the parity tests: do they notice a kernel that drops a reference quirk?
+
+  python tools/mutation_check.py build        (build container: hipcc, no GPU needed)
+      copies cmhse_amd/csrc to build/mutants/<name>/, applies ONE source edit per mutant, and builds
+      build/mutants/libcmhse_<name>.so (same ABI; the product sources and library are untouched).
+  python tools/mutation_check.py run          (GPU box)
+      runs the selected GPU tests once per mutant with CMHSE_HIP_LIB pointing at it and reports
+      which tests FAILED — a mutant that no test kills is a hole in the suite.  Also runs the same
+      selection on the product library (must pass).
+
+Mutants:
+  attn_eps_fwd   gru.hip: the masked softmax's `+ 0.0001f` (layers.py:158-162) -> `+ 0.0f`
+  attn_eps_bwd   bwd.hip: the same epsilon in the attention backward
+  norm_by_n      sim.hip / step_loss.hpp: nothing — `norm` is covered by values that differ by a factor n
+                 (listed for completeness; not built)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, 'build', 'mutants')
+
+MUTANTS = {
+    'attn_eps_fwd': ('gru.hip', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
+    'attn_eps_bwd': ('bwd.hip', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
+}
+# the tests that must kill them (and pass on the product library)
+SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_parity.py', '-k',
+          'epsilon or test_layers_vs_golden or test_layer_backward_vs_golden or test_model_vs_golden']
+
+
+def build():
+  from cmhse_amd import build as b
+  os.makedirs(OUT, exist_ok=True)
+  for name, (fname, old, new) in MUTANTS.items():
+    root = os.path.join(OUT, name)
+    shutil.rmtree(root, ignore_errors=True)
+    src = os.path.join(root, 'cmhse_amd', 'csrc')          # (the sources include ../../include/cmhse_hip.h)
+    shutil.copytree(b.CSRC, src)
+    shutil.copytree(os.path.join(REPO, 'include'), os.path.join(root, 'include'))
+    text = open(os.path.join(src, fname)).read()
+    assert text.count(old) == 1, (name, text.count(old))
+    open(os.path.join(src, fname), 'w').write(text.replace(old, new))
+    target = os.path.join(OUT, 'libcmhse_%s.so' % name)
+    cmd = [b._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
+    cmd += list(b.DEVICE_FLAGS) + ['-o', target]
+    cmd += [os.path.join(src, s) for s in b.SOURCES]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+      raise SystemExit('hipcc failed for %s:\n%s' % (name, res.stdout[-3000:]))
+    shutil.rmtree(root)
+    print('built', target)
+
+
+def run():
+  results = {}
+  for name in [None] + sorted(MUTANTS):
+    env = dict(os.environ)
+    if name:
+      env['CMHSE_HIP_LIB'] = os.path.join(OUT, 'libcmhse_%s.so' % name)
+    res = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                          '--tb=line'] + SELECT, cwd=REPO, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    failed = [l for l in res.stdout.splitlines() if l.startswith('FAILED')]
+    tail = res.stdout.strip().splitlines()[-1] if res.stdout.strip() else ''
+    results[name or 'product'] = (res.returncode, failed, tail)
+    print('=== %s: rc %d  %s' % (name or 'product library', res.returncode, tail))
+    for l in failed:
+      print('   ', l[:240])
+    for l in res.stdout.splitlines():
+      if 'Max absolute difference' in l or 'Mismatched elements' in l:
+        print('      ', l.strip())
+  ok = results['product'][0] == 0 and all(results[m][1] for m in MUTANTS)
+  print('mutation check:', 'every mutant killed, product green' if ok else 'HOLE: see above')
+  return 0 if ok else 1
+
+
+if __name__ == '__main__':
+  sys.exit(build() if sys.argv[1:] == ['build'] else run())
