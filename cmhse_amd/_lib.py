@@ -45,7 +45,7 @@ class GruJob(ctypes.Structure):
   _fields_ = [('seqs', ctypes.POINTER(SeqBatch)), ('weights', ctypes.POINTER(GruWeights)),
               ('pool_mode', c_int32), ('out', c_void_p), ('workspace', c_void_p),
               ('workspace_bytes', c_size_t), ('tail_stream', c_void_p), ('stream', c_void_p),
-              ('side_stream', c_void_p)]
+              ('side_stream', c_void_p), ('out_ready_event', c_void_p)]
 
 
 class GruBwdJob(ctypes.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     'cmhse_gru_pool_fwd_multi': (ctypes.c_int, [ctypes.POINTER(GruJob), c_int32, c_void_p]),
     'cmhse_pull_steps': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                         c_int32, c_void_p]),
+    'cmhse_push_rows': (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
     'cmhse_pad_rows': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p]),
     'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),

@@ -1456,6 +1456,31 @@ __global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// HBM -> host hand-over of finished embedding rows (the `.data.cpu()` of evaluation.py:120-125):
+// a plain byte copy into page-locked, device-writable host memory, done by a FEW single-wave
+// workgroups.  The runtime's own device-to-host copy of this size is a chip-wide blit kernel: beside
+// the level-2 step chain (which needs its workgroups resident together) it held that chain back by
+// 2 ms and the launches queued behind it by another (profiles/r06_api_path.txt).  PCIe writes are
+// posted: a few dozen waves keep the link full.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void push_bytes_kernel(const float4* __restrict__ src,
+                                                        float4* __restrict__ dst, size_t n16,
+                                                        const unsigned char* __restrict__ src_tail,
+                                                        unsigned char* __restrict__ dst_tail, int tail) {
+  const size_t nthr = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 7 * nthr < n16; i += 8 * nthr) {
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = src[i + q * nthr];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[i + q * nthr] = v[q];
+  }
+  for (; i < n16; i += nthr) dst[i] = src[i];
+  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
 // split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
 // (k beyond K zero-filled), see nt_phase_bf3.
@@ -1765,6 +1790,8 @@ struct FwdJob {
   hipStream_t own_stream;    // optional stream ALL launches of this request go to (forked from / joined into the call's)
   hipStream_t side_stream;   // optional stream for throughput work beside a small-batch chain (projection chunks, attention)
   bool pooled;               // attention already launched (early, beside the others' tail)
+  hipEvent_t ready_event;    // optional: recorded where `out` of this request becomes final (cmhse_gru_job.out_ready_event)
+  bool ready_marked;
   int64_t att_rows_done;     // packed rows whose attention energies are already launched
   const int32_t* kind_count; // HOST [Tmax]: active sequences the KIND of step t's kernel is chosen from — the batch's own
                              // step counts, or the caller's step_plan_host (the counts of the whole split this batch is a share of)
@@ -2337,6 +2364,13 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
   }
 }
 
+// `out` of job j is final behind everything queued on `stream` so far: tell the caller's event.
+static inline void mark_ready(FwdJob& j, hipStream_t stream) {
+  if (j.ready_event == nullptr || j.ready_marked) return;
+  (void)hipEventRecord(j.ready_event, stream);
+  j.ready_marked = true;
+}
+
 int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
   int Tmax = 0, launches = 0;
   XprojPlan plan[kMaxJobs];
@@ -2611,8 +2645,10 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
     for (int k = 0; k < n; ++k) {   // a chain on its own stream pools as soon as it ends
       FwdJob& j = jobs[k];
       if (!j.pooled && js[k] != main_stream && js[k] == j.own_stream && j.pool_mode == CMHSE_POOL_ATTN &&
-          t == j.b->Tmax - 1 && launch_attention(j, js[k], j.sum_T, true) == CMHSE_OK)
+          t == j.b->Tmax - 1 && launch_attention(j, js[k], j.sum_T, true) == CMHSE_OK) {
         j.pooled = true;
+        mark_ready(j, js[k]);
+      }
     }
     for (int k = 0; k < n; ++k) {
       FwdJob& j = jobs[k];
@@ -2626,7 +2662,10 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
           others = true;
         }
       if (!others) continue;
-      if (launch_attention(j, main_stream, j.sum_T, true) == CMHSE_OK) j.pooled = true;
+      if (launch_attention(j, main_stream, j.sum_T, true) == CMHSE_OK) {
+        j.pooled = true;
+        mark_ready(j, main_stream);      // this request's rows can leave while the others' tail runs
+      }
       // ... and behind it the attention projection of what the OTHER attention-pooled chains have
       // produced so far: only the rows of their remaining tail steps are left for after the tail
       for (int m = 0; m < n; ++m) {
@@ -2775,6 +2814,8 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     jobs[k].side_stream = static_cast<hipStream_t>(reqs[k].side_stream);
     jobs[k].pooled = false;
     jobs[k].att_rows_done = 0;
+    jobs[k].ready_event = static_cast<hipEvent_t>(reqs[k].out_ready_event);
+    jobs[k].ready_marked = false;
   }
   // the first job's step_timer (if any) spans the step launches of the whole group
   Timer* timer = static_cast<Timer*>(jobs[0].b->step_timer);
@@ -2797,6 +2838,7 @@ extern "C" int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* reqs, int32_t n_job
     const int rc = launch_attention(jobs[k], stream, jobs[k].sum_T, true);
     if (rc != CMHSE_OK) return rc;
   }
+  for (int k = 0; k < n_jobs; ++k) mark_ready(jobs[k], stream);     // (whatever was not final earlier)
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
@@ -2813,6 +2855,7 @@ extern "C" int cmhse_gru_pool_fwd(const cmhse_seq_batch* b, const cmhse_gru_weig
   req.tail_stream = nullptr;
   req.stream = nullptr;
   req.side_stream = nullptr;
+  req.out_ready_event = nullptr;
   return cmhse_gru_pool_fwd_multi(&req, 1, stream_);
 }
 
@@ -2838,6 +2881,26 @@ extern "C" int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t*
   const unsigned grid = static_cast<unsigned>(n_active < cap ? n_active : cap);
   hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(thr), 0,
                      static_cast<hipStream_t>(stream_), p);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
+extern "C" int cmhse_push_rows(const void* src, void* dst_pinned, size_t bytes, int32_t workgroups,
+                               int32_t waves, void* stream_) {
+  if ((!src || !dst_pinned) && bytes) return CMHSE_ERR_ARG;
+  if (workgroups < 0 || workgroups > 1024 || waves < 0 || waves > 4) return CMHSE_ERR_ARG;
+  if (bytes == 0) return CMHSE_OK;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_pinned)) & 15u)
+    return CMHSE_ERR_ARG;      // (rows of fp32 matrices out of the allocator: always 16-byte aligned)
+  const size_t n16 = bytes >> 4;
+  const int tail = static_cast<int>(bytes & 15u);
+  unsigned grid = static_cast<unsigned>(workgroups ? workgroups : 8);
+  const unsigned thr = 64u * static_cast<unsigned>(waves ? waves : 1);
+  const size_t need = (n16 + thr - 1) / thr;
+  if (need < grid) grid = static_cast<unsigned>(need ? need : 1);
+  hipLaunchKernelGGL(push_bytes_kernel, dim3(grid), dim3(thr), 0, static_cast<hipStream_t>(stream_),
+                     static_cast<const float4*>(src), static_cast<float4*>(dst_pinned), n16,
+                     static_cast<const unsigned char*>(src) + (n16 << 4),
+                     static_cast<unsigned char*>(dst_pinned) + (n16 << 4), tail);
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 

@@ -290,7 +290,7 @@ def split_step_plan(batches):
   return plan_from_histograms(length_histograms(batches))
 
 
-def encode_group(model, group, contextual_model=True, device=None, plan=None, step_plan=None, early=None):
+def encode_group(model, group, contextual_model=True, device=None, plan=None, step_plan=None, stage=None):
   """Encode a list of loader batches (12-tuples) as ONE super-batch.  Returns a dict of device
   tensors: the six un-normalised embedding matrices plus their L2-normalised versions, rows in
   loader order.  Arithmetic per sequence is identical to per-batch encoding (sequences are
@@ -299,13 +299,14 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None, st
   held in HBM across epochs; bench.py): the level-1 schedules (sort, step counts, the uploaded
   pointer tables) are built on the first pass and reused afterwards — 2 ms of host work in front
   of the first launch, 5 % of a rank's 45 ms share of the split.
-  `early`: a callable that receives {'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx'} (normalised) as
-  soon as level 1 has been queued, before level 2 is — encode_data starts their device-to-host
-  copies there, under the level-2 encoders and the ranking (the values do not depend on it)."""
+  `stage`: a HostStage (encode_data): the level-1 matrices of each tower are normalised on ITS copy
+  stream and start for the host as soon as that tower's level-1 output is final — the visual
+  tower's while the text tower's few-sequence tail still steps, the text tower's under level 2 —
+  instead of after the whole pass (the values do not depend on it)."""
   device = device or torch.device('cuda', torch.cuda.current_device())
   sp = step_plan or {}
   if plan is not None and plan.get('key') == _plan_key(group) and GROUP_TOWERS[0] and not TWO_STREAMS[0]:
-    return _encode_group_planned(model, group, contextual_model, device, plan, sp, early)
+    return _encode_group_planned(model, group, contextual_model, device, plan, sp, stage)
   clips_l, caps_l, vids_l, pars_l = [], [], [], []
   len_clip, len_cap, len_vid, len_par = [], [], [], []
   num_clips, num_caps = [], []
@@ -428,15 +429,16 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None, st
                   n_cap=n_cap, n_vid=n_vid, num_clips=np.asarray(num_clips, dtype=np.int64),
                   num_caps=np.asarray(num_caps, dtype=np.int64),
                   batch_sizes=[len(b[8]) for b in group], keep=(clips_l, vids_l, caps_l, pars_l))
+    ready = None if stage is None else stage.tower_events()
     (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
         clip_rnn.request_ptrs(v_lens, img_dim, device, x_ptrs=v_ptrs,
                               sched=v_sched, step_events=v_events, step_plan=sp.get('v1')),
         txt_rnn.request_ptrs(t_lens, table.shape[1], device,
                              tok_ptrs=t_ptrs, table=table, sched=t_sched,
-                             step_plan=sp.get('t1'))], tail_stream=tail)
+                             step_plan=sp.get('t1'))], tail_stream=tail, ready_events=ready)
     clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
     cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
-    lvl1 = _early_level1(early, clip_emb, cap_emb, vid_ctx, para_ctx)
+    lvl1 = None if stage is None else stage.level1(ready, clip_emb, cap_emb, vid_ctx, para_ctx)
 
     def level2_request(enc, rows, counts, ctx_rows, Hin, tower):
       counts = np.asarray(counts, dtype=np.int64)
@@ -463,17 +465,7 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None, st
               batch_sizes=[len(b[8]) for b in group])
 
 
-def _early_level1(early, clip_emb, cap_emb, vid_ctx, para_ctx):
-  """The four level-1 matrices normalised NOW and handed to `early` (encode_group), or None."""
-  if early is None:
-    return None
-  n = ops.l2norm_rows
-  lvl1 = dict(clip_emb=n(clip_emb), cap_emb=n(cap_emb), vid_ctx=n(vid_ctx), para_ctx=n(para_ctx))
-  early(lvl1)
-  return lvl1
-
-
-def _encode_group_planned(model, group, contextual_model, device, plan, sp, early=None):
+def _encode_group_planned(model, group, contextual_model, device, plan, sp, stage=None):
   """encode_group's grouped schedule with the level-1 schedules of an earlier pass over the same
   batches (encode_group(plan=...)): same launches, same values."""
   clip_rnn, txt_rnn = model.clip_enc.rnn, model.txt_enc.rnn
@@ -482,15 +474,16 @@ def _encode_group_planned(model, group, contextual_model, device, plan, sp, earl
   table = model.txt_enc.embed.weight.detach()
   n_clip, n_cap = plan['n_clip'], plan['n_cap']
   tail = _tail_stream(device) if EARLY_POOL[0] else None
+  ready = None if stage is None else stage.tower_events()
   (vis, _), (txt, _) = ops.gru_pool_fwd_multi([
       clip_rnn.request_ptrs(plan['v_lens'], plan['img_dim'], device, x_ptrs=plan['v_ptrs'],
                             sched=plan['v_sched'], step_plan=sp.get('v1')),
       txt_rnn.request_ptrs(plan['t_lens'], table.shape[1], device, tok_ptrs=plan['t_ptrs'],
                            table=table, sched=plan['t_sched'], step_plan=sp.get('t1'))],
-      tail_stream=tail)
+      tail_stream=tail, ready_events=ready)
   clip_emb, vid_ctx = vis[:n_clip], vis[n_clip:]
   cap_emb, para_ctx = txt[:n_cap], txt[n_cap:]
-  lvl1 = _early_level1(early, clip_emb, cap_emb, vid_ctx, para_ctx)
+  lvl1 = None if stage is None else stage.level1(ready, clip_emb, cap_emb, vid_ctx, para_ctx)
 
   def level2_request(enc, rows, counts, ctx_rows, Hin, tower):
     starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
@@ -591,9 +584,9 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
       model.logger = val_logger                     # evaluation.py:99
       enc = encode_group(model, group, contextual_model,
                          plan=None if plan is None else plan.setdefault(gi, {}), step_plan=step_plan,
-                         early=None if stage is None else stage.put)
+                         stage=stage)
       if stage is not None:
-        stage.put({k: enc[k] for k in outs})     # (what `early` has taken is skipped)
+        stage.put({k: enc[k] for k in outs})     # (what left early is skipped)
       for k in outs:
         outs[k].append(enc[k])
       # per-loader-batch 'Letest' loss (evaluation.py:129), all on device, one sync per group
@@ -620,6 +613,7 @@ def encode_data_device(opt, model, data_loader, log_step=10, logging=print, cont
 
 
 MATRICES = ('vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx')
+PUSH_KERNEL = [True]     # device-to-host staging by cmhse_push_rows (a few waves) instead of hipMemcpyAsync
 
 
 class HostStage(object):
@@ -639,20 +633,64 @@ class HostStage(object):
     self.seen = set()
     self.copy = _copy_stream(device)
     self._keep = []      # the staged device tensors: their ids stay unique until wait()
+    self._events = []    # recycled between groups
+
+  def tower_events(self):
+    """Two events (visual, text) for gru_pool_fwd_multi(ready_events=): recorded once here so that
+    they own a handle; the library re-records each where its tower's level-1 output is final."""
+    main = torch.cuda.current_stream(self.device)
+    evs = []
+    for _ in range(2):
+      ev = self._events.pop() if self._events else torch.cuda.Event()
+      ev.record(main)
+      evs.append(ev)
+    return evs
+
+  def level1(self, ready, clip_emb, cap_emb, vid_ctx, para_ctx):
+    """Normalise the four level-1 matrices on the copy stream, each tower behind ITS ready event,
+    and send them off; returns them ({name: normalised device tensor}).  The caller's stream is
+    made to wait for the normalisations (not for the copies) before it returns."""
+    main = torch.cuda.current_stream(self.device)
+    out = {}
+    normed = self._events.pop() if self._events else torch.cuda.Event()
+    towers = ((ready[0], (('clip_emb', clip_emb), ('vid_ctx', vid_ctx))),
+              (ready[1], (('cap_emb', cap_emb), ('para_ctx', para_ctx))))
+    for i, (ev, pair) in enumerate(towers):
+      self.copy.wait_event(ev)
+      with torch.cuda.stream(self.copy):
+        for k, raw in pair:
+          raw.record_stream(self.copy)
+          out[k] = ops.l2norm_rows(raw)
+      if i == len(towers) - 1:
+        normed.record(self.copy)      # (behind the first tower's copies, in front of the last one's)
+      self._send([(k, out[k]) for k, _ in pair])
+    main.wait_event(normed)           # consumers of the returned tensors on the caller's stream
+    for t in out.values():
+      t.record_stream(main)
+    self._events += list(ready) + [normed]
+    return out
 
   def put(self, mats):
     todo = [(k, t) for k, t in mats.items() if k in self.host and id(t) not in self.seen]
     if not todo:
       return
-    main = torch.cuda.current_stream(self.device)
-    self.copy.wait_stream(main)
-    with torch.cuda.stream(self.copy):
-      for k, t in todo:
-        n = t.shape[0]
-        self.host[k][self.filled[k]:self.filled[k] + n].copy_(t, non_blocking=True)
-        t.record_stream(self.copy)
-        self.filled[k] += n
-        self.seen.add(id(t))
+    self.copy.wait_stream(torch.cuda.current_stream(self.device))
+    self._send(todo)
+
+  def _send(self, todo):
+    for k, t in todo:
+      n = t.shape[0]
+      dst = self.host[k][self.filled[k]:self.filled[k] + n]
+      if PUSH_KERNEL[0]:
+        tc = t.contiguous()
+        self._keep.append(tc)
+        ops.push_rows(tc, dst, self.copy)
+      else:             # the runtime's copy: a chip-wide blit kernel on this image (A/B only)
+        with torch.cuda.stream(self.copy):
+          dst.copy_(t, non_blocking=True)
+      t.record_stream(self.copy)
+      self.filled[k] += n
+      self.seen.add(id(t))
     self._keep += [t for _, t in todo]
 
   def wait(self):
@@ -684,6 +722,7 @@ def _stage_for(model, batches, device):
 # returned AND the bytes those arrays hold now still equal the device copies (the arrays view pinned
 # memory: checking is one 20 MB upload + a compare per matrix, well under the ranking it saves).  One
 # entry, replaced by the next encode_data, dropped when either array is garbage-collected.
+TRACE = None           # tools/api_path_profile.py: a list that receives (phase, perf_counter) marks
 SPECULATE_RANKS = [True]
 SUPERBATCH_BYTES = [48 << 30]    # padded feature bytes per super-batch of encode_data (288 GB of HBM)
 _LAST_ENCODE = [None]
@@ -692,6 +731,11 @@ CACHE_STATS = {'hits': 0, 'stale': 0}
 
 def _forget_last_encode(_ref=None):
   _LAST_ENCODE[0] = None
+
+
+def _mark(name):
+  if TRACE is not None:
+    TRACE.append((name, time.perf_counter()))
 
 
 def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_model=True):
@@ -705,9 +749,11 @@ def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_
   batches = list(data_loader)
   device = torch.device('cuda', torch.cuda.current_device())
   stage = _stage_for(model, batches, device)
+  _mark('pinned matrices allocated')
   cat, num_clips_total, cur_vid_total, finish_log = encode_data_device(
       opt, model, batches, log_step, logging, contextual_model, superbatch_bytes=SUPERBATCH_BYTES[0],
       defer_logging=True, stage=stage)
+  _mark('encoders queued')
   ranks_host = ranks_event = None
   if SPECULATE_RANKS[0] and cat['vid_emb'].shape == cat['para_emb'].shape:
     r_i, t_i = ops.sim_rank(cat['vid_emb'], cat['para_emb'])
@@ -716,11 +762,15 @@ def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_
     ranks_host.copy_(torch.stack([r_i, t_i, r_t, t_t]), non_blocking=True)
     ranks_event = torch.cuda.Event()
     ranks_event.record()
+  _mark('ranking queued')
   finish_log()          # the per-batch 'Letest' meters (evaluation.py:129), behind everything queued
+  _mark('Letest values on the host (encoders done)')
   host = stage.wait()
+  _mark('six matrices on the host')
   arrays = {k: host[k].numpy() for k in MATRICES}
   if ranks_event is not None:
     ranks_event.synchronize()
+    _mark('ranks on the host')
     _LAST_ENCODE[0] = dict(
         vid=weakref.ref(arrays['vid_emb'], _forget_last_encode),
         para=weakref.ref(arrays['para_emb'], _forget_last_encode),
@@ -771,7 +821,10 @@ def _from_last_encode(images, captions):
   dev = e['vid_dev'].device
   up_v = e['vid_host'].to(dev, non_blocking=True)
   up_p = e['para_host'].to(dev, non_blocking=True)
-  if _bits_equal(up_v, e['vid_dev']) and _bits_equal(up_p, e['para_dev']):
+  _mark('content check queued')
+  same = _bits_equal(up_v, e['vid_dev']) and _bits_equal(up_p, e['para_dev'])
+  _mark('content check done')
+  if same:
     CACHE_STATS['hits'] += 1
     return e['ranks'], None
   CACHE_STATS['stale'] += 1

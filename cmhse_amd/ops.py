@@ -478,6 +478,27 @@ def pull_steps(sched, row_floats, copy_stream, chunk=8):
   return events
 
 
+PUSH_WORKGROUPS = [8]      # workgroups x wavefronts of cmhse_push_rows (tools/api_path_profile.py --push_wgs / --push_waves)
+PUSH_WAVES = [1]
+
+
+def push_rows(src, dst_pinned, stream):
+  """cmhse_push_rows: contiguous device tensor `src` -> page-locked host tensor `dst_pinned` (same
+  byte count) as a small kernel on `stream` (a torch stream).  Asynchronous: the caller orders
+  `stream` behind the producer of `src` and synchronises it before reading `dst_pinned`."""
+  _require_cuda(src, 'src')
+  if dst_pinned.is_cuda or not dst_pinned.is_pinned():
+    raise RuntimeError('push_rows: the destination must be page-locked host memory')
+  if not src.is_contiguous() or not dst_pinned.is_contiguous():
+    raise ValueError('push_rows: contiguous tensors only')
+  nbytes = src.numel() * src.element_size()
+  if nbytes != dst_pinned.numel() * dst_pinned.element_size():
+    raise ValueError('push_rows: byte counts differ')
+  rc = _lib.load().cmhse_push_rows(src.data_ptr(), dst_pinned.data_ptr(), nbytes, PUSH_WORKGROUPS[0],
+                                   PUSH_WAVES[0], ctypes.c_void_p(stream.cuda_stream))
+  _lib.check(rc, 'cmhse_push_rows')
+
+
 def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
                  constant_input=False, sched=None, step_events=None, side=True, step_plan=None):
@@ -557,7 +578,7 @@ def gru_pool_fwd(weights, pool_mode, lens, I, H, device, **kw):
                                   device=device, **kw)])[0]
 
 
-def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, hold=None):
+def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, hold=None, ready_events=None):
   """cmhse_gru_pool_fwd_multi: `requests` is a list of keyword dicts (the arguments of
   gru_pool_fwd) for INDEPENDENT encoders; their time steps share launches.  Returns a list of
   (out, ctx), bit-identical to separate gru_pool_fwd calls.  With `tail_stream` (a torch stream,
@@ -569,7 +590,9 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, 
   join=False (CMHSE_NO_JOIN) leaves the job streams un-joined: the outputs are ready on their job
   stream only — for a caller that queues the consumer on the same stream next and joins later; it
   must pass `hold`, a list that receives everything the queued work uses and that it keeps until
-  that later join."""
+  that later join.  `ready_events`: one torch.cuda.Event (already recorded once, so that it owns a
+  handle) or None per request; the call records it where that request's output becomes final
+  (cmhse_gru_job.out_ready_event) — early for a request whose chain ends while others still step."""
   lib = _lib.load()
   if not 1 <= len(requests) <= MAX_JOBS:
     raise ValueError('gru_pool_fwd_multi takes 1..%d requests' % MAX_JOBS)
@@ -584,6 +607,10 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, 
     jobs[k].workspace_bytes = job['ws_bytes']
     if job_streams is not None:
       jobs[k].stream = ctypes.c_void_p(job_streams[k].cuda_stream)
+    if ready_events is not None and ready_events[k] is not None:
+      if not ready_events[k].cuda_event:
+        raise ValueError('ready_events: record the event once before handing it over')
+      jobs[k].out_ready_event = ctypes.c_void_p(ready_events[k].cuda_event)
     if job['mode_flags'] & SAVE_FOR_BACKWARD and job['side']:   # a training call: throughput work beside the chain
       side = side_stream(job_streams[k] if job_streams is not None else None)
       if side is not None:
@@ -597,7 +624,7 @@ def gru_pool_fwd_multi(requests, tail_stream=None, job_streams=None, join=True, 
     handle = lib.cmhse_timer_create()
     prepared[0][0]['b'].step_timer = handle
     StepTimers.active.items.append((handle, [m for _, m in prepared]))
-  if len(prepared) == 1 and job_streams is None and not jobs[0].side_stream:
+  if len(prepared) == 1 and job_streams is None and not jobs[0].side_stream and not jobs[0].out_ready_event:
     job = prepared[0][0]
     rc = lib.cmhse_gru_pool_fwd(ctypes.byref(job['b']), ctypes.byref(job['w']), job['mode_flags'],
                                 job['out'].data_ptr(), job['ws'].data_ptr(), job['ws_bytes'],

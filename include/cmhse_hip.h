@@ -196,6 +196,13 @@ typedef struct cmhse_gru_job {
                           stands in front of the chain, the others run on side_stream beside it, step
                           t waiting (event) for the chunk that holds its rows.  Results do not
                           depend on it. */
+  void* out_ready_event; /* optional hipEvent_t (or NULL), recorded by the call where this request's
+                          `out` becomes final: right behind its pooling pass when that is launched
+                          early (tail_stream: its chain ended while other requests still step), else
+                          at the end of the call on `stream`.  A consumer on another stream — the
+                          device-to-host hand-over of evaluation.encode_data (evaluation.py:120-125) —
+                          waits on it instead of on the whole call, and so runs beside the other
+                          requests' remaining steps. */
 } cmhse_gru_job;
 int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* stream);
 
@@ -209,6 +216,16 @@ int cmhse_gru_pool_fwd_multi(const cmhse_gru_job* jobs, int32_t n_jobs, void* st
  * stream of its own, record an event, hand it to the consumer via step_events_host). */
 int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t* dst_rows, const int32_t* lens,
                      int32_t n_active, int32_t row_floats, int32_t t0, int32_t t1, void* stream);
+
+/* HBM -> host hand-over of finished embedding rows: what evaluation.encode_data does with
+ * `.data.cpu()` + list.extend per batch (evaluation.py:120-125, 139-144).  `bytes` bytes from `src`
+ * (device) to `dst_pinned` (page-locked host memory that is device-writable, as hipHostMalloc /
+ * torch pinned memory is; both 16-byte aligned), as a kernel of `workgroups` workgroups (0 = 8) of
+ * `waves` wavefronts (1..4, 0 = 1) on `stream`: small enough to run beside the level-2 encoders
+ * and the ranking without taking their CUs, which the runtime's chip-wide blit copy does.
+ * Asynchronous; record an event on `stream` (or synchronise it) before the host reads. */
+int cmhse_push_rows(const void* src, void* dst_pinned, size_t bytes, int32_t workgroups, int32_t waves,
+                    void* stream);
 
 /* The padding half of the loader's collate_fn (activity_net/data.py:114-150, didemo_dev/data.py:
  * 133-165) as an index kernel: S ragged sequences stored back to back, row r of sequence s at

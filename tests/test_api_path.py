@@ -132,3 +132,21 @@ def test_the_entry_dies_with_the_arrays(small):
   del out
   gc.collect()
   assert ev._LAST_ENCODE[0] is None
+
+
+@pytest.mark.parametrize('nbytes', [16, 4 * 1024 * 37 + 4, 8 << 20, (8 << 20) + 12])
+def test_push_rows_moves_exactly_the_bytes(nbytes):
+  """cmhse_push_rows: device bytes -> page-locked host bytes, sizes that are not a multiple of 16
+  included; bytes behind the end stay untouched; the runtime's copy gives the same result."""
+  from cmhse_amd import ops
+  dev = torch.device('cuda', 0)
+  src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev)
+  dst = torch.full((nbytes + 64,), 7, dtype=torch.uint8).pin_memory()
+  stream = ops.stream_set(dev)[1]
+  stream.wait_stream(torch.cuda.current_stream())
+  ops.push_rows(src, dst[:nbytes], stream)
+  stream.synchronize()
+  assert torch.equal(dst[:nbytes], src.cpu())
+  assert bool((dst[nbytes:] == 7).all())
+  with pytest.raises(RuntimeError):
+    ops.push_rows(src, torch.empty(nbytes, dtype=torch.uint8), stream)        # pageable destination
