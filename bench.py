@@ -72,12 +72,28 @@ from cmhse_amd.model import VSE  # noqa: E402
 from bench_common import (BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS, WORKLOADS, build_loader,  # noqa: E402,F401
                           device_batch, gru_flops_per_step, make_opt)
 from bench_legs import (TRAIN_CONFIGS, cpu_baseline, dropin_validate_bench, fast_mode_bench,  # noqa: E402,F401
-                        measured_clock_ghz,
+                        isa_audit, measured_clock_ghz, profile_source,
                         measured_step_latency_us, measured_traffic, rank_check, rank_noise_floor,
                         train_bench, train_step_work)
 
 def costs_sum(costs, idx):
   return float(sum(costs[i][0] for i in idx))
+
+
+def rank_environments(n, n_gpus, port, base):
+  """The environment of each of the `n` rank processes launch_ranks starts on a box with `n_gpus`
+  GPUs: the torch.distributed rendezvous variables (127.0.0.1: the container's hostname may not
+  resolve), one GPU per rank (LOCAL_RANK), dmabuf IPC for RCCL (HSA_ENABLE_IPC_MODE_LEGACY=0), and —
+  with fewer GPUs than ranks — the gloo backend, ranks sharing GPUs round-robin (RCCL needs one device
+  per rank): a functional run of the N-rank path, reported as such ("backend" in the JSON)."""
+  env = dict(base)
+  env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(n),
+             HSA_ENABLE_IPC_MODE_LEGACY=base.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  if n_gpus < n:
+    env['CMHSE_BENCH_BACKEND'] = 'gloo'
+  else:
+    env.pop('CMHSE_BENCH_BACKEND', None)
+  return [dict(env, RANK=str(r), LOCAL_RANK=str(r % n_gpus)) for r in range(n)]
 
 
 def launch_ranks(n):
@@ -94,18 +110,11 @@ def launch_ranks(n):
   with socket.socket() as sk:
     sk.bind(('127.0.0.1', 0))
     port = sk.getsockname()[1]
-  env = dict(os.environ)
-  env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(n),
-             HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
   if n_gpus < n:
-    # fewer GPUs than ranks: the ranks share them and talk over gloo (RCCL needs one device per
-    # rank) — a functional run of the N-rank path, reported as such ("backend" in the JSON)
-    env['CMHSE_BENCH_BACKEND'] = 'gloo'
     sys.stderr.write('bench.py: %d GPU(s) for %d ranks: sharing GPUs over a gloo group\n'
                      % (n_gpus, n))
   procs = []
-  for r in range(n):
-    e = dict(env, RANK=str(r), LOCAL_RANK=str(r % n_gpus))
+  for r, e in enumerate(rank_environments(n, n_gpus, port, os.environ)):
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                   stdout=None if r == 0 else subprocess.DEVNULL))
   worst, live = 0, set(range(n))
@@ -132,9 +141,9 @@ def main():
   ap.add_argument('--rnn_type', default='attention', choices=['attention', 'maxout', 'seq2seq'])
   ap.add_argument('--embed', type=int, default=1024)
   ap.add_argument('--n_videos', type=int, default=0, help='override the split size (debug)')
-  ap.add_argument('--fast_steps', type=int, default=0,
-                  help='also time this many passes in the opt-in bf16x3 math mode (default 0 = skip: the '
-                       'mode is outside the bit-identical-ranks contract, DESIGN.md section 9)')
+  ap.add_argument('--fast_steps', type=int, default=5,
+                  help='also time this many passes in the opt-in bf16x3 math mode (0 = skip).  Reported as the '
+                       'fenced `fast_mode` object: the mode is outside the bit-identical-ranks contract and never `value`')
   ap.add_argument('--train_steps', type=int, default=10,
                   help='also time this many VSE.train_emb steps per BASELINE training config (0 = skip)')
   ap.add_argument('--train_configs', default='anet_c3d_tau0,anet_icep_tau0,anet_icep_recon,didemo_icep_recon',
@@ -372,6 +381,7 @@ def main():
                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP32_MFMA_PEAK_TFLOPS,
                      'traffic': traffic,
+                     'traffic_source': profile_source('r*_pmc_hbm_traffic.json'),
                      'traffic_unit': 'fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + '
                                      'WRITE_SIZE, newest profiles/r*_pmc_hbm_traffic.json)',
                      'algorithmic_bytes_per_launch': (alg_bytes / launches) if launches else None,
@@ -387,6 +397,7 @@ def main():
                      # context: `peak` assumes 2.4 GHz; an instrumented build of this kernel read
                      # this in-kernel clock under load (profiles/r01_tile_trace.txt)
                      'in_kernel_clock_ghz': clk,
+                     'in_kernel_clock_source': profile_source('r*_tile_trace.txt'),
                      'all_step_kernels': {
                          'achieved': flops_all / (ms_all * 1e-3) / 1e12 if ms_all > 0 else None,
                          'launches': launches_all,
@@ -402,8 +413,10 @@ def main():
         'algorithmic_bytes_per_launch': (sum(4.0 * (x[1] + x[2]) * x[3] + 8.0 * x[1] for x in sims)
                                          / len(sims)) if sims else None,
         'traffic': measured_traffic('sim_kernel<1'),
+        'traffic_source': profile_source('r*_pmc_hbm_traffic.json'),
         'note': '2*nrows*M*D FLOP per direction / HIP-event time of the counting pass alone '
                 '(cmhse_sim_rank_ex timer); rank 0\'s stripe when n_gpus > 1'}
+    out['library'] = isa_audit()       # cmhse_version() + the ISA audit of the library this run loaded
     leg_seconds = out['leg_seconds'] = {}
 
     def leg(name, fn):

@@ -809,4 +809,4 @@ extern "C" const char* cmhse_strerror(int code) {
   }
 }
 
-extern "C" const char* cmhse_version(void) { return "cmhse_hip 0.4.0 gfx950"; }
+extern "C" const char* cmhse_version(void) { return "cmhse_hip 0.6.0 gfx950"; }

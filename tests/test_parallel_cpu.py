@@ -273,3 +273,126 @@ def test_split_step_plan_counts_active_sequences_per_step():
     tot[:len(a[k])] += a[k]
     tot[:len(b[k])] += b[k]
     np.testing.assert_array_equal(tot, evaluation.length_histograms(batches)[k])
+
+
+# ------------------------------------------------------------------------------------------------
+# RCCL first contact: `bench.py --gpus 8` runs for the first time on a box the
+# builder never sees.  Everything of that run that is not a kernel or an RCCL call, at the REAL
+# sizes: the rank environments, the by-work deal of the 154 loader batches of N = 4917, the step
+# plan all ranks must agree on, the padded all-gather shapes, the stripes, and the merge back to
+# loader order — an 8-rank gloo world over length-only batches.
+# ------------------------------------------------------------------------------------------------
+def test_rank_environments_of_a_bare_multi_gpu_launch():
+  import bench
+  base = {'PATH': '/usr/bin', 'CMHSE_BENCH_BACKEND': 'stale'}
+  envs = bench.rank_environments(8, 8, 29511, base)
+  assert [e['RANK'] for e in envs] == [str(r) for r in range(8)]
+  assert [e['LOCAL_RANK'] for e in envs] == [str(r) for r in range(8)]      # one GPU per rank
+  for e in envs:
+    assert e['WORLD_SIZE'] == '8' and e['MASTER_ADDR'] == '127.0.0.1' and e['MASTER_PORT'] == '29511'
+    assert e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'          # dmabuf IPC: RCCL fails without it here
+    assert 'CMHSE_BENCH_BACKEND' not in e                  # -> nccl (= RCCL)
+  shared = bench.rank_environments(8, 1, 1, {'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+  assert all(e['CMHSE_BENCH_BACKEND'] == 'gloo' and e['LOCAL_RANK'] == '0' for e in shared)
+  assert base['CMHSE_BENCH_BACKEND'] == 'stale'           # the caller's environment is not edited
+
+
+N_FULL, B_FULL, D_FAKE = 4917, 32, 24
+
+
+def _full_split_lengths():
+  from cmhse_amd import parallel_eval, synthetic
+  spec = synthetic.anet_like_spec(N_FULL, seed=0, dataset='anet')
+  lens = synthetic.batch_lengths(spec, B_FULL)
+  costs = [parallel_eval.batch_cost(lc, lv, lw, lp, 2048, 300, 1024) for lc, lv, lw, lp in lens]
+  return spec, lens, costs
+
+
+def _first_contact_worker(rank, world, port, out_dir):
+  sys.path.insert(0, REPO)
+  from cmhse_amd import parallel_eval, synthetic
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  torch.set_num_threads(1)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  spec, lens, costs = _full_split_lengths()
+  assignment = parallel_eval.assign_batches(costs, world)      # bench.py:197-199
+  own = set(assignment[rank])
+  a, b = synthetic.correlated_embeddings(N_FULL, D_FAKE, 2.0, seed=3)
+  # the rank's loader as bench_common.build_loader makes it: own batches carry their length members
+  # (features stay absent: length-only), the others are stubs with num_clips alone
+  batches, clip_pos = [], 0
+  for bi, b0 in enumerate(range(0, N_FULL, B_FULL)):
+    b1 = min(N_FULL, b0 + B_FULL)
+    nclips = tuple(spec.num_clips[b0:b1])
+    bt = [None] * 12
+    bt[8] = nclips
+    if bi in own:
+      lc, lv, lw, lp = lens[bi]
+      bt[4], bt[5], bt[6], bt[7] = (np.asarray(lc), np.asarray(lw), np.asarray(lv), np.asarray(lp))
+      bt[9] = nclips
+      bt[0] = (b0, b1)
+    batches.append(tuple(bt))
+    clip_pos += sum(nclips)
+  seen = {}
+
+  def encode_fn(opt, model, mine):
+    rows = np.concatenate([np.arange(m[0][0], m[0][1]) for m in mine])
+    seen['rows'] = len(rows)
+    return torch.from_numpy(a[rows]), torch.from_numpy(b[rows])
+
+  def rank_fn(q, g, row0, nrows):
+    seen.setdefault('stripes', []).append((int(q.shape[0]), int(g.shape[0]), int(row0), int(nrows)))
+    d = q[row0:row0 + nrows].numpy().astype(np.float64) @ g.numpy().astype(np.float64).T
+    diag = d[np.arange(nrows), row0 + np.arange(nrows)][:, None]
+    return (torch.from_numpy((d > diag).sum(1).astype(np.int32)),
+            torch.from_numpy(d.argmax(1).astype(np.int32)))
+
+  plan = parallel_eval.global_step_plan([batches[i] for i in assignment[rank]], None, 'cpu')
+  res = parallel_eval.validate_sharded(None, None, batches, encode_fn=encode_fn, rank_fn=rank_fn,
+                                       device='cpu', dim=D_FAKE, assignment=assignment)
+  np.savez(os.path.join(out_dir, 'fc%d.npz' % rank), ranks_i=res[2], ranks_t=res[3], top1_i=res[4],
+           top1_t=res[5], rows=seen['rows'], stripes=np.array(seen['stripes']),
+           **{'plan_' + k: v for k, v in plan.items()})
+  dist.destroy_process_group()
+
+
+def test_eight_rank_first_contact_at_the_real_split_sizes(tmp_path, oracle):
+  """8 gloo ranks over the N = 4917 split's LENGTHS (no features, fake embeddings keyed by the
+  global video index): every rank derives bench.py's by-work deal, holds a 544-704 video share,
+  agrees on the whole split's step plan, all-gathers shards padded to the largest, scores its own
+  [row0, row0 + nrows) stripe of the full 4917-row gallery, and the merged ranks / top-1 come out
+  in loader order equal to the single-process oracle's."""
+  from cmhse_amd import evaluation, parallel_eval, synthetic
+  world = 8
+  mp.spawn(_first_contact_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  spec, lens, costs = _full_split_lengths()
+  assignment = parallel_eval.assign_batches(costs, world)
+  sizes = [min(N_FULL, b0 + B_FULL) - b0 for b0 in range(0, N_FULL, B_FULL)]
+  counts = [sum(sizes[i] for i in assignment[r]) for r in range(world)]
+  assert sum(counts) == N_FULL and min(counts) >= 544 and max(counts) <= 704, counts
+  work = [sum(costs[i][0] for i in assignment[r]) for r in range(world)]
+  assert max(work) / min(work) < 1.06                 # the deal balances GRU work (to one batch), not video counts
+  # the whole split's plan from its lengths alone
+  full = []
+  for bi, (lc, lv, lw, lp) in enumerate(lens):
+    bt = [None] * 12
+    bt[4], bt[5], bt[6], bt[7] = np.asarray(lc), np.asarray(lw), np.asarray(lv), np.asarray(lp)
+    b0 = bi * B_FULL
+    bt[8] = bt[9] = tuple(spec.num_clips[b0:min(N_FULL, b0 + B_FULL)])
+    full.append(tuple(bt))
+  want_plan = evaluation.split_step_plan(full)
+  a, b = synthetic.correlated_embeddings(N_FULL, D_FAKE, 2.0, seed=3)
+  _, top1_i, ranks_i = oracle.i2t(a, b, np.float64)
+  _, top1_t, ranks_t = oracle.t2i(a, b, np.float64)
+  for r in range(world):
+    got = np.load(os.path.join(str(tmp_path), 'fc%d.npz' % r))
+    assert int(got['rows']) == counts[r]
+    row0 = sum(counts[:r])
+    assert got['stripes'].tolist() == [[N_FULL, N_FULL, row0, counts[r]]] * 2
+    for k in evaluation.TOWERS:
+      np.testing.assert_array_equal(got['plan_' + k], want_plan[k])
+    np.testing.assert_array_equal(got['ranks_i'], ranks_i)
+    np.testing.assert_array_equal(got['ranks_t'], ranks_t)
+    np.testing.assert_array_equal(got['top1_i'], top1_i)
+    np.testing.assert_array_equal(got['top1_t'], top1_t)

@@ -265,13 +265,24 @@ def fast_mode_bench(opt, model, batches, N, n_steps):
   pert_i, _ = ops.sim_rank(ops.l2norm_rows(ad + dev_v), ops.l2norm_rows(bd + dev_p))
   pert_t, _ = ops.sim_rank(ops.l2norm_rows(bd + dev_p), ops.l2norm_rows(ad + dev_v))
   moved_corr = int((pert_i != base_i).sum()) + int((pert_t != base_t).sum())
+  from cmhse_amd.evaluation import report_from_ranks
+  keys = ('r1', 'r5', 'r10', 'medr')
+
+  def same_report(a, b):
+    ra, rb = report_from_ranks(a.cpu().numpy()), report_from_ranks(b.cpu().numpy())
+    return {k: bool(ra[k] == rb[k]) for k in keys}
   return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x8_bf16_1k pairs, fp32 '
                   'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
                   'attention projection); ranking kernel exact fp32',
+          'contract': 'OUTSIDE the bit-identical-ranks contract: an opt-in (ops.set_math_mode), never `value`',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
           'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
           'rank_rows_moved_vs_fp32_random_init': moved, 'rank_rows_total': 2 * N,
           'rank_rows_moved_on_correlated_embeddings': moved_corr,
+          # Recall@1 / @5 / @50 ('r10' upstream) / median rank of each direction: equal to the exact path's?
+          'report_equal_exact_random_init': {'i2t': same_report(r_i, ref_i), 't2i': same_report(r_t, ref_t)},
+          'report_equal_exact_correlated': {'i2t': same_report(pert_i, base_i), 't2i': same_report(pert_t, base_t)},
+          'isa_audit': isa_audit(),
           'roofline': {'kernel': 'gru_step_kernel<bf16x3>', 'bound': 'mfma', 'achieved': achieved,
                        'peak': peak, 'unit': 'TFLOP/s (fp32-equivalent products)',
                        'frac': achieved / peak, 'launches': launches,
@@ -463,6 +474,7 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           'dependent_steps': chain,
           'mfma_floor_ms': mfma_floor_ms, 'chain_floor_ms': chain_floor_ms,
           'chain_step_us': step_us,
+          'chain_step_us_source': profile_source('r*_step_latency.json'),
           'frac_of_floor': (floor / (dt * 1e3)) if floor > 0 else None,
           # the LOOSER yardstick (it assumes chains and products cannot overlap at all); the bar is
           # frac_of_floor, against max() of the two floors
@@ -470,6 +482,48 @@ def train_bench(name, embed, rnn_type, n_steps, device):
           'bound': 'max(FLOPs / 157.3 TFLOP/s fp32 MFMA, dependent steps x the measured latency '
                    'of one small-batch step launch on an idle chip)',
           'last_losses': losses}
+
+
+def profile_source(pattern):
+  """Provenance of a number that bench.py READS from a committed artefact instead of measuring it in
+  the run (VERDICT r05 item 8): {"file", "sha256_12", "commit"} of the newest profiles/<pattern>;
+  `commit` from profiles/SOURCES.json (tools/profile_sources.py writes it in the build container:
+  the GPU box has no .git).  None if no such file."""
+  import glob
+  import hashlib
+  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', pattern)))
+  if not paths:
+    return None
+  rel = os.path.relpath(paths[-1], REPO)
+  commits = {}
+  try:
+    commits = json.load(open(os.path.join(REPO, 'profiles', 'SOURCES.json')))
+  except (OSError, ValueError):
+    pass
+  return {'file': rel, 'sha256_12': hashlib.sha256(open(paths[-1], 'rb').read()).hexdigest()[:12],
+          'commit': commits.get(rel), 'measured_in_this_run': False}
+
+
+def isa_audit():
+  """build.audit_isa() of the library this process loaded ({} = clean) plus cmhse_version(): the
+  device code holds neither v_pk_fma_f32 nor a double-rate matrix instruction.
+  Needs llvm-objdump (present in this image); reported as unavailable otherwise."""
+  from cmhse_amd import _lib, build
+  if _ISA_AUDIT:
+    return dict(_ISA_AUDIT[0])
+  out = {'library': os.path.relpath(_lib.LIB_PATH, REPO),
+         'version': _lib.load().cmhse_version().decode()}
+  try:
+    out['forbidden_instructions_found'] = build.audit_isa(_lib.LIB_PATH)
+    out['clean'] = not out['forbidden_instructions_found']
+    out['checked_for'] = list(build.FORBIDDEN_ISA)
+  except Exception as e:      # noqa: BLE001
+    out['error'] = '%s: %s' % (type(e).__name__, e)
+  _ISA_AUDIT.append(dict(out))
+  return out
+
+
+_ISA_AUDIT = []
 
 
 def measured_step_latency_us():
