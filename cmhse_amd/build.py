@@ -55,9 +55,7 @@ def audit_isa(path=None, forbidden=FORBIDDEN_ISA):
   """{mnemonic prefix: count} of forbidden instructions in the library's device code (empty = clean)."""
   import tempfile
   path = path or LIB
-  objdump = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), 'lib', 'llvm', 'bin', 'llvm-objdump')
-  if not os.path.exists(objdump):
-    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+  objdump = _objdump()
   objs = code_objects(path)
   if not objs:
     raise RuntimeError('%s: no gfx950 code object found' % path)
@@ -80,6 +78,16 @@ def audit_isa(path=None, forbidden=FORBIDDEN_ISA):
   return found
 
 
+def _objdump():
+  cands = [os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), 'lib', 'llvm', 'bin', 'llvm-objdump'),
+           '/opt/rocm/lib/llvm/bin/llvm-objdump', shutil.which('llvm-objdump')]
+  for cand in cands:
+    if cand and os.path.exists(cand):
+      return cand
+  raise RuntimeError('llvm-objdump not found (looked beside hipcc, in /opt/rocm/lib/llvm/bin and on PATH): the '
+                     'ISA audit of the built library cannot run; build(audit=False) skips it explicitly')
+
+
 def _hipcc():
   for cand in [shutil.which('hipcc'), '/opt/rocm/bin/hipcc']:
     if cand and os.path.exists(cand):
@@ -95,10 +103,11 @@ def is_stale():
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=(), out=None, device_flags=None):
+def build(force=False, verbose=False, extra_flags=(), out=None, device_flags=None, audit=True):
   """Build the product library (default) or, with `out` / `extra_flags` / `device_flags`, another
   build of the same sources at another path (tools/: instrumented and A/B builds; load it through
-  CMHSE_HIP_LIB).  The product build is audited (audit_isa) before it replaces the library."""
+  CMHSE_HIP_LIB).  EVERY build is audited (audit_isa) before it replaces its target; an experiment
+  that breaks the device-code rules on purpose says so with audit=False."""
   global LIB
   if out is None and not extra_flags and device_flags is None and not force and not is_stale():
     return LIB
@@ -113,7 +122,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, device_flags=Non
     raise RuntimeError('hipcc failed:\n' + res.stdout)
   if verbose:
     print(res.stdout)
-  if not extra_flags and device_flags is None:      # (experimental builds may break the rules on purpose)
+  if audit:
     bad = audit_isa(target + '.tmp')
     if bad:
       os.unlink(target + '.tmp')

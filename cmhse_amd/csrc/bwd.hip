@@ -789,7 +789,6 @@ struct RecPartParams {
   int32_t S_next, H, K, k_slice, m_pad, n_tiles;
 };
 
-constexpr int kRecFusedMaxTiles = 1024;   // arrival words of bwd_step_fused_kernel (column tiles x row blocks of a step)
 constexpr int kRecThreads = 512;   // 8 waves: two per SIMD, so one wave's chunk barrier and LDS round trip hide under the other's MFMAs
 
 // The product of one (32-row block, 128-column tile, K slice): acc[mb][reg] = element (row 16 mb +
@@ -957,410 +956,6 @@ __global__ __launch_bounds__(kThreads) void bwd_gates_kernel(const GatesBwdParam
   *reinterpret_cast<float4*>(gh + H) = dzp;
   *reinterpret_cast<float4*>(gh + 2 * H) = dnr;
   *reinterpret_cast<float4*>(q.carry + static_cast<int64_t>(m) * H + u) = car;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same step as ONE launch (round 5; opt-in, Tunables::bwd_fused_step): split-K with a
-// last-arriver epilogue.  Grid = (column tiles x row blocks of S_t, K slices).  A slice workgroup
-// computes its partial tile exactly as bwd_rec_part_kernel does (rec_part_tile), writes it THROUGH
-// the non-coherent L2s (16-byte sc1 stores from an LDS transpose of the accumulators — a dword
-// sc1 store is one fabric write each), drains its stores (s_waitcnt vmcnt(0) by every wave, then
-// the workgroup barrier) and bumps the tile's arrival word (one agent-scope atomic add).  The
-// workgroup whose add returns splits - 1 is the last: it puts the word back to 0 for the next
-// step's launch, re-reads the `splits` partial tiles IN SLICE ORDER with sc1 loads (so the sum is
-// bitwise the one bwd_gates_kernel forms) and evaluates bwd_gates_kernel's arithmetic for the
-// tile's 32 x 128 elements.  No spinning, no co-residency requirement, no grid barrier: the
-// dependency between steps stays a kernel boundary, one per step instead of two.  Row blocks past
-// S_next (sequences whose last step is t: no continuing gradient) have no product: their slice-0
-// workgroup runs the gates alone.  Bit-identical to the two launches
-// (test_bptt_step_as_one_launch_with_a_last_arriver_epilogue) and SLOWER, hence opt-in: 23.4 us per
-// launch against 16.3 + 5.4 at 152 sequences — the epilogue (arrival's return, then the partials'
-// round trip past the L2s, then the stores) sits on the launch's critical path behind its SLOWEST
-// slice and runs on one workgroup per tile, which costs as much as the second launch's gap plus a
-// gates kernel spread over the whole chip: +0.9 ... +1.9 us per step stand-alone, +0.08 ... +0.28 ms
-// per training step (profiles/r05_bptt_one_launch.txt; round 3 measured the same sign).
-// ---------------------------------------------------------------------------------------------
-struct RecFusedParams {
-  RecPartParams r;
-  BwdStepParams s;
-  unsigned* arrive;    // [tiles] arrival words: zero between launches
-  int32_t splits;
-};
-
-__global__ __launch_bounds__(kRecThreads) void bwd_step_fused_kernel(const RecFusedParams f) {
-  CHAIN_WAVE_PRIORITY();
-  __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
-  __shared__ int s_last;
-  const RecPartParams& q = f.r;
-  const BwdStepParams& g = f.s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int H = q.H, K = q.K;
-  const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
-  const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
-  const int y = static_cast<int>(blockIdx.y);
-  const bool product = m0 < q.S_next;
-  if (!product && y != 0) return;
-  typedef int i32x4v __attribute__((ext_vector_type(4)));
-  __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(q.part, 0, 0x7fffffff, 0x00020000);
-  constexpr int TLd = kRecBN + 4;
-  if (product) {
-    f32x4v acc[2];
-    rec_part_tile(q, lds, m0, n0, y, acc);
-    // accumulators -> LDS tile [32][132] -> 16-byte write-through stores
-    float* T = &lds[0][0];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) T[(16 * mb + 4 * kq + reg) * TLd + 16 * wave + r16] = acc[mb][reg];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pc = tid + kRecThreads * i, row = pc >> 5, c4 = pc & 31;
-      if (m0 + row < q.S_next && n0 + 4 * c4 < H) {
-        const float4 tv = *reinterpret_cast<const float4*>(&T[row * TLd + 4 * c4]);
-        const i32x4v v = {__builtin_bit_cast(int, tv.x), __builtin_bit_cast(int, tv.y),
-                          __builtin_bit_cast(int, tv.z), __builtin_bit_cast(int, tv.w)};
-        const int64_t off = ((static_cast<int64_t>(y) * q.m_pad + m0 + row) * H + n0 + 4 * c4) * 4;
-        __builtin_amdgcn_raw_buffer_store_b128(v, part_rs, static_cast<int>(off), 0, 16);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0);     // this wave's write-through stores have been performed
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(f.arrive + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == static_cast<unsigned>(f.splits - 1);
-      if (last) __hip_atomic_store(f.arrive + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-  }
-  // ---- the tile's gates (bwd_gates_kernel's arithmetic), by the last slice to arrive ----
-  // Two (sequence, 4 units) elements per thread.  Everything an element needs is requested before
-  // anything is used — the operands that do not depend on the product first, then the partials
-  // eight slices at a time — so the epilogue is two or three memory round trips, not one per slice.
-  bool live[2], cont[2];
-  int mm[2], uu[2];
-  float4 e_car[2], e_dp[2], e_g[2][4], e_hp[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pc = tid + kRecThreads * i, row = pc >> 5, c4 = pc & 31;
-    const int m = m0 + row, u = n0 + 4 * c4;
-    mm[i] = m; uu[i] = u;
-    live[i] = m < g.S_t && u < H;
-    cont[i] = live[i] && m < g.S_next;
-    const int mc = live[i] ? m : 0, uc = live[i] ? u : 0;
-    const int64_t p = g.off_cur + mc;
-    e_car[i] = *reinterpret_cast<const float4*>(g.carry + static_cast<int64_t>(mc) * H + uc);
-    e_dp[i] = *reinterpret_cast<const float4*>(g.dpool + p * H + uc);
-    const float* gp = g.gates + p * 4 * H + uc;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) e_g[i][c] = *reinterpret_cast<const float4*>(gp + static_cast<int64_t>(c) * H);
-    e_hp[i] = zero4();
-    if (g.t > 0)
-      e_hp[i] = *reinterpret_cast<const float4*>(g.hs + (g.off_prev + mc) * H + uc);
-    else if (g.h0_rows != nullptr)
-      e_hp[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.h0_rows[mc]) + uc);
-  }
-  float4 sum[2] = {zero4(), zero4()};
-  if (product) {
-    const int stride = q.m_pad * H * 4;      // bytes between consecutive slices' partial tiles
-    for (int y0 = 0; y0 < f.splits; y0 += 8) {
-      i32x4v pv[2][8];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int base = ((cont[i] ? mm[i] : 0) * H + (cont[i] ? uu[i] : 0)) * 4;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const int yy = (y0 + jj < f.splits) ? (y0 + jj) : (f.splits - 1);
-          pv[i][jj] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, base + yy * stride, 0, 16);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-          if (y0 + jj < f.splits) {   // slice order: the sum bwd_gates_kernel forms
-            // (__int_as_float, not __builtin_bit_cast: the latter applied to an element of an ext
-            // vector reads the vector's FIRST element for .y/.z/.w too — clang 19 / ROCm 7.2)
-            sum[i].x += __int_as_float(pv[i][jj].x); sum[i].y += __int_as_float(pv[i][jj].y);
-            sum[i].z += __int_as_float(pv[i][jj].z); sum[i].w += __int_as_float(pv[i][jj].w);
-          }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (!live[i]) continue;
-    const int m = mm[i], u = uu[i];
-    float4 rec = zero4();
-    if (cont[i]) {
-      rec = e_car[i];
-      rec.x += sum[i].x; rec.y += sum[i].y; rec.z += sum[i].z; rec.w += sum[i].w;
-    }
-    const int64_t p = g.off_cur + m;
-    const float4 dp = e_dp[i], rg = e_g[i][0], zg = e_g[i][1], ng = e_g[i][2], ghn = e_g[i][3], hp = e_hp[i];
-    float4 drp, dzp, dnp, dnr, car;
-#define GATE_LANE_(c)                                            \
-  {                                                                   \
-    const float dh = rec.c + dp.c;                                    \
-    const float dn_pre = dh * (1.0f - zg.c) * (1.0f - ng.c * ng.c);   \
-    dzp.c = dh * (hp.c - ng.c) * zg.c * (1.0f - zg.c);                \
-    drp.c = dn_pre * ghn.c * rg.c * (1.0f - rg.c);                    \
-    dnp.c = dn_pre;                                                   \
-    dnr.c = dn_pre * rg.c;                                            \
-    car.c = dh * zg.c;                                                \
-  }
-    GATE_LANE_(x) GATE_LANE_(y) GATE_LANE_(z) GATE_LANE_(w)
-#undef GATE_LANE_
-    float* gx = g.dgx + p * K + u;
-    float* gh = g.dgh + p * K + u;
-    *reinterpret_cast<float4*>(gx) = drp;
-    *reinterpret_cast<float4*>(gx + H) = dzp;
-    *reinterpret_cast<float4*>(gx + 2 * H) = dnp;
-    *reinterpret_cast<float4*>(gh) = drp;
-    *reinterpret_cast<float4*>(gh + H) = dzp;
-    *reinterpret_cast<float4*>(gh + 2 * H) = dnr;
-    *reinterpret_cast<float4*>(g.carry + static_cast<int64_t>(m) * H + u) = car;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The training-size BPTT steps (32 < S_t <= kChainMaxRows) of a chain as ONE resident kernel per
-// run of steps (round 4).  What the two launches per step above cost in the training step is not
-// their stand-alone 22 us but 43 us: beside the other tower's chain and the weight-gradient
-// products, every workgroup of bwd_rec_part_kernel re-pulls its 64 KB slice of W_hh^T through the
-// L2 -> CU fabric the other kernels are also bound by (80 % of the step's operand bytes), and each
-// launch pays its ramp and drain.  Here the SAME decomposition — the product dGh_{t+1} . W_hh as
-// [rows x 128 columns] tiles with K = 3H cut into 128-wide slices, partial tiles added in slice
-// order by a gates phase — runs inside a kernel whose (H / 128) x (3H / 128) workgroups (192 at
-// H = 1024: the other 64 CUs stay free for the text chain's resident tail) stay on their CUs:
-//   * the workgroup's W_hh^T slice (128 x 128 floats, 66 KB with padding) is loaded into LDS ONCE;
-//   * phase A, per 32-row block of dGh_{t+1}: the block's 128-float row segments (16 KB, sc1 loads:
-//     they were written by all workgroups one phase earlier) are staged through a double-buffered
-//     LDS tile, eight waves x 16 columns x two 16x16x4 accumulators run the slice's 128 k, and the
-//     partial tile goes out with sc1 stores;
-//   * grid barrier (grid_sync.hpp);
-//   * phase B: one thread per (sequence, 4 hidden units), the element assignment fixed for the
-//     whole kernel, so the carry dh_{t+1} z_{t+1} stays in a register: partials added in slice
-//     order (sc1 loads), gate derivatives exactly as bwd_gates_kernel, dGh rows published with
-//     sc1 stores; the operands that do not depend on the chain (dpool, gates, h_{t-1}) are
-//     requested before phase A;
-//   * grid barrier, next step.
-// A run ends where a weight-gradient chunk closes (the products beside the chain need the rows
-// produced so far: the host launches the next run behind the chunk's event) or where the batch
-// leaves the size range.  Results equal the two-launch path to fp32 rounding (K is cut into 24
-// slices here, 6-8 there) and are bitwise reproducible.
-// ---------------------------------------------------------------------------------------------
-constexpr int kChainBN = 128, kChainBK = 128, kChainLd = kChainBK + 4, kChainBM = 32;
-constexpr int kChainMaxRows = 256, kChainMinRows = 33, kChainThreads = 512, kChainMaxElems = 6;
-
-struct BwdChainParams {
-  const float* whh_t;        // [H, 3H]
-  const float* dpool;        // [sumT, H]
-  const float* gates;        // [sumT, 4H]
-  const float* hs;           // [sumT, H]
-  const uint64_t* h0_rows;   // initial states (t == 0) or NULL
-  const int32_t* step_off;   // device [Tmax + 1]
-  float* carry;              // [S, H]
-  float* dgx;                // [sumT, 3H]
-  float* dgh;                // [sumT, 3H]
-  float* part;               // [splits][kChainMaxRows][H]
-  GridSync sync;
-  int32_t H, Tmax, t_hi, t_lo, n_tiles, splits;
-};
-
-// NE = phase B elements per thread (1 at H = 1024: 132 registers, so the workgroup leaves a wave
-// slot per SIMD and 58 KB of LDS to the kernels that run beside the chain; 2 / 3 / 6 at
-// H = 512 / 256 / 128).
-template <int NE>
-__global__ __launch_bounds__(kChainThreads) void gru_bwd_chain_kernel(const BwdChainParams q) {
-  CHAIN_WAVE_PRIORITY();
-  __shared__ __attribute__((aligned(16))) float Wl[kChainBN * kChainLd];
-  __shared__ __attribute__((aligned(16))) float Al[2][kChainBM * kChainLd];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int H = q.H, K = 3 * H, h4 = H / 4;
-  const int nb = static_cast<int>(blockIdx.x) % q.n_tiles, ks = static_cast<int>(blockIdx.x) / q.n_tiles;
-  const int n0 = nb * kChainBN, k0 = ks * kChainBK;
-  // the resident operand: W_hh^T[n0 .. n0 + 127][k0 .. k0 + 127]
-  for (int pc = tid; pc < kChainBN * (kChainBK / 4); pc += kChainThreads) {
-    const int row = pc / (kChainBK / 4), c4 = pc % (kChainBK / 4);
-    *reinterpret_cast<float4*>(&Wl[row * kChainLd + 4 * c4]) =
-        *reinterpret_cast<const float4*>(q.whh_t + static_cast<int64_t>(n0 + row) * K + k0 + 4 * c4);
-  }
-  // phase B elements of this thread: e = first + i * stride, (sequence m, units u .. u + 3) = (e / h4, 4 (e % h4))
-  const int stride = static_cast<int>(gridDim.x) * kChainThreads;
-  const int first = static_cast<int>(blockIdx.x) * kChainThreads + tid;
-  const int n_el = (kChainMaxRows * h4 - first + stride - 1) / stride;   // <= NE (launcher)
-  float4 carry[NE];
-  {
-    const int S_in = (q.t_hi + 1 < q.Tmax) ? (q.step_off[q.t_hi + 2] - q.step_off[q.t_hi + 1]) : 0;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      carry[i] = zero4();
-      const int e = first + i * stride, m = e / h4;
-      if (i < n_el && m < S_in)
-        carry[i] = *reinterpret_cast<const float4*>(q.carry + static_cast<int64_t>(m) * H + 4 * (e % h4));
-    }
-  }
-  __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(q.part, 0, 0x7fffffff, 0x00020000);
-  typedef int i32x4v __attribute__((ext_vector_type(4)));
-  unsigned arrivals = 0;
-  int S_t = 0;
-  for (int t = q.t_hi; t >= q.t_lo; --t) {
-    const int off_cur = q.step_off[t], off_next = q.step_off[t + 1];
-    const int off_prev = (t > 0) ? q.step_off[t - 1] : 0;
-    S_t = off_next - off_cur;
-    const int S_next = (t + 1 < q.Tmax) ? (q.step_off[t + 2] - off_next) : 0;
-    // what phase B needs that does not depend on the chain, for the thread's first element
-    // (H = 1024: its only one): requested now, used after the product
-    float4 e_dp = zero4(), e_g[4] = {zero4(), zero4(), zero4(), zero4()}, e_hp = zero4();
-    auto load_elem = [&](int e, float4& dp, float4 (&g)[4], float4& hp) {
-      const int m = e / h4, u = 4 * (e % h4);
-      const int64_t p = static_cast<int64_t>(off_cur) + m;
-      dp = *reinterpret_cast<const float4*>(q.dpool + p * H + u);
-      const float* gp = q.gates + p * 4 * H + u;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) g[c] = *reinterpret_cast<const float4*>(gp + static_cast<int64_t>(c) * H);
-      if (t > 0)
-        hp = *reinterpret_cast<const float4*>(q.hs + (static_cast<int64_t>(off_prev) + m) * H + u);
-      else if (q.h0_rows != nullptr)
-        hp = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(q.h0_rows[m]) + u);
-      else
-        hp = zero4();
-    };
-    if (n_el > 0 && first / h4 < S_t) load_elem(first, e_dp, e_g, e_hp);
-
-    if (S_next > 0) {
-      // ---- phase A: partial[ks][m][n0 .. n0 + 127] = dGh_{t+1}[m][k0 .. k0 + 127] . Wl^T ----
-      __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
-          q.dgh + static_cast<int64_t>(off_next) * K, 0, 0x7fffffff, 0x00020000);
-      const int nblk = (S_next + kChainBM - 1) / kChainBM;
-      // staging: piece pc = tid + 512 i (i < 2): row pc >> 5 of the block, float4 pc & 31 of its segment
-      i32x4v ar[2];
-      auto issue = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int pc = tid + kChainThreads * i, row = pc >> 5, c4 = pc & 31;
-          const int m = b * kChainBM + row, mc = (m < S_next) ? m : (S_next - 1);
-          ar[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, (mc * K + k0 + 4 * c4) * 4, 0, 16);
-        }
-      };
-      auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int pc = tid + kChainThreads * i, row = pc >> 5, c4 = pc & 31;
-          *reinterpret_cast<i32x4v*>(&Al[buf][row * kChainLd + 4 * c4]) = ar[i];
-        }
-      };
-      issue(0);
-      stage(0);
-      __syncthreads();      // (also orders the W slice's LDS writes before the first fragment reads)
-      for (int b = 0; b < nblk; ++b) {
-        const int cur = b & 1;
-        if (b + 1 < nblk) issue(b + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-        const float* A = &Al[cur][0] + r16 * kChainLd + 4 * kq;
-        const float* B = &Wl[0] + (16 * wave + r16) * kChainLd + 4 * kq;
-#pragma unroll
-        for (int kb = 0; kb < kChainBK / 16; ++kb) {
-          const float4 a0 = *reinterpret_cast<const float4*>(A + kb * 16);
-          const float4 a1 = *reinterpret_cast<const float4*>(A + 16 * kChainLd + kb * 16);
-          const float4 bv = *reinterpret_cast<const float4*>(B + kb * 16);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[1], 0, 0, 0);
-        }
-        // the slice's partial tile: element (row r, col c) of a 16 x 16 block sits in lane
-        // (r >> 2) * 16 + c, register r & 3; written through (the gates phase of OTHER workgroups reads it)
-        const int n = n0 + 16 * wave + r16;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int m = b * kChainBM + 16 * mb + 4 * kq + reg;
-            if (m < S_next)
-              __builtin_amdgcn_raw_buffer_store_b32(
-                  __float_as_int(acc[mb][reg]), part_rs,
-                  ((ks * kChainMaxRows + m) * H + n) * 4, 0, 16);
-          }
-        if (b + 1 < nblk) stage(cur ^ 1);
-        __syncthreads();
-      }
-      __builtin_amdgcn_s_waitcnt(0);
-      arrivals += gridDim.x;
-      if (!grid_sync_wait(q.sync, arrivals)) return;
-    }
-
-    // ---- phase B: the gate derivatives of step t (bwd_gates_kernel's arithmetic) ----
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = first + i * stride, m = e / h4, u = 4 * (e % h4);
-      if (i >= n_el || m >= S_t) continue;
-      float4 dp = e_dp, hp = e_hp, g[4] = {e_g[0], e_g[1], e_g[2], e_g[3]};
-      if (i > 0) load_elem(e, dp, g, hp);
-      float4 rec = zero4();
-      if (m < S_next) {
-        float4 sum = zero4();
-#pragma unroll 8
-        for (int y = 0; y < q.splits; ++y) {
-          const i32x4v pv = __builtin_amdgcn_raw_buffer_load_b128(
-              part_rs, ((y * kChainMaxRows + m) * H + u) * 4, 0, 16);
-          sum.x += __int_as_float(pv.x); sum.y += __int_as_float(pv.y);
-          sum.z += __int_as_float(pv.z); sum.w += __int_as_float(pv.w);
-        }
-        rec.x = carry[i].x + sum.x; rec.y = carry[i].y + sum.y;
-        rec.z = carry[i].z + sum.z; rec.w = carry[i].w + sum.w;
-      }
-      const float4 rg = g[0], zg = g[1], ng = g[2], ghn = g[3];
-      float4 drp, dzp, dnp, dnr, car;
-#define GATE_LANE_(c)                                                 \
-  {                                                                   \
-    const float dh = rec.c + dp.c;                                    \
-    const float dn_pre = dh * (1.0f - zg.c) * (1.0f - ng.c * ng.c);   \
-    dzp.c = dh * (hp.c - ng.c) * zg.c * (1.0f - zg.c);                \
-    drp.c = dn_pre * ghn.c * rg.c * (1.0f - rg.c);                    \
-    dnp.c = dn_pre;                                                   \
-    dnr.c = dn_pre * rg.c;                                            \
-    car.c = dh * zg.c;                                                \
-  }
-      GATE_LANE_(x) GATE_LANE_(y) GATE_LANE_(z) GATE_LANE_(w)
-#undef GATE_LANE_
-      const int64_t p = static_cast<int64_t>(off_cur) + m;
-      float* gx = q.dgx + p * K + u;
-      *reinterpret_cast<float4*>(gx) = drp;
-      *reinterpret_cast<float4*>(gx + H) = dzp;
-      *reinterpret_cast<float4*>(gx + 2 * H) = dnp;
-      // the next step's A operand, in every workgroup: write through to where all XCDs see it
-      __amdgpu_buffer_rsrc_t gh_rs = __builtin_amdgcn_make_buffer_rsrc(q.dgh + p * K, 0, 0x7fffffff, 0x00020000);
-      auto st4 = [&](const float4& v, int col) {
-        i32x4v iv = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(iv, gh_rs, col * 4, 0, 16);
-      };
-      st4(drp, u);
-      st4(dzp, H + u);
-      st4(dnr, 2 * H + u);
-      carry[i] = car;
-    }
-    if (t == q.t_lo) break;
-    __builtin_amdgcn_s_waitcnt(0);
-    arrivals += gridDim.x;
-    if (!grid_sync_wait(q.sync, arrivals)) return;
-  }
-  // hand the carry over to whatever serves step t_lo - 1
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    const int e = first + i * stride, m = e / h4;
-    if (i < n_el && m < S_t)
-      *reinterpret_cast<float4*>(q.carry + static_cast<int64_t>(m) * H + 4 * (e % h4)) = carry[i];
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1810,11 +1405,6 @@ static size_t rec_part_floats(int S, int H) {
   if (H % 4 != 0) return 0;
   const int n_tiles = (H + kRecBN - 1) / kRecBN;
   size_t rows = static_cast<size_t>(256 / n_tiles + 1 + (S + 31) / 32) * 32;
-  // the resident chain kernel (gru_bwd_chain_kernel): one [kChainMaxRows, H] partial per 128-wide K slice
-  if (H % kChainBN == 0 && S >= kChainMinRows) {
-    const size_t chain_rows = static_cast<size_t>(3 * H / kChainBK) * kChainMaxRows;
-    rows = rows > chain_rows ? rows : chain_rows;
-  }
   return rows * H;
 }
 
@@ -1829,7 +1419,7 @@ static size_t wg_part_floats(int64_t sum_T, int I, int H) {
 
 struct BwdWs {
   size_t dgx, dgh, dpool, carry, whh_t, wih_t, wlin_t, du, de, xaddr, hpaddr, dxaddr, hsaddr, p_t, zero_row,
-      tail_sync, rec_cnt, colsum, dx_part, wg_part, rec_part, total;
+      tail_sync, colsum, dx_part, wg_part, rec_part, total;
 };
 
 static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32_t mode) {
@@ -1852,7 +1442,6 @@ static BwdWs bwd_ws_layout(int32_t S, int64_t sum_T, int32_t I, int32_t H, int32
   L.p_t = take(static_cast<size_t>(sum_T) * 4);
   L.zero_row = take(static_cast<size_t>(H > I ? H : I) * 4);
   L.tail_sync = take(256);      // (right behind zero_row: one memset clears both)
-  L.rec_cnt = take(kRecFusedMaxTiles * sizeof(unsigned));   // ... and the fused BPTT step's arrival words
   L.colsum = take(static_cast<size_t>((sum_T + kColsumRows - 1) / kColsumRows) * 3 * H * 4);
   L.dx_part = take(det_split_scratch_bytes(sum_T, I > H ? I : H));   // (also the attention backward's dpool product: N = H)
   L.wg_part = take(wg_part_floats(sum_T, I, H) * sizeof(float));
@@ -1898,11 +1487,6 @@ struct BwdJob {
   bool chunk_first;
   hipStream_t st;         // the stream of this request's chain (its own, or the call's)
   int tail_lo;            // steps >= tail_lo run inside ONE resident kernel (gru_bwd_tail_kernel); -1 = none
-  // gru_bwd_chain_kernel: the training-size steps in resident runs.  chain_on: this request uses
-  // it; [chain_lo, chain_hi]: the steps collected for the next launch (chain_hi < 0: none);
-  // chain_seg: launches so far (each has its own barrier words behind tail_sync)
-  bool chain_on;
-  int chain_hi, chain_lo, chain_seg;
 };
 
 int bwd_prepare(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t pool_mode,
@@ -1962,7 +1546,7 @@ void bwd_begin(BwdJob& j, hipStream_t st) {
   const int pool_mode = j.pool_mode;
   const bool beside = j.side != st;
 
-  (void)hipMemsetAsync(zero_row, 0, L.rec_cnt + kRecFusedMaxTiles * sizeof(unsigned) - L.zero_row, st);   // zero_row, the tail kernel's barrier counter, the fused step's arrival words
+  (void)hipMemsetAsync(zero_row, 0, L.tail_sync + 256 - L.zero_row, st);   // zero_row and the tail kernel's barrier counter
   (void)hipMemsetAsync(carry, 0, static_cast<size_t>(S) * H * 4, st);
   if (beside) stream_after(j.side, st);     // fork: the caller's inputs (and zero_row) are ready
   // W_hh^T for the chain depends on the weights only: with a side stream it is the FIRST thing
@@ -2131,7 +1715,7 @@ static void bwd_tail(BwdJob& j) {
   j.tail_lo = -1;
   const cmhse_seq_batch* b = j.b;
   const int H = b->H, Tmax = b->Tmax;
-  const int min_steps = tunables().bwd_tail_min_steps.load(std::memory_order_relaxed);
+  const int min_steps = multi_step_knob(tunables().bwd_tail_min_steps);
   if (min_steps <= 0 || H % 16 != 0 || H > 1024 || !b->step_off || !resident_fits(H / 16)) return;
   int lo = Tmax;
   while (lo - 1 >= 1 && b->step_count_host[lo - 1] <= kTailMaxSeqs) --lo;
@@ -2161,56 +1745,6 @@ static void bwd_tail(BwdJob& j) {
   j.tail_lo = lo;
 }
 
-// Steps a resident chain run may serve: a training-size batch at step t AND at step t + 1 (whose
-// rows are its A operand).
-static bool chain_step_ok(const cmhse_seq_batch* b, int t) {
-  if (t < 0) return false;
-  const int S_t = b->step_count_host[t];
-  const int S_next = (t + 1 < b->Tmax) ? b->step_count_host[t + 1] : 0;
-  return S_t >= kChainMinRows && S_t <= kChainMaxRows && S_next <= kChainMaxRows;
-}
-
-static int chain_grid(int H) { return (H / kChainBN) * (3 * H / kChainBK); }
-
-// How many steps of job j a resident chain kernel could serve (0: not this job).
-static int chain_steps_of(const BwdJob& j) {
-  const cmhse_seq_batch* b = j.b;
-  const int H = b->H;
-  if (tunables().bwd_chain_min_steps.load(std::memory_order_relaxed) <= 0) return 0;
-  if (H % kChainBN != 0 || !b->step_off || !resident_fits_wgs(chain_grid(H) + 64)) return 0;
-  if (static_cast<int64_t>(kChainMaxRows) * (H / 4) > static_cast<int64_t>(kChainMaxElems) * chain_grid(H) * kChainThreads)
-    return 0;
-  int n = 0;
-  for (int t = 0; t < b->Tmax; ++t) n += chain_step_ok(b, t) ? 1 : 0;
-  return n;
-}
-
-// Launch the collected run [chain_lo, chain_hi] of job j (if any) on its chain stream.
-static void chain_flush(BwdJob& j) {
-  if (j.chain_hi < 0) return;
-  const cmhse_seq_batch* b = j.b;
-  const BwdStepParams& sp = j.sp;
-  BwdChainParams q;
-  q.whh_t = sp.whh_t; q.dpool = sp.dpool; q.gates = sp.gates; q.hs = sp.hs;
-  q.h0_rows = sp.h0_rows;
-  q.step_off = b->step_off;
-  q.carry = sp.carry; q.dgx = sp.dgx; q.dgh = sp.dgh;
-  q.part = reinterpret_cast<float*>(j.ws + j.L.rec_part);
-  unsigned* words = reinterpret_cast<unsigned*>(j.ws + j.L.tail_sync);
-  q.sync = make_grid_sync(words + 1 + 2 * j.chain_seg, words + 2 + 2 * j.chain_seg);
-  q.H = b->H; q.Tmax = b->Tmax; q.t_hi = j.chain_hi; q.t_lo = j.chain_lo;
-  q.n_tiles = b->H / kChainBN; q.splits = 3 * b->H / kChainBK;
-  const dim3 grid(static_cast<unsigned>(chain_grid(b->H))), block(kChainThreads);
-  const int ne = static_cast<int>((static_cast<int64_t>(kChainMaxRows) * (b->H / 4) + static_cast<int64_t>(grid.x) * kChainThreads - 1) /
-                                  (static_cast<int64_t>(grid.x) * kChainThreads));
-  if (ne <= 1) hipLaunchKernelGGL(gru_bwd_chain_kernel<1>, grid, block, 0, j.st, q);
-  else if (ne <= 2) hipLaunchKernelGGL(gru_bwd_chain_kernel<2>, grid, block, 0, j.st, q);
-  else if (ne <= 3) hipLaunchKernelGGL(gru_bwd_chain_kernel<3>, grid, block, 0, j.st, q);
-  else hipLaunchKernelGGL(gru_bwd_chain_kernel<kChainMaxElems>, grid, block, 0, j.st, q);
-  ++j.chain_seg;
-  j.chain_hi = -1;
-}
-
 // Phase 2: BPTT of all jobs, last step first.  Launch i serves step Tmax_k - 1 - i of every job k
 // that still has one (and the extra t = -1 launch of a job that wants d h0); jobs of equal block
 // size share the launch.
@@ -2218,21 +1752,6 @@ void bwd_steps(BwdJob* jobs, int n) {
   constexpr int nw8_max = kBwdNw8Max;
   int longest = 0;
   for (int k = 0; k < n; ++k) longest = jobs[k].b->Tmax > longest ? jobs[k].b->Tmax : longest;
-  // at most ONE request of the call runs its training-size steps in resident chain kernels (192
-  // workgroups at H = 1024, a CU each): the one with the most such steps
-  {
-    int best = -1, best_n = 0;
-    for (int k = 0; k < n; ++k) {
-      jobs[k].chain_on = false;
-      jobs[k].chain_hi = -1;
-      jobs[k].chain_lo = 0;
-      jobs[k].chain_seg = 0;
-      const int c = chain_steps_of(jobs[k]);
-      if (c > best_n) best = k, best_n = c;
-    }
-    if (best >= 0 && best_n >= tunables().bwd_chain_min_steps.load(std::memory_order_relaxed))
-      jobs[best].chain_on = true;
-  }
   for (int i = 0; i <= longest; ++i) {
     int kind[CMHSE_MAX_JOBS];      // 0 = not in this launch, 1 = 4 waves, 2 = 8 waves, +4 = scalar loads; 8 | shape bits = gru_bwd_step_mid_kernel
     unsigned grid_k[CMHSE_MAX_JOBS];
@@ -2253,12 +1772,6 @@ void bwd_steps(BwdJob* jobs, int n) {
       sp.off_prev = (t > 0) ? j.off - b->step_count_host[t - 1] : 0;
       if (i == 0) bwd_tail(j);                 // the chain's few-sequence tail, if it has one: one kernel
       if (j.tail_lo >= 0 && t >= j.tail_lo) continue;   // (kind 0) the resident kernel does this step
-      if (j.chain_on && j.chain_seg < 30 && chain_step_ok(b, t)) {   // (kind 0) collected for the next chain run
-        if (j.chain_hi < 0) j.chain_hi = t;
-        j.chain_lo = t;
-        continue;
-      }
-      chain_flush(j);       // a step the chain kernel does not serve: what was collected goes first
       grid_k[k] = static_cast<unsigned>((b->H + 31) / 32) * ((S_t + 31) / 32);
       // few active sequences: a pure latency chain on an under-filled chip -> 8 waves split K
       kind[k] = ((S_t <= nw8_max) ? 2 : 1) | ((b->H % 4 == 0) ? 0 : 4);
@@ -2291,16 +1804,6 @@ void bwd_steps(BwdJob* jobs, int n) {
         rp.k_slice = ((K + splits - 1) / splits + kRecBK - 1) / kRecBK * kRecBK;
         splits = (K + rp.k_slice - 1) / rp.k_slice;
         rp.m_pad = m_tiles * kRecBM;
-        const int all_tiles = rp.n_tiles * ((sp.S_t + kRecBM - 1) / kRecBM);
-        if (sp.t >= 0 && all_tiles <= kRecFusedMaxTiles &&
-            tunables().bwd_fused_step.load(std::memory_order_relaxed) != 0) {
-          RecFusedParams fp;      // ONE launch: the last K slice of a tile to arrive runs its gates
-          fp.r = rp; fp.s = sp; fp.splits = splits;
-          fp.arrive = reinterpret_cast<unsigned*>(j.ws + j.L.rec_cnt);
-          hipLaunchKernelGGL(bwd_step_fused_kernel, dim3(all_tiles, splits), dim3(kRecThreads), 0, j.st, fp);
-          kind[k] = 0;
-          continue;
-        }
         hipLaunchKernelGGL(bwd_rec_part_kernel, dim3(tiles, splits), dim3(kRecThreads), 0, j.st, rp);
         gp.part = rp.part; gp.splits = splits; gp.m_pad = rp.m_pad;
       }
@@ -2349,12 +1852,10 @@ void bwd_steps(BwdJob* jobs, int n) {
       const int t = j.b->Tmax - 1 - i;
       if (t < 0) continue;
       if (t == 0 || j.chunk_hi - j.off >= tunables().bwd_chunk_rows.load(std::memory_order_relaxed)) {
-        chain_flush(j);     // the chunk's rows must have been produced (launched) before its event
         bwd_chunk(j, j.st);
       }
     }
   }
-  for (int k = 0; k < n; ++k) chain_flush(jobs[k]);
 }
 
 // Join: everything the side stream did for job j is ordered in front of what follows on `st`.

@@ -545,34 +545,19 @@ void attn_energy_kernel(const AttnEnergyParams p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kChainMaxSteps = kChainMaxStepsWs;
 constexpr int kXcds = 8;
-// Tasks of a queue come in PHASES, the same number of tickets in every queue:
-//   phase 2 s      (s < nsteps)  the GRU tiles of step t0 + s: (request, row tile) x the queue's column tiles;
-//   phase 2 s + 3                the attention-energy tiles (attn_energy_tile: e = w_att . tanh(W_lin h + b), the
-//                                first half of layers.py:105-106's pooling) of the rows step t0 + s produced —
-//                                handed out after the GRU tiles of step s + 1, whose x phases need nothing, so
-//                                that by then the rows they read are (almost always) complete; they fill the
-//                                slots the recurrence leaves empty (a rank's share of the split: steps of one
-//                                round of workgroups or less; the ragged end of any chain) instead of running
-//                                as a launch of their own behind the chain.
-// (phases 1 and 2 nsteps are empty.)  tick[p] = tickets of a queue in front of phase p.
-constexpr int kChainPhases = 2 * kChainMaxSteps + 2;
+// Tasks of a queue come in PHASES, one per time step, the same number of tickets in every queue:
+// phase s (s < nsteps) = the GRU tiles of step t0 + s: (request, row tile) x the queue's column tiles.
+// tick[p] = tickets of a queue in front of phase p.
+constexpr int kChainPhases = kChainMaxSteps;
 struct GruChainGroup {
   GruStepParams j[kMaxJobs];            // (t, S_t, off_prev, off_cur unused: derived per task)
-  AttnEnergyParams att[kMaxJobs];       // attention-pooled requests whose energies are tasks of this launch (att_on)
   const int32_t* step_off[kMaxJobs];    // device: first packed row of every step of request k
   unsigned* done[kMaxJobs];             // zeroed counters [nsteps][rt_stride[k]] of request k
   int32_t rt_stride[kMaxJobs];          // row tiles of request k at step t0 (its maximum)
-  int32_t att_on[kMaxJobs];
   uint32_t tick[kChainPhases + 1];
   unsigned* ticket;                     // [kXcds] zeroed: next task of every queue
   GridSync sync;
   int32_t n, t0, nsteps, n_tiles;
-  int32_t att_tiles;                    // 256-column tiles of W_lin (4 or 8 when any att_on)
-  int32_t col_map;                      // 0: queue x serves column tiles x, x + 8, ... of EVERY row tile;
-                                        // 1 (n_tiles = 16, experiment chain_col_map): queue x serves column tiles
-                                        //   x % 4 + {0, 4, 8, 12} of the row tiles of parity x / 4 — an XCD then
-                                        //   pulls HALF the A rows (4x instead of 8x over the chip) and four weight
-                                        //   slices instead of two
 };
 
 // Queues.  n_tiles % 8 == 0: eight, column tile c of the GRU step in queue c % 8 (an XCD's L2 keeps
@@ -586,16 +571,14 @@ struct GruChainGroup {
 // can always run.
 __device__ __host__ __forceinline__ int chain_queues(int n_tiles) { return (n_tiles % kXcds == 0) ? kXcds : 1; }
 
-// ATT: the instantiation that also serves attention-energy tasks (chain_attention); the default one
-// does not contain that tile, whose live ranges would cost it registers (256 + spills against 230).
-template <bool VEC, int MSUB, bool ATT = false>
+template <bool VEC, int MSUB>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
 void gru_step_chain_kernel(const GruChainGroup g) {
   constexpr int BM = 64 * MSUB;
   __shared__ unsigned s_task[2];
   const unsigned nq = static_cast<unsigned>(chain_queues(g.n_tiles));
   const unsigned cols = static_cast<unsigned>(g.n_tiles) / nq;
-  const int n_phases = 2 * g.nsteps + 2;
+  const int n_phases = g.nsteps;
   const unsigned per_queue = g.tick[n_phases];
   if (threadIdx.x == 0) {
     // home queue: workgroups are dealt to the XCDs round-robin by their index (b and b + 8 share an
@@ -625,84 +608,28 @@ void gru_step_chain_kernel(const GruChainGroup g) {
     const int mid = (lo + hi + 1) >> 1;
     if (g.tick[mid] <= tk) lo = mid; else hi = mid - 1;
   }
-  const int ph = lo;
-  const unsigned local = tk - g.tick[ph];
-  if ((ph & 1) == 0) {
-    // ---- a GRU tile of step s ----
-    const int s = ph >> 1, t = g.t0 + s;
-    unsigned rem;
-    int c, k = 0, S_t = 0;
-    if (g.col_map == 0) {
-      rem = local / cols;
-      c = static_cast<int>(queue + nq * (local % cols));
-      for (; k < g.n; ++k) {
-        S_t = g.step_off[k][t + 1] - g.step_off[k][t];
-        const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
-        if (rem < rt || k == g.n - 1) break;
-        rem -= rt;
-      }
-    } else {
-      unsigned j = local >> 2;                          // (row tile of this queue's parity, 4 column tiles each)
-      c = static_cast<int>((queue & 3u) + 4u * (local & 3u));
-      unsigned rt_n = 0;
-      bool found = false;
-      for (; k < g.n; ++k) {
-        S_t = g.step_off[k][t + 1] - g.step_off[k][t];
-        rt_n = static_cast<unsigned>((S_t + BM - 1) / BM);
-        const unsigned cnt = (rt_n + 1) >> 1;
-        if (j < cnt) {
-          found = true;
-          break;
-        }
-        j -= cnt;
-      }
-      if (!found) return;
-      rem = 2 * j + (queue >> 2);
-      if (rem >= rt_n) return;                          // (odd count: the padding ticket of the odd-parity queues)
-    }
-    const GruStepParams& p = g.j[k];
-    const int64_t off_cur = g.step_off[k][t];
-    const int64_t off_prev = (t > 0) ? g.step_off[k][t - 1] : 0;
-    ChainDep dep;
-    dep.sync = g.sync;
-    dep.need = static_cast<unsigned>(g.n_tiles);
-    dep.done = g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rem;
-    dep.wait = (s > 0) ? g.done[k] + static_cast<size_t>(s - 1) * g.rt_stride[k] + rem : nullptr;
-    gru_step_tile<VEC, MSUB, false, true>(p, rem * static_cast<unsigned>(g.n_tiles) + static_cast<unsigned>(c), t, S_t,
-                                          off_prev, off_cur, dep);
-    return;
-  }
-  if (!ATT) return;   // (no attention tickets are handed out to this instantiation)
-  // ---- an attention-energy tile of the rows step s produced ----
-  // 8 column tiles (H = 2048): tile a in queue a, every row tile.  4 (H = 1024): tile a in queues a
-  // and a + 4, the even row tiles in the first, the odd ones in the second (an XCD's L2 then serves one
-  // 1 MB slice of W_lin); a queue's ticket whose row tile does not exist (odd count) is a no-op — the
-  // price of equal queues.
-  const int s = (ph - 3) >> 1, t = g.t0 + s;
-  const unsigned par = static_cast<unsigned>(kXcds / g.att_tiles);    // 1 or 2
-  const int a = static_cast<int>(queue % static_cast<unsigned>(g.att_tiles));
-  unsigned rem = local;
+  // ---- the GRU tile of step s this ticket stands for ----
+  const int s = lo, t = g.t0 + s;
+  const unsigned local = tk - g.tick[s];
+  unsigned rem = local / cols;
+  const int c = static_cast<int>(queue + nq * (local % cols));
   int k = 0, S_t = 0;
-  unsigned rt_n = 0;
-  bool found = false;
   for (; k < g.n; ++k) {
-    if (!g.att_on[k]) continue;
     S_t = g.step_off[k][t + 1] - g.step_off[k][t];
-    rt_n = static_cast<unsigned>((S_t + BM - 1) / BM);
-    const unsigned cnt = (rt_n + par - 1) / par;
-    if (rem < cnt) {
-      found = true;
-      break;
-    }
-    rem -= cnt;
+    const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
+    if (rem < rt || k == g.n - 1) break;
+    rem -= rt;
   }
-  if (!found) return;
-  const unsigned rt = par * rem + (par == 2 ? queue / static_cast<unsigned>(g.att_tiles) : 0u);
-  if (rt >= rt_n) return;
-  if (!flag_wait(g.sync, g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rt, static_cast<unsigned>(g.n_tiles)))
-    return;
-  const int64_t row0 = g.step_off[k][t];
-  attn_energy_tile<VEC, MSUB, false, false>(g.att[k], a, row0 + static_cast<int64_t>(rt) * BM, row0 + S_t);
+  const GruStepParams& p = g.j[k];
+  const int64_t off_cur = g.step_off[k][t];
+  const int64_t off_prev = (t > 0) ? g.step_off[k][t - 1] : 0;
+  ChainDep dep;
+  dep.sync = g.sync;
+  dep.need = static_cast<unsigned>(g.n_tiles);
+  dep.done = g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rem;
+  dep.wait = (s > 0) ? g.done[k] + static_cast<size_t>(s - 1) * g.rt_stride[k] + rem : nullptr;
+  gru_step_tile<VEC, MSUB, false, true>(p, rem * static_cast<unsigned>(g.n_tiles) + static_cast<unsigned>(c), t, S_t,
+                                        off_prev, off_cur, dep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1689,6 +1616,15 @@ GridSync make_grid_sync(unsigned* counter, unsigned* abort_word) {
 
 static Tunables& global_tunables();
 
+// Per device: the multi-step kernels (step chain, resident tails) are off after an acknowledged timeout.
+static std::atomic<int> g_multi_off[kMaxDevices];
+
+int multi_step_knob(const std::atomic<int>& knob) {
+  const int dev = event_device();
+  if (dev >= 0 && g_multi_off[dev].load(std::memory_order_relaxed) != 0) return 0;
+  return knob.load(std::memory_order_relaxed);
+}
+
 static int resident_status(bool clear) {
   const int dev = event_device();
   if (dev < 0) return CMHSE_OK;
@@ -1697,18 +1633,13 @@ static int resident_status(bool clear) {
   if (w == nullptr || *w == 0) return CMHSE_OK;
   if (clear) {
     *w = 0;
-    // A timeout means this device does not give the multi-step kernels what they need (workgroups
+    // A timeout means THIS device does not give the multi-step kernels what they need (workgroups
     // started in index order / all resident: a CU mask, another tenant).  The caller has been told
-    // (this status); from here on the process uses one launch per time step, which needs neither —
-    // cmhse_tune() re-enables the kernels explicitly.
-    Tunables* both[2] = {&tunables(), &global_tunables()};    // the caller's context and the process defaults
-    for (Tunables* t : both) {
-      t->chain_min_steps.store(0, std::memory_order_relaxed);
-      t->fwd_tail_min_steps.store(0, std::memory_order_relaxed);
-      t->infer_tail_min_steps.store(0, std::memory_order_relaxed);
-      t->bwd_tail_min_steps.store(0, std::memory_order_relaxed);
-      t->bwd_chain_min_steps.store(0, std::memory_order_relaxed);
-    }
+    // (this status); from here on every call on this device — whatever tuning context it runs in —
+    // uses one launch per time step, which needs neither.  Other devices are not touched.
+    // Setting one of the three knobs to a positive value (cmhse_tune / cmhse_ctx_tune) with this
+    // device current re-enables them here.
+    g_multi_off[dev].store(1, std::memory_order_relaxed);
   }
   return CMHSE_ERR_TIMEOUT;
 }
@@ -2132,7 +2063,6 @@ struct XprojPlan {
 // which tile height (kind, bit 2048 = 128 rows) and on which stream.
 struct ChainPlan {
   bool in_chain[kMaxJobs];
-  bool att[kMaxJobs];      // the request's attention energies of these steps are tasks of the launch
   int end, kind;
   hipStream_t stream;
 };
@@ -2140,12 +2070,12 @@ struct ChainPlan {
 static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, const bool* done,
                             const hipStream_t* js, int tiled_wgs) {
   ChainPlan c;
-  for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = c.att[k] = false;
+  for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = false;
   c.end = 0;
   c.kind = -1;
   c.stream = nullptr;
 
-  const int min_steps = tunables().chain_min_steps.load(std::memory_order_relaxed);
+  const int min_steps = multi_step_knob(tunables().chain_min_steps);
   int n_c = 0, tiles_c = -1;
   bool ok = min_steps > 0;
   for (int k = 0; k < n && ok; ++k) {
@@ -2197,21 +2127,6 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
       if (!same) break;
       ++c.end;
     }
-    // Attention energies as tasks of the chain (chain_attention): an attention-pooled request whose
-    // rows in front of step t are all projected already (so that the rows this launch projects
-    // extend that prefix), at widths whose 256-column tiles of W_lin deal evenly onto the eight
-    // queues (H = 1024: 4 tiles x 2 row-tile parities; H = 2048: 8 tiles).
-    const int att_tiles_c = tiles_c > 0 ? (jobs[0].b->H + kAttBN - 1) / kAttBN : 0;
-    if (tunables().chain_attention.load(std::memory_order_relaxed) != 0 && chain_queues(tiles_c) == kXcds)
-      for (int k = 0; k < n; ++k) {
-        const FwdJob& j = jobs[k];
-        if (!c.in_chain[k] || j.pool_mode != CMHSE_POOL_ATTN || j.pooled) continue;
-        const int at = (j.b->H + kAttBN - 1) / kAttBN;
-        int64_t rows_before = 0;
-        for (int q = 0; q < t; ++q) rows_before += j.b->step_count_host[q];
-        c.att[k] = (at == 4 || at == 8) && j.b->H % kAttBN == 0 && j.att_rows_done == rows_before;
-      }
-    (void)att_tiles_c;
     // one workgroup per task: HIP rejects a launch of more than 2^32 - 1 threads, i.e. 2^24 - 1
     // workgroups of 256 (halve the chain until it fits)
     for (;;) {
@@ -2220,7 +2135,7 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
       for (int q = t; q < c.end; ++q)
         for (int k = 0; k < n; ++k)
           if (c.in_chain[k])
-            units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c) * (c.att[k] ? 2 : 1);
+            units_c += static_cast<uint64_t>((jobs[k].b->step_count_host[q] + bm_c - 1) / bm_c);
       if (units_c * static_cast<uint64_t>(tiles_c) * kThreads <= 0xffffffffULL || c.end - t <= 1) break;
       c.end = t + (c.end - t) / 2;
     }
@@ -2228,7 +2143,7 @@ static ChainPlan plan_chain(const FwdJob* jobs, int n, int t, const int* kind, c
   }
   if (!ok || n_c == 0) {
     c.end = 0;
-    for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = c.att[k] = false;
+    for (int k = 0; k < kMaxJobs; ++k) c.in_chain[k] = false;
   }
   return c;
 }
@@ -2241,18 +2156,12 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
   cg.t0 = t;
   cg.nsteps = c.end - t;
   cg.ticket = nullptr;
-  cg.att_tiles = 4;
-  cg.col_map = 0;
   unsigned* abort_word = nullptr;
   const int bm = (c.kind & 2048) != 0 ? 128 : 64;
-  bool any_att = false;
-  int slot_of[kMaxJobs];
   for (int k = 0; k < n; ++k) {
-    slot_of[k] = -1;
     if (!c.in_chain[k]) continue;
     FwdJob& j = jobs[k];
     const int q = cg.n++;
-    slot_of[k] = q;
     cg.j[q] = j.p;
     cg.n_tiles = j.p.n_tiles;
     cg.step_off[q] = j.b->step_off;
@@ -2265,32 +2174,17 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
       cg.ticket = words;
       abort_word = words + kXcds;
     }
-    cg.att_on[q] = c.att[k] ? 1 : 0;
-    AttnEnergyParams& ep = cg.att[q];
-    ep.hs_s = nullptr; ep.hs = j.p.hs; ep.w_lin = j.w->w_lin; ep.w_lin_s = nullptr;
-    ep.b_lin = j.w->b_lin; ep.w_att = j.w->w_att;
-    ep.e_part = reinterpret_cast<float*>(j.wsb + j.L.e_part);
-    ep.v = nullptr;
-    ep.rows = j.sum_T; ep.row_begin = 0; ep.row_end = 0;
-    ep.H = j.b->H; ep.n_tiles = (j.b->H + kAttBN - 1) / kAttBN;
-    if (c.att[k]) {
-      any_att = true;
-      cg.att_tiles = ep.n_tiles;
-    }
     j.chain_until = c.end;
   }
   for (int q = cg.n; q < kMaxJobs; ++q) {
     cg.step_off[q] = nullptr;
     cg.done[q] = nullptr;
     cg.rt_stride[q] = 0;
-    cg.att_on[q] = 0;
   }
-  // per-queue tickets, phase by phase (GruChainGroup): G(s) at phase 2 s, A(s) at phase 2 s + 3
+  // per-queue tickets, step by step (GruChainGroup)
   const int nq = chain_queues(cg.n_tiles);
   const unsigned cols = static_cast<unsigned>(cg.n_tiles / nq);
-  if (cg.n_tiles == 16 && tunables().chain_col_map.load(std::memory_order_relaxed) == 1) cg.col_map = 1;
-  const unsigned par = static_cast<unsigned>(kXcds / cg.att_tiles);
-  const int n_phases = 2 * cg.nsteps + 2;
+  const int n_phases = cg.nsteps;
   uint32_t count[kChainPhases];
   for (int p = 0; p < kChainPhases; ++p) count[p] = 0;
   double flops = 0.0, bytes = 0.0;
@@ -2299,15 +2193,10 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
       if (!c.in_chain[k]) continue;
       const int S_k = jobs[k].b->step_count_host[t + sidx];
       const unsigned rt = static_cast<unsigned>((S_k + bm - 1) / bm);
-      count[2 * sidx] += cg.col_map == 1 ? ((rt + 1) / 2) * 4 : rt * cols;
+      count[sidx] += rt * cols;
       const double I = jobs[k].p.I, H = jobs[k].p.H;
       flops += S_k * (2.0 * 3.0 * H * (I + H) + 14.0 * H);
       bytes += S_k * 4.0 * (I + 2.0 * H) + 12.0 * H * (I + H);
-      if (c.att[k]) {
-        count[2 * sidx + 3] += (rt + par - 1) / par;
-        flops += S_k * (2.0 * H * H + 6.0 * H);       // attention pooling, per time step
-        bytes += 4.0 * H * H;                          // (h_t is read again from cache; W_lin once per step)
-      }
     }
   }
   uint64_t total = 0;
@@ -2328,33 +2217,16 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
     if (e0 && e1) (void)hipEventRecord(e0, c.stream);
   }
   const bool cvec = (c.kind & 4) == 0;
-#define CHAIN_LAUNCH_(V, M, A, SMEM) \
-  hipLaunchKernelGGL((gru_step_chain_kernel<V, M, A>), dim3(cgrid), dim3(kThreads), SMEM, c.stream, cg)
+#define CHAIN_LAUNCH_(V, M, SMEM) \
+  hipLaunchKernelGGL((gru_step_chain_kernel<V, M>), dim3(cgrid), dim3(kThreads), SMEM, c.stream, cg)
   if (bm == 128) {
-    if (any_att) {
-      if (cvec) CHAIN_LAUNCH_(true, 2, true, (TileSmem<128, kAttBN>::kBytes));
-      else CHAIN_LAUNCH_(false, 2, true, (TileSmem<128, kAttBN>::kBytes));
-    } else {
-      if (cvec) CHAIN_LAUNCH_(true, 2, false, (TileSmem<128, 3 * kGruBU>::kBytes));
-      else CHAIN_LAUNCH_(false, 2, false, (TileSmem<128, 3 * kGruBU>::kBytes));
-    }
+    if (cvec) CHAIN_LAUNCH_(true, 2, (TileSmem<128, 3 * kGruBU>::kBytes));
+    else CHAIN_LAUNCH_(false, 2, (TileSmem<128, 3 * kGruBU>::kBytes));
   } else {
-    if (any_att) {
-      if (cvec) CHAIN_LAUNCH_(true, 1, true, (TileSmem<64, kAttBN>::kBytes));
-      else CHAIN_LAUNCH_(false, 1, true, (TileSmem<64, kAttBN>::kBytes));
-    } else {
-      if (cvec) CHAIN_LAUNCH_(true, 1, false, (TileSmem<64, 3 * kGruBU>::kBytes));
-      else CHAIN_LAUNCH_(false, 1, false, (TileSmem<64, 3 * kGruBU>::kBytes));
-    }
+    if (cvec) CHAIN_LAUNCH_(true, 1, (TileSmem<64, 3 * kGruBU>::kBytes));
+    else CHAIN_LAUNCH_(false, 1, (TileSmem<64, 3 * kGruBU>::kBytes));
   }
 #undef CHAIN_LAUNCH_
-  // the rows these steps produce are projected: the attention pass behind the steps starts after them
-  for (int k = 0; k < n; ++k)
-    if (c.att[k]) {
-      int64_t rows = 0;
-      for (int q = 0; q < c.end; ++q) rows += jobs[k].b->step_count_host[q];
-      jobs[k].att_rows_done = rows;
-    }
   if (e0 && e1) {
     (void)hipEventRecord(e1, c.stream);
     timer->tiled_events.push_back(e0);
@@ -2397,32 +2269,21 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       if (!seen) stream_after(jobs[k].own_stream, main_stream);
       js[k] = jobs[k].own_stream;
     }
-  // The few-sequence tail of a chain as one resident kernel (below): of a training chain on its own
-  // stream, and — opt-in, infer_tail_min_steps — of an inference chain behind its small-batch steps
-  // (the end of a rank's share of the validation split is the text tower's tail, 319 dependent
-  // launches of 7-11 us with at most 32 paragraphs still active).  The tail kernel's arithmetic is the
-  // small-batch kernel's (gru_step_mid_kernel<1, 16, 8>), so the choice follows the LOCAL counts and
-  // leaves the bits alone; it only ever replaces small-batch steps (t > t_mid).  Measured SLOWER for
-  // inference (a share 40.3 -> 42.2 ms, the split 271.6 -> 277.7: 64 resident workgroups at a barrier
-  // per step beside the attention pass lose to 7-us launches that use every CU; profiles/r05_rank_share.txt).
+  // The few-sequence tail of a TRAINING chain on its own stream as one resident kernel (below).  The tail
+  // kernel's arithmetic is the small-batch kernel's (gru_step_mid_kernel<1, 16, 8>), so the choice
+  // follows the LOCAL counts and leaves the bits alone.  (For an inference chain the same kernel was
+  // measured slower than 7-us launches that use every CU, profiles/r05_rank_share.txt: not offered.)
   for (int k = 0; k < n; ++k) {
     FwdJob& j = jobs[k];
     j.tail_lo = -1;
     j.chain_until = 0;
     const cmhse_seq_batch* b = j.b;
-    const int min_steps = j.save ? tunables().fwd_tail_min_steps.load(std::memory_order_relaxed)
-                                 : tunables().infer_tail_min_steps.load(std::memory_order_relaxed);
-    if (min_steps <= 0 || j.bf3 || !j.vec || b->H % 16 != 0 || b->H > 1024 || timer != nullptr ||
+    const int min_steps = multi_step_knob(tunables().fwd_tail_min_steps);
+    if (!j.save || min_steps <= 0 || j.bf3 || !j.vec || b->H % 16 != 0 || b->H > 1024 || timer != nullptr ||
         !resident_fits(b->H / 16))
       continue;
-    int floor_t = 1;
-    if (j.save) {
-      if (js[k] == main_stream || j.t_mid != 0) continue;
-    } else {
-      // (its hoisted projection is launched or waited for at t_mid: the tail starts behind that step)
-      if (j.own_stream != nullptr || b->step_events_host != nullptr || j.t_mid >= b->Tmax) continue;
-      floor_t = j.t_mid + 1;
-    }
+    const int floor_t = 1;
+    if (js[k] == main_stream || j.t_mid != 0) continue;
     int lo = b->Tmax;
     while (lo - 1 >= floor_t && b->step_count_host[lo - 1] <= kFwdTailMaxSeqs) --lo;
     if (b->Tmax - lo < min_steps) continue;
@@ -2678,7 +2539,16 @@ int launch_steps(FwdJob* jobs, int n, hipStream_t main_stream, Timer* timer) {
       }
     }
   }
-  if (forked) stream_after(main_stream, side);   // rejoin: what follows is ordered on the caller's stream
+  // an early projection nobody waited for (defensive: step t_mid always does) still owns an event, and
+  // the side stream then holds work the caller's stream has not been ordered behind
+  bool side_pending = false;
+  for (int k = 0; k < kMaxJobs; ++k) {
+    if (early_xproj[k] == nullptr) continue;
+    if (early_xproj[k] != reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(1))) event_put(early_xproj[k], false);
+    early_xproj[k] = nullptr;
+    side_pending = true;
+  }
+  if (forked || side_pending) stream_after(main_stream, side);   // rejoin: what follows is ordered on the caller's stream
   return launches;
 }
 
@@ -2708,9 +2578,12 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   ep.row_end = row_end;
   ep.H = b->H;
   ep.n_tiles = att_tiles;
-  const bool att_bf3 = job.bf3 && sum_T > tiny_max_seqs();
+  // (bf16x3 or fp32 for the projection is a function of the PLAN's packed rows — the whole split's when
+  // the batch is a share of one — never of the share's own: the same bits in any share)
+  int64_t plan_rows = 0;
+  for (int q = 0; q < b->Tmax; ++q) plan_rows += job.kind_count[q];
+  const bool att_bf3 = job.bf3 && plan_rows > tiny_max_seqs();
   const int att_bm = att_bf3 ? 128 : 64 * msub;
-  // (a step chain may already have projected rows beyond the ones asked for: its attention tasks)
   if (row_end < job.att_rows_done) row_end = job.att_rows_done;
   ep.row_end = row_end;
   const int64_t m_tiles = (row_end - job.att_rows_done + att_bm - 1) / att_bm;
@@ -2963,18 +2836,11 @@ extern "C" int cmhse_tune(const char* name, int32_t value, int32_t* old_value) {
 extern "C" void* cmhse_ctx_create(void) {
   Tunables* c = new (std::nothrow) Tunables;
   if (c == nullptr) return nullptr;
-  // a copy of the process defaults as they are now, name by name
+  // a copy of the process defaults as they are now, member by member (the one table, gru_ws.hpp)
   Tunables& g = global_tunables();
-  static const char* const names[] = {
-      "tiny_max_seqs", "mid_max_seqs", "mid_units", "mid_waves", "tall_tile_min_wgs", "bwd_mid_max_seqs",
-      "bwd_split_min_seqs", "bwd_tail_min_steps", "fwd_tail_min_steps", "infer_tail_min_steps", "mid_tall_min_seqs", "bwd_chunk_rows",
-      "bwd_chain_min_steps", "bwd_fused_step", "xproj_chunk_rows", "tn_rows_bm", "chain_min_steps", "chain_attention",
-      "chain_col_map", "early_xproj", "chain_tall_min_wgs", "resident_timeout_ms"};
-  for (const char* n : names) {
-    int32_t v = 0;
-    (void)tune_in(g, n, -1, &v);
-    (void)tune_in(*c, n, v, nullptr);
-  }
+#define CMHSE_COPY_(name, dflt) c->name.store(g.name.load(std::memory_order_relaxed), std::memory_order_relaxed);
+  CMHSE_TUNABLES(CMHSE_COPY_)
+#undef CMHSE_COPY_
   return c;
 }
 
@@ -2997,17 +2863,26 @@ extern "C" void* cmhse_ctx_enter(void* ctx) {
 
 namespace {
 int tune_in(Tunables& t, const char* name, int32_t value, int32_t* old_value) {
+  if (strcmp(name, "multi_step_off") == 0) {       // not a crossover: the current DEVICE's fallback flag
+    const int dev = event_device();
+    if (dev < 0) return CMHSE_ERR_ARG;
+    const int old = (value >= 0) ? g_multi_off[dev].exchange(value != 0 ? 1 : 0) : g_multi_off[dev].load();
+    if (old_value) *old_value = old;
+    return CMHSE_OK;
+  }
   TuneEntry table[] = {
-      {"tiny_max_seqs", &t.tiny_max_seqs},         {"mid_max_seqs", &t.mid_max_seqs},
-      {"mid_units", &t.mid_units},                 {"mid_waves", &t.mid_waves},
-      {"tall_tile_min_wgs", &t.tall_tile_min_wgs}, {"bwd_mid_max_seqs", &t.bwd_mid_max_seqs},
-      {"bwd_split_min_seqs", &t.bwd_split_min_seqs}, {"bwd_tail_min_steps", &t.bwd_tail_min_steps}, {"fwd_tail_min_steps", &t.fwd_tail_min_steps}, {"infer_tail_min_steps", &t.infer_tail_min_steps}, {"mid_tall_min_seqs", &t.mid_tall_min_seqs},
-      {"bwd_chunk_rows", &t.bwd_chunk_rows}, {"bwd_chain_min_steps", &t.bwd_chain_min_steps}, {"bwd_fused_step", &t.bwd_fused_step}, {"xproj_chunk_rows", &t.xproj_chunk_rows}, {"tn_rows_bm", &t.tn_rows_bm}, {"chain_min_steps", &t.chain_min_steps}, {"chain_attention", &t.chain_attention}, {"chain_col_map", &t.chain_col_map}, {"early_xproj", &t.early_xproj}, {"chain_tall_min_wgs", &t.chain_tall_min_wgs},
-      {"resident_timeout_ms", &t.resident_timeout_ms}};
+#define CMHSE_ENTRY_(name, dflt) {#name, &t.name},
+      CMHSE_TUNABLES(CMHSE_ENTRY_)
+#undef CMHSE_ENTRY_
+  };
   for (auto& e : table)
     if (strcmp(name, e.name) == 0) {
       const int old = (value >= 0) ? e.v->exchange(value) : e.v->load();
       if (old_value) *old_value = old;
+      if (value > 0 && (e.v == &t.chain_min_steps || e.v == &t.fwd_tail_min_steps || e.v == &t.bwd_tail_min_steps)) {
+        const int dev = event_device();      // an explicit re-enable after an acknowledged timeout
+        if (dev >= 0) g_multi_off[dev].store(0, std::memory_order_relaxed);
+      }
       return CMHSE_OK;
     }
   return CMHSE_ERR_ARG;

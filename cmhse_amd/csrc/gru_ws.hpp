@@ -44,56 +44,39 @@ struct GruWs {
   size_t hs, e_part, gates, argmax, v, wih_s, whh_s, wlin_s, xs, hs_s, h0_s, gx, tail_sync, chain_sync, total;
 };
 
-// Kernel-shape crossovers a caller may move (cmhse_tune, include/cmhse_hip.h): values, never
-// results.  Read with relaxed atomics at every call.
+// Kernel-shape crossovers a caller may move (cmhse_tune / cmhse_ctx_tune; documented one by one in
+// include/cmhse_hip.h): values, never results.  Read with relaxed atomics at every call.  ONE table:
+// the struct's members, the name lookup of cmhse_tune and the copy a new context starts from are all
+// generated from it, so a knob cannot exist in one of them only.
+//   X(name, default)
+#define CMHSE_TUNABLES(X)                                                                                          \
+  X(tiny_max_seqs, 1024)      /* active sequences at or below which a forward step runs on the small-batch kernels */ \
+  X(mid_max_seqs, 1024)       /* ... on gru_step_mid_kernel (hoisted input projection + split-K recurrent part); 0 disables it */ \
+  X(mid_units, 0)             /* 16 | 8 | 4 forces the mid-size step's unit tile (0 = by grid size) */             \
+  X(mid_waves, 0)             /* 4 | 8 forces its waves per workgroup (0 = by schedule) */                         \
+  X(tall_tile_min_wgs, 2048)  /* 64-row workgroups from which a tiled per-step launch uses 128-row tiles (0 = never) */ \
+  X(bwd_mid_max_seqs, 512)    /* active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel */  \
+  X(bwd_chunk_rows, 2048)     /* packed rows a weight-gradient chunk spans before it is issued beside the chain */ \
+  X(bwd_split_min_seqs, 33)   /* ... from which (up to bwd_mid_max_seqs) the BPTT step is two launches with K split over the grid */ \
+  X(bwd_tail_min_steps, 4)    /* <= 32-sequence steps at the end of a chain from which its BPTT runs them in one resident kernel */ \
+  X(fwd_tail_min_steps, 4)    /* the same for the forward chain of a training call (gru_fwd_tail_kernel) */        \
+  X(mid_tall_min_seqs, 129)   /* active sequences from which the mid-size forward step takes 64 sequences per workgroup */ \
+  X(resident_timeout_ms, 5000) /* wall time one wait of a multi-step kernel may take before the launch gives up (grid_sync.hpp) */ \
+  X(xproj_chunk_rows, 1536)   /* packed rows per chunk of a training chain's hoisted input projection beside the chain */ \
+  X(tn_rows_bm, 0)            /* tile height of the weight-gradient products: 128, 192, or 0 = by shape (tn_rows.hpp) */ \
+  X(chain_min_steps, 2)       /* consecutive LDS-tiled inference steps from which they are ONE launch of gru_step_chain_kernel */ \
+  X(early_xproj, 1)           /* 1: an inference call's hoisted projection starts on the side stream before the first step */ \
+  X(chain_tall_min_wgs, 256)  /* 64-row workgroups per step from which a step chain uses 128-row tiles */
+
 struct Tunables {
-  // active sequences at or below which a forward step runs on the small-batch kernels instead of
-  // the LDS-tiled one (tests set 0 to force the tiled kernels onto small fixtures)
-  std::atomic<int> tiny_max_seqs{1024};
-  // active sequences at or below which a step runs on the mid-size kernel (gru_step_mid_kernel:
-  // the input projection of those steps hoisted into one GEMM, split-K 16x16x4 MFMA tiles for
-  // the recurrent part); 0 disables it
-  std::atomic<int> mid_max_seqs{1024};
-  std::atomic<int> mid_units{0};          // 16 | 8 | 4 forces the mid-size step's unit tile (0 = by grid size)
-  std::atomic<int> mid_waves{0};          // 4 | 8 forces its waves per workgroup (0 = by schedule)
-  std::atomic<int> tall_tile_min_wgs{2048};  // 64-row workgroups from which a tiled launch uses 128-row tiles (0 = never)
-  std::atomic<int> bwd_mid_max_seqs{512};    // active sequences at or below which a BPTT step runs on gru_bwd_step_mid_kernel
-  std::atomic<int> bwd_chunk_rows{2048};     // packed rows a weight-gradient chunk spans before it is issued beside the chain
-  std::atomic<int> bwd_split_min_seqs{33};   // ... and from which (up to bwd_mid_max_seqs) it runs as two launches with K split over the grid (0 = never)
-  std::atomic<int> bwd_tail_min_steps{4};    // steps with <= 32 active sequences at the end of a chain from which its BPTT runs them in one resident kernel (0 = never)
-  std::atomic<int> mid_tall_min_seqs{129};   // active sequences from which the mid-size forward step takes 64 sequences per workgroup (0 = never)
-  // training-size BPTT steps (33-256 active sequences) from which one request of a call runs them in
-  // resident chain kernels (gru_bwd_chain_kernel); 0 = never — the DEFAULT: measured slower than the
-  // two launches per step it replaces (profiles/r04_chain_resident.txt: 39 against 22 us per step
-  // stand-alone at 152 sequences, +0.4 ... +1.0 ms per training step): every exchange between
-  // workgroups is a round trip past the non-coherent L2s plus a grid barrier, twice per step
-  std::atomic<int> bwd_chain_min_steps{0};
-  // the two-launch BPTT step (bwd_split_min_seqs) as ONE launch: split-K whose last-arriving slice adds
-  // the partials in slice order and runs the gate derivatives (bwd_step_fused_kernel); 0 = two launches
-  std::atomic<int> bwd_fused_step{0};
-  std::atomic<int> resident_timeout_ms{5000};  // wall time one grid barrier of a resident kernel may take before the launch gives up (grid_sync.hpp)
-  std::atomic<int> xproj_chunk_rows{1536};   // packed rows per chunk of a training chain's hoisted input projection beside the chain (0 = one launch in front of it)
-  std::atomic<int> tn_rows_bm{0};            // tile height of the weight-gradient products: 128, 192, or 0 = 192 where 3H is a whole number of them (tn_rows.hpp)
-  std::atomic<int> chain_min_steps{2};       // consecutive LDS-tiled steps (inference calls) from which they run as ONE launch of gru_step_chain_kernel; 0 = never
-  // 1: the attention energies of a chain's steps are tasks of the chain launch (H = 1024 / 2048); 0
-  // (default): a launch of their own behind the steps.  Bit-identical; measured 0.9 % (full split)
-  // to 2.2 % (a 615-video share) SLOWER as tasks: the projection is throughput work that the old
-  // schedule already runs beside the text tower's latency-bound tail — inside the chain it lengthens
-  // the launch that tail has to wait for (profiles/r05_chain_attention.txt)
-  std::atomic<int> chain_attention{0};
-  // experiment (H = 1024): 1 = an XCD's queue serves FOUR column tiles of the row tiles of one parity
-  // instead of two column tiles of every row tile: half the A-row traffic over the fabric, twice the
-  // weight slices per L2 (profiles/r05_dual_column_tile.txt)
-  std::atomic<int> chain_col_map{0};
-  // 1: the hoisted input projection of an inference call's small-batch steps is launched on the
-  // call's side stream before the first step (beside the tiled steps) instead of in front of the
-  // few-sequence tail; 0: in order on the chain's stream.  Results do not depend on it.
-  std::atomic<int> early_xproj{1};
-  std::atomic<int> chain_tall_min_wgs{256};  // 64-row workgroups per step from which a step chain uses 128-row tiles (per-step launches: tall_tile_min_wgs)
-  std::atomic<int> fwd_tail_min_steps{4};    // the same for the forward chain of a training call (gru_fwd_tail_kernel)
-  std::atomic<int> infer_tail_min_steps{0};  // (opt-in; measured slower, profiles/r05_rank_share.txt) the same for the few-sequence tail of an inference chain
+#define CMHSE_TUNABLE_MEMBER_(name, dflt) std::atomic<int> name{dflt};
+  CMHSE_TUNABLES(CMHSE_TUNABLE_MEMBER_)
+#undef CMHSE_TUNABLE_MEMBER_
 };
 Tunables& tunables();
+// A multi-step knob (chain_min_steps, *_tail_min_steps) as the current device sees it: 0 once a timeout
+// of a multi-step kernel has been acknowledged there (cmhse_async_status(1)), else the knob's value.
+int multi_step_knob(const std::atomic<int>& knob);
 static inline int mid_max_seqs() { return tunables().mid_max_seqs.load(std::memory_order_relaxed); }
 
 // Upper bound of the packed rows whose input projection is hoisted (the rows of the steps with at

@@ -89,13 +89,16 @@ def _f32c(t, name):
 
 
 def tune(name, value=-1):
-  """cmhse_tune: set (value >= 0) or read (value < 0) one kernel-shape crossover of the library;
-  returns its previous value.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
+  """cmhse_tune / cmhse_ctx_tune: set (value >= 0) or read (value < 0) one kernel-shape crossover;
+  returns its previous value.  Inside a `with TuneContext(...)` block the call goes to THAT context
+  (the one every library call of this thread reads); outside, to the process defaults new contexts
+  are initialised from.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
   tall_tile_min_wgs, mid_tall_min_seqs, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
-  fwd_tail_min_steps, infer_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, bwd_chain_min_steps,
-  bwd_fused_step, chain_min_steps, chain_attention, chain_col_map, early_xproj, chain_tall_min_wgs,
-  resident_timeout_ms
-  (include/cmhse_hip.h)."""
+  fwd_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, chain_min_steps, early_xproj,
+  chain_tall_min_wgs, resident_timeout_ms (include/cmhse_hip.h)."""
+  ctx = TuneContext.current()
+  if ctx is not None:
+    return ctx.tune(name, value)
   old = ctypes.c_int32(0)
   _lib.check(_lib.load().cmhse_tune(name.encode(), int(value), ctypes.byref(old)), 'cmhse_tune(%s)' % name)
   return int(old.value)
@@ -142,7 +145,7 @@ class TuneContext(object):
     self.handle = self._lib.cmhse_ctx_create()
     if not self.handle:
       raise MemoryError('cmhse_ctx_create failed')
-    self._prev = []
+    self._depth = 0          # live `with` blocks over all threads (the handle outlives them)
     for k, v in kw.items():
       self.tune(k, v)
 
@@ -152,19 +155,30 @@ class TuneContext(object):
                'cmhse_ctx_tune(%s)' % name)
     return int(old.value)
 
+  # The enter / exit stack lives with the THREAD: two threads inside the same context
+  # at once — autograd's device threads re-entering a forward pass's context, workers sharing one —
+  # each restore their own previous context.
   def __enter__(self):
-    self._prev.append((self._lib.cmhse_ctx_enter(self.handle), getattr(TuneContext._current, 'ctx', None)))
-    TuneContext._current.ctx = self
+    tl = TuneContext._current
+    stack = getattr(tl, 'stack', None)
+    if stack is None:
+      stack = tl.stack = []
+    stack.append((self, self._lib.cmhse_ctx_enter(self.handle), getattr(tl, 'ctx', None)))
+    tl.ctx = self
+    self._depth += 1
     return self
 
   def __exit__(self, *a):
-    prev_handle, prev_obj = self._prev.pop()
+    tl = TuneContext._current
+    me, prev_handle, prev_obj = tl.stack.pop()
+    assert me is self, 'TuneContext blocks must nest'
     self._lib.cmhse_ctx_enter(prev_handle)
-    TuneContext._current.ctx = prev_obj
+    tl.ctx = prev_obj
+    self._depth -= 1
 
   def __del__(self):
     try:
-      if self.handle and not self._prev:
+      if self.handle and self._depth == 0:
         self._lib.cmhse_ctx_destroy(self.handle)
         self.handle = None
     except Exception:      # noqa: BLE001  (interpreter shutdown)

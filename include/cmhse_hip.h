@@ -468,22 +468,10 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             workgroups resident (one per CU): at most four such chains at once
  *   "fwd_tail_min_steps"   4  the same for the forward chain of a training call
  *                             (CMHSE_SAVE_FOR_BACKWARD, job on its own stream)
- *   "infer_tail_min_steps"  0 (opt-in; measured slower than one launch per step) ... and for the
- *                             few-sequence tail (<= 32 active) of an inference chain behind its
- *                             small-batch steps; bit-identical to the per-step launches it replaces
- *   "bwd_chain_min_steps"  0  (opt-in; measured slower than the default two launches per step,
- *                             profiles/r04_chain_resident.txt) BPTT steps with 33-256 active sequences from which ONE request of a call
- *                             (the one with the most) runs them inside resident kernels — (H / 128) x
- *                             (3H / 128) workgroups that keep their W_hh^T slice in LDS, two grid
- *                             barriers per step instead of two launches; H % 128 == 0; 0 = never.
- *                             Gradients equal the per-step path's to fp32 rounding
  *   "resident_timeout_ms" 5000  wall time a grid barrier of a resident kernel / a dependency wait of
  *                             the step chain may take before the launch gives up (cmhse_async_status);
  *                             0 = give up at the second clock check of a wait (tests: walks the
  *                             abort path)
- *   "bwd_fused_step"       0  (opt-in; measured slower, profiles/r05_bptt_one_launch.txt) the two-launch
- *                             BPTT step as ONE: split-K whose last-arriving slice adds the partials in
- *                             slice order and runs the gate derivatives; bit-identical
  *   "bwd_chunk_rows"    2048  packed rows a weight-gradient chunk spans before its products are
  *                             issued beside the chain (changes the order in which chunks are
  *                             accumulated, i.e. the gradients to fp32 rounding)
@@ -492,25 +480,28 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *   "chain_min_steps"      2  consecutive LDS-tiled steps of an inference call from which they run as
  *                             ONE launch (gru_step_chain_kernel: per-row-tile dependencies instead
  *                             of a launch per time step; bit-identical); 0 = never
- *   "chain_attention"      0  (opt-in; measured 0.9-2.2 % slower, profiles/r05_chain_attention.txt) 1: the
- *                             attention energies e = w_att . tanh(W_lin h + b) of a chain's steps are
- *                             tasks of the same launch (H = 1024 / 2048), handed out one step behind the
- *                             GRU tiles that produce their rows; bit-identical
  *   "early_xproj"          1  the hoisted input projection of an inference call's small-batch steps on
  *                             the call's side stream (tail_stream) before the first step, beside the
  *                             tiled steps; 0 = in order in front of those steps (results identical)
- *   "chain_col_map"        0  (experiment, H = 1024) 1: an XCD's queue serves four column tiles of the row
- *                             tiles of one parity (profiles/r05_dual_column_tile.txt); bit-identical
  *   "chain_tall_min_wgs" 256  64-row workgroups per step from which such a chain uses 128-row tiles
  *                             (four times that when a request of the chain has I < H)
  *   "tn_rows_bm"           0  tile height of the weight-gradient products: 128 | 192; 0 = 192 where
  *                             every product's row count (3H, H) is a whole number of them, else 128
  *                             (the row split into parts follows the tile count, i.e. the gradients
  *                             to fp32 rounding; profiles/r04_wgrad_rate.txt)
+ *   "multi_step_off"       0  (not a crossover, and per DEVICE rather than per context) 1 while the
+ *                             multi-step kernels are switched off on the calling thread's current device
+ *                             after an acknowledged timeout (cmhse_async_status below); readable, and
+ *                             settable either way
  * These are the PROCESS DEFAULTS (atomics): set them between calls, not while calls that size
  * workspaces with them (`*_workspace` reads mid_max_seqs) are in flight on other threads.  A caller
  * that wants its own values — two models tuned differently in one process, a library that must not
- * disturb its host's settings — uses a context instead (below).  Unknown name: CMHSE_ERR_ARG. */
+ * disturb its host's settings — uses a context instead (below).  Unknown name: CMHSE_ERR_ARG.
+ * (Five opt-ins of rounds 4-5 that measured slower than the defaults — a resident BPTT chain, the
+ * one-launch BPTT step, attention tiles as chain tasks, a second ticket map, a resident inference
+ * tail — left the library in round 6; docs/HISTORY.md and profiles/r04_chain_resident.txt,
+ * r05_bptt_one_launch.txt, r05_chain_attention.txt, r05_dual_column_tile.txt, r05_rank_share.txt keep
+ * the measurements, the git history the code.) */
 int cmhse_tune(const char* name, int32_t value, int32_t* old_value);
 
 /* Tuning contexts (round 5; SURVEY 8b "re-entrant, no global state").  A context is a private copy
@@ -525,19 +516,22 @@ void cmhse_ctx_destroy(void* ctx);
 int cmhse_ctx_tune(void* ctx, const char* name, int32_t value, int32_t* old_value);
 void* cmhse_ctx_enter(void* ctx);
 
-/* The kernels that stay resident over several time steps of a chain (the few-sequence tails and
- * the training-size BPTT runs: "*_tail_min_steps", "bwd_chain_min_steps") synchronise their
- * workgroups with a grid barrier, which needs all of them on the chip at once.  The launchers check
+/* The kernels that stay resident over several time steps of a chain (the few-sequence tails of a
+ * training chain: "*_tail_min_steps") synchronise their workgroups with a grid barrier, which needs
+ * all of them on the chip at once; the step chain ("chain_min_steps") waits on per-row-tile counters
+ * and needs its workgroups to start in index order.  The launchers check
  * the CU count; what they cannot see — another process holding CUs, a CU mask — ends in a timeout
  * ("resident_timeout_ms", default 5000): the kernel's workgroups all leave, the call's results are
  * invalid, and a word in pinned host memory is raised.  This function returns CMHSE_ERR_TIMEOUT
  * while that word is set for the calling thread's current device (CMHSE_OK otherwise) and clears
  * it when `clear` != 0; cmhse_gru_pool_fwd[_multi] / cmhse_gru_pool_bwd[_multi] check it on entry
  * and return CMHSE_ERR_TIMEOUT without launching.  Clearing a raised status also switches the
- * multi-step kernels off for the rest of the process ("chain_min_steps", "*_tail_min_steps",
- * "bwd_chain_min_steps" = 0: one launch per time step, which needs neither co-residency nor
- * in-order workgroup starts); cmhse_tune() switches them back on.  The status is asynchronous: it reflects launches
- * that have RUN, so poll it after a stream synchronisation (or once per step, one step late). */
+ * multi-step kernels off ON THAT DEVICE, for every tuning context and the process defaults alike
+ * ("chain_min_steps", "*_tail_min_steps" read as 0 there: one launch per time step, which needs
+ * neither co-residency nor in-order workgroup starts) — other devices keep them; setting one of those
+ * knobs to a positive value (cmhse_tune / cmhse_ctx_tune) with the device current switches them back
+ * on.  The status is asynchronous: it reflects launches that have RUN, so poll it after a stream
+ * synchronisation (or once per step, one step late). */
 int cmhse_async_status(int32_t clear);
 
 /* Self-test of that barrier and of its failure path (tests): launches `workgroups` (<= 1024)

@@ -462,6 +462,21 @@ def test_step_plan_makes_every_share_of_a_split_bit_identical(dev, rnn_type):
     early, _, _ = evaluation.encode_data_device(opt, model, batches, logging=quiet)
     for k in KEYS6:
       assert torch.equal(inorder[k], whole[k]) and torch.equal(early[k], whole[k]), k
+  # ... and in the opt-in bf16x3 math mode (the attention projection's choice between the
+  # bf16x3 and the fp32 tile must follow the plan too, not the share's own packed rows)
+  ops.set_math_mode('bf16x3')
+  try:
+    whole3, _, _ = evaluation.encode_data_device(opt, model, batches, logging=quiet)
+    for r in range(3):
+      own = [i for i in range(len(batches)) if i % 3 == r]
+      got, _, _ = evaluation.encode_data_device(opt, model, [batches[i] for i in own], logging=quiet, step_plan=plan)
+      vid_rows = np.concatenate([np.arange(sizes[i], sizes[i + 1]) for i in own])
+      clip_rows = np.concatenate([np.arange(csizes[i], csizes[i + 1]) for i in own])
+      for k in KEYS6:
+        rows = torch.from_numpy(clip_rows if k in ('clip_emb', 'cap_emb') else vid_rows).to(dev)
+        assert torch.equal(got[k], whole3[k][rows]), ('bf16x3', r, k)
+  finally:
+    ops.set_math_mode('fp32')
 
 
 def test_step_plan_is_validated_by_the_library(dev):
@@ -852,125 +867,6 @@ def test_bptt_tail_as_one_resident_kernel(dev, oracle, pool, cls, H, S, n_long, 
     grad_close(resident[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
     grad_close(resident[1].cpu().numpy(), dh0, pool + ' dh0')
     for (pn, _), got in zip(layer.named_parameters(), resident[2:]):
-      grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('pool,cls,H,S,T', [('attention', 'Attention', 128, 70, 21), ('maxout', 'Maxout', 256, 150, 17),
-                                            ('seq2seq', 'Seq2Seq', 128, 300, 9), ('attention', 'Attention', 1024, 152, 23),
-                                            ('maxout', 'Maxout', 512, 256, 7)])
-def test_bptt_training_size_steps_as_resident_chain_kernel(dev, oracle, pool, cls, H, S, T, tune):
-  """The BPTT steps of a training-size batch (33-256 active sequences) inside resident kernels
-  (gru_bwd_chain_kernel: W_hh^T slices in LDS, two grid barriers per step, the gate-derivative rows
-  and the K-slice partials written through / read past the non-coherent L2s; a new run behind every
-  weight-gradient chunk) against two launches per step (bwd_chain_min_steps = 0): every gradient
-  equal to fp32 rounding (K is cut into 128-wide slices here, wider ones there), bitwise
-  reproducible run after run, and against the float64 oracle where that is cheap.  Shapes: 1 / 2 /
-  3 / 6 gate elements per thread (H = 1024 ... 128), ragged lengths so that the active count grows
-  through the range step by step, a batch that starts ABOVE the range (S = 300: the first steps
-  per-step launches, then the chain), one that also has a few-sequence tail (H = 128, S = 70), small
-  weight-gradient chunks so that a chain is cut into several runs, initial states."""
-  from cmhse_amd import layers
-  rng = np.random.RandomState(17 + H + S)
-  I = 24 if H < 1024 else 64
-  torch.manual_seed(4)
-  layer = getattr(layers, cls)(I, H)
-  with torch.no_grad():
-    layer.rnn.bias_ih_l0.normal_(0, 0.1)
-    layer.rnn.bias_hh_l0.normal_(0, 0.1)
-  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
-  layer = layer.to(dev)
-  lens = rng.randint(1, T + 1, size=S)
-  lens[:40] = T                                    # >= 40 sequences at every step ...
-  if S == 70:
-    lens[:] = rng.randint(1, 6, size=S)            # ... except here: a tail of 20, then 60-70 active
-    lens[:20] = T
-    lens[20:60] = rng.randint(8, 12, size=40)
-  x = np.zeros((S, T, I), dtype=np.float32)
-  for i, l in enumerate(lens):
-    x[i, :l] = rng.standard_normal((l, I))
-  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
-  w = rng.standard_normal((S, H)).astype(np.float32)
-
-  def run(min_steps, chunk_rows=512):
-    tune(bwd_chain_min_steps=min_steps, bwd_chunk_rows=chunk_rows)
-    layer.zero_grad()
-    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
-    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
-    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
-    torch.cuda.synchronize()
-    from cmhse_amd import _lib
-    assert _lib.load().cmhse_async_status(0) == 0
-    return [xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
-
-  per_step, chain, again = run(0), run(2), run(2)
-  for a, b, c in zip(per_step, chain, again):
-    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max()))
-    assert torch.equal(b, c), 'not reproducible from run to run'
-  one_run = run(2, chunk_rows=1 << 30)             # the whole chain as ONE run
-  for a, b in zip(chain, one_run):
-    assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(a.abs().max()))
-  if H <= 256:
-    _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
-    grads, dx, dh0 = oracle.pooled_gru_backward(cache, w.astype(np.float64))
-    grad_close(chain[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
-    grad_close(chain[1].cpu().numpy(), dh0, pool + ' dh0')
-    for (pn, _), got in zip(layer.named_parameters(), chain[2:]):
-      grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
-
-
-@pytest.mark.parametrize('pool,cls,H,S,T', [('attention', 'Attention', 128, 70, 21), ('maxout', 'Maxout', 256, 150, 17),
-                                            ('seq2seq', 'Seq2Seq', 1024, 152, 9), ('attention', 'Attention', 96, 300, 12)])
-def test_bptt_step_as_one_launch_with_a_last_arriver_epilogue(dev, oracle, pool, cls, H, S, T, tune):
-  """The two-launch BPTT step (K split over the grid + ordered gate kernel) as ONE launch
-  (bwd_step_fused_kernel, tunable bwd_fused_step): the slice workgroup whose arrival completes a
-  tile re-reads the partials in slice order and runs the gate derivatives.  Same slices, same
-  order, same arithmetic: every gradient equals the two-launch path's to the last bits the
-  compiler's contraction may move (held to 1e-6 relative; bit-identity is reported), is bitwise
-  reproducible run after run, and matches the float64 oracle.  Shapes: ragged lengths so that the
-  active count grows through the step range (row blocks past S_next run their gates alone),
-  H = 96 (a partial column tile), H = 1024 (8 column tiles, 6 slices)."""
-  from cmhse_amd import layers
-  rng = np.random.RandomState(23 + H + S)
-  I = 24 if H < 1024 else 64
-  torch.manual_seed(6)
-  layer = getattr(layers, cls)(I, H)
-  with torch.no_grad():
-    layer.rnn.bias_ih_l0.normal_(0, 0.1)
-    layer.rnn.bias_hh_l0.normal_(0, 0.1)
-  sd = {'rnn.' + k: v.detach().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
-  layer = layer.to(dev)
-  lens = rng.randint(1, T + 1, size=S)
-  lens[:40] = T
-  x = np.zeros((S, T, I), dtype=np.float32)
-  for i, l in enumerate(lens):
-    x[i, :l] = rng.standard_normal((l, I))
-  h0 = (0.5 * rng.standard_normal((S, H))).astype(np.float32)
-  w = rng.standard_normal((S, H)).astype(np.float32)
-  tune(bwd_tail_min_steps=0, fwd_tail_min_steps=0)
-
-  def run(fused):
-    tune(bwd_fused_step=fused)
-    layer.zero_grad()
-    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
-    ht = torch.from_numpy(h0).to(dev).requires_grad_(True)
-    (layer(xt, torch.from_numpy(lens), ht) * torch.from_numpy(w).to(dev)).sum().backward()
-    torch.cuda.synchronize()
-    return [xt.grad.clone(), ht.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
-
-  two, one, again = run(0), run(1), run(1)
-  exact = True
-  for a, b, c in zip(two, one, again):
-    assert float((a - b).abs().max()) <= 1e-6 * max(1e-6, float(a.abs().max()))
-    assert torch.equal(b, c), 'not reproducible from run to run'
-    exact = exact and torch.equal(a, b)
-  print('one-launch BPTT step bit-identical to the two-launch step:', exact)
-  if H <= 256:
-    _, cache = oracle.pooled_gru_forward_cache(pool, x, lens, sd, h0)
-    grads, dx, dh0 = oracle.pooled_gru_backward(cache, w.astype(np.float64))
-    grad_close(one[0].cpu().numpy()[:, :dx.shape[1]], dx, pool + ' dx')
-    grad_close(one[1].cpu().numpy(), dh0, pool + ' dh0')
-    for (pn, _), got in zip(layer.named_parameters(), one[2:]):
       grad_close(got.cpu().numpy(), grads['rnn.' + pn], pool + ' ' + pn)
 
 
@@ -1485,7 +1381,6 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     return r
 
   tune(tiny_max_seqs=0, mid_max_seqs=0)       # every step on the LDS-tiled kernel
-  tune(chain_attention=1)                     # (opt-in) attention energies as tasks of the chain launch
   if shape == 'one_xcd_queue':
     reqs = [request(300, 9, 24, 64, ops.POOL_ATTN)]
   elif shape == 'two_requests':
@@ -1529,10 +1424,6 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     for (o1, h1), (o2, h2) in zip(per_step, run(2)):
       assert torch.equal(o1, o2)
       assert torch.equal(h1, h2)
-  tune(chain_attention=0)                     # (the default) the attention projection as a launch of its own behind the chain
-  for (o1, h1), (o2, h2) in zip(per_step, run(2)):
-    assert torch.equal(o1, o2) and torch.equal(h1, h2)
-  tune(chain_attention=1)
   with ops.StepTimers() as timers:            # the timed form (an event pair around the launch)
     timed = run(2)
   spans = timers.collect()
@@ -1548,68 +1439,6 @@ def test_step_chain_launch_is_bit_identical_to_per_step_launches(dev, tune, shap
     for (o1, h1), (o2, h2) in zip(run(0), chained):
       assert torch.equal(o1, o2)
       assert torch.equal(h1, h2)
-
-
-@pytest.mark.parametrize('shape', ['text_tower', 'all_small', 'two_towers'])
-def test_inference_tail_as_one_resident_kernel_is_bit_identical(dev, tune, shape):
-  """The few-sequence tail of an INFERENCE chain (the steps behind the last one with more than 32 active
-  sequences: the long paragraphs of the text tower, 319 dependent launches at the end of a rank's share of the
-  validation split) inside ONE resident kernel (gru_fwd_tail_kernel, a grid barrier per step;
-  infer_tail_min_steps, opt-in: measured slower, profiles/r05_rank_share.txt) against one small-batch
-  launch per step (= 0, the default): pooled outputs and every hidden state equal bit for bit, for every
-  pooling, repeated, no timeout recorded.
-    text_tower   2400 short sequences + a few long ones: LDS-tiled steps (a chain), small-batch steps, then the tail
-    all_small    a request that is small-batch from its first step (the level-2 encoders' shape), initial states
-    two_towers   a second, tiled request still running when the first one's tail starts: the tail forks to the
-                 side stream, the attention pass of the request that ends first overlaps it"""
-  from cmhse_amd import _lib, ops
-  rng = np.random.RandomState(5)
-  g = torch.Generator().manual_seed(18)
-  keep = []
-
-  def request(lens, I, H, mode, h0=False):
-    S, T = len(lens), int(max(lens))
-    w = dict(w_ih=torch.randn(3 * H, I, generator=g).mul_(0.2), w_hh=torch.randn(3 * H, H, generator=g).mul_(0.1),
-             b_ih=torch.randn(3 * H, generator=g).mul_(0.1), b_hh=torch.randn(3 * H, generator=g).mul_(0.1))
-    if mode == ops.POOL_ATTN:
-      w.update(w_lin=torch.randn(H, H, generator=g).mul_(0.1), b_lin=torch.randn(H, generator=g).mul_(0.1),
-               w_att=torch.randn(1, H, generator=g).mul_(0.2))
-    x = torch.randn(S, T, I, generator=g).to(dev)
-    keep.append(x)
-    r = dict(weights={k: v.to(dev) for k, v in w.items()}, pool_mode=mode, lens=np.asarray(lens, dtype=np.int64),
-             I=I, H=H, device=dev, x_ptrs=ops.padded_row_ptrs(x))
-    if h0:
-      h = torch.randn(S, H, generator=g).to(dev)
-      keep.append(h)
-      r.update(h0_ptrs=ops.padded_row_ptrs(h))
-    return r
-
-  def long_tailed(n_short, t_short, n_long, t_long):
-    return np.concatenate([rng.randint(1, t_short + 1, size=n_short), rng.randint(t_short, t_long + 1, size=n_long)])
-
-  if shape == 'text_tower':
-    reqs = [request(long_tailed(2400, 9, 40, 70), 300, 1024, m) for m in (ops.POOL_ATTN, ops.POOL_MAX)]
-  elif shape == 'all_small':
-    reqs = [request(long_tailed(100, 6, 20, 45), 64, 256, ops.POOL_LAST, h0=True),
-            request(long_tailed(60, 5, 30, 40), 64, 256, ops.POOL_ALL)]
-  else:
-    reqs = [request(long_tailed(1500, 8, 30, 60), 300, 1024, ops.POOL_ATTN),
-            request(np.full(1300, 48), 128, 1024, ops.POOL_ATTN)]
-
-  def run(min_steps):
-    tune(infer_tail_min_steps=min_steps)
-    res = ops.gru_pool_fwd_multi(reqs)
-    torch.cuda.synchronize()
-    assert _lib.load().cmhse_async_status(0) == 0
-    return [(o.clone(), c['ws'][:c['sched'].sum_T * c['H'] * 4].clone()) for o, c in res]
-
-  per_step = run(0)
-  for _ in range(3):
-    for (o1, h1), (o2, h2) in zip(per_step, run(16)):
-      assert torch.equal(o1, o2)
-      assert torch.equal(h1, h2)
-  for (o1, h1), (o2, h2) in zip(per_step, run(1)):      # (a tail of any length)
-    assert torch.equal(o1, o2) and torch.equal(h1, h2)
 
 
 def test_step_chain_failure_modes_are_an_error_or_a_correct_result(dev, tune):
@@ -1661,7 +1490,7 @@ def test_step_chain_failure_modes_are_an_error_or_a_correct_result(dev, tune):
       ops.gru_pool_fwd(**req)
     assert lib.cmhse_async_status(1) == -5    # the caller acknowledges ...
     assert lib.cmhse_async_status(0) == 0
-    assert ops.tune('chain_min_steps') == 0   # ... and the library has fallen back to per-step launches
+    assert ops.tune('multi_step_off') == 1    # ... and the library has fallen back to per-step launches on this device
     tune(resident_timeout_ms=5000)
     out, _ = ops.gru_pool_fwd(**req)
     torch.cuda.synchronize()
@@ -3051,13 +2880,16 @@ def test_grid_barrier_timeout_is_an_error_not_a_trap(dev, tune):
       with torch.no_grad():
         layer(x, lens)
     assert ops.async_status(clear=True) == -5 and ops.async_status() == 0
-    # acknowledging a timeout switches the multi-step kernels off for the process (round 5)
-    assert [ops.tune(k) for k in ('chain_min_steps', 'fwd_tail_min_steps', 'bwd_tail_min_steps')] == [0, 0, 0]
+    # acknowledging a timeout switches the multi-step kernels off on THIS device — for every tuning
+    # context, the knobs themselves untouched (round 6)
+    assert ops.tune('multi_step_off') == 1
+    assert [ops.tune(k) for k in ('chain_min_steps', 'fwd_tail_min_steps', 'bwd_tail_min_steps')] == [2, 4, 4]
+    with ops.TuneContext() as other:
+      assert other.tune('multi_step_off') == 1
     with torch.no_grad():
       y = layer(x, lens)
     assert torch.isfinite(y).all()
   finally:
     ops.async_status(clear=True)
-    ops.tune('chain_min_steps', 2)       # (this box is fine: back to the defaults for the tests that follow)
-    ops.tune('fwd_tail_min_steps', 4)
-    ops.tune('bwd_tail_min_steps', 4)
+    ops.tune('chain_min_steps', 2)       # (this box is fine: a positive set re-enables the multi-step kernels here)
+    assert ops.tune('multi_step_off') == 0

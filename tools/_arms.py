@@ -12,7 +12,7 @@ from cmhse_amd import evaluation, model as model_mod, ops
 
 TUNE_DEFAULTS = dict(tiny_max_seqs=1024, mid_max_seqs=1024, mid_units=0, mid_waves=0,
                      tall_tile_min_wgs=2048, bwd_mid_max_seqs=512, bwd_split_min_seqs=33, bwd_tail_min_steps=4, bwd_chunk_rows=2048,
-                     fwd_tail_min_steps=4, infer_tail_min_steps=0, mid_tall_min_seqs=129, bwd_chain_min_steps=0, bwd_fused_step=0, xproj_chunk_rows=1536, tn_rows_bm=0, chain_min_steps=2, chain_tall_min_wgs=256, chain_attention=0, chain_col_map=0, early_xproj=1)
+                     fwd_tail_min_steps=4, mid_tall_min_seqs=129, xproj_chunk_rows=1536, tn_rows_bm=0, chain_min_steps=2, chain_tall_min_wgs=256, early_xproj=1)
 
 
 def parse(spec):

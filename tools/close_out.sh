@@ -1,20 +1,24 @@
 #!/bin/bash
 # round close-out: full GPU test suite, the default bench line, profiles (tools/collect_profiles.sh); copy the results to profiles/rNN_*
-out=gpurun_out/r05_final
+R=${1:-r06_final}
+N=${2:-6}
+out=gpurun_out/$R
 mkdir -p $out
 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1
 echo "pytest gpu rc=$?" | tee $out/summary.txt
 grep -h "passed\|failed" $out/pytest_gpu.log | tail -2 | tee -a $out/summary.txt
 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?" | tee -a $out/summary.txt
-bash tools/collect_profiles.sh r05_final 5 > $out/collect.log 2>&1
-python - <<'PY' | tee -a gpurun_out/r05_final/summary.txt
-import json
-d = json.loads([l for l in open('gpurun_out/r05_final/bench.json') if l.startswith('{')][0])
+bash tools/collect_profiles.sh $R $N > $out/collect.log 2>&1
+python - $out <<'PY' | tee -a $out/summary.txt
+import json, sys
+d = json.loads([l for l in open(sys.argv[1] + '/bench.json') if l.startswith('{')][0])
 print('ms', round(d['ms_per_step'], 2), 'value', round(d['value'] / 1e6, 2), 'M pairs/s  frac', round(d['roofline']['frac'], 4), 'crc', d['ranks_crc32'])
 print('leg_seconds', d.get('leg_seconds'))
 print('cpu_baseline', {k: d['cpu_baseline'].get(k) for k in ('value', 'cores', 'kind')} if 'cpu_baseline' in d else None)
 print('noise', {k: d['rank_noise_floor'].get(k) for k in ('videos', 'max_abs_embedding_diff', 'random_init', 'scorer_only', 'correlated')} if 'rank_noise_floor' in d else None)
 print('train', {k: round(v['ms_per_step'], 2) for k, v in d.get('train_steps', {}).items() if isinstance(v, dict) and 'ms_per_step' in v})
 print('pcie', d.get('pcie_inclusive', {}).get('ms_per_step'))
+print('dropin_validate', {k: (round(v['ms_per_step'], 2), v.get('vs_device_pass') or v.get('vs_pcie_inclusive')) for k, v in d.get('dropin_validate', {}).items() if isinstance(v, dict)})
+print('fast_mode', {k: d.get('fast_mode', {}).get(k) for k in ('ms_per_step', 'max_abs_embedding_diff_vs_fp32', 'rank_rows_moved_on_correlated_embeddings')})
 PY

@@ -2,8 +2,8 @@
 # rocprofv3 kernel stats + trace of the default bench pass, PMC fabric traffic (two separate passes, as
 # MI355X_MICROARCH.md prescribes), SQ MFMA-busy counters, in-kernel clock of the tiled step.
 #   bash tools/collect_profiles.sh <dir under gpurun_out> <round label>; copy the results to profiles/rNN_*
-OUT=${1:-r05_final}
-ROUND=${2:-5}
+OUT=${1:-r06_final}
+ROUND=${2:-6}
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 D=$R/gpurun_out/$OUT

@@ -24,22 +24,8 @@ sys.path.insert(0, R)
 from cmhse_amd import _lib, ops  # noqa: E402
 
 
-CANARY_SRC = os.path.join(R, 'tools', 'microbench', 'canary.hip')
-CANARY_LIB = os.path.join(R, 'tools', 'microbench', 'canary.so')
-
-
-def build_canary():
-  """tools/microbench/canary.so, rebuilt when missing or older than its source.  Built WITHOUT the library's
-  device flags on purpose: the victim loop must keep its v_pk_fma_f32."""
-  import subprocess
-  if os.path.exists(CANARY_LIB) and os.path.getmtime(CANARY_LIB) >= os.path.getmtime(CANARY_SRC):
-    return CANARY_LIB
-  res = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', CANARY_LIB + '.tmp',
-                        CANARY_SRC], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-  if res.returncode != 0:
-    raise RuntimeError('hipcc failed:\n' + res.stdout)
-  os.replace(CANARY_LIB + '.tmp', CANARY_LIB)
-  return CANARY_LIB
+sys.path.insert(0, os.path.join(R, 'tools'))
+from canary_build import CANARY_LIB, CANARY_SRC, build_canary  # noqa: E402,F401
 
 
 def main():
