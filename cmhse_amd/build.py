@@ -12,10 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libcmhse_hip.so')
 SOURCES = ['gru.hip', 'sim.hip', 'bwd.hip']
-HEADERS = [os.path.join(CSRC, 'nt_core.hpp'), os.path.join(CSRC, 'tn_core.hpp'),
-           os.path.join(CSRC, 'tn_rows.hpp'), os.path.join(CSRC, 'step_loss.hpp'),
-           os.path.join(CSRC, 'gru_ws.hpp'), os.path.join(CSRC, 'grid_sync.hpp'),
-           os.path.join(os.path.dirname(HERE), 'include', 'cmhse_hip.h')]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')) + \
+    [os.path.join(os.path.dirname(HERE), 'include', 'cmhse_hip.h')]
 
 
 # Device-code rules of this library on gfx950 (profiles/r05_bf16_mfma_bystander.txt: while waves of one kernel

@@ -25,1177 +25,11 @@
 #include "tn_rows.hpp"
 #include "step_loss.hpp"
 
+#include "bwd_pool_kernels.hpp"
+#include "bwd_step_kernels.hpp"
+#include "bwd_loss_kernels.hpp"
+
 namespace cmhse {
-
-// ---------------------------------------------------------------------------------------------
-// small utility kernels
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void transpose_kernel(const float* __restrict__ in,
-                                                             float* __restrict__ out, int R,
-                                                             int C) {
-  __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int i = ty; i < 32; i += 8)
-    if (r0 + i < R && c0 + tx < C) tile[i][tx] = in[static_cast<int64_t>(r0 + i) * C + c0 + tx];
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8)
-    if (c0 + i < C && r0 + tx < R) out[static_cast<int64_t>(c0 + i) * R + r0 + tx] = tile[tx][i];
-}
-
-// Column sums over the packed rows: out[c] = sum_p w[p] * in[p][c] (w == NULL -> 1), two stages,
-// both in a fixed order (bitwise reproducible): stage 1 sums kColsumRows-row slabs (64 columns per
-// workgroup, one per lane, the 4 waves interleave the slab's rows), stage 2 adds the slabs.
-constexpr int kColsumRows = 512;
-
-__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(const float* __restrict__ in,
-                                                                  const float* __restrict__ w,
-                                                                  float* __restrict__ part,
-                                                                  int64_t rows, int cols,
-                                                                  int64_t ld) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * kColsumRows;
-  const int64_t r1 = (r0 + kColsumRows < rows) ? r0 + kColsumRows : rows;
-  float s = 0.f;
-  if (c < cols)
-    for (int64_t p = r0 + wave; p < r1; p += 4) s += (w ? w[p] : 1.0f) * in[p * ld + c];
-  __shared__ float red[4][64];
-  red[wave][lane] = s;
-  __syncthreads();
-  if (wave == 0 && c < cols)
-    part[static_cast<int64_t>(blockIdx.y) * cols + c] =
-        red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-}
-
-__global__ __launch_bounds__(kThreads) void colsum_final_kernel(const float* __restrict__ part,
-                                                                float* __restrict__ out,
-                                                                int slabs, int cols) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int i = 0; i < slabs; ++i) s += part[static_cast<int64_t>(i) * cols + c];
-  out[c] = s;
-}
-
-// Per packed row p = (t, s): addresses of x_{t,s} and of h_{t-1,s} (a zero row when there is none).
-struct RowAddrParams {
-  const uint64_t* x_rows;
-  const uint64_t* tok_rows;
-  const float* emb;
-  const uint64_t* h0_rows;
-  const int32_t* step_off;
-  const float* hs;
-  const float* zero_row;
-  uint64_t* xaddr;
-  uint64_t* hpaddr;
-  uint64_t* hsaddr;   // address of h_{t,s} itself (the B rows of dW_lin), or NULL
-  int32_t* p_t;
-  int32_t Tmax, I, H, vocab, x_step;
-  int64_t sum_T;
-};
-
-__global__ void row_addr_kernel(const RowAddrParams q) {
-  const int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (p >= q.sum_T) return;
-  int lo = 0, hi = q.Tmax;  // largest t with step_off[t] <= p
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (q.step_off[mid] <= p) lo = mid; else hi = mid;
-  }
-  const int t = lo, s = static_cast<int>(p - q.step_off[t]);
-  if (q.p_t != nullptr) q.p_t[p] = t;
-  if (q.tok_rows != nullptr) {
-    long long tok = reinterpret_cast<const long long*>(q.tok_rows[s])[t];
-    tok = tok < 0 ? 0 : (tok >= q.vocab ? q.vocab - 1 : tok);
-    q.xaddr[p] = reinterpret_cast<uint64_t>(q.emb + tok * q.I);
-  } else {
-    q.xaddr[p] = q.x_rows[s] + static_cast<uint64_t>(t) * q.x_step * 4u;
-  }
-  if (q.hsaddr != nullptr) q.hsaddr[p] = reinterpret_cast<uint64_t>(q.hs + p * q.H);
-  if (q.hpaddr == nullptr) return;
-  if (t > 0)
-    q.hpaddr[p] = reinterpret_cast<uint64_t>(q.hs + (static_cast<int64_t>(q.step_off[t - 1]) + s) * q.H);
-  else if (q.h0_rows != nullptr)
-    q.hpaddr[p] = q.h0_rows[s];
-  else
-    q.hpaddr[p] = reinterpret_cast<uint64_t>(q.zero_row);
-}
-
-// ---------------------------------------------------------------------------------------------
-// pooling backward: fills dpool[p][u] = d loss / d h_p[u] coming from the pooling
-// ---------------------------------------------------------------------------------------------
-struct PoolBwdParams {
-  const float* dout;  // [S, H] indexed by out_row
-  const int32_t* lens;
-  const int32_t* out_row;
-  const int32_t* step_off;
-  const int32_t* argmax;
-  float* dpool;
-  int32_t S, H, mode;
-};
-
-__global__ __launch_bounds__(kThreads) void pool_scatter_bwd_kernel(const PoolBwdParams q) {
-  const int s = blockIdx.x;
-  if (q.mode == CMHSE_POOL_ALL) {  // every hidden state is an output row: out_row[s] + t
-    const int len = q.lens[s];
-    for (int t = 0; t < len; ++t) {
-      const float* g = q.dout + (static_cast<int64_t>(q.out_row[s]) + t) * q.H;
-      float* d = q.dpool + (static_cast<int64_t>(q.step_off[t]) + s) * q.H;
-      for (int u = threadIdx.x; u < q.H; u += kThreads) d[u] = g[u];
-    }
-    return;
-  }
-  const float* g = q.dout + static_cast<int64_t>(q.out_row[s]) * q.H;
-  for (int u = threadIdx.x; u < q.H; u += kThreads) {
-    const int t = (q.mode == CMHSE_POOL_MAX) ? q.argmax[static_cast<int64_t>(s) * q.H + u]
-                                             : (q.lens[s] - 1);
-    q.dpool[(static_cast<int64_t>(q.step_off[t]) + s) * q.H + u] = g[u];
-  }
-}
-
-// attention: a_t = exp(e_t)/(sum exp + 1e-4); da_t = g . h_t; de_t = a_t (da_t - sum a da);
-// dpool[p] = a_t g.  One workgroup per sequence.
-struct AttnBwdParams {
-  const float* dout;
-  const float* hs;
-  const float* e_part;
-  const int32_t* lens;
-  const int32_t* out_row;
-  const int32_t* step_off;
-  float* dpool;
-  float* de;  // [sumT]
-  int64_t rows;
-  int32_t H, n_tiles;
-};
-
-// One workgroup per sequence; its four waves take the time steps round-robin and need no barrier
-// per step (a wave reduces its own dot products with shuffles, and pass 2 revisits exactly the
-// steps the same wave handled in pass 1, so it reads back its own da_t).  The previous form walked
-// the steps one by one with two workgroup barriers each: 0.22-0.34 ms per call at T <= 80, at the
-// head of each tower's backward pass.
-constexpr int kPoolBwdThreads = 1024;   // 16 waves: a sequence of 80 steps is 5 steps per wave
-__global__ __launch_bounds__(kPoolBwdThreads) void attn_pool_bwd_kernel(const AttnBwdParams q) {
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int len = q.lens[s], H = q.H;
-  const float* g = q.dout + static_cast<int64_t>(q.out_row[s]) * H;
-  constexpr int NT = kPoolBwdThreads, NW = NT / 64;
-  __shared__ float red[NT];
-  __shared__ float s_den, s_c;
-  __shared__ float wpart[NW];
-  auto energy = [&](int t) {
-    const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
-    float e = 0.f;
-    for (int k = 0; k < q.n_tiles; ++k) e += q.e_part[k * q.rows + row];
-    return e;
-  };
-  float part = 0.f;
-  for (int t = tid; t < len; t += NT) part += expf(energy(t));
-  red[tid] = part;
-  __syncthreads();
-  if (tid == 0) {
-    float d = 0.f;
-    const int used = len < NT ? len : NT;      // threads past `len` hold 0
-    for (int i = 0; i < used; ++i) d += red[i];
-    s_den = d + 0.0001f;
-  }
-  __syncthreads();
-  const float den = s_den;
-  // pass 1: da_t = g . h_t (one wave per step) -> de scratch holds da_t; c = sum_t a_t da_t
-  float c_acc = 0.f;
-  for (int t = wave; t < len; t += NW) {
-    const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
-    const float* hr = q.hs + row * H;
-    float d = 0.f;
-    for (int u = lane; u < H; u += 64) d += g[u] * hr[u];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
-    const float a = expf(energy(t)) / den;
-    if (lane == 0) q.de[row] = d;  // temporarily da_t
-    c_acc += a * d;
-  }
-  if (lane == 0) wpart[wave] = c_acc;
-  __syncthreads();
-  if (tid == 0) {
-    float cs = 0.f;
-    for (int w = 0; w < NW; ++w) cs += wpart[w];
-    s_c = cs;
-  }
-  __syncthreads();
-  const float c = s_c;
-  // pass 2: de_t and dpool rows (same wave -> same steps as in pass 1)
-  for (int t = wave; t < len; t += NW) {
-    const int64_t row = static_cast<int64_t>(q.step_off[t]) + s;
-    const float a = expf(energy(t)) / den;
-    float* dp = q.dpool + row * H;
-    for (int u = lane; u < H; u += 64) dp[u] = a * g[u];
-    if (lane == 0) q.de[row] = a * (q.de[row] - c);
-  }
-}
-
-// du[p][n] = de[p] * w_att[n] * (1 - v[p][n]^2)
-__global__ __launch_bounds__(kThreads) void attn_du_kernel(const float* __restrict__ de,
-                                                           const float* __restrict__ v,
-                                                           const float* __restrict__ w_att,
-                                                           float* __restrict__ du, int64_t rows,
-                                                           int H) {
-  const int64_t p = blockIdx.x;
-  const float d = de[p];
-  for (int n = threadIdx.x; n < H; n += kThreads) {
-    const float tv = v[p * H + n];
-    du[p * H + n] = d * w_att[n] * (1.0f - tv * tv);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// generic GEMM kernels
-// ---------------------------------------------------------------------------------------------
-struct TnParams {
-  const float* a;  // [K, lda], columns m
-  int64_t lda;
-  const float* b;  // [K, ldb] or rows through b_addr
-  int64_t ldb;
-  const uint64_t* b_addr;
-  float* c;  // [M, ldc]
-  int64_t ldc;
-  int32_t M, N, n_tiles;
-  int64_t K;
-  const float* scale;  // optional device scalar multiplied into C
-  // several products in one launch (blockIdx.y = block b, rows blk_off[b] .. blk_off[b+1] of the
-  // caller's row-blocked operands): A is the block's [n_b, n_b] matrix at a + b * blk_stride
-  // (lda = n_b), B / C are rows blk_off[b].. of b / c; M = K = n_b
-  const int32_t* blk_off;
-  int64_t blk_stride;
-};
-
-template <bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const TnParams q_) {
-  TnParams q = q_;
-  if (q.blk_off != nullptr) {
-    const int b = blockIdx.y, off = q.blk_off[b], nb = q.blk_off[b + 1] - off;
-    q.a += b * q.blk_stride;
-    q.lda = nb;
-    q.b += static_cast<int64_t>(off) * q.ldb;
-    q.c += static_cast<int64_t>(off) * q.ldc;
-    q.M = nb;
-    q.K = nb;
-    if ((blockIdx.x / q.n_tiles) * 128 >= nb) return;   // M tile outside this (smaller) block
-  }
-  constexpr int BM = 128, BN = 128;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = (blockIdx.x % q.n_tiles) * BN, m0 = (blockIdx.x / q.n_tiles) * BM;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-  tn_mainloop<BM, BN, VEC>(smem, q.a, q.lda, q.M, q.b, q.ldb, q.b_addr, q.N, q.K, m0, n0, acc);
-  const float sc = q.scale ? *q.scale : 1.0f;
-#pragma unroll
-  for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
-        const int n = n0 + wn * 64 + ns * 32 + acc_col(lane);
-        if (m < q.M && n < q.N) q.c[static_cast<int64_t>(m) * q.ldc + n] = sc * acc[ms][ns][r];
-      }
-}
-
-// C[m][n] = sum_k A[m][k] B[n][k]; output row m goes to c_addr[m] (or c + m*ldc);
-// mode 0 store, 1 accumulate (+=), 2 atomic add (rows may repeat: embedding-table scatter),
-// 3 store the partial product of K segment blockIdx.y at c + blockIdx.y * M * ldc (dense scratch;
-// splitk_reduce_kernel adds the segments in a fixed order).
-struct NtOutParams {
-  const float* a;  // [M, lda]
-  int64_t lda;
-  const float* b;  // [N, ldb]
-  int64_t ldb;
-  float* c;
-  int64_t ldc;
-  const uint64_t* c_addr;
-  int32_t M, N, K, n_tiles, mode;
-  int32_t k_seg;   // split-K: blockIdx.y takes k in [y*k_seg, min(K, (y+1)*k_seg)); 0 = no split
-};
-
-template <bool VEC>
-__global__ __launch_bounds__(kThreads) void gemm_nt_out_kernel(const NtOutParams q) {
-  constexpr int BM = 128, BN = 128;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, srow = tid >> 2;
-  const int n0 = (blockIdx.x % q.n_tiles) * BN, m0 = (blockIdx.x / q.n_tiles) * BM;
-  rowaddr_t ar[2], br[2];
-  bool av[2], bv[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + srow + 64 * i, n = n0 + srow + 64 * i;
-    av[i] = m < q.M;
-    bv[i] = n < q.N;
-    ar[i] = row_addr(q.a + static_cast<int64_t>(av[i] ? m : 0) * q.lda);
-    br[i] = row_addr(q.b + static_cast<int64_t>(bv[i] ? n : 0) * q.ldb);
-  }
-  int K = q.K;
-  if (q.k_seg > 0) {
-    const int k0 = static_cast<int>(blockIdx.y) * q.k_seg;
-    K = (q.K - k0 < q.k_seg) ? (q.K - k0) : q.k_seg;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ar[i] += static_cast<rowaddr_t>(k0) * 4u;
-      br[i] += static_cast<rowaddr_t>(k0) * 4u;
-    }
-  }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-  const int b_row0[2] = {wn * 64, wn * 64 + 32};
-  nt_phase<BM, BN, 2, 2, 2, 1, VEC>(smem, ar, av, br, bv, K, wm * 64, b_row0, acc);
-#pragma unroll
-  for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + ms * 32 + acc_row(r, lane);
-      if (m >= q.M) continue;
-      float* crow = (q.c_addr && q.mode != 3) ? reinterpret_cast<float*>(q.c_addr[m])
-                                              : q.c + static_cast<int64_t>(m) * q.ldc;
-      if (q.mode == 3) crow += static_cast<int64_t>(blockIdx.y) * q.M * q.ldc;
-#pragma unroll
-      for (int ns = 0; ns < 2; ++ns) {
-        const int n = n0 + b_row0[ns] + acc_col(lane);
-        if (n >= q.N) continue;
-        const float v = acc[ms][ns][r];
-        if (q.mode == 0 || q.mode == 3) crow[n] = v;
-        else if (q.mode == 1) crow[n] += v;
-        else atomicAdd(crow + n, v);
-      }
-    }
-}
-
-// out row m (at c_addr[m], or c + m * ldc) = [its old value +] part[0][m] + part[1][m] + ... in segment
-// order (bitwise reproducible)
-__global__ __launch_bounds__(kThreads) void splitk_reduce_kernel(const float* __restrict__ part,
-                                                                 const uint64_t* __restrict__ c_addr,
-                                                                 float* __restrict__ c, int64_t ldc, int add,
-                                                                 int splits, int M, int N) {
-  const int m = blockIdx.x;
-  float* dst = c_addr ? reinterpret_cast<float*>(c_addr[m]) : c + m * ldc;
-  for (int n = threadIdx.x; n < N; n += kThreads) {
-    float s = 0.f;
-    for (int y = 0; y < splits; ++y) s += part[(static_cast<int64_t>(y) * M + m) * N + n];
-    dst[n] = add ? dst[n] + s : s;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// BPTT step (latency-shaped like gru_step_tiny_kernel): 32 sequences x 32 hidden units per
-// workgroup, the 4 waves split K = 3H of  rec = dGh_{t+1} . W_hh  (W_hh^T rows are K-contiguous),
-// fixed-order LDS combine, then the gate derivatives of step t in the epilogue.
-// ---------------------------------------------------------------------------------------------
-struct BwdStepParams {
-  const float* dgh_next;  // rows of step t+1: [S_next, 3H]
-  const float* whh_t;     // [H, 3H]
-  const float* dpool;     // [sumT, H]
-  const float* gates;     // [sumT, 4H]
-  const float* hs;        // [sumT, H]
-  const uint64_t* h0_rows;
-  const int32_t* out_row;
-  float* carry;  // [S, H]  dh_{t+1} * z_{t+1}
-  float* dgx;    // [sumT, 3H]
-  float* dgh;    // [sumT, 3H]
-  float* dh0;    // [S, H] by out_row (final launch only)
-  int32_t H, t, S_t, S_next;
-  int64_t off_cur, off_prev;
-};
-
-// Up to CMHSE_MAX_JOBS independent BPTT chains share one launch per step (cmhse_gru_pool_bwd_multi):
-// workgroups [start[k], start[k+1]) belong to job k, like GruStepGroup in the forward pass.
-struct BwdStepGroup {
-  BwdStepParams j[CMHSE_MAX_JOBS];
-  uint32_t start[CMHSE_MAX_JOBS];
-  int32_t n;
-};
-
-template <bool VEC, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void gru_bwd_step_kernel(const BwdStepGroup grp) {
-  CHAIN_WAVE_PRIORITY();
-  __shared__ float red[NW][16][64];
-  int ji = 0;
-#pragma unroll
-  for (int k = 1; k < CMHSE_MAX_JOBS; ++k)
-    if (k < grp.n && blockIdx.x >= grp.start[k]) ji = k;
-  const BwdStepParams& q = grp.j[ji];
-  const unsigned wg = blockIdx.x - grp.start[ji];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = q.H, K = 3 * H;
-  const int u_tiles = (H + 31) / 32;
-  const int u0 = (wg % u_tiles) * 32, m0 = (wg / u_tiles) * 32;
-  const int row = lane & 31, hi = lane >> 5;
-  f32x16 acc = zero16();
-  if (q.S_next > 0) {
-    const int m = m0 + row;
-    const int mc = (m < q.S_next) ? m : (q.S_next - 1);
-    const int u = u0 + row;
-    const int uc = (u < H) ? u : (H - 1);
-    tiny_phase<VEC, NW>(row_addr(q.dgh_next + static_cast<int64_t>(mc) * K),
-                    row_addr(q.whh_t + static_cast<int64_t>(uc) * K), u < H, K, wave, hi, acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-  __syncthreads();
-  // 4 elements per thread: tile row er, columns ec..ec+3
-  const int er = tid >> 3, ec = (tid & 7) * 4;
-  const int m = m0 + er;
-  if (tid >= 256 || m >= q.S_t) return;   // (with NW = 8 the upper four waves only split K)
-  const int reg = (er & 3) | ((er >> 3) << 2);
-  const int lb = 32 * ((er >> 2) & 1) + ec;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int u = u0 + ec + j;
-    if (u >= H) continue;
-    float rec = 0.f;
-    if (m < q.S_next)
-    {
-      rec = q.carry[static_cast<int64_t>(m) * H + u];
-      float part = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) part += red[w][reg][lb + j];
-      rec += part;
-    }
-    if (q.t < 0) {  // final launch: d loss / d h0
-      q.dh0[static_cast<int64_t>(q.out_row[m]) * H + u] = rec;
-      continue;
-    }
-    const int64_t p = q.off_cur + m;
-    const float dh = rec + q.dpool[p * H + u];
-    const float* gp = q.gates + p * 4 * H + u;
-    const float rg = gp[0], zg = gp[H], ng = gp[2 * H], ghn = gp[3 * H];
-    float hp = 0.f;
-    if (q.t > 0)
-      hp = q.hs[(q.off_prev + m) * H + u];
-    else if (q.h0_rows != nullptr)
-      hp = reinterpret_cast<const float*>(q.h0_rows[m])[u];
-    const float dn_pre = dh * (1.0f - zg) * (1.0f - ng * ng);
-    const float dz_pre = dh * (hp - ng) * zg * (1.0f - zg);
-    const float dr_pre = dn_pre * ghn * rg * (1.0f - rg);
-    float* gx = q.dgx + p * K + u;
-    float* gh = q.dgh + p * K + u;
-    gx[0] = dr_pre;
-    gx[H] = dz_pre;
-    gx[2 * H] = dn_pre;
-    gh[0] = dr_pre;
-    gh[H] = dz_pre;
-    gh[2 * H] = dn_pre * rg;
-    q.carry[static_cast<int64_t>(m) * H + u] = dh * zg;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// BPTT step for few active sequences (every step of a training batch): the same product on the
-// tile shape of the forward mid-size step (gru_step_mid_kernel): 32 (or 16) sequences x BU = 16, 8
-// or 4 hidden units per workgroup, one 16 x 16 x 4 MFMA column block, 8 waves split K = 3H with one
-// 128-byte line pair in flight each (mid_phase), fixed-order LDS combine, the epilogue's operands
-// requested before the K loop.  The 32 x 32 tiles above leave H/32 = 32 workgroups at S_t <= 32,
-// each pulling 768 KB of operands through one CU; here 64-256 workgroups pull 430-580 KB each.
-// ---------------------------------------------------------------------------------------------
-constexpr int kBwdMidNW = 8, kBwdMidRing = 2;
-
-template <int MB, int BU>
-__global__ __launch_bounds__(64 * kBwdMidNW) void gru_bwd_step_mid_kernel(const BwdStepGroup grp) {
-  CHAIN_WAVE_PRIORITY();
-  constexpr int NW = kBwdMidNW, BM = 16 * MB;
-  constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);
-  __shared__ f32x4v red[NW][MB][64];
-  int ji = 0;
-#pragma unroll
-  for (int k = 1; k < CMHSE_MAX_JOBS; ++k)
-    if (k < grp.n && blockIdx.x >= grp.start[k]) ji = k;
-  const BwdStepParams& q = grp.j[ji];
-  const unsigned wg = blockIdx.x - grp.start[ji];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = q.H, K = 3 * H;
-  const int u_tiles = (H + BU - 1) / BU;
-  const int u0 = (wg % u_tiles) * BU, m0 = (wg / u_tiles) * BM;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const bool final_launch = q.t < 0;
-
-  // epilogue operands first (clamped, branch-free): output o = tid + 512 q -> row o / BU, unit o % BU
-  float e_carry[NOUT], e_dpool[NOUT], e_g[NOUT][4], e_hp[NOUT];
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    const int o = tid + 64 * NW * i;
-    const int m = m0 + (o / BU) % BM, u = u0 + (o % BU);
-    const int mc = (m < q.S_t) ? m : (q.S_t - 1), uc = (u < H) ? u : (H - 1);
-    const int mn = (mc < q.S_next) ? mc : 0;
-    e_carry[i] = (q.S_next > 0) ? q.carry[static_cast<int64_t>(mn) * H + uc] : 0.f;
-    e_dpool[i] = 0.f;
-    e_hp[i] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) e_g[i][g] = 0.f;
-    if (!final_launch) {
-      const int64_t p = q.off_cur + mc;
-      e_dpool[i] = q.dpool[p * H + uc];
-      const float* gp = q.gates + p * 4 * H + uc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) e_g[i][g] = gp[static_cast<int64_t>(g) * H];
-      if (q.t > 0)
-        e_hp[i] = q.hs[(q.off_prev + mc) * H + uc];
-      else if (q.h0_rows != nullptr)
-        e_hp[i] = reinterpret_cast<const float*>(q.h0_rows[mc])[uc];
-    }
-  }
-
-  const bool have_rec = m0 < q.S_next;   // (workgroup-uniform) some row of this block continues
-  if (have_rec) {
-    rowaddr_t arow[MB], brow[1];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = m0 + 16 * mb + r16;
-      const int mc = (m < q.S_next) ? m : (q.S_next - 1);   // rows past S_next: computed, never used
-      arow[mb] = row_addr(q.dgh_next + static_cast<int64_t>(mc) * K);
-    }
-    const int uu = u0 + ((r16 < BU) ? r16 : (BU - 1)), uc = (uu < H) ? uu : (H - 1);
-    brow[0] = row_addr(q.whh_t + static_cast<int64_t>(uc) * K);
-    f32x4v acc[MB][1];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb][0] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    mid_phase<MB, 1, NW, kBwdMidRing>(arow, brow, K, wave, kq, acc);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) red[wave][mb][lane] = acc[mb][0];
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    const int o = tid + 64 * NW * i;
-    if (o >= OUTS) continue;
-    const int er = o / BU, eu = o % BU;
-    const int m = m0 + er, u = u0 + eu;
-    if (m >= q.S_t || u >= H) continue;
-    float rec = 0.f;
-    if (m < q.S_next) {
-      const int mb = er >> 4, rr = er & 15;
-      const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
-      float part = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) part += reinterpret_cast<const float*>(&red[w][mb][sl])[reg];
-      rec = e_carry[i] + part;
-    }
-    if (final_launch) {  // d loss / d h0
-      q.dh0[static_cast<int64_t>(q.out_row[m]) * H + u] = rec;
-      continue;
-    }
-    const int64_t p = q.off_cur + m;
-    const float dh = rec + e_dpool[i];
-    const float rg = e_g[i][0], zg = e_g[i][1], ng = e_g[i][2], ghn = e_g[i][3];
-    const float hp = e_hp[i];
-    const float dn_pre = dh * (1.0f - zg) * (1.0f - ng * ng);
-    const float dz_pre = dh * (hp - ng) * zg * (1.0f - zg);
-    const float dr_pre = dn_pre * ghn * rg * (1.0f - rg);
-    float* gx = q.dgx + p * K + u;
-    float* gh = q.dgh + p * K + u;
-    gx[0] = dr_pre;
-    gx[H] = dz_pre;
-    gx[2 * H] = dn_pre;
-    gh[0] = dr_pre;
-    gh[H] = dz_pre;
-    gh[2 * H] = dn_pre * rg;
-    q.carry[static_cast<int64_t>(m) * H + u] = dh * zg;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The long few-sequence TAIL of a BPTT chain as ONE resident kernel.  The whole-paragraph /
-// whole-video sequences of a training batch run tens of steps past the last sentence / clip with
-// at most 32 sequences still active (ActivityNet, batch 32: ~95 of the text chain's 124 steps,
-// and every step of the level-2 encoders and of the decoders);
-// backward those steps come FIRST, each a dependent launch of gru_bwd_step_mid_kernel<1, 16> —
-// 12.8 us apiece on an idle chip, 24 us beside the other tower's chain — and the step's own work
-// is a 16 x 16 output tile per workgroup.  Here the H / 16 workgroups of that kernel stay resident
-// from step Tmax - 1 down to the first step with more than 16 active sequences:
-//   * the workgroup's W_hh^T slice (16 columns x 3H) is loaded into registers ONCE, in the MFMA
-//     operand layout of mid_phase;
-//   * per step, the rows dGh_{t+1} — written one step earlier by ALL workgroups — are the only
-//     operand that crosses workgroups.  The 8 XCDs' L2s are not coherent with each other, and the
-//     cache maintenance the HIP memory model prescribes for that (write-back + invalidate per
-//     fence) costs 24-74 us per step (tools/microbench/grid_barrier.hip).  But every dGh row is
-//     written exactly once, to an address nobody read before, and read only after the step's
-//     barrier: agent-scope (sc1) stores that write through and sc1 loads that bypass the
-//     non-coherent caches are enough — 1.8-4.2 us for the barrier itself (64 / 256 workgroups), no
-//     cache maintenance at all;
-//   * the barrier is a counter in the call's workspace: one agent-scope atomic add per workgroup
-//     and a bounded spin.  All workgroups are co-resident by construction (at most 256 of them,
-//     8 waves and 8 KB of LDS each; nothing they wait for waits for them); should they not be (a
-//     shared GPU), the barrier times out and the call is reported failed (grid_sync.hpp);
-//   * carry (dh_{t+1} z_{t+1}) lives in a register of the thread that owns the output.
-// Block ownership of the 8 waves, accumulation order and combine order are those of
-// gru_bwd_step_mid_kernel<1, 16>; the results agree with it to fp32 rounding (the compiler
-// contracts the gate arithmetic of the two kernels into different FMAs) and are bitwise
-// reproducible from run to run (tested).
-// ---------------------------------------------------------------------------------------------
-struct BwdTailParams {
-  const float* whh_t;       // [H, 3H]
-  const float* dpool;       // [sumT, H]
-  const float* gates;       // [sumT, 4H]
-  const float* hs;          // [sumT, H]
-  const int32_t* step_off;  // device [Tmax + 1]
-  float* carry;             // [S, H]: written for the rows of step t_lo when the kernel ends
-  float* dgx;               // [sumT, 3H]
-  float* dgh;               // [sumT, 3H]
-  GridSync sync;            // grid barrier words (zeroed by the caller)
-  int32_t H, t_hi, t_lo;    // steps t_hi = Tmax - 1 down to t_lo >= 1, at most 32 active sequences each
-};
-
-constexpr int kTailMaxSeqs = 32;   // two 16-row blocks per workgroup
-
-template <int KBMAX, int MB>
-__global__ __launch_bounds__(512) void gru_bwd_tail_kernel(const BwdTailParams q) {
-  CHAIN_WAVE_PRIORITY();
-  constexpr int NW = 8;
-  __shared__ f32x4v red[NW][MB][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = q.H, K = 3 * H;
-  const int u0 = blockIdx.x * 16;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int nkb = K / 16;
-  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };   // mid_phase's ownership
-  int nmine = 0;
-  while (nmine < KBMAX && block_of(nmine) < nkb) ++nmine;
-  // B operand: column r16 of the tile = unit u0 + r16 of W_hh^T, resident for the whole tail
-  float4 wreg[KBMAX];
-  {
-    const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
-    const float* brow = q.whh_t + static_cast<int64_t>(uc) * K;
-#pragma unroll
-    for (int i = 0; i < KBMAX; ++i)
-      wreg[i] = (i < nmine) ? *reinterpret_cast<const float4*>(brow + block_of(i) * 16 + 4 * kq)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // the output this thread owns (threads 0..255): tile row er = sequence, unit u
-  const int er = tid >> 4, eu = tid & 15;
-  const int u = u0 + eu;
-  const bool owner = er < 16 * MB && u < H;     // threads 0..255 at MB = 1, all 512 at MB = 2
-  float carry = 0.f;
-  unsigned arrivals = 0;
-  int S_next = 0;
-  for (int t = q.t_hi; t >= q.t_lo; --t) {
-    const int off_cur = q.step_off[t], off_next = q.step_off[t + 1], off_prev = q.step_off[t - 1];
-    const int S_t = off_next - off_cur;
-    // the epilogue's own operands do not depend on the chain: request them before the product
-    float e_dpool = 0.f, e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_hp = 0.f;
-    const int64_t p = off_cur + er;
-    if (owner && er < S_t) {
-      e_dpool = q.dpool[p * H + u];
-      const float* gp = q.gates + p * 4 * H + u;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) e_g[g] = gp[static_cast<int64_t>(g) * H];
-      e_hp = q.hs[(static_cast<int64_t>(off_prev) + er) * H + u];
-    }
-    if (S_next > 0) {
-      // A operand: rows of step t + 1, published by every workgroup before the barrier below;
-      // one 16-row block at a time (its 96 registers are reused by the second block)
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(q.dgh + static_cast<int64_t>(off_next) * K), 0, 0x7fffffff, 0x00020000);
-      typedef int i32x4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        if (16 * mb < S_next) {      // (workgroup-uniform)
-          const int m = 16 * mb + r16;
-          const int row_b = ((m < S_next) ? m : (S_next - 1)) * K * 4;
-          i32x4v areg[KBMAX];
-#pragma unroll
-          for (int i = 0; i < KBMAX; ++i)
-            if (i < nmine)
-              areg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
-#pragma unroll
-          for (int i = 0; i < KBMAX; ++i) {
-            if (i >= nmine) continue;   // wave-uniform
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].x), wreg[i].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].y), wreg[i].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].z), wreg[i].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(areg[i].w), wreg[i].w, acc, 0, 0, 0);
-          }
-        }
-        red[wave][mb][lane] = acc;
-      }
-      __syncthreads();
-    }
-    if (owner && er < S_t) {
-      float rec = 0.f;
-      if (er < S_next) {
-        const int mb = er >> 4, rr = er & 15;
-        const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
-        float part = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) part += reinterpret_cast<const float*>(&red[w][mb][sl])[reg];
-        rec = carry + part;
-      }
-      const float dh = rec + e_dpool;
-      const float rg = e_g[0], zg = e_g[1], ng = e_g[2], ghn = e_g[3];
-      const float dn_pre = dh * (1.0f - zg) * (1.0f - ng * ng);
-      const float dz_pre = dh * (e_hp - ng) * zg * (1.0f - zg);
-      const float dr_pre = dn_pre * ghn * rg * (1.0f - rg);
-      float* gx = q.dgx + p * K + u;
-      float* gh = q.dgh + p * K + u;
-      gx[0] = dr_pre;
-      gx[H] = dz_pre;
-      gx[2 * H] = dn_pre;
-      // the next step's A operand, in every workgroup: write through to where all XCDs see it
-      __hip_atomic_store(gh, dr_pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(gh + H, dz_pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(gh + 2 * H, dn_pre * rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      carry = dh * zg;
-    }
-    S_next = S_t;
-    if (t == q.t_lo) break;
-    // grid barrier: this workgroup's rows are written through, then everybody's are
-    __builtin_amdgcn_s_waitcnt(0);
-    arrivals += gridDim.x;
-    if (!grid_sync_wait(q.sync, arrivals)) return;
-  }
-  if (owner && er < S_next) q.carry[static_cast<int64_t>(er) * H + u] = carry;
-}
-
-// ---------------------------------------------------------------------------------------------
-// BPTT step of a training-size batch (32 < S_t <= bwd_mid_max_seqs) as TWO launches that move a
-// third of the bytes.  The product of a step,  rec[S, H] = dGh_{t+1}[S, 3H] . W_hh[3H, H],  is a
-// skinny GEMM: a handful of row tiles, K = 3H.  gru_bwd_step_mid_kernel covers it with 32 x 16
-// tiles that each walk ALL of K — 320 workgroups x 576 KB = 184 MB of operands through the cache
-// fabric per step at S_t = 152, which is what bounds it (8 TB/s for 1 GFLOP) and what makes two
-// chains and the weight-gradient products beside them slow each other down.  Here:
-//   bwd_rec_part_kernel   32 x 128 tiles, K cut into `splits` slices over the grid's second
-//                         dimension (240-256 workgroups in all): operands staged through LDS in
-//                         32-k chunks (whole 128-byte lines per row), eight waves each owning 16
-//                         columns (two 16x16x4 accumulators); writes the slice's partial tile to scratch.  Operand bytes per step:
-//                         outputs x K x 4 x (1/128 + 1/32) = 76 MB at S_t = 152.
-//   bwd_gates_kernel      adds the partials in slice order (bitwise reproducible), then the gate
-//                         derivatives of step t exactly as the one-launch kernels' epilogue.
-// (Measured late in round 3: both in ONE launch — a ticket per tile, the last K slice to arrive adds
-// the slices and evaluates the tile's gates, partials exchanged through agent-scope stores / loads —
-// is correct and 0.1 ms per training step SLOWER: the epilogue then waits for the slowest slice and
-// runs on 32 workgroups instead of the whole chip; the second launch's gap is cheaper than that.)
-// ---------------------------------------------------------------------------------------------
-constexpr int kRecBM = 32, kRecBN = 128, kRecBK = 32, kRecLd = kRecBK + 4;
-
-struct RecPartParams {
-  const float* a;     // dGh_{t+1} rows [S_next, K]
-  const float* b;     // W_hh^T rows [H, K]
-  float* part;        // [splits][m_pad][H]
-  int32_t S_next, H, K, k_slice, m_pad, n_tiles;
-};
-
-constexpr int kRecThreads = 512;   // 8 waves: two per SIMD, so one wave's chunk barrier and LDS round trip hide under the other's MFMAs
-
-// The product of one (32-row block, 128-column tile, K slice): acc[mb][reg] = element (row 16 mb +
-// 4 kq + reg, column 16 wave + r16) of the slice's partial tile.  Ends with a workgroup barrier
-// (the LDS buffers may be reused).
-typedef float (*RecLds)[(kRecBM + kRecBN) * kRecLd];
-__device__ __forceinline__ void rec_part_tile(const RecPartParams& q, RecLds lds, const int m0, const int n0,
-                                              const int y, f32x4v (&acc)[2]) {
-  constexpr int ROWS = kRecBM + kRecBN, PIECES = ROWS * (kRecBK / 4), NP = (PIECES + kRecThreads - 1) / kRecThreads;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = y * q.k_slice;
-  const int k1 = (k0 + q.k_slice < q.K) ? (k0 + q.k_slice) : q.K;
-  const int nchunks = (k1 - k0 + kRecBK - 1) / kRecBK;
-  // staging: a row of a chunk is 32 floats = 8 x 16 B: piece p = tid + 512 i -> staged row p >> 3
-  // (0..31 rows of dGh, 32..159 rows of W_hh^T), slot p & 7 — eight lanes read one whole 128-byte line
-  rowaddr_t rbase[NP];
-  int lds_off[NP], slot_k[NP];
-  bool live[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int pc = tid + kRecThreads * i;
-    live[i] = pc < PIECES;
-    const int row = live[i] ? (pc >> 3) : 0, slot = pc & 7;
-    if (row < kRecBM) {
-      const int m = m0 + row;
-      rbase[i] = row_addr(q.a + static_cast<int64_t>(m < q.S_next ? m : (q.S_next - 1)) * q.K);
-    } else {
-      const int n = n0 + row - kRecBM;
-      rbase[i] = row_addr(q.b + static_cast<int64_t>(n < q.H ? n : (q.H - 1)) * q.K);
-    }
-    slot_k[i] = slot * 4;
-    lds_off[i] = row * kRecLd + slot * 4;
-  }
-  float4 r[NP];
-  auto issue = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (live[i]) r[i] = issue_row4<true>(rbase[i], k0 + c * kRecBK + slot_k[i], k1);
-  };
-  auto stage = [&](int buf, int c) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (live[i])
-        *reinterpret_cast<float4*>(&lds[buf][lds_off[i]]) =
-            finish_row4<true>(r[i], true, k0 + c * kRecBK + slot_k[i], k1);
-  };
-  // wave w owns the 16 columns 16 w .. 16 w + 15 of the 32 x 128 tile, both 16-row blocks:
-  // v_mfma_f32_16x16x4_f32, lane (r16 = lane & 15, kq = lane >> 4) feeds k = 4 kq + j of a 16-k block
-  acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  const int r16 = lane & 15, kq = lane >> 4;
-  auto compute = [&](int cur) {
-    const float* A = &lds[cur][0] + r16 * kRecLd + 4 * kq;
-    const float* B = &lds[cur][0] + (kRecBM + 16 * wave + r16) * kRecLd + 4 * kq;
-#pragma unroll
-    for (int kb = 0; kb < kRecBK / 16; ++kb) {
-      const float4 a0 = *reinterpret_cast<const float4*>(A + kb * 16);
-      const float4 a1 = *reinterpret_cast<const float4*>(A + 16 * kRecLd + kb * 16);
-      const float4 b = *reinterpret_cast<const float4*>(B + kb * 16);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, acc[1], 0, 0, 0);
-    }
-  };
-  issue(0);
-  stage(0, 0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    if (c + 1 < nchunks) issue(c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(cur);
-    if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(kRecThreads) void bwd_rec_part_kernel(const RecPartParams q) {
-  CHAIN_WAVE_PRIORITY();
-  __shared__ __attribute__((aligned(16))) float lds[2][(kRecBM + kRecBN) * kRecLd];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int n0 = static_cast<int>(blockIdx.x % q.n_tiles) * kRecBN;
-  const int m0 = static_cast<int>(blockIdx.x / q.n_tiles) * kRecBM;
-  f32x4v acc[2];
-  rec_part_tile(q, lds, m0, n0, static_cast<int>(blockIdx.y), acc);
-  // the slice's partial tile (element (row r, col c) of a 16 x 16 block: lane (r >> 2) * 16 + c,
-  // register r & 3); rows past S_next hold a clamped row's garbage and are never read
-  float* P = q.part + (static_cast<int64_t>(blockIdx.y) * q.m_pad + m0) * q.H;
-  const int n = n0 + 16 * wave + r16;
-  if (n < q.H) {
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        P[static_cast<int64_t>(16 * mb + 4 * kq + reg) * q.H + n] = acc[mb][reg];
-  }
-}
-
-struct GatesBwdParams {
-  BwdStepParams s;
-  const float* part;   // [splits][m_pad][H] or NULL (no continuing gradient: the chain's first launch)
-  int32_t splits, m_pad;
-};
-
-// one thread per (sequence, 4 hidden units)
-__global__ __launch_bounds__(kThreads) void bwd_gates_kernel(const GatesBwdParams g) {
-  CHAIN_WAVE_PRIORITY();
-  const BwdStepParams& q = g.s;
-  const int H = q.H, K = 3 * H, h4 = H / 4;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (e >= static_cast<int64_t>(q.S_t) * h4) return;
-  const int m = static_cast<int>(e / h4), u = static_cast<int>(e % h4) * 4;
-  float4 rec = zero4();
-  if (m < q.S_next) {
-    rec = *reinterpret_cast<const float4*>(q.carry + static_cast<int64_t>(m) * H + u);
-    float4 sum = zero4();
-    for (int y = 0; y < g.splits; ++y) {
-      const float4 p = *reinterpret_cast<const float4*>(
-          g.part + (static_cast<int64_t>(y) * g.m_pad + m) * H + u);
-      sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
-    }
-    rec.x += sum.x; rec.y += sum.y; rec.z += sum.z; rec.w += sum.w;
-  }
-  if (q.t < 0) {  // final launch: d loss / d h0
-    *reinterpret_cast<float4*>(q.dh0 + static_cast<int64_t>(q.out_row[m]) * H + u) = rec;
-    return;
-  }
-  const int64_t p = q.off_cur + m;
-  const float4 dp = *reinterpret_cast<const float4*>(q.dpool + p * H + u);
-  const float* gp = q.gates + p * 4 * H + u;
-  const float4 rg = *reinterpret_cast<const float4*>(gp);
-  const float4 zg = *reinterpret_cast<const float4*>(gp + H);
-  const float4 ng = *reinterpret_cast<const float4*>(gp + 2 * H);
-  const float4 ghn = *reinterpret_cast<const float4*>(gp + 3 * H);
-  float4 hp = zero4();
-  if (q.t > 0)
-    hp = *reinterpret_cast<const float4*>(q.hs + (q.off_prev + m) * H + u);
-  else if (q.h0_rows != nullptr)
-    hp = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(q.h0_rows[m]) + u);
-  float4 drp, dzp, dnp, dnr, car;
-#define GATE_LANE_(c)                                            \
-  {                                                                   \
-    const float dh = rec.c + dp.c;                                    \
-    const float dn_pre = dh * (1.0f - zg.c) * (1.0f - ng.c * ng.c);   \
-    dzp.c = dh * (hp.c - ng.c) * zg.c * (1.0f - zg.c);                \
-    drp.c = dn_pre * ghn.c * rg.c * (1.0f - rg.c);                    \
-    dnp.c = dn_pre;                                                   \
-    dnr.c = dn_pre * rg.c;                                            \
-    car.c = dh * zg.c;                                                \
-  }
-  GATE_LANE_(x) GATE_LANE_(y) GATE_LANE_(z) GATE_LANE_(w)
-#undef GATE_LANE_
-  float* gx = q.dgx + p * K + u;
-  float* gh = q.dgh + p * K + u;
-  *reinterpret_cast<float4*>(gx) = drp;
-  *reinterpret_cast<float4*>(gx + H) = dzp;
-  *reinterpret_cast<float4*>(gx + 2 * H) = dnp;
-  *reinterpret_cast<float4*>(gh) = drp;
-  *reinterpret_cast<float4*>(gh + H) = dzp;
-  *reinterpret_cast<float4*>(gh + 2 * H) = dnr;
-  *reinterpret_cast<float4*>(q.carry + static_cast<int64_t>(m) * H + u) = car;
-}
-
-// ---------------------------------------------------------------------------------------------
-// F.normalize backward: dx = (g - y (y.g)) / max(||x||, eps), y = x / max(||x||, eps)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(const float* __restrict__ x,
-                                                              const float* __restrict__ g,
-                                                              float* __restrict__ dx, int cols) {
-  const int64_t row = blockIdx.x;
-  const float* xr = x + row * cols;
-  const float* gr = g + row * cols;
-  float ss = 0.f, sg = 0.f;
-  for (int c = threadIdx.x; c < cols; c += kThreads) {
-    ss += xr[c] * xr[c];
-    sg += xr[c] * gr[c];
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    ss += __shfl_xor(ss, o, 64);
-    sg += __shfl_xor(sg, o, 64);
-  }
-  __shared__ float p1[4], p2[4];
-  __shared__ float s_inv, s_dot;
-  if ((threadIdx.x & 63) == 0) {
-    p1[threadIdx.x >> 6] = ss;
-    p2[threadIdx.x >> 6] = sg;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float n2 = p1[0] + p1[1] + p1[2] + p1[3];
-    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
-    s_inv = inv;
-    s_dot = (p2[0] + p2[1] + p2[2] + p2[3]) * inv * inv;  // (y.g)/||x||
-  }
-  __syncthreads();
-  const float inv = s_inv, d = s_dot;
-  for (int c = threadIdx.x; c < cols; c += kThreads) dx[row * cols + c] = (gr[c] - xr[c] * d) * inv;
-}
-
-// ---------------------------------------------------------------------------------------------
-// ContrastiveLoss backward: G = d loss / d scores (loss.py:94-117 differentiated), then
-// d im = G . s and d s = G^T . im as TN GEMMs on G^T and G.
-// ---------------------------------------------------------------------------------------------
-struct LossBwdParams {
-  const float* scores;  // [n, n]
-  const float* gout;    // device scalar: upstream gradient
-  int32_t n, max_violation, norm;
-  float margin;
-  int32_t* row_arg;  // [n] max_violation: argmax_j cost_s(i,j) (or -1 when the max is 0)
-  int32_t* col_arg;  // [n] max_violation: argmax_i cost_im(i,j)
-  float* row_cnt;    // [n] sum_j g_s(i,j)
-  float* col_cnt;    // [n] sum_i g_im(i,j)
-  float* G;          // [n, n]
-  float* GT;         // [n, n]
-  // several independent losses in one launch set (cmhse_contrastive_blocks_bwd): block
-  // b = blockIdx.y has n = blk_off[b+1] - blk_off[b]; its scores / G / GT start b * blk_stride
-  // floats into their buffers (leading dimension = its own n), its vectors b * vec_stride, its
-  // upstream gradient is gout[b]
-  const int32_t* blk_off;
-  int64_t blk_stride;     // floats between the blocks of G / GT
-  int64_t score_stride;   // floats between the blocks of the stored scores (the forward's layout)
-  int32_t vec_stride;
-};
-
-// the parameters of block blockIdx.y (or the struct itself for a single loss)
-__device__ __forceinline__ LossBwdParams loss_bwd_block(const LossBwdParams& q_) {
-  LossBwdParams q = q_;
-  if (q.blk_off != nullptr) {
-    const int b = blockIdx.y;
-    q.n = q.blk_off[b + 1] - q.blk_off[b];
-    q.scores += b * q.score_stride;
-    q.G += b * q.blk_stride;
-    q.GT += b * q.blk_stride;
-    q.row_arg += b * q.vec_stride;
-    q.col_arg += b * q.vec_stride;
-    q.row_cnt += b * q.vec_stride;
-    q.col_cnt += b * q.vec_stride;
-    q.gout += b;
-  }
-  return q;
-}
-
-// one wave per row (rows pass) or per column (columns pass): counts / argmax of violating entries
-__global__ __launch_bounds__(kThreads) void loss_bwd_stats_kernel(const LossBwdParams q_) {
-  const LossBwdParams q = loss_bwd_block(q_);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = q.n;
-  const int idx = blockIdx.x * 4 + wave;  // [0, 2n): rows then columns
-  if (idx >= 2 * n) return;
-  const bool is_row = idx < n;
-  const int i = is_row ? idx : idx - n;
-  const float dii = q.scores[static_cast<int64_t>(i) * n + i];
-  float cnt = 0.f, best = 0.f;
-  int arg = 0x7fffffff;
-  for (int j = lane; j < n; j += 64) {
-    if (j == i) continue;
-    const float sv = is_row ? q.scores[static_cast<int64_t>(i) * n + j]
-                            : q.scores[static_cast<int64_t>(j) * n + i];
-    const float c = fmaxf(q.margin + sv - dii, 0.f);
-    cnt += (c > 0.f) ? 1.f : 0.f;
-    if (c > best) {  // first maximum along the reduced index
-      best = c;
-      arg = j;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    cnt += __shfl_xor(cnt, o, 64);
-    const float ob = __shfl_xor(best, o, 64);
-    const int oa = __shfl_xor(arg, o, 64);
-    if (ob > best || (ob == best && oa < arg)) {
-      best = ob;
-      arg = oa;
-    }
-  }
-  if (lane == 0) {
-    const int a = (best > 0.f) ? arg : -1;
-    const float c = q.max_violation ? ((best > 0.f) ? 1.f : 0.f) : cnt;
-    if (is_row) {
-      q.row_arg[i] = a;
-      q.row_cnt[i] = c;
-    } else {
-      q.col_arg[i] = a;
-      q.col_cnt[i] = c;
-    }
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void loss_bwd_build_kernel(const LossBwdParams q_) {
-  const LossBwdParams q = loss_bwd_block(q_);
-  const int n = q.n;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (e >= static_cast<int64_t>(n) * n) return;
-  const int i = static_cast<int>(e / n), j = static_cast<int>(e % n);
-  float scale = *q.gout;
-  if (q.norm) scale /= static_cast<float>(static_cast<int64_t>(n) * n);
-  float g;
-  if (i == j) {
-    g = -(q.row_cnt[i] + q.col_cnt[i]);
-  } else if (q.max_violation) {
-    g = ((q.row_arg[i] == j) ? 1.f : 0.f) + ((q.col_arg[j] == i) ? 1.f : 0.f);
-  } else {
-    const float sv = q.scores[e];
-    const float cs = q.margin + sv - q.scores[static_cast<int64_t>(i) * n + i];
-    const float ci = q.margin + sv - q.scores[static_cast<int64_t>(j) * n + j];
-    g = ((cs > 0.f) ? 1.f : 0.f) + ((ci > 0.f) ? 1.f : 0.f);
-  }
-  g *= scale;
-  q.G[e] = g;
-  q.GT[static_cast<int64_t>(j) * n + i] = g;
-}
-
-// GroupWiseContrastiveLoss backward: spread G_red[i][j] over block (i, j) of d scores (uniformly
-// for the block mean, onto the arg-max for the block max); writes dS and dS^T.
-struct ExpandParams {
-  const float* g_red;  // [B, B]
-  const int32_t* arg;  // [B, B]
-  const int32_t* row_off;
-  const int32_t* col_off;
-  float* dS;
-  float* dST;
-  int32_t n, B, use_max;
-};
-
-__global__ __launch_bounds__(kThreads) void groupwise_expand_kernel(const ExpandParams q) {
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  const int r0 = q.row_off[bi], r1 = q.row_off[bi + 1], c0 = q.col_off[bj], c1 = q.col_off[bj + 1];
-  const int w = c1 - c0, cnt = (r1 - r0) * w;
-  const float g = q.g_red[bi * q.B + bj];
-  const int a = q.arg[bi * q.B + bj];
-  for (int e = threadIdx.x; e < cnt; e += kThreads) {
-    const int r = r0 + e / w, c = c0 + e % w;
-    const float v = q.use_max ? ((r * q.n + c == a) ? g : 0.f) : g / static_cast<float>(cnt);
-    q.dS[static_cast<int64_t>(r) * q.n + c] = v;
-    q.dST[static_cast<int64_t>(c) * q.n + r] = v;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// EuclideanLoss (decoder/loss.py:17-26): per-row distances, fixed-order fp64 total
-// ---------------------------------------------------------------------------------------------
-struct EuclidParams {
-  const float* a;
-  const float* b;
-  const uint64_t* b_rows;
-  float* dist;  // [rows]
-  float* d_a;   // backward
-  const float* gout;
-  float* loss;
-  int32_t rows, cols, norm;
-};
-
-__global__ __launch_bounds__(kThreads) void euclid_rows_kernel(const EuclidParams q, int backward) {
-  const int64_t r = blockIdx.x;
-  const float* ar = q.a + r * q.cols;
-  const float* br = q.b_rows ? reinterpret_cast<const float*>(q.b_rows[r]) : q.b + r * q.cols;
-  float ss = 0.f;
-  for (int c = threadIdx.x; c < q.cols; c += kThreads) {
-    const float d = ar[c] - br[c];
-    ss += d * d;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  __shared__ float part[4];
-  __shared__ float s_d;
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
-  __syncthreads();
-  if (threadIdx.x == 0) s_d = sqrtf(part[0] + part[1] + part[2] + part[3]);
-  __syncthreads();
-  const float dist = s_d;
-  if (!backward) {
-    if (threadIdx.x == 0) q.dist[r] = dist;
-    return;
-  }
-  // d sqrt(ss) / d a = (a - b) / dist: no epsilon, like autograd through torch.sqrt upstream
-  // (decoder/loss.py:21) — an exactly reconstructed row (dist == 0) gives NaN there and here
-  float sc = *q.gout / dist;
-  if (q.norm) sc /= static_cast<float>(q.rows);
-  for (int c = threadIdx.x; c < q.cols; c += kThreads) q.d_a[r * q.cols + c] = (ar[c] - br[c]) * sc;
-}
-
-// Sum of the row distances in a FIXED order (bitwise reproducible): thread i adds rows i, i + 256,
-// ... in double, then a pairwise LDS tree.  (--lowest_reconstruct_loss sums one row per frame /
-// word of the batch, 1e4 and more: a single-thread dependent load chain took milliseconds.)
-__global__ __launch_bounds__(kThreads) void euclid_final_kernel(const EuclidParams q) {
-  __shared__ double part[kThreads];
-  double t = 0.0;
-  for (int r = threadIdx.x; r < q.rows; r += kThreads) t += q.dist[r];
-  part[threadIdx.x] = t;
-  __syncthreads();
-  for (int w = kThreads / 2; w >= 1; w >>= 1) {
-    if (static_cast<int>(threadIdx.x) < w) part[threadIdx.x] += part[threadIdx.x + w];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    double total = part[0];
-    if (q.norm) total /= q.rows;
-    *q.loss = static_cast<float>(total);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers

@@ -39,1480 +39,16 @@
 #include "grid_sync.hpp"
 #include "nt_core.hpp"
 
+#include "gru_step_tile.hpp"
+#include "gru_attention.hpp"
+#include "gru_chain.hpp"
+#include "gru_small_batch.hpp"
+#include "gru_rows.hpp"
+
 namespace cmhse {
-
-struct GruStepParams {
-  const uint64_t* x_rows;
-  const uint64_t* tok_rows;
-  const float* emb;
-  const uint64_t* h0_rows;
-  const int32_t* lens;
-  const int32_t* out_row;
-  const float* w_ih;
-  const float* w_hh;
-  const float* b_ih;
-  const float* b_hh;
-  float* hs;
-  float* out;
-  const float* w_ih_s;  // bf16x3 pre-split weights (rows of split_ld(K) float units) or NULL
-  const float* w_hh_s;
-  const float* xs;      // bf16x3: pre-split input rows, packed row p at xs + p * split_ld(I)
-  float* hs_s;          // bf16x3: pre-split hidden states, packed row p at hs_s + p * split_ld(H)
-  const float* h0_s;    // bf16x3: pre-split initial hidden states, sorted sequence s at h0_s + s * split_ld(H)
-  float* gates;     // [sumT, 4H] r,z,n,(W_hn h + b_hn) per packed row, or NULL (inference)
-  int32_t* argmax;  // [S, H] step of the running maximum (max pooling, training), or NULL
-  int32_t I, H, t, S_t, vocab, pool_mode, n_tiles, x_step;
-  // mid-size step (gru_step_mid_kernel): hoisted input projection x W_ih^T of the small-batch steps,
-  // row (off_cur + m - gx_p0) for an ordinary input, row m (the sorted sequence) for a
-  // time-constant one
-  const float* gx;
-  int64_t gx_p0;
-  int32_t gx_per_seq;
-  int64_t off_prev, off_cur;
-};
-
-// Up to kMaxJobs independent GRU chains share one launch per time step: workgroups
-// [start[k], start[k+1]) belong to job k.  Halves (or better) the number of dependent launches and
-// of partially filled last waves of workgroups when two encoders run side by side.
-constexpr int kMaxJobs = CMHSE_MAX_JOBS;
-struct GruStepGroup {
-  GruStepParams j[kMaxJobs];
-  uint32_t start[kMaxJobs];
-  int32_t n;
-};
-
-#ifdef TILE_TRACE_BUILD
-// Timing-only debug build (tools/tile_trace.py): per-workgroup stamps of the tiled step —
-// [0] first instruction, [1] K loops start, [2] after the kernarg reads, [3] K loops end,
-// [4] state stores drained (s_memrealtime, 10 ns); [5]/[7] s_memtime at [1]/[3]; [6] HW_ID | XCC_ID << 32.
-__device__ uint64_t* g_trace = nullptr;
-#define TRACE_MARK(i)                                                              \
-  do {                                                                             \
-    if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + (i)] = wall_clock64(); \
-  } while (0)
-#else
-#define TRACE_MARK(i) do {} while (0)
-#endif
-
-__device__ __forceinline__ int group_job(const GruStepGroup& g, unsigned* bx) {
-  int ji = 0;
-#pragma unroll
-  for (int k = 1; k < kMaxJobs; ++k)
-    if (k < g.n && blockIdx.x >= g.start[k]) ji = k;
-  *bx = blockIdx.x - g.start[ji];
-  return ji;
-}
-
-// Gate nonlinearities on the hardware exp/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the
-// epilogue evaluates 3 of them per (sequence, unit) per step, and the libm-accurate forms cost
-// ~6 % of the step kernel.  Absolute error ~1e-7, far inside the 1e-4 parity bar.
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-__device__ __forceinline__ float tanhf_(float x) {
-  // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates cleanly for |x| large (exp -> inf or 0)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
-}
-
-__device__ __forceinline__ bool aligned16(const void* p) {
-  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-}
-
-constexpr int kGruBU = 64;   // hidden units per workgroup (x3 gates = 192 weight rows)
-
-// What a tile of the step-CHAIN kernel (gru_step_chain_kernel below) waits for and signals: the
-// counter of the same row tile one step earlier must have reached `need` (all its column tiles)
-// before the h phase starts, and `done` is bumped once this tile's state rows have left the CU.
-struct ChainDep {
-  const unsigned* wait;   // NULL: nothing to wait for (the chain's first step)
-  unsigned need;
-  unsigned* done;
-  GridSync sync;          // abort word / status word / timeout of the launch (counter unused)
-};
-
-// One tile of the LDS-tiled GRU step: sequences [m0, m0 + BM) x hidden units [u0, u0 + BU) of step
-// `t`.  CHAIN = false: the body of gru_step_kernel (one launch per time step).  CHAIN = true: the
-// same arithmetic inside gru_step_chain_kernel — the x phase (which does not depend on the
-// previous step) first, then the wait for the previous step's rows, the h phase, and the new state
-// written THROUGH the non-coherent L2 (agent-scope stores) before `done` is signalled.
-template <bool VEC, int MSUB, bool BF3, bool CHAIN>
-__device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsigned wg, const int t,
-                                              const int S_t, const int64_t off_prev,
-                                              const int64_t off_cur, const ChainDep& dep) {
-  constexpr int BM = 64 * MSUB, BU = kGruBU, BNR = 3 * BU;
-#ifdef TILE_TRACE_BUILD
-  const uint64_t t_first = wall_clock64();
-#endif
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  TRACE_MARK(2);
-#ifdef TILE_TRACE_BUILD
-  if (threadIdx.x == 0 && g_trace) {
-    g_trace[static_cast<size_t>(blockIdx.x) * 8 + 6] =
-        static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
-        (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32);
-    g_trace[static_cast<size_t>(blockIdx.x) * 8 + 0] = t_first;
-  }
-#endif
-  // 1-D grid, N tile fastest: blocks b and b+8 land on the same XCD (round-robin dispatch), so
-  // with H/BU a multiple of 8 every XCD's L2 keeps re-serving the same two weight-row slices.
-  const int u0 = static_cast<int>(wg % p.n_tiles) * BU;
-  const int m0 = static_cast<int>(wg / p.n_tiles) * BM;
-  const int srow = tid >> 2;
-  const int I = p.I, H = p.H;
-
-  // Rows this thread stages.  A: sequences m0 + srow + 64 i.  B: gate g, unit u0 + (row % BU).
-  // Out-of-range rows are clamped to a valid row and flagged invalid (read as zeros).
-  rowaddr_t ax[BM / 64];
-  rowaddr_t ah[BM / 64];
-  bool av[BM / 64];
-#pragma unroll
-  for (int i = 0; i < BM / 64; ++i) {
-    const int m = m0 + srow + 64 * i;
-    av[i] = m < S_t;
-    const int mc = av[i] ? m : (S_t - 1);
-    if (BF3) {
-      ax[i] = row_addr(p.xs + (off_cur + mc) * split_ld(I));   // (token lookups included)
-    } else if (p.tok_rows != nullptr) {
-      long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[t];
-      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
-      ax[i] = row_addr(p.emb + tok * I);
-    } else {
-      ax[i] = p.x_rows[mc] + static_cast<rowaddr_t>(t) * p.x_step * 4u;
-    }
-    if (t > 0)
-      ah[i] = BF3 ? row_addr(p.hs_s + (off_prev + mc) * split_ld(H))
-                  : row_addr(p.hs + (off_prev + mc) * H);
-    else if (p.h0_rows != nullptr)
-      ah[i] = BF3 ? row_addr(p.h0_s + static_cast<int64_t>(mc) * split_ld(H)) : p.h0_rows[mc];
-    else
-      ah[i] = row_addr(p.w_hh);  // unused: the h phase is skipped
-  }
-  rowaddr_t bx[BNR / 64];
-  rowaddr_t bh[BNR / 64];
-  bool bv[BNR / 64];
-#pragma unroll
-  for (int i = 0; i < BNR / 64; ++i) {
-    const int br = srow + 64 * i;
-    const int g = br / BU, u = u0 + (br % BU);
-    bv[i] = u < H;
-    const int uc = bv[i] ? u : (H - 1);
-    if (BF3) {
-      bx[i] = row_addr(p.w_ih_s + (static_cast<int64_t>(g) * H + uc) * split_ld(I));
-      bh[i] = row_addr(p.w_hh_s + (static_cast<int64_t>(g) * H + uc) * split_ld(H));
-    } else {
-      bx[i] = row_addr(p.w_ih + (static_cast<int64_t>(g) * H + uc) * I);
-      bh[i] = row_addr(p.w_hh + (static_cast<int64_t>(g) * H + uc) * H);
-    }
-  }
-
-  // accumulators per 32-sequence sub-tile: 0 = r, 1 = z, 2 = W_in x, 3 = W_hn h
-  f32x16 acc[MSUB][4];
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-    for (int a = 0; a < 4; ++a) acc[ms][a] = zero16();
-
-  const int a_row0 = wm * 32 * MSUB;
-  const int b_row0[3] = {0 * BU + wn * 32, 1 * BU + wn * 32, 2 * BU + wn * 32};
-  const bool have_h = (t > 0) || (p.h0_rows != nullptr);
-
-  const int pool_mode = p.pool_mode;
-  float* const hs = p.hs;
-  float* const gates = p.gates;
-  float* const out = p.out;
-  int32_t* const argmax = p.argmax;
-  const uint64_t* const h0_rows = p.h0_rows;
-  const int32_t* const out_row = p.out_row;
-  const int32_t* const lens = p.lens;
-  TRACE_MARK(1);
-#ifdef TILE_TRACE_BUILD
-  if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime();
-#endif
-  if (BF3) {
-    // pre-split A operands: xs, then hs_s of the previous step (or the pre-split initial states)
-    nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2, true>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
-    if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
-  } else {
-    nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
-    if (CHAIN) {
-      // the previous step's rows of this row tile: complete (written through by their tiles)?
-      if (dep.wait != nullptr && !flag_wait(dep.sync, dep.wait, dep.need)) return;
-    }
-    if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
-  }
-  TRACE_MARK(3);
-#ifdef TILE_TRACE_BUILD
-  if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_memtime();
-#endif
-
-  // ---- epilogue: gates, state update, pooling ----
-  // The operands that do not come from the MFMA chain — the previous state of this lane's 16
-  // (sequence, unit) elements and the four bias terms — are requested all at once, branch-free
-  // (clamped indices): ONE memory round trip per sub-tile instead of one per element.  The gate
-  // math is then straight-line with predicated stores.  (Requesting them before the K loops would
-  // hide that trip too, but the 20 extra live registers cost the third wave per SIMD.)
-  const int u = u0 + wn * 32 + acc_col(lane);
-  const bool uv = u < H;
-  const int uc = uv ? u : (H - 1);
-  const float b_r = p.b_ih[uc] + p.b_hh[uc];
-  const float b_z = p.b_ih[H + uc] + p.b_hh[H + uc];
-  const float b_in = p.b_ih[2 * H + uc];
-  const float b_hn = p.b_hh[2 * H + uc];
-  // previous states of BOTH 32-row sub-tiles first: the stores of sub-tile 0
-  // may alias the loads of sub-tile 1 as far as the compiler knows, so left inside the loop below
-  // the second round trip starts only after the first sub-tile's gate math and stores
-  float hp_all[MSUB][16];
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms) {
-    const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
-#if defined(TILE_TRACE_BUILD) && defined(TILE_TRACE_NO_HP)
-    // timing-only bound (tools/tile_trace.py, TRACE_FLAGS=-DTILE_TRACE_NO_HP; wrong results): the
-    // epilogue WITHOUT its re-read of the previous states — what capturing them from the h
-    // phase's LDS tiles could save at most
-    if (t > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hp_all[ms][r] = 0.f;
-    } else
-#endif
-    if (t > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow0 + acc_row(r, lane);
-        hp_all[ms][r] = hs[(off_prev + (m < S_t ? m : (S_t - 1))) * H + uc];
-      }
-    } else if (h0_rows != nullptr) {
-      rowaddr_t hrow[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow0 + acc_row(r, lane);
-        hrow[r] = h0_rows[m < S_t ? m : (S_t - 1)];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hp_all[ms][r] = reinterpret_cast<const float*>(hrow[r])[uc];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hp_all[ms][r] = 0.f;
-    }
-  }
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms) {
-    const int mrow0 = m0 + wm * 32 * MSUB + ms * 32;
-    float hn[16];
-    const float (&hp)[16] = hp_all[ms];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mrow0 + acc_row(r, lane);
-      const float rg = sigmoidf_(acc[ms][0][r] + b_r);
-      const float zg = sigmoidf_(acc[ms][1][r] + b_z);
-      const float ghn = acc[ms][3][r] + b_hn;
-      const float ng = tanhf_(acc[ms][2][r] + b_in + rg * ghn);
-      hn[r] = (1.0f - zg) * ng + zg * hp[r];
-      if (BF3) {
-        // the state once more in pre-split form for the next step's / the attention's A operand:
-        // units u, u+1 sit in neighbouring lanes; even lanes store the (hi, lo) bf16 pairs
-        const float other = __shfl_xor(hn[r], 1, 64);
-        if (uv && m < S_t && (lane & 1) == 0) {
-          const float o1 = (u + 1 < H) ? other : 0.f;
-          const uint32_t hi = pack_bf16(hn[r], o1);
-          const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
-          const uint32_t lo = pack_bf16(hn[r] - f0, o1 - f1);
-          uint32_t* dst = reinterpret_cast<uint32_t*>(p.hs_s) + (off_cur + m) * split_ld(H) +
-                          (u >> 4) * 16 + ((u & 15) >> 1);
-          dst[0] = hi;
-          dst[8] = lo;
-        }
-      }
-      if (uv && m < S_t) {
-        if (CHAIN)   // read by the next step's tiles on other XCDs: past this XCD's L2 (sc1)
-          __hip_atomic_store(&hs[(off_cur + m) * H + u], hn[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-          hs[(off_cur + m) * H + u] = hn[r];
-        if (gates != nullptr) {
-          float* gp = gates + (off_cur + m) * 4 * H + u;
-          gp[0] = rg;
-          gp[H] = zg;
-          gp[2 * H] = ng;
-          gp[3 * H] = ghn;
-        }
-      }
-    }
-#ifdef TILE_TRACE_BUILD
-    if (ms == MSUB - 1) {   // stores of the state drained: what the slot's successor waits for
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      TRACE_MARK(4);
-    }
-#endif
-    if (pool_mode == CMHSE_POOL_ATTN) continue;   // pooled by attn_energy / attn_pool from hs
-
-    // pooling fused into the step: index loads four rows at a time, then the dependent accesses
-#pragma unroll
-    for (int r4 = 0; r4 < 16; r4 += 4) {
-      int orow[4], len[4];
-      float cur[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = mrow0 + acc_row(r4 + i, lane);
-        const int mc = m < S_t ? m : (S_t - 1);
-        orow[i] = out_row[mc];
-        len[i] = (pool_mode == CMHSE_POOL_LAST) ? lens[mc] : 0;
-      }
-      if (pool_mode == CMHSE_POOL_MAX && t > 0) {
-        // (CHAIN: the running maximum was written by the previous step's tile, on another CU — an
-        // agent-scope load, which neither this CU's L1 nor a non-coherent L2 serves)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          cur[i] = CHAIN ? __hip_atomic_load(&out[static_cast<int64_t>(orow[i]) * H + uc], __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT)
-                         : out[static_cast<int64_t>(orow[i]) * H + uc];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = mrow0 + acc_row(r4 + i, lane);
-        if (!(uv && m < S_t)) continue;
-        const float v = hn[r4 + i];
-        if (pool_mode == CMHSE_POOL_MAX) {
-          if (t == 0 || v > cur[i]) {  // strict '>': the first maximum wins, like max_pool1d
-            if (CHAIN)
-              __hip_atomic_store(&out[static_cast<int64_t>(orow[i]) * H + u], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-              out[static_cast<int64_t>(orow[i]) * H + u] = v;
-            if (argmax != nullptr) argmax[static_cast<int64_t>(m) * H + u] = t;
-          }
-        } else if (pool_mode == CMHSE_POOL_LAST) {
-          if (t == len[i] - 1) out[static_cast<int64_t>(orow[i]) * H + u] = v;
-        } else {  // CMHSE_POOL_ALL
-          out[(static_cast<int64_t>(orow[i]) + t) * H + u] = v;
-        }
-      }
-    }
-  }
-  if (CHAIN) {
-    __builtin_amdgcn_s_waitcnt(0);   // this wave's write-through state stores have been performed
-    flag_signal(dep.done);
-  }
-}
-
-template <bool VEC, int MSUB, bool BF3>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
-void gru_step_kernel(const GruStepGroup grp) {
-  unsigned wg;
-  const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  ChainDep none;
-  none.wait = nullptr;
-  none.need = 0;
-  none.done = nullptr;
-  gru_step_tile<VEC, MSUB, BF3, false>(p, wg, p.t, p.S_t, p.off_prev, p.off_cur, none);
-}
-
-// ---------------------------------------------------------------------------------------------
-// attention energies: e_part[nt][row] = sum_{n in N tile nt} w_att[n] * tanh(W_lin[n,:] . h_row + b)
-// ---------------------------------------------------------------------------------------------
-struct AttnEnergyParams {
-  const float* hs_s;   // bf16x3: pre-split hidden states (rows of split_ld(H) units) or NULL
-  const float* hs;     // [rows, H]
-  const float* w_lin;  // [H, H]
-  const float* w_lin_s;  // bf16x3 pre-split copy or NULL
-  const float* b_lin;
-  const float* w_att;
-  float* e_part;  // [n_tiles, rows]
-  float* v;       // [rows, H] tanh(W_lin h + b) kept for the backward pass, or NULL
-  int64_t rows;   // all packed rows (stride of e_part)
-  int64_t row_begin, row_end;   // the rows this launch computes
-  int32_t H, n_tiles;
-};
-
-
-// One tile: packed rows [m0, m0 + 64 MSUB) (those below row_end) x columns [256 nt, 256 nt + 256).
-// The body of attn_energy_kernel, and a task of the step chain (gru_step_chain_kernel).  A row's
-// result does not depend on the tile height or on which rows share its tile.
-template <bool VEC, int MSUB, bool BF3, bool ASPLIT>
-__device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, const int nt, const int64_t m0,
-                                                 const int64_t row_end) {
-  constexpr int BM = 64 * MSUB, BN = kAttBN;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = nt * BN;
-  const int srow = tid >> 2;
-  const int H = p.H;
-
-  rowaddr_t ar[BM / 64];
-  rowaddr_t br[BN / 64];
-  bool av[BM / 64], bv[BN / 64];
-#pragma unroll
-  for (int i = 0; i < BM / 64; ++i) {
-    const int64_t m = m0 + srow + 64 * i;
-    av[i] = m < row_end;
-    ar[i] = ASPLIT ? row_addr(p.hs_s + (av[i] ? m : (row_end - 1)) * split_ld(H))
-                   : row_addr(p.hs + (av[i] ? m : (row_end - 1)) * H);
-  }
-#pragma unroll
-  for (int i = 0; i < BN / 64; ++i) {
-    const int n = n0 + srow + 64 * i;
-    bv[i] = n < H;
-    br[i] = BF3 ? row_addr(p.w_lin_s + static_cast<int64_t>(bv[i] ? n : (H - 1)) * split_ld(H))
-                : row_addr(p.w_lin + static_cast<int64_t>(bv[i] ? n : (H - 1)) * H);
-  }
-  constexpr int NS = BN / 64;   // 32-column sub-tiles per wave
-  f32x16 acc[MSUB][NS];
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-    for (int a = 0; a < NS; ++a) acc[ms][a] = zero16();
-  int b_row0[NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
-  if (BF3)
-    nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1, ASPLIT>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-  else
-    nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
-
-  // epilogue: per-row partial dot over this wave's BN/2 columns, then the two N-waves via LDS
-  float wa[NS], bl[NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns) {
-    const int n = n0 + b_row0[ns] + acc_col(lane);
-    wa[ns] = (n < H) ? p.w_att[n] : 0.f;
-    bl[ns] = (n < H) ? p.b_lin[n] : 0.f;
-  }
-  float* red = smem;  // [2 (wn)][BM]; main loop ended with a barrier
-#pragma unroll
-  for (int ms = 0; ms < MSUB; ++ms) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float s = 0.f;
-      const int64_t vm = m0 + wm * 32 * MSUB + ms * 32 + acc_row(r, lane);
-#pragma unroll
-      for (int ns = 0; ns < NS; ++ns) {
-        const float tv = tanhf_(acc[ms][ns][r] + bl[ns]);
-        s += wa[ns] * tv;
-        const int n = n0 + b_row0[ns] + acc_col(lane);
-        if (p.v != nullptr && vm < row_end && n < H) p.v[vm * H + n] = tv;
-      }
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-      if ((lane & 31) == 0) red[wn * BM + wm * 32 * MSUB + ms * 32 + acc_row(r, lane)] = s;
-    }
-  }
-  __syncthreads();
-  if (tid < BM) {
-    const int64_t m = m0 + tid;
-    if (m < row_end) p.e_part[static_cast<int64_t>(nt) * p.rows + m] = red[tid] + red[BM + tid];
-  }
-}
-
-template <bool VEC, int MSUB, bool BF3, bool ASPLIT = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
-void attn_energy_kernel(const AttnEnergyParams p) {
-  attn_energy_tile<VEC, MSUB, BF3, ASPLIT>(p, static_cast<int>(blockIdx.x % p.n_tiles),
-                                           p.row_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * (64 * MSUB),
-                                           p.row_end);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Step CHAIN: the LDS-tiled steps t0 .. t0 + nsteps - 1 of up to kMaxJobs encoders in ONE launch.
-//
-// Per-step launches drain the chip at every time step: the last round of a step's workgroups runs
-// on a partly empty chip (a full split: ~2 % of the kernel's time; a rank's 615-video share, whose
-// steps are one or two rounds each: 15 %), although row tile r of step t + 1 needs nothing but row
-// tile r of step t — the sequences are sorted by length, so the active set of a step is a prefix
-// of the previous one's — and two thirds of its work (the x phase, K = I) nothing at all.  Here
-// every (step, request, row tile, column tile) is a TASK; a workgroup takes the next task of its
-// XCD's queue (tasks in step order; column tile c belongs to queue c % 8, so an XCD's L2 keeps
-// re-serving the same weight rows exactly as with the per-step launches' block order), runs the
-// tile's x phase, waits until the counter of (request, step - 1, row tile) has reached the number
-// of column tiles, runs the h phase and the epilogue, writes the new state rows through to memory
-// (agent-scope stores: the next step's tiles run on other XCDs, whose L2s are not coherent with
-// this one; nobody has read those addresses — whole cache lines: H % 32 == 0 is a condition of the
-// chain — before they were written, so the readers' plain loads miss their L2 and are served
-// from memory) and bumps its own counter.  Results are
-// bit-identical to the per-step launches (same tiles, same k order).
-//
-// Progress: a workgroup takes its task when it starts (queue = its index modulo 8), workgroups
-// start in index order, every queue lists its tasks in step order, and a task depends only on
-// tasks of the previous step.  So the queues advance in step with each other, and the earliest
-// unfinished task overall is either running (everything it waits for is earlier, hence done) or
-// the next one its queue hands out, with every task that is already held at most a step ahead of
-// it — some held task can always run.  No co-residency requirement (the grid is one workgroup per
-// task, dispatched as slots free up); a workgroup whose queue is exhausted takes a task of another
-// queue.  That argument needs EQUAL queues: it holds when the column tiles are a whole multiple of
-// the 8 XCDs (H = 512, 1024, 1536 ...); for every other count there is one queue for the whole
-// chip (chain_queues), whose tickets are a topological order of the tasks.  The wait is bounded
-// like the resident kernels' barrier (grid_sync.hpp): CMHSE_ERR_TIMEOUT, not a hang.
-// ---------------------------------------------------------------------------------------------
-constexpr int kChainMaxSteps = kChainMaxStepsWs;
-constexpr int kXcds = 8;
-// Tasks of a queue come in PHASES, one per time step, the same number of tickets in every queue:
-// phase s (s < nsteps) = the GRU tiles of step t0 + s: (request, row tile) x the queue's column tiles.
-// tick[p] = tickets of a queue in front of phase p.
-constexpr int kChainPhases = kChainMaxSteps;
-struct GruChainGroup {
-  GruStepParams j[kMaxJobs];            // (t, S_t, off_prev, off_cur unused: derived per task)
-  const int32_t* step_off[kMaxJobs];    // device: first packed row of every step of request k
-  unsigned* done[kMaxJobs];             // zeroed counters [nsteps][rt_stride[k]] of request k
-  int32_t rt_stride[kMaxJobs];          // row tiles of request k at step t0 (its maximum)
-  uint32_t tick[kChainPhases + 1];
-  unsigned* ticket;                     // [kXcds] zeroed: next task of every queue
-  GridSync sync;
-  int32_t n, t0, nsteps, n_tiles;
-};
-
-// Queues.  n_tiles % 8 == 0: eight, column tile c of the GRU step in queue c % 8 (an XCD's L2 keeps
-// re-serving the same weight rows, as with the per-step launches' block order), every queue the same
-// number of tickets.  Any other count (H = 128, 192, 256, 320, 768, 1280 ...): ONE queue holds all
-// the tasks in (step, row tile, column tile) order — with uneven queues the workgroups of the XCDs
-// with fewer (or no) columns overflow into the others, those queues run steps ahead of the short
-// ones and can fill every resident slot with workgroups waiting for tasks nobody is left to start
-// (a discrete-event model of the ticket logic deadlocks at n_tiles = 2, 4, 12, 20).
-// With one ticket every held task depends on earlier tickets only, so the earliest unfinished one
-// can always run.
-__device__ __host__ __forceinline__ int chain_queues(int n_tiles) { return (n_tiles % kXcds == 0) ? kXcds : 1; }
-
-template <bool VEC, int MSUB>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSUB == 1 ? 3 : 2)))
-void gru_step_chain_kernel(const GruChainGroup g) {
-  constexpr int BM = 64 * MSUB;
-  __shared__ unsigned s_task[2];
-  const unsigned nq = static_cast<unsigned>(chain_queues(g.n_tiles));
-  const unsigned cols = static_cast<unsigned>(g.n_tiles) / nq;
-  const int n_phases = g.nsteps;
-  const unsigned per_queue = g.tick[n_phases];
-  if (threadIdx.x == 0) {
-    // home queue: workgroups are dealt to the XCDs round-robin by their index (b and b + 8 share an
-    // XCD — what the per-step kernels' block order relies on too), so this IS the workgroup's XCD on
-    // an unpartitioned MI355X; derived from the index rather than read from XCC_ID so that the
-    // queues advance in step with the dispatch order whatever the partition mode
-    const unsigned x = blockIdx.x & (nq - 1);
-    unsigned got = 0xffffffffu, queue = 0xffffffffu;
-    for (unsigned d = 0; d < nq; ++d) {
-      const unsigned y = (x + d) & (nq - 1);
-      const unsigned tk = __hip_atomic_fetch_add(g.ticket + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk < per_queue) {
-        got = tk;
-        queue = y;
-        break;
-      }
-    }
-    s_task[0] = got;
-    s_task[1] = queue;
-  }
-  __syncthreads();
-  const unsigned queue = __builtin_amdgcn_readfirstlane(s_task[1]);
-  if (queue == 0xffffffffu) return;      // every queue is empty (cannot happen: one workgroup per ticket)
-  const unsigned tk = __builtin_amdgcn_readfirstlane(s_task[0]);
-  int lo = 0, hi = n_phases - 1;         // the last phase whose first ticket is <= tk
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (g.tick[mid] <= tk) lo = mid; else hi = mid - 1;
-  }
-  // ---- the GRU tile of step s this ticket stands for ----
-  const int s = lo, t = g.t0 + s;
-  const unsigned local = tk - g.tick[s];
-  unsigned rem = local / cols;
-  const int c = static_cast<int>(queue + nq * (local % cols));
-  int k = 0, S_t = 0;
-  for (; k < g.n; ++k) {
-    S_t = g.step_off[k][t + 1] - g.step_off[k][t];
-    const unsigned rt = static_cast<unsigned>((S_t + BM - 1) / BM);
-    if (rem < rt || k == g.n - 1) break;
-    rem -= rt;
-  }
-  const GruStepParams& p = g.j[k];
-  const int64_t off_cur = g.step_off[k][t];
-  const int64_t off_prev = (t > 0) ? g.step_off[k][t - 1] : 0;
-  ChainDep dep;
-  dep.sync = g.sync;
-  dep.need = static_cast<unsigned>(g.n_tiles);
-  dep.done = g.done[k] + static_cast<size_t>(s) * g.rt_stride[k] + rem;
-  dep.wait = (s > 0) ? g.done[k] + static_cast<size_t>(s - 1) * g.rt_stride[k] + rem : nullptr;
-  gru_step_tile<VEC, MSUB, false, true>(p, rem * static_cast<unsigned>(g.n_tiles) + static_cast<unsigned>(c), t, S_t,
-                                        off_prev, off_cur, dep);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Latency-shaped GRU step for small active sets (training batches, the long ragged tails of
-// paragraphs): with S_t <= ~1k sequences the 64 x 64 tile above fills only part of the chip and every
-// launch costs one full K loop (~100 us).  Here a workgroup owns 32 sequences x 8 hidden units:
-//   * ONE MFMA per k-step computes all three gates of those 8 units: the 32 B columns of
-//     v_mfma_f32_32x32x2_f32 are [r x8 | z x8 | n x8 | 8 unused];
-//   * the x phase and the h phase accumulate into two separate 32x32 accumulators (the n gate
-//     needs W_in x and W_hn h apart), so there are 2 x 16 accumulator registers per lane;
-//   * the 4 waves split K four ways (wave w takes k-blocks w, w+4, ...), operand fragments go
-//     global -> registers directly in MFMA layout through a 4-deep register ring (no LDS, no
-//     barrier in the loop), and the partial tiles meet in LDS in a fixed order (deterministic);
-//   * H/8 x ceil(S_t/32) workgroups: 128 even for a single active sequence at H = 1024.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTinyBM = 32;
-constexpr int kTinyBU = 8;
-
-// NW = waves per workgroup splitting K: 4, or 8 when so few sequences are active that the launch
-// is a pure latency chain (half the MFMA chain per wave, twice the waves on an under-filled chip).
-template <bool VEC, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void gru_step_tiny_kernel(const GruStepGroup grp) {
-  CHAIN_WAVE_PRIORITY();
-  constexpr int BM = kTinyBM, BU = kTinyBU;
-  unsigned wg;
-  const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  __shared__ float red[NW][2][16][64];  // [wave][x|h accumulator][register][lane], 8 KB per wave
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int u_tiles = (p.H + BU - 1) / BU;
-  const int u0 = (wg % u_tiles) * BU;  // unit tile fastest: b, b+8 share an XCD's L2
-  const int m0 = (wg / u_tiles) * BM;
-  const int I = p.I, H = p.H;
-  const int row = lane & 31, hi = lane >> 5;
-
-  // A fragment row of this lane: sequence m0 + row (clamped; rows are independent, and rows past
-  // S_t are never stored)
-  const int m = m0 + row;
-  const int mc = (m < p.S_t) ? m : (p.S_t - 1);
-  rowaddr_t ax, ah;
-  if (p.tok_rows != nullptr) {
-    long long tok = reinterpret_cast<const long long*>(p.tok_rows[mc])[p.t];
-    tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
-    ax = row_addr(p.emb + tok * I);
-  } else {
-    ax = p.x_rows[mc] + static_cast<rowaddr_t>(p.t) * p.x_step * 4u;
-  }
-  const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-  if (p.t > 0)
-    ah = row_addr(p.hs + (p.off_prev + mc) * H);
-  else if (p.h0_rows != nullptr)
-    ah = p.h0_rows[mc];
-  else
-    ah = row_addr(p.w_hh);
-  // B fragment row of this lane: column `row` of the MFMA = gate row>>3 of unit u0 + (row&7)
-  const int g = row >> 3, uu = u0 + (row & 7);
-  const bool bvalid = (g < 3) && (uu < H);
-  const int gc = (g < 3) ? g : 2, uc = (uu < H) ? uu : (H - 1);
-  const rowaddr_t bx = row_addr(p.w_ih + (static_cast<int64_t>(gc) * H + uc) * I);
-  const rowaddr_t bh = row_addr(p.w_hh + (static_cast<int64_t>(gc) * H + uc) * H);
-
-  f32x16 acc_x = zero16(), acc_h = zero16();
-  tiny_phase<VEC, NW>(ax, bx, bvalid, I, wave, hi, acc_x);
-  if (have_h) tiny_phase<VEC, NW>(ah, bh, bvalid, H, wave, hi, acc_h);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    red[wave][0][r][lane] = acc_x[r];
-    red[wave][1][r][lane] = acc_h[r];
-  }
-  __syncthreads();
-
-  // epilogue: one (sequence, unit) per thread; its three gate columns sit in lanes col, col+8,
-  // col+16 of the half-wave that owns the row
-  const int er = tid >> 3, eu = tid & 7;         // tile row 0..31, unit 0..7
-  const int em = m0 + er, u = u0 + eu;
-  if (tid >= 256 || em >= p.S_t || u >= H) return;   // (with NW = 8 the upper four waves only split K)
-  const int reg = (er & 3) | ((er >> 3) << 2);
-  const int lbase = 32 * ((er >> 2) & 1) + eu;
-  float xr = 0.f, xz = 0.f, xn = 0.f, hr = 0.f, hz = 0.f, hn_ = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    xr += red[w][0][reg][lbase];
-    xz += red[w][0][reg][lbase + 8];
-    xn += red[w][0][reg][lbase + 16];
-    hr += red[w][1][reg][lbase];
-    hz += red[w][1][reg][lbase + 8];
-    hn_ += red[w][1][reg][lbase + 16];
-  }
-  float hp = 0.f;
-  if (p.t > 0)
-    hp = p.hs[(p.off_prev + em) * H + u];
-  else if (p.h0_rows != nullptr)
-    hp = reinterpret_cast<const float*>(p.h0_rows[em])[u];
-  const float rg = sigmoidf_(xr + hr + p.b_ih[u] + p.b_hh[u]);
-  const float zg = sigmoidf_(xz + hz + p.b_ih[H + u] + p.b_hh[H + u]);
-  const float ghn = hn_ + p.b_hh[2 * H + u];
-  const float ng = tanhf_(xn + p.b_ih[2 * H + u] + rg * ghn);
-  const float hn = (1.0f - zg) * ng + zg * hp;
-  p.hs[(p.off_cur + em) * H + u] = hn;
-  if (p.gates != nullptr) {
-    float* gp = p.gates + (p.off_cur + em) * 4 * H + u;
-    gp[0] = rg;
-    gp[H] = zg;
-    gp[2 * H] = ng;
-    gp[3 * H] = ghn;
-  }
-  if (p.pool_mode == CMHSE_POOL_MAX) {
-    float* o = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
-    if (p.t == 0 || hn > *o) {
-      *o = hn;
-      if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(em) * H + u] = p.t;
-    }
-  } else if (p.pool_mode == CMHSE_POOL_LAST) {
-    if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
-  } else if (p.pool_mode == CMHSE_POOL_ALL) {
-    p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Mid-size GRU step: 1 <= S_t <= ~1k active sequences (every step of a training batch, the level-2
-// encoders, the long few-sequence tails of paragraphs).  Such a step is one [S_t, K] x [K, 3H]
-// product with S_t far too small to fill 256 CUs from LDS-tiled 64-row tiles, and the 32 x 8-unit
-// tiles of gru_step_tiny_kernel pull every operand row through L2 once per tile (~220 MB per step
-// at S_t = 152: that kernel is L2-bandwidth-bound, not latency-bound).  Two changes:
-//   * the input projection x_t W_ih^T has no time dependence: for all these steps together it is
-//     ONE well-shaped GEMM (xproj_kernel, tiled like the attention projection) into gx[rows, 3H];
-//     the sequential part keeps only K = H;
-//   * tile = 32 (or 16) sequences x 16, 8 or 4 hidden units x {r, z, n}: blocks of
-//     v_mfma_f32_16x16x4_f32, 8 waves split K, operands global -> registers in MFMA layout through
-//     a ring of ONE 128-byte line pair per wave, fixed-order LDS combine, the epilogue's operands
-//     requested before the K loop; H/BU x ceil(S_t/32) workgroups of 512 threads.
-// In-kernel stamps (tools/mid_trace.py): the loop is bound by how fast ONE CU pulls its operands
-// through L1 (a 32 x 16 tile needs 320 KB; 40-50 GB/s per CU for a plain stream of an L2-resident
-// slice, tools/microbench/weights_reread.hip).  Measured (tools/step_sweep.py, us per step at
-// H = 1024): deeper rings are SLOWER (4 waves x 4 blocks in flight: 22.0 at S_t = 96; 8 x 2: 17.2;
-// 8 x 4: 19.9; 8 x 8 on the 4-unit tile: 21.5 against 9.5 at S_t = 16), with non-temporal loads
-// too (slower still at every depth: the second half of a line does hit L1): the loop wants many
-// waves with little in flight each.  Also measured (late round 3): the BPTT step's form — the
-// product as 32 x 128 LDS-staged tiles with K split over the grid (bwd_rec_part_kernel on
-// h_{t-1} . W_hh^T) plus a gates kernel, two launches — for the steps of a training chain with
-// more than 32 sequences: correct, and 0.4 ms per training step SLOWER (ICEP 9.19 -> 9.60 ms, C3D
-// 7.88 -> 8.33): with K = H instead of 3H there are 96 tiles of two short slices, and the second
-// launch costs more than the better-coalesced loads save (DiDeMo, ~210 sequences at every step:
-// 10.82 -> 11.19 ms).  And 16 waves on 16 K slices (1024
-// threads) instead of 8 on 8: 21.0 -> 21.6 us at S_t = 117, 30.9 -> 34.1 at 152.
-// ---------------------------------------------------------------------------------------------
-// MB = 16-row blocks of sequences per workgroup: 2 (32 sequences), or 1 when at most 16 are active.
-// BU = hidden units per workgroup (16, 8 or 4).  The 3 BU gate columns (gate-major: column
-// f = gate * BU + unit) fill NB = ceil(3 BU / 16) MFMA column blocks.  A step with few sequences
-// has only H / 16 x ceil(S_t / 32) tiles of 16 units — 64 workgroups at S_t <= 32, H = 1024, each
-// pulling 320 KB through ONE CU's L2 port (~40-50 GB/s, tools/microbench/weights_reread.hip) while
-// three quarters of the chip idle; narrower unit tiles spread the same W_hh over up to 256 CUs
-// (176 KB per workgroup at BU = 4: the 32 h rows are then the larger part).  mid_units() picks BU.
-// Waves per workgroup (NW, splitting K) and 16-k blocks in flight per wave (D).  8 x 2 is the
-// fastest shape for a chain that has the chip to itself (a training step's towers, the level-2
-// encoders).  A chain that runs BESIDE other kernels — the few-sequence tail of the text encoder
-// on the side stream while the visual encoder still launches LDS-tiled steps or runs its attention
-// pass — uses 4 waves: a 512-thread workgroup needs two free wave slots on every SIMD of one CU at
-// once and starves among 256-thread workgroups that refill slots one by one (615-video share of
-// the split: 50.2 ms per pass with 8 waves, 42.5 with 4).
-constexpr int kMidRing = 2;   // 16-k blocks in flight per wave (4 and 8 measured slower, see above)
-
-// K is always cut into kMidSlices = 8 slices with one accumulator each, combined in slice order:
-// with 8 waves every wave owns one slice, with 4 waves wave w runs slices w and w + 4 one after
-// the other — the same arithmetic, so both shapes give bit-identical results and the choice
-// between them is free to follow the schedule.
-constexpr int kMidSlices = 8;
-
-template <int MB, int BU, int NW>
-__global__ __launch_bounds__(64 * NW) void gru_step_mid_kernel(const GruStepGroup grp) {
-  CHAIN_WAVE_PRIORITY();
-  constexpr int BM = 16 * MB, NB = (3 * BU + 15) / 16, VS = kMidSlices / NW;
-  static_assert(NW * VS == kMidSlices, "4 or 8 waves");
-  constexpr int OUTS = BM * BU, NOUT = (OUTS + 64 * NW - 1) / (64 * NW);   // outputs (per thread)
-  unsigned wg;
-  const GruStepParams& p = grp.j[group_job(grp, &wg)];
-  __shared__ f32x4v red[kMidSlices][MB * NB][64];   // [K slice][M block x column block][lane]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = p.H;
-  const int u_tiles = (H + BU - 1) / BU;
-  const int u0 = (wg % u_tiles) * BU;    // unit tile fastest: b, b+8 share an XCD's L2
-  const int m0 = (wg / u_tiles) * BM;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const bool have_h = (p.t > 0) || (p.h0_rows != nullptr);
-#ifdef TILE_TRACE_BUILD
-  // tools/mid_trace.py: stamps of step t, workgroup wg at g_trace[(t * gridDim.x + blockIdx.x) * 8 + i]
-#define MID_MARK(i)                                                                       \
-  do {                                                                                    \
-    if (threadIdx.x == 0 && g_trace)                                                      \
-      g_trace[(static_cast<size_t>(p.t) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); \
-  } while (0)
-#else
-#define MID_MARK(i) do {} while (0)
-#endif
-  MID_MARK(0);
-  // The epilogue's own operands do not depend on the K loop: request them first (branch-free,
-  // clamped), so their memory round trip hides under it.  Output o of this thread: tile row
-  // er = o / BU, unit eu = o % BU, o = tid + 256 q.
-  float e_gx[NOUT][3], e_hp[NOUT], e_b[NOUT][4];
-#pragma unroll
-  for (int q = 0; q < NOUT; ++q) {
-    const int o = tid + 64 * NW * q;
-    const int em = m0 + (o / BU) % BM, u = u0 + (o % BU);
-    const int emc = (em < p.S_t) ? em : (p.S_t - 1), uc = (u < H) ? u : (H - 1);
-    const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(emc) : (p.off_cur + emc - p.gx_p0);
-    const float* gxr = p.gx + gxrow * 3 * H;
-    e_gx[q][0] = gxr[uc];
-    e_gx[q][1] = gxr[H + uc];
-    e_gx[q][2] = gxr[2 * H + uc];
-    if (p.t > 0)
-      e_hp[q] = p.hs[(p.off_prev + emc) * H + uc];
-    else if (p.h0_rows != nullptr)
-      e_hp[q] = reinterpret_cast<const float*>(p.h0_rows[emc])[uc];
-    else
-      e_hp[q] = 0.f;
-    e_b[q][0] = p.b_ih[uc] + p.b_hh[uc];
-    e_b[q][1] = p.b_ih[H + uc] + p.b_hh[H + uc];
-    e_b[q][2] = p.b_ih[2 * H + uc];
-    e_b[q][3] = p.b_hh[2 * H + uc];
-  }
-  if (have_h) {
-    rowaddr_t arow[MB], brow[NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = m0 + 16 * mb + r16;
-      const int mc = (m < p.S_t) ? m : (p.S_t - 1);   // rows past S_t are never stored
-      arow[mb] = (p.t > 0) ? row_addr(p.hs + (p.off_prev + mc) * H) : p.h0_rows[mc];
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      // column 16 j + r16 of the gate-major tile; columns past 3 BU (and units past H) compute on
-      // a clamped row and are never read back
-      const int fc = (16 * j + r16 < 3 * BU) ? (16 * j + r16) : (3 * BU - 1);
-      const int uu = u0 + fc % BU, uc = (uu < H) ? uu : (H - 1);
-      brow[j] = row_addr(p.w_hh + (static_cast<int64_t>(fc / BU) * H + uc) * H);
-    }
-    MID_MARK(1);
-#pragma unroll
-    for (int v = 0; v < VS; ++v) {
-      const int slice = wave + NW * v;
-      f32x4v acc[MB][NB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[mb][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      mid_phase<MB, NB, kMidSlices, kMidRing>(arow, brow, H, slice, kq, acc);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) red[slice][mb * NB + j][lane] = acc[mb][j];
-    }
-    MID_MARK(2);
-    __syncthreads();
-    MID_MARK(3);
-  }
-
-  // epilogue.  Element (row r, col c) of a 16x16 block sits in lane (r >> 2) * 16 + c, register r & 3.
-#pragma unroll
-  for (int q = 0; q < NOUT; ++q) {
-    const int o = tid + 64 * NW * q;
-    if (o >= OUTS) continue;
-    const int er = o / BU, eu = o % BU;
-    const int em = m0 + er, u = u0 + eu;
-    if (em >= p.S_t || u >= H) continue;
-    float hg[3] = {0.f, 0.f, 0.f};
-    if (have_h) {
-      const int mb = er >> 4, rr = er & 15, reg = rr & 3;
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const int fc = g * BU + eu;
-        const int sl = (rr >> 2) * 16 + (fc & 15);
-#pragma unroll
-        for (int w = 0; w < kMidSlices; ++w)
-          hg[g] += reinterpret_cast<const float*>(&red[w][mb * NB + (fc >> 4)][sl])[reg];
-      }
-    }
-    const float hr = hg[0], hz = hg[1], hn_ = hg[2];
-    const float rg = sigmoidf_(e_gx[q][0] + hr + e_b[q][0]);
-    const float zg = sigmoidf_(e_gx[q][1] + hz + e_b[q][1]);
-    const float ghn = hn_ + e_b[q][3];
-    const float ng = tanhf_(e_gx[q][2] + e_b[q][2] + rg * ghn);
-    const float hn = (1.0f - zg) * ng + zg * e_hp[q];
-    p.hs[(p.off_cur + em) * H + u] = hn;
-    if (p.gates != nullptr) {
-      float* gp = p.gates + (p.off_cur + em) * 4 * H + u;
-      gp[0] = rg;
-      gp[H] = zg;
-      gp[2 * H] = ng;
-      gp[3 * H] = ghn;
-    }
-    if (p.pool_mode == CMHSE_POOL_MAX) {
-      float* op = p.out + static_cast<int64_t>(p.out_row[em]) * H + u;
-      if (p.t == 0 || hn > *op) {
-        *op = hn;
-        if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(em) * H + u] = p.t;
-      }
-    } else if (p.pool_mode == CMHSE_POOL_LAST) {
-      if (p.t == p.lens[em] - 1) p.out[static_cast<int64_t>(p.out_row[em]) * H + u] = hn;
-    } else if (p.pool_mode == CMHSE_POOL_ALL) {
-      p.out[(static_cast<int64_t>(p.out_row[em]) + p.t) * H + u] = hn;
-    }
-  }
-#ifdef TILE_TRACE_BUILD
-  __builtin_amdgcn_s_waitcnt(0);
-  MID_MARK(5);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// The few-sequence TAIL of a training chain as ONE resident kernel (the forward twin of
-// gru_bwd_tail_kernel, bwd.hip — read its header for the why and for the coherence argument): the
-// steps t >= t_lo with at most 32 active sequences, each a 16- or 32-sequence x 16-unit tile per
-// workgroup.  The
-// workgroup's 48 rows of W_hh (3 gates x 16 units) sit in registers in mid_phase's operand layout;
-// per step only h_{t-1} crosses workgroups: written through (agent-scope stores — every hs row is
-// written once, to an address nobody read in this kernel), read past the non-coherent L2s
-// (sc1 buffer loads) behind the step's grid barrier.  Block ownership, accumulation and combine
-// order are gru_step_mid_kernel<1, 16, 8>'s.
-// ---------------------------------------------------------------------------------------------
-struct FwdTailParams {
-  GruStepParams p;           // as for a step of the chain; t / S_t / off_* are derived per step
-  const int32_t* step_off;   // device [Tmax + 1]
-  GridSync sync;             // grid barrier words (zeroed by the caller)
-  int32_t t_lo, t_hi;        // steps t_lo >= 1 ... t_hi = Tmax - 1
-};
-
-constexpr int kFwdTailMaxSeqs = 32;             // two 16-row blocks per workgroup
-
-template <int KBMAX, int MB>
-__global__ __launch_bounds__(512) void gru_fwd_tail_kernel(const FwdTailParams q) {
-  CHAIN_WAVE_PRIORITY();
-  constexpr int NW = 8, NB = 3, BU = 16;
-  const GruStepParams& p = q.p;
-  __shared__ f32x4v red[NW][MB * NB][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = p.H;
-  const int u0 = blockIdx.x * BU;
-  const int r16 = lane & 15, kq = lane >> 4;
-  const int nkb = H / 16;
-  auto block_of = [&](int i) { return (i >> 1) * 2 * NW + 2 * wave + (i & 1); };   // mid_phase's ownership
-  int nmine = 0;
-  while (nmine < KBMAX && block_of(nmine) < nkb) ++nmine;
-  // B operand: column 16 j + r16 of the gate-major tile = row (gate j, unit u0 + r16) of W_hh
-  float4 wreg[NB][KBMAX];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int uu = u0 + r16, uc = (uu < H) ? uu : (H - 1);
-    const float* brow = p.w_hh + (static_cast<int64_t>(j) * H + uc) * H;
-#pragma unroll
-    for (int i = 0; i < KBMAX; ++i)
-      wreg[j][i] = (i < nmine) ? *reinterpret_cast<const float4*>(brow + block_of(i) * 16 + 4 * kq)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // the output this thread owns (16 MB x 16 of them: threads 0..255 at MB = 1, all 512 at MB = 2):
-  // tile row er = sorted sequence, unit u
-  const int er = tid >> 4, eu = tid & 15;
-  const int u = u0 + eu;
-  const bool owner = er < 16 * MB && u < H;
-  float e_b[4] = {0.f, 0.f, 0.f, 0.f};
-  if (owner) {
-    e_b[0] = p.b_ih[u] + p.b_hh[u];
-    e_b[1] = p.b_ih[H + u] + p.b_hh[H + u];
-    e_b[2] = p.b_ih[2 * H + u];
-    e_b[3] = p.b_hh[2 * H + u];
-  }
-  float hprev = 0.f;
-  {
-    const int off_prev = q.step_off[q.t_lo - 1];
-    const int S_lo = q.step_off[q.t_lo + 1] - q.step_off[q.t_lo];
-    if (owner && er < S_lo) hprev = p.hs[(static_cast<int64_t>(off_prev) + er) * H + u];
-  }
-  unsigned arrivals = 0;
-  for (int t = q.t_lo; t <= q.t_hi; ++t) {
-    const int off_cur = q.step_off[t], off_prev = q.step_off[t - 1];
-    const int S_t = q.step_off[t + 1] - off_cur;
-    // the epilogue's own operands do not depend on the chain: request them first
-    float e_gx[3] = {0.f, 0.f, 0.f};
-    if (owner && er < S_t) {
-      const int64_t gxrow = p.gx_per_seq ? static_cast<int64_t>(er)
-                                         : (static_cast<int64_t>(off_cur) + er - p.gx_p0);
-      const float* gxr = p.gx + gxrow * 3 * H;
-      e_gx[0] = gxr[u];
-      e_gx[1] = gxr[H + u];
-      e_gx[2] = gxr[2 * H + u];
-    }
-    {
-      // A operand: the rows of step t - 1 (the previous kernel's for t = t_lo, else published by
-      // every workgroup before the barrier at the end of the previous trip)
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          p.hs + static_cast<int64_t>(off_prev) * H, 0, 0x7fffffff, 0x00020000);
-      typedef int i32x4v __attribute__((ext_vector_type(4)));
-      i32x4v areg[MB][KBMAX];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int m = 16 * mb + r16;
-        const int row_b = ((m < S_t) ? m : (S_t - 1)) * H * 4;
-#pragma unroll
-        for (int i = 0; i < KBMAX; ++i)
-          if (i < nmine && 16 * mb < S_t)
-            areg[mb][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, row_b + (block_of(i) * 16 + 4 * kq) * 4, 0, 16);
-      }
-      f32x4v acc[MB][NB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[mb][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < KBMAX; ++i) {
-        if (i >= nmine) continue;   // wave-uniform
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            if (16 * mb >= S_t) continue;   // (workgroup-uniform) an empty row block
-            const int ai = (c == 0) ? areg[mb][i].x : (c == 1) ? areg[mb][i].y : (c == 2) ? areg[mb][i].z : areg[mb][i].w;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const float bv = (c == 0) ? wreg[j][i].x : (c == 1) ? wreg[j][i].y : (c == 2) ? wreg[j][i].z : wreg[j][i].w;
-              acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(ai), bv, acc[mb][j], 0, 0, 0);
-            }
-          }
-      }
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) red[wave][mb * NB + j][lane] = acc[mb][j];
-      __syncthreads();
-    }
-    if (owner && er < S_t) {
-      const int mb = er >> 4, rr = er & 15;
-      const int sl = (rr >> 2) * 16 + eu, reg = rr & 3;
-      float hg[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int w = 0; w < NW; ++w) hg[g] += reinterpret_cast<const float*>(&red[w][mb * NB + g][sl])[reg];
-      const float rg = sigmoidf_(e_gx[0] + hg[0] + e_b[0]);
-      const float zg = sigmoidf_(e_gx[1] + hg[1] + e_b[1]);
-      const float ghn = hg[2] + e_b[3];
-      const float ng = tanhf_(e_gx[2] + e_b[2] + rg * ghn);
-      const float hn = (1.0f - zg) * ng + zg * hprev;
-      hprev = hn;
-      const int64_t row = static_cast<int64_t>(off_cur) + er;
-      // next step's A operand, in every workgroup: write through to where all XCDs see it
-      __hip_atomic_store(&p.hs[row * H + u], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (p.gates != nullptr) {
-        float* gp = p.gates + row * 4 * H + u;
-        gp[0] = rg;
-        gp[H] = zg;
-        gp[2 * H] = ng;
-        gp[3 * H] = ghn;
-      }
-      if (p.pool_mode == CMHSE_POOL_MAX) {
-        float* op = p.out + static_cast<int64_t>(p.out_row[er]) * H + u;
-        if (hn > *op) {      // (t >= 1 here: the running maximum exists)
-          *op = hn;
-          if (p.argmax != nullptr) p.argmax[static_cast<int64_t>(er) * H + u] = t;
-        }
-      } else if (p.pool_mode == CMHSE_POOL_LAST) {
-        if (t == p.lens[er] - 1) p.out[static_cast<int64_t>(p.out_row[er]) * H + u] = hn;
-      } else if (p.pool_mode == CMHSE_POOL_ALL) {
-        p.out[(static_cast<int64_t>(p.out_row[er]) + t) * H + u] = hn;
-      }
-    }
-    if (t == q.t_hi) break;
-    __builtin_amdgcn_s_waitcnt(0);
-    arrivals += gridDim.x;
-    if (!grid_sync_wait(q.sync, arrivals)) return;
-  }
-}
-
-// Hoisted input projection of the mid-size steps: gx[m][n] = sum_k x_row(m)[k] W_ih[n][k] for the
-// packed rows p0 + m of steps >= t_first (or, for a time-constant input, for the sequences
-// themselves), 64 x 192 tiles on the shared exact-fp32 NT tile loop.
-struct XprojParams {
-  const uint64_t* x_rows;
-  const uint64_t* tok_rows;
-  const float* emb;
-  const int32_t* step_off;
-  const float* w_ih;
-  float* gx;
-  int64_t p0, rows;      // gx row m is packed row p0 + m; this launch computes gx rows [m_begin, rows)
-  int64_t m_begin;
-  int32_t I, N, vocab, x_step, Tmax, t_first, n_tiles, per_seq;
-};
-
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3)))
-void xproj_kernel(const XprojParams p) {
-  constexpr int BM = 64, BN = 192, NS = 3;   // the step kernel's tile shape (3 x 32 columns per wave)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = (blockIdx.x % p.n_tiles) * BN;
-  const int64_t m0 = p.m_begin + static_cast<int64_t>(blockIdx.x / p.n_tiles) * BM;
-  const int srow = tid >> 2;
-  rowaddr_t ar[1], br[BN / 64];
-  bool av[1], bv[BN / 64];
-  {
-    int64_t m = m0 + srow;
-    av[0] = m < p.rows;
-    if (!av[0]) m = p.rows - 1;
-    int t = 0;
-    int64_t sidx = m;
-    if (!p.per_seq) {
-      // packed row -> (step, sorted sequence): the last step whose first row is <= the row
-      const int64_t pr = p.p0 + m;
-      int lo = p.t_first, hi = p.Tmax - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (static_cast<int64_t>(p.step_off[mid]) <= pr) lo = mid; else hi = mid - 1;
-      }
-      t = lo;
-      sidx = pr - p.step_off[t];
-    }
-    if (p.tok_rows != nullptr) {
-      long long tok = reinterpret_cast<const long long*>(p.tok_rows[sidx])[t];
-      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
-      ar[0] = row_addr(p.emb + tok * p.I);
-    } else {
-      ar[0] = p.x_rows[sidx] + static_cast<rowaddr_t>(t) * p.x_step * 4u;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < BN / 64; ++i) {
-    const int n = n0 + srow + 64 * i;
-    bv[i] = n < p.N;
-    br[i] = row_addr(p.w_ih + static_cast<int64_t>(bv[i] ? n : (p.N - 1)) * p.I);
-  }
-  f32x16 acc[1][NS];
-#pragma unroll
-  for (int a = 0; a < NS; ++a) acc[0][a] = zero16();
-  int b_row0[NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
-  nt_phase<BM, BN, 1, NS, NS, NS - 1, true>(smem, ar, av, br, bv, p.I, wm * 32, b_row0, acc);
-  // Epilogue.  48 dword stores per lane (one per accumulator element) made this kernel
-  // store-ISSUE-bound (65 % MFMA-busy against 86 % for the step kernel on the same tile loop): the
-  // tile goes through the now idle LDS, 32 rows at a time, and leaves as 16-byte stores of whole
-  // row segments (6 per thread and half).
-  constexpr int kLd = BN + 4;                  // row stride of the staging image, floats
-  float* stage = smem;                         // 32 x 196 x 4 B = 25 KB of the 40 KB tile buffers
-  const bool vec_out = (p.N % 4 == 0) && (n0 + BN <= p.N);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
-          stage[acc_row(r, lane) * kLd + b_row0[ns] + acc_col(lane)] = acc[0][ns][r];
-    }
-    __syncthreads();
-    const int64_t mh = m0 + 32 * half;
-    if (vec_out) {
-#pragma unroll
-      for (int i = 0; i < (32 * BN / 4) / kThreads; ++i) {
-        const int idx = tid + kThreads * i;
-        const int row = idx / (BN / 4), c4 = idx % (BN / 4);
-        if (mh + row < p.rows)
-          *reinterpret_cast<float4*>(p.gx + (mh + row) * p.N + n0 + 4 * c4) =
-              *reinterpret_cast<const float4*>(stage + row * kLd + 4 * c4);
-      }
-    } else {
-      for (int idx = tid; idx < 32 * BN; idx += kThreads) {
-        const int row = idx / BN, c = idx % BN;
-        if (mh + row < p.rows && n0 + c < p.N) p.gx[(mh + row) * p.N + n0 + c] = stage[row * kLd + c];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// attention pooling: out[s] = sum_t a_t h_t,  a_t = exp(e_t) [t < len] / (sum_t exp(e_t) + 1e-4)
-// one workgroup per sequence; reads each hidden row once (HBM-bound).
-// ---------------------------------------------------------------------------------------------
-struct AttnPoolParams {
-  const float* hs;
-  const float* e_part;
-  const int32_t* lens;
-  const int32_t* out_row;
-  const int32_t* step_off;
-  float* out;
-  int64_t rows;
-  int32_t H, n_tiles;
-};
-
-__global__ __launch_bounds__(kThreads) void attn_pool_kernel(const AttnPoolParams p) {
-  const int s = blockIdx.x;
-  const int len = p.lens[s];
-  const int tid = threadIdx.x;
-  __shared__ float s_w[kThreads];
-  __shared__ int64_t s_row[kThreads];
-  __shared__ float s_den;
-  // pass 1: denominator sum_t exp(e_t) + 1e-4 (each exp evaluated by exactly one thread)
-  float part = 0.f;
-  for (int t = tid; t < len; t += kThreads) {
-    const int64_t row = static_cast<int64_t>(p.step_off[t]) + s;
-    float e = 0.f;
-    for (int q = 0; q < p.n_tiles; ++q) e += p.e_part[q * p.rows + row];
-    part += expf(e);
-  }
-  s_w[tid] = part;
-  __syncthreads();
-  if (tid == 0) {
-    float d = 0.f;
-    for (int i = 0; i < kThreads; ++i) d += s_w[i];
-    s_den = d + 0.0001f;
-  }
-  __syncthreads();
-  const float den = s_den;
-  const int H = p.H;
-  float* o = p.out + static_cast<int64_t>(p.out_row[s]) * H;
-  const bool vec = (H % 4 == 0) && aligned16(p.hs) && aligned16(o);
-  // pass 2: weighted sum over the sequence's rows; the weights AND the packed row numbers of 256
-  // steps at a time are staged in LDS, so the row loads of consecutive steps are independent of any
-  // other global load and pipeline freely (HBM-bound: each hidden row is read once, 16 B per lane)
-  for (int ub = 0; ub < H; ub += 4 * kThreads) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int u = ub + 4 * tid;
-    for (int t0 = 0; t0 < len; t0 += kThreads) {
-      __syncthreads();
-      if (t0 + tid < len) {
-        const int64_t row = static_cast<int64_t>(p.step_off[t0 + tid]) + s;
-        float e = 0.f;
-        for (int q = 0; q < p.n_tiles; ++q) e += p.e_part[q * p.rows + row];
-        s_w[tid] = expf(e) / den;
-        s_row[tid] = row;
-      }
-      __syncthreads();
-      const int cnt = (len - t0 < kThreads) ? (len - t0) : kThreads;
-      if (vec && u + 3 < H) {
-#pragma unroll 4
-        for (int j = 0; j < cnt; ++j) {
-          const float4 h = *reinterpret_cast<const float4*>(p.hs + s_row[j] * H + u);
-          const float wgt = s_w[j];
-          a0 += wgt * h.x;
-          a1 += wgt * h.y;
-          a2 += wgt * h.z;
-          a3 += wgt * h.w;
-        }
-      } else {
-        for (int j = 0; j < cnt; ++j) {
-          const float* hrow = p.hs + s_row[j] * H;
-          const float wgt = s_w[j];
-          if (u < H) a0 += wgt * hrow[u];
-          if (u + 1 < H) a1 += wgt * hrow[u + 1];
-          if (u + 2 < H) a2 += wgt * hrow[u + 2];
-          if (u + 3 < H) a3 += wgt * hrow[u + 3];
-        }
-      }
-    }
-    if (vec && u + 3 < H) {
-      *reinterpret_cast<float4*>(o + u) = make_float4(a0, a1, a2, a3);
-    } else {
-      if (u < H) o[u] = a0;
-      if (u + 1 < H) o[u + 1] = a1;
-      if (u + 2 < H) o[u + 2] = a2;
-      if (u + 3 < H) o[u + 3] = a3;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// F.normalize: y = x / max(||x||_2, 1e-12), one workgroup per row.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void l2norm_rows_kernel(const float* __restrict__ x,
-                                                               float* __restrict__ y, int cols,
-                                                               int64_t ld) {
-  const int64_t row = blockIdx.x;
-  const float* xr = x + row * ld;
-  float* yr = y + row * ld;
-  float ss = 0.f;
-  for (int c = threadIdx.x; c < cols; c += kThreads) {
-    const float v = xr[c];
-    ss += v * v;
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
-  __shared__ float s_part[kThreads / 64];
-  __shared__ float s_inv;
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int i = 0; i < kThreads / 64; ++i) t += s_part[i];
-    s_inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
-  }
-  __syncthreads();
-  const float inv = s_inv;
-  for (int c = threadIdx.x; c < cols; c += kThreads) yr[c] = xr[c] * inv;
-}
-
-// nn.Embedding lookup as a plain row gather (only used when the caller asks for the word tensor,
-// model.py:94,98; the encoders fuse the lookup into their operand loads instead).
-__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table,
-                                                               const long long* __restrict__ ids,
-                                                               float* __restrict__ out, int cols,
-                                                               int vocab) {
-  const int64_t r = blockIdx.x;
-  long long id = ids[r];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  const float* src = table + id * cols;
-  float* dst = out + r * cols;
-  for (int c = threadIdx.x; c < cols; c += kThreads) dst[c] = src[c];
-}
-
-// ---------------------------------------------------------------------------------------------
-// Host -> HBM upload of time steps [t0, t1) of every still-active sequence, straight out of the
-// loader's pinned host tensors (device-readable, zero-copy over PCIe): the unit the step pipeline
-// consumes.  Padding rows (t >= len) are never read on the host side nor written here.
-// A few dozen waves saturate PCIe (tools/microbench/h2d_chunked.hip), so the grid is small: the
-// kernel runs beside the MFMA-bound step kernels and must not crowd their CUs.
-// ---------------------------------------------------------------------------------------------
-struct PullParams {
-  const uint64_t* src_rows;   // [S] host (pinned) address of step 0 of sorted sequence s
-  const uint64_t* dst_rows;   // [S] device address of step 0 of sorted sequence s
-  const int32_t* lens;        // [S] non-increasing
-  int32_t n_active, row_floats, t0, t1;
-};
-
-__global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p) {
-  const unsigned nthr = blockDim.x;
-  for (int s = blockIdx.x; s < p.n_active; s += gridDim.x) {
-    const int len = p.lens[s];
-    const int te = (p.t1 < len) ? p.t1 : len;
-    if (te <= p.t0) break;     // sorted longest first: every later sequence is shorter still
-    const size_t off = static_cast<size_t>(p.t0) * p.row_floats * 4u;
-    const size_t n = static_cast<size_t>(te - p.t0) * p.row_floats;
-    const rowaddr_t src = p.src_rows[s] + off, dst = p.dst_rows[s] + off;
-    if (((src | dst) & 15u) == 0 && (n & 3u) == 0) {
-      const float4* sp = reinterpret_cast<const float4*>(src);
-      float4* dp = reinterpret_cast<float4*>(dst);
-      const size_t n4 = n >> 2;
-      size_t i = threadIdx.x;
-      // eight 16-byte PCIe reads in flight per lane: few waves must keep the link busy, because
-      // every resident pull wave costs the MFMA-bound step kernel beside it a workgroup slot
-      for (; i + 7 * nthr < n4; i += 8 * nthr) {
-        float4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = sp[i + q * nthr];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dp[i + q * nthr] = v[q];
-      }
-      for (; i < n4; i += nthr) dp[i] = sp[i];
-    } else {
-      const float* sp = reinterpret_cast<const float*>(src);
-      float* dp = reinterpret_cast<float*>(dst);
-      for (size_t i = threadIdx.x; i < n; i += nthr) dp[i] = sp[i];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// HBM -> host hand-over of finished embedding rows (the `.data.cpu()` of evaluation.py:120-125):
-// a plain byte copy into page-locked, device-writable host memory, done by a FEW single-wave
-// workgroups.  The runtime's own device-to-host copy of this size is a chip-wide blit kernel: beside
-// the level-2 step chain (which needs its workgroups resident together) it held that chain back by
-// 2 ms and the launches queued behind it by another (profiles/r06_api_path.txt).  PCIe writes are
-// posted: a few dozen waves keep the link full.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void push_bytes_kernel(const float4* __restrict__ src,
-                                                        float4* __restrict__ dst, size_t n16,
-                                                        const unsigned char* __restrict__ src_tail,
-                                                        unsigned char* __restrict__ dst_tail, int tail) {
-  const size_t nthr = static_cast<size_t>(gridDim.x) * blockDim.x;
-  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  for (; i + 7 * nthr < n16; i += 8 * nthr) {
-    float4 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = src[i + q * nthr];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) dst[i + q * nthr] = v[q];
-  }
-  for (; i < n16; i += nthr) dst[i] = src[i];
-  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
-}
-
-// bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
-// split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
-// (k beyond K zero-filled), see nt_phase_bf3.
-__global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __restrict__ W,
-                                                                uint32_t* __restrict__ out, int R,
-                                                                int K) {
-  const int64_t ld = split_ld(K);
-  const int64_t pairs = ld / 2;  // one thread per (row, k pair)
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (idx >= static_cast<int64_t>(R) * pairs) return;
-  const int r = static_cast<int>(idx / pairs);
-  const int pp = static_cast<int>(idx % pairs);
-  const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
-  const float x0 = (k < K) ? W[static_cast<int64_t>(r) * K + k] : 0.f;
-  const float x1 = (k + 1 < K) ? W[static_cast<int64_t>(r) * K + k + 1] : 0.f;
-  const uint32_t hi = pack_bf16(x0, x1);
-  const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
-  const uint32_t lo = pack_bf16(x0 - f0, x1 - f1);
-  uint32_t* o = out + static_cast<int64_t>(r) * ld + c * 16;
-  o[q] = hi;
-  o[8 + q] = lo;
-}
-
-static void launch_split(const float* W, float* out, int R, int K, hipStream_t st) {
-  const int64_t n = static_cast<int64_t>(R) * (split_ld(K) / 2);
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)),
-                     dim3(kThreads), 0, st, W, reinterpret_cast<uint32_t*>(out), R, K);
-}
-
-// bf16x3 pre-split of the INPUT rows of the packed steps [0, rows): row p of `out` (split_ld(I)
-// float units, same chunk layout as split_bf16x3_kernel) = split(x row of packed row p), the token
-// lookup included.  One workgroup per packed row; one pass over the inputs at HBM speed.
-struct SplitRowsParams {
-  const uint64_t* x_rows;
-  const uint64_t* tok_rows;
-  const float* emb;
-  const int32_t* step_off;
-  uint32_t* out;
-  int32_t I, vocab, x_step, Tmax;
-};
-
-__global__ __launch_bounds__(kThreads) void split_rows_kernel(const SplitRowsParams p) {
-  const int64_t pr = blockIdx.x;
-  __shared__ rowaddr_t s_src;
-  if (threadIdx.x == 0) {
-    int lo = 0, hi = p.Tmax - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (static_cast<int64_t>(p.step_off[mid]) <= pr) lo = mid; else hi = mid - 1;
-    }
-    const int64_t sidx = pr - p.step_off[lo];
-    if (p.tok_rows != nullptr) {
-      long long tok = reinterpret_cast<const long long*>(p.tok_rows[sidx])[lo];
-      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
-      s_src = row_addr(p.emb + tok * p.I);
-    } else {
-      s_src = p.x_rows[sidx] + static_cast<rowaddr_t>(lo) * p.x_step * 4u;
-    }
-  }
-  __syncthreads();
-  const float* src = reinterpret_cast<const float*>(s_src);
-  const int64_t ld = split_ld(p.I);
-  uint32_t* o = p.out + pr * ld;
-  for (int pp = threadIdx.x; pp < ld / 2; pp += kThreads) {
-    const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
-    const float x0 = (k < p.I) ? src[k] : 0.f;
-    const float x1 = (k + 1 < p.I) ? src[k + 1] : 0.f;
-    const uint32_t hi = pack_bf16(x0, x1);
-    const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
-    o[c * 16 + q] = hi;
-    o[c * 16 + 8 + q] = pack_bf16(x0 - f0, x1 - f1);
-  }
-}
 
 // small-batch / tiled crossover of the forward steps (Tunables::tiny_max_seqs)
 static int tiny_max_seqs() { return tunables().tiny_max_seqs.load(std::memory_order_relaxed); }
-
-// ---------------------------------------------------------------------------------------------
-// collate_fn's padding (activity_net/data.py:114-150) as an index kernel: S ragged sequences stored
-// back to back (row r of sequence s at src + (first_row[s] + r) * row_bytes) -> the zero-padded
-// [S, Tmax, row] block.  One 16-byte (or 4-byte) word per thread, grid-stride; HBM-bound.
-// ---------------------------------------------------------------------------------------------
-struct PadRowsParams {
-  const char* src;
-  const int64_t* first_row;
-  const int32_t* lens;
-  char* dst;
-  int64_t words;       // S * Tmax * words_per_row
-  int32_t Tmax, words_per_row;
-};
-
-template <typename W>
-__global__ __launch_bounds__(kThreads) void pad_rows_kernel(const PadRowsParams q) {
-  const W* src = reinterpret_cast<const W*>(q.src);
-  W* dst = reinterpret_cast<W*>(q.dst);
-  const int64_t per_seq = static_cast<int64_t>(q.Tmax) * q.words_per_row;
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(kThreads) + threadIdx.x; i < q.words;
-       i += static_cast<int64_t>(gridDim.x) * kThreads) {
-    const int64_t s = i / per_seq, r = i - s * per_seq;
-    const int t = static_cast<int>(r / q.words_per_row);
-    W v{};
-    if (t < q.lens[s]) v = src[q.first_row[s] * q.words_per_row + r];
-    dst[i] = v;
-  }
-}
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -1,0 +1,228 @@
+// gru_rows.hpp
+//
+// Row kernels around the encoders: F.normalize, the embedding gather, host <-> HBM hand-over of
+// feature / embedding rows (pull_steps, push_bytes), the bf16x3 operand pre-split, collate_fn's
+// padding.  Included by gru.hip only.
+#pragma once
+
+namespace cmhse {
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize: y = x / max(||x||_2, 1e-12), one workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void l2norm_rows_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ y, int cols,
+                                                               int64_t ld) {
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * ld;
+  float* yr = y + row * ld;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < cols; c += kThreads) {
+    const float v = xr[c];
+    ss += v * v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d, 64);
+  __shared__ float s_part[kThreads / 64];
+  __shared__ float s_inv;
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kThreads / 64; ++i) t += s_part[i];
+    s_inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  for (int c = threadIdx.x; c < cols; c += kThreads) yr[c] = xr[c] * inv;
+}
+
+// nn.Embedding lookup as a plain row gather (only used when the caller asks for the word tensor,
+// model.py:94,98; the encoders fuse the lookup into their operand loads instead).
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table,
+                                                               const long long* __restrict__ ids,
+                                                               float* __restrict__ out, int cols,
+                                                               int vocab) {
+  const int64_t r = blockIdx.x;
+  long long id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float* src = table + id * cols;
+  float* dst = out + r * cols;
+  for (int c = threadIdx.x; c < cols; c += kThreads) dst[c] = src[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host -> HBM upload of time steps [t0, t1) of every still-active sequence, straight out of the
+// loader's pinned host tensors (device-readable, zero-copy over PCIe): the unit the step pipeline
+// consumes.  Padding rows (t >= len) are never read on the host side nor written here.
+// A few dozen waves saturate PCIe (tools/microbench/h2d_chunked.hip), so the grid is small: the
+// kernel runs beside the MFMA-bound step kernels and must not crowd their CUs.
+// ---------------------------------------------------------------------------------------------
+struct PullParams {
+  const uint64_t* src_rows;   // [S] host (pinned) address of step 0 of sorted sequence s
+  const uint64_t* dst_rows;   // [S] device address of step 0 of sorted sequence s
+  const int32_t* lens;        // [S] non-increasing
+  int32_t n_active, row_floats, t0, t1;
+};
+
+__global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p) {
+  const unsigned nthr = blockDim.x;
+  for (int s = blockIdx.x; s < p.n_active; s += gridDim.x) {
+    const int len = p.lens[s];
+    const int te = (p.t1 < len) ? p.t1 : len;
+    if (te <= p.t0) break;     // sorted longest first: every later sequence is shorter still
+    const size_t off = static_cast<size_t>(p.t0) * p.row_floats * 4u;
+    const size_t n = static_cast<size_t>(te - p.t0) * p.row_floats;
+    const rowaddr_t src = p.src_rows[s] + off, dst = p.dst_rows[s] + off;
+    if (((src | dst) & 15u) == 0 && (n & 3u) == 0) {
+      const float4* sp = reinterpret_cast<const float4*>(src);
+      float4* dp = reinterpret_cast<float4*>(dst);
+      const size_t n4 = n >> 2;
+      size_t i = threadIdx.x;
+      // eight 16-byte PCIe reads in flight per lane: few waves must keep the link busy, because
+      // every resident pull wave costs the MFMA-bound step kernel beside it a workgroup slot
+      for (; i + 7 * nthr < n4; i += 8 * nthr) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = sp[i + q * nthr];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dp[i + q * nthr] = v[q];
+      }
+      for (; i < n4; i += nthr) dp[i] = sp[i];
+    } else {
+      const float* sp = reinterpret_cast<const float*>(src);
+      float* dp = reinterpret_cast<float*>(dst);
+      for (size_t i = threadIdx.x; i < n; i += nthr) dp[i] = sp[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// HBM -> host hand-over of finished embedding rows (the `.data.cpu()` of evaluation.py:120-125):
+// a plain byte copy into page-locked, device-writable host memory, done by a FEW single-wave
+// workgroups.  The runtime's own device-to-host copy of this size is a chip-wide blit kernel: beside
+// the level-2 step chain (which needs its workgroups resident together) it held that chain back by
+// 2 ms and the launches queued behind it by another (profiles/r06_api_path.txt).  PCIe writes are
+// posted: a few dozen waves keep the link full.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void push_bytes_kernel(const float4* __restrict__ src,
+                                                        float4* __restrict__ dst, size_t n16,
+                                                        const unsigned char* __restrict__ src_tail,
+                                                        unsigned char* __restrict__ dst_tail, int tail) {
+  const size_t nthr = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 7 * nthr < n16; i += 8 * nthr) {
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = src[i + q * nthr];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[i + q * nthr] = v[q];
+  }
+  for (; i < n16; i += nthr) dst[i] = src[i];
+  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+// bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
+// split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
+// (k beyond K zero-filled), see nt_phase_bf3.
+__global__ __launch_bounds__(kThreads) void split_bf16x3_kernel(const float* __restrict__ W,
+                                                                uint32_t* __restrict__ out, int R,
+                                                                int K) {
+  const int64_t ld = split_ld(K);
+  const int64_t pairs = ld / 2;  // one thread per (row, k pair)
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (idx >= static_cast<int64_t>(R) * pairs) return;
+  const int r = static_cast<int>(idx / pairs);
+  const int pp = static_cast<int>(idx % pairs);
+  const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
+  const float x0 = (k < K) ? W[static_cast<int64_t>(r) * K + k] : 0.f;
+  const float x1 = (k + 1 < K) ? W[static_cast<int64_t>(r) * K + k + 1] : 0.f;
+  const uint32_t hi = pack_bf16(x0, x1);
+  const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
+  const uint32_t lo = pack_bf16(x0 - f0, x1 - f1);
+  uint32_t* o = out + static_cast<int64_t>(r) * ld + c * 16;
+  o[q] = hi;
+  o[8 + q] = lo;
+}
+
+static void launch_split(const float* W, float* out, int R, int K, hipStream_t st) {
+  const int64_t n = static_cast<int64_t>(R) * (split_ld(K) / 2);
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, st, W, reinterpret_cast<uint32_t*>(out), R, K);
+}
+
+// bf16x3 pre-split of the INPUT rows of the packed steps [0, rows): row p of `out` (split_ld(I)
+// float units, same chunk layout as split_bf16x3_kernel) = split(x row of packed row p), the token
+// lookup included.  One workgroup per packed row; one pass over the inputs at HBM speed.
+struct SplitRowsParams {
+  const uint64_t* x_rows;
+  const uint64_t* tok_rows;
+  const float* emb;
+  const int32_t* step_off;
+  uint32_t* out;
+  int32_t I, vocab, x_step, Tmax;
+};
+
+__global__ __launch_bounds__(kThreads) void split_rows_kernel(const SplitRowsParams p) {
+  const int64_t pr = blockIdx.x;
+  __shared__ rowaddr_t s_src;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = p.Tmax - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (static_cast<int64_t>(p.step_off[mid]) <= pr) lo = mid; else hi = mid - 1;
+    }
+    const int64_t sidx = pr - p.step_off[lo];
+    if (p.tok_rows != nullptr) {
+      long long tok = reinterpret_cast<const long long*>(p.tok_rows[sidx])[lo];
+      tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
+      s_src = row_addr(p.emb + tok * p.I);
+    } else {
+      s_src = p.x_rows[sidx] + static_cast<rowaddr_t>(lo) * p.x_step * 4u;
+    }
+  }
+  __syncthreads();
+  const float* src = reinterpret_cast<const float*>(s_src);
+  const int64_t ld = split_ld(p.I);
+  uint32_t* o = p.out + pr * ld;
+  for (int pp = threadIdx.x; pp < ld / 2; pp += kThreads) {
+    const int c = pp / 8, q = pp % 8, k = c * 16 + 2 * q;
+    const float x0 = (k < p.I) ? src[k] : 0.f;
+    const float x1 = (k + 1 < p.I) ? src[k + 1] : 0.f;
+    const uint32_t hi = pack_bf16(x0, x1);
+    const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
+    o[c * 16 + q] = hi;
+    o[c * 16 + 8 + q] = pack_bf16(x0 - f0, x1 - f1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// collate_fn's padding (activity_net/data.py:114-150) as an index kernel: S ragged sequences stored
+// back to back (row r of sequence s at src + (first_row[s] + r) * row_bytes) -> the zero-padded
+// [S, Tmax, row] block.  One 16-byte (or 4-byte) word per thread, grid-stride; HBM-bound.
+// ---------------------------------------------------------------------------------------------
+struct PadRowsParams {
+  const char* src;
+  const int64_t* first_row;
+  const int32_t* lens;
+  char* dst;
+  int64_t words;       // S * Tmax * words_per_row
+  int32_t Tmax, words_per_row;
+};
+
+template <typename W>
+__global__ __launch_bounds__(kThreads) void pad_rows_kernel(const PadRowsParams q) {
+  const W* src = reinterpret_cast<const W*>(q.src);
+  W* dst = reinterpret_cast<W*>(q.dst);
+  const int64_t per_seq = static_cast<int64_t>(q.Tmax) * q.words_per_row;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(kThreads) + threadIdx.x; i < q.words;
+       i += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const int64_t s = i / per_seq, r = i - s * per_seq;
+    const int t = static_cast<int>(r / q.words_per_row);
+    W v{};
+    if (t < q.lens[s]) v = src[q.first_row[s] * q.words_per_row + r];
+    dst[i] = v;
+  }
+}
+
+}  // namespace cmhse
