@@ -234,7 +234,7 @@ def _plan_key(group):
   sentence counts (hashed in full) and the base addresses of its four feature / token tensors.  An
   in-place edit of any batch's lengths, a swapped or re-uploaded batch anywhere in the list, or a
   different number of batches gives a different key, and encode_group rebuilds the plan
-  (tests/test_gpu_parity.py::test_plan_key_*).  What the key cannot see is an in-place edit of the
+  (tests/test_gpu_pipeline.py::test_plan_key_*).  What the key cannot see is an in-place edit of the
   feature VALUES — those are read afresh on every pass anyway (a plan holds addresses and
   schedules, not data).  A plan keeps its group's device tensors alive (`keep`): the whole resident
   split, 14.7 GB for ActivityNet-ICEP val; drop the plan dict to release them."""

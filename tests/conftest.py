@@ -58,6 +58,31 @@ def golden_batches(g):
   return out
 
 
+@pytest.fixture(scope='module')
+def dev():
+  """cuda:0 with the HIP library loaded (GPU tests only: fails loudly when either is missing)."""
+  import torch
+  assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+  from cmhse_amd import _lib
+  _lib.load()     # fail loudly if the HIP library is missing
+  return torch.device('cuda', 0)
+
+
+@pytest.fixture
+def tune(dev):
+  """Move kernel-shape crossovers of the library (cmhse_tune) for one test; restored afterwards."""
+  from cmhse_amd import ops
+  saved = {}
+
+  def _set(**kw):
+    for k, v in kw.items():
+      old = ops.tune(k, v)
+      saved.setdefault(k, old)
+  yield _set
+  for k, v in saved.items():
+    ops.tune(k, v)
+
+
 @pytest.fixture(scope='session')
 def oracle():
   sys.path.insert(0, os.path.join(REPO, 'oracle'))

@@ -16,14 +16,6 @@ from conftest import GOLDEN_TOL, assert_emb_close, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def dev():
-  assert torch.cuda.is_available(), 'GPU tests need the MI355X'
-  from cmhse_amd import _lib
-  _lib.load()
-  return torch.device('cuda', 0)
-
-
 def _quirk_layer(g, tag, dev):
   from cmhse_amd import layers
   layer = layers.Attention(24, 32)

@@ -1,5 +1,5 @@
 """Builds tools/microbench/canary.so, the bystander canary of the lost-update tests
-(tools/pkfma_canary.py, tests/test_gpu_parity.py).  No torch import: __graft_entry__.build() calls
+(tools/pkfma_canary.py, tests/test_gpu_chain.py).  No torch import: __graft_entry__.build() calls
 this in the build step.  Built WITHOUT the library's device flags on purpose: the
 victim loop must keep its v_pk_fma_f32."""
 import os

@@ -29,7 +29,7 @@ MUTANTS = {
     'attn_eps_bwd': ('bwd.hip', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
 }
 # the tests that must kill them (and pass on the product library)
-SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_parity.py', '-k',
+SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_golden.py', '-k',
           'epsilon or test_layers_vs_golden or test_layer_backward_vs_golden or test_model_vs_golden']
 
 
