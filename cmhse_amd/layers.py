@@ -364,21 +364,34 @@ def _lens_numpy(q_len):
 
 class _GRUPoolBase(nn.Module):
   POOL = None
+  # What `rnn_bidirectional=True` means upstream differs per layer (every reference call site passes
+  # False, model.py:107-114): Seq2Seq builds a bidirectional nn.GRU and concatenates the two final
+  # states (layers.py:31-34,58-59); Attention builds one too, but its `lin` stays H -> H, so its
+  # forward fails on the 2H-wide states (layers.py:75-80,105); Maxout stores the flag and builds a
+  # unidirectional GRU regardless (layers.py:167-172).  The same here, state-dict keys included
+  # (`rnn.weight_ih_l0_reverse`, ...).
+  BIDIRECTIONAL_GRU = True
 
   def __init__(self, embedding_features, rnn_features, rnn_bidirectional=False):
     super(_GRUPoolBase, self).__init__()
-    if rnn_bidirectional:
-      raise ValueError('cmhse_amd: bidirectional encoders are not on the reference hot path '
-                       '(every reference call site passes bidirectional=False, model.py:107-114)')
     self.bidirectional = rnn_bidirectional
     self.features = rnn_features
     self.rnn = nn.GRU(input_size=embedding_features, hidden_size=rnn_features, num_layers=1,
-                      batch_first=True, bidirectional=False)
+                      batch_first=True, bidirectional=bool(rnn_bidirectional) and self.BIDIRECTIONAL_GRU)
     self._build_extra(rnn_features)
     self._init_rnn(self.rnn.weight_ih_l0)
     self._init_rnn(self.rnn.weight_hh_l0)
     self.rnn.bias_ih_l0.data.zero_()
     self.rnn.bias_hh_l0.data.zero_()
+
+  def _two_directions(self):
+    return self.rnn.bidirectional
+
+  def _no_bidirectional(self, what):
+    if self._two_directions():
+      raise RuntimeError('cmhse_amd: %s of a bidirectional %s is not supported (upstream only '
+                         'Seq2Seq.forward(q_emb, q_len) works with rnn_bidirectional=True)'
+                         % (what, type(self).__name__))
 
   def _build_extra(self, rnn_features):
     pass
@@ -391,30 +404,37 @@ class _GRUPoolBase(nn.Module):
   def _extra_weights(self):
     return None, None, None
 
-  def _run(self, spec, x, hidden, table):
+  def _run(self, spec, x, hidden, table, reverse=False):
+    self._no_bidirectional('this entry point') if (self._two_directions() and spec.kind != 'padded') else None
     w_lin, b_lin, w_att = self._extra_weights()
+    sfx = '_reverse' if reverse else ''
+    gru = [getattr(self.rnn, n + sfx) for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
     spec.need_grad = torch.is_grad_enabled() and any(
-        t is not None and t.requires_grad
-        for t in (x, hidden, table, self.rnn.weight_ih_l0, self.rnn.weight_hh_l0,
-                  self.rnn.bias_ih_l0, self.rnn.bias_hh_l0, w_lin, b_lin, w_att))
-    return _PackedGRUPoolFn.apply(spec, x, hidden, table, self.rnn.weight_ih_l0,
-                                  self.rnn.weight_hh_l0, self.rnn.bias_ih_l0,
-                                  self.rnn.bias_hh_l0, w_lin, b_lin, w_att)
+        t is not None and t.requires_grad for t in [x, hidden, table] + gru + [w_lin, b_lin, w_att])
+    return _PackedGRUPoolFn.apply(spec, x, hidden, table, gru[0], gru[1], gru[2], gru[3], w_lin, b_lin, w_att)
 
   def forward(self, q_emb, q_len, hidden=None):
+    if self._two_directions():
+      return self._forward_bidirectional(q_emb, q_len, hidden)
     if isinstance(q_emb, ops.Ragged):   # a packed (un-padded) batch: plain data, no gradient wrt it
       if hidden is not None:
         raise ValueError('a Ragged input takes no initial hidden state (level-1 encoders only)')
       return self.forward_multi([q_emb], [q_len])
     return self._run(SeqInput('padded', _lens_numpy(q_len), self.POOL), q_emb, hidden, None)
 
+  def _forward_bidirectional(self, q_emb, q_len, hidden):
+    raise RuntimeError('cmhse_amd: %s.forward with rnn_bidirectional=True fails upstream as well (its '
+                       'pooling is built for H-wide states, layers.py:75-80,105)' % type(self).__name__)
+
   def forward_rows(self, rows, counts, hidden=None):
     """Level-2 form (VSE.structure_emb): sequence s is `counts[s]` consecutive rows of `rows`;
     differentiable wrt `rows` and `hidden`."""
+    self._no_bidirectional('forward_rows')
     counts = np.asarray(counts, dtype=np.int64)
     return self._run(SeqInput('rows', counts, self.POOL, counts=counts), rows, hidden, None)
 
   def _weights(self):
+    self._no_bidirectional('the fused inference entry points')
     w_lin, b_lin, w_att = self._extra_weights()
     weights = dict(w_ih=self.rnn.weight_ih_l0.detach(), w_hh=self.rnn.weight_hh_l0.detach(),
                    b_ih=self.rnn.bias_ih_l0.detach(), b_hh=self.rnn.bias_hh_l0.detach())
@@ -424,20 +444,24 @@ class _GRUPoolBase(nn.Module):
 
   # -- call descriptions for run_grouped(): (layer, SeqInput, x, hidden, table) -------------------
   def call_multi(self, tensors, lens_list, sched=None, step_events=None):
+    self._no_bidirectional('a grouped call')
     lens = np.concatenate([_lens_numpy(l) for l in lens_list])
     return (self, SeqInput('multi', lens, self.POOL, tensors=list(tensors), sched=sched,
                            step_events=step_events), None, None, None)
 
   def call_tokens_multi(self, token_tensors, lens_list, table, sched=None, side=True):
+    self._no_bidirectional('a grouped call')
     lens = np.concatenate([_lens_numpy(l) for l in lens_list])
     return (self, SeqInput('multi', lens, self.POOL, tokens=list(token_tensors), sched=sched,
                            side=side), None, None, table)
 
   def call_rows(self, rows, counts, hidden=None):
+    self._no_bidirectional('a grouped call')
     counts = np.asarray(counts, dtype=np.int64)
     return (self, SeqInput('rows', counts, self.POOL, counts=counts), rows, hidden, None)
 
   def call_repeat(self, rows, counts):
+    self._no_bidirectional('a grouped call')
     counts = np.asarray(counts, dtype=np.int64)
     return (self, SeqInput('repeat', counts, self.POOL), rows, None, None)
 
@@ -479,14 +503,41 @@ class _GRUPoolBase(nn.Module):
                        None, table)
 
 
+def _reverse_valid_steps(q_emb, lens):
+  """q_emb [S, T, I] with step t of sequence s moved to step len_s - 1 - t (padding stays where it
+  is): what the reverse direction of a bidirectional nn.GRU over a packed batch consumes.  An index
+  gather — data movement, differentiable."""
+  S, T = q_emb.shape[0], q_emb.shape[1]
+  t = torch.arange(T)[None, :]
+  ln = torch.as_tensor(lens, dtype=torch.int64)[:, None]
+  idx = torch.where(t < ln, ln - 1 - t, t).to(q_emb.device)
+  return torch.gather(q_emb, 1, idx[:, :, None].expand(S, T, q_emb.shape[2]))
+
+
 class Seq2Seq(_GRUPoolBase):
-  """/root/reference/layers.py:26-66 — final hidden state."""
+  """/root/reference/layers.py:26-66 — final hidden state; with rnn_bidirectional=True the final
+  states of the two directions side by side ([S, 2H], layers.py:58-59): the reverse direction is
+  the same packed GRU kernel over the time-reversed valid steps with the `_reverse` weights."""
   POOL = ops.POOL_LAST
+
+  def _forward_bidirectional(self, q_emb, q_len, hidden):
+    if hidden is not None:      # upstream hands nn.GRU a (1, N, H) state where it expects (2, N, H)
+      raise RuntimeError('Expected hidden size (2, %d, %d), got [1, %d, %d]'
+                         % (hidden.shape[0], hidden.shape[1], hidden.shape[0], hidden.shape[1]))
+    if isinstance(q_emb, ops.Ragged):
+      raise RuntimeError('cmhse_amd: a bidirectional Seq2Seq takes padded [S, T, I] input')
+    lens = _lens_numpy(q_len)
+    fwd = self._run(SeqInput('padded', lens, self.POOL), q_emb, None, None)
+    bwd = self._run(SeqInput('padded', lens, self.POOL), _reverse_valid_steps(q_emb, lens), None, None,
+                    reverse=True)
+    return torch.cat([fwd, bwd], dim=1)
 
 
 class Maxout(_GRUPoolBase):
-  """/root/reference/layers.py:164-204 — per-sequence max over valid steps."""
+  """/root/reference/layers.py:164-204 — per-sequence max over valid steps (always one direction:
+  upstream builds its GRU with bidirectional=False whatever the flag says, :167-172)."""
   POOL = ops.POOL_MAX
+  BIDIRECTIONAL_GRU = False
 
 
 class Attention(_GRUPoolBase):

@@ -467,3 +467,26 @@ def test_device_code_holds_neither_half_of_the_lost_update_pair():
   assert build.audit_isa(lib) == {}
   # the audit does see what it is looking for: the matrix instructions the library DOES use
   assert build.audit_isa(lib, forbidden=('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x8_bf16_1k'))
+
+
+def test_bidirectional_flag_means_what_it_means_upstream():
+  """layers.py:27-34, 70-79, 165-172: Seq2Seq and Attention build a bidirectional nn.GRU (state-dict
+  keys `rnn.*_reverse`), Maxout stores the flag and stays unidirectional; Attention's forward cannot
+  work with it upstream (its `lin` is H -> H) and says so here; a bidirectional layer is refused by
+  the fused / grouped entry points (no reference call site uses one, model.py:107-114)."""
+  import torch
+  from cmhse_amd import layers
+  s2s = layers.Seq2Seq(6, 8, rnn_bidirectional=True)
+  att = layers.Attention(6, 8, rnn_bidirectional=True)
+  mo = layers.Maxout(6, 8, rnn_bidirectional=True)
+  assert s2s.bidirectional and att.bidirectional and mo.bidirectional
+  assert 'rnn.weight_hh_l0_reverse' in s2s.state_dict() and 'rnn.weight_ih_l0_reverse' in att.state_dict()
+  assert not any(k.endswith('_reverse') for k in mo.state_dict())
+  x, lens = torch.zeros(2, 3, 6), torch.tensor([3, 1])
+  with pytest.raises(RuntimeError, match='fails upstream'):
+    att(x, lens)
+  with pytest.raises(RuntimeError, match='Expected hidden size'):
+    s2s(x, lens, torch.zeros(2, 8))
+  with pytest.raises(RuntimeError, match='bidirectional'):
+    s2s.call_rows(torch.zeros(4, 6), [3, 1])
+  assert layers.Seq2Seq(6, 8).state_dict().keys() == layers.Maxout(6, 8, rnn_bidirectional=True).state_dict().keys()

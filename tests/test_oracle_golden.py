@@ -304,3 +304,23 @@ def test_attention_epsilon_quirk_cases(oracle, a):
   one = np.flatnonzero(lens == 1)
   miss = np.abs(hs[one, 0] - g[tag + '.out'][one]).max()
   assert miss > 1000 * TOL, miss
+
+
+def test_bidirectional_seq2seq_golden(oracle):
+  """layers.Seq2Seq(rnn_bidirectional=True) (layers.py:31-34,58-59): the final states of the forward
+  GRU and of the `_reverse` GRU over the time-reversed valid steps, side by side — restated with the
+  oracle's unidirectional GRU, against the reference's output.  Maxout ignores the flag upstream."""
+  g = load_golden('quirks.npz')
+  p = {k[len('bidir.sd.'):]: g[k] for k in g.files if k.startswith('bidir.sd.')}
+  x, lens = g['x'], g['lens']
+  _, h_f = oracle.gru_forward(x, lens, p['rnn.rnn.weight_ih_l0'], p['rnn.rnn.weight_hh_l0'],
+                              p['rnn.rnn.bias_ih_l0'], p['rnn.rnn.bias_hh_l0'])
+  xr = np.zeros_like(x)
+  for s, l in enumerate(lens):
+    xr[s, :l] = x[s, :l][::-1]
+  _, h_b = oracle.gru_forward(xr, lens, p['rnn.rnn.weight_ih_l0_reverse'], p['rnn.rnn.weight_hh_l0_reverse'],
+                              p['rnn.rnn.bias_ih_l0_reverse'], p['rnn.rnn.bias_hh_l0_reverse'])
+  np.testing.assert_allclose(np.concatenate([h_f, h_b], 1), g['bidir.out'], atol=TOL, rtol=0)
+  pm = {k[len('bidir_maxout.sd.'):]: g[k] for k in g.files if k.startswith('bidir_maxout.sd.')}
+  assert not any(k.endswith('_reverse') for k in pm)
+  np.testing.assert_allclose(oracle.maxout_forward(x, lens, pm), g['bidir_maxout.out'], atol=TOL, rtol=0)

@@ -128,3 +128,36 @@ def test_config0_plumbing_at_its_stated_dimensions(dev, oracle):
     assert ok.mean() > 0.5
     if ok.all():
       assert rep == report_from_ranks(r64.astype(np.float64))
+
+
+def test_bidirectional_seq2seq_vs_the_reference(dev):
+  """layers.Seq2Seq(rnn_bidirectional=True).forward (layers.py:47-66): [S, 2H] = forward | reverse
+  final states, and the reference-autograd gradients of sum(out * w) wrt the input and all eight GRU
+  parameters; Maxout with the flag set equals the unidirectional layer (upstream ignores it)."""
+  from cmhse_amd import layers
+  g = load_golden('quirks.npz')
+  layer = layers.Seq2Seq(24, 32, rnn_bidirectional=True)
+  layer.load_state_dict({k[len('bidir.sd.rnn.'):]: torch.from_numpy(g[k]) for k in g.files
+                         if k.startswith('bidir.sd.rnn.')})
+  layer = layer.to(dev)
+  x = torch.from_numpy(g['x']).to(dev)
+  lens = torch.from_numpy(g['lens'])
+  with torch.no_grad():
+    y = layer(x, lens).cpu().numpy()
+  assert y.shape == (len(g['lens']), 64)
+  assert_emb_close(y, g['bidir.out'], 'bidirectional Seq2Seq')
+  xg = x.clone().requires_grad_(True)
+  layer.zero_grad()
+  (layer(xg, lens) * torch.from_numpy(g['bidir.w']).to(dev)).sum().backward()
+
+  def close(got, want, name):
+    err = float(np.abs(got - want).max()) / max(1e-6, float(np.abs(want).max()))
+    assert err < 2e-5, (name, err)
+  close(xg.grad.cpu().numpy(), g['bidir.bwd.dx'], 'dx')
+  for pn, pp in layer.named_parameters():
+    close(pp.grad.cpu().numpy(), g['bidir.bwd.grad.rnn.' + pn], pn)
+  mo = layers.Maxout(24, 32, rnn_bidirectional=True)
+  mo.load_state_dict({k[len('bidir_maxout.sd.rnn.'):]: torch.from_numpy(g[k]) for k in g.files
+                      if k.startswith('bidir_maxout.sd.rnn.')})
+  with torch.no_grad():
+    assert_emb_close(mo.to(dev)(x, lens).cpu().numpy(), g['bidir_maxout.out'], 'Maxout ignores the flag')

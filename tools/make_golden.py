@@ -178,6 +178,30 @@ def golden_quirks(ref_layers, out):
     cases[tag + '.bwd.dh0'] = hg.grad.numpy()
     for pn, pp in layer.named_parameters():
       cases[tag + '.bwd.grad.rnn.' + pn] = pp.grad.detach().numpy().copy()
+  # rnn_bidirectional=True: upstream only Seq2Seq.forward(q_emb, q_len) works with it (layers.py:58-59:
+  # the two directions' final states side by side); Maxout ignores the flag (:167-172)
+  torch.manual_seed(77)
+  bi = ref_layers.Seq2Seq(I, H, rnn_bidirectional=True)
+  randomize_biases(bi, gen)
+  for k, v in sd_np(bi, 'rnn.').items():
+    cases['bidir.sd.' + k] = v
+  with torch.no_grad():
+    cases['bidir.out'] = bi(x, torch.tensor(lens)).numpy()
+  w2 = torch.randn(S, 2 * H, generator=gen)
+  cases['bidir.w'] = w2.numpy()
+  xg = x.clone().requires_grad_(True)
+  bi.zero_grad()
+  (bi(xg, torch.tensor(lens)) * w2).sum().backward()
+  cases['bidir.bwd.dx'] = xg.grad.numpy()
+  for pn, pp in bi.named_parameters():
+    cases['bidir.bwd.grad.rnn.' + pn] = pp.grad.detach().numpy().copy()
+  torch.manual_seed(78)
+  mo = ref_layers.Maxout(I, H, rnn_bidirectional=True)
+  randomize_biases(mo, gen)
+  for k, v in sd_np(mo, 'rnn.').items():
+    cases['bidir_maxout.sd.' + k] = v
+  with torch.no_grad():
+    cases['bidir_maxout.out'] = mo(x, torch.tensor(lens)).numpy()
   np.savez_compressed(os.path.join(out, 'quirks.npz'), **cases)
 
 
