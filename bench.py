@@ -181,6 +181,10 @@ def main():
   # CMHSE_BENCH_BACKEND=gloo: the N-rank path (deal, gathers, merge, per-rank report) with ranks
   # sharing GPUs on a box that has fewer of them than ranks (set by launch_ranks)
   backend = os.environ.get('CMHSE_BENCH_BACKEND', 'nccl')
+  # The ISA audit of the loaded library disassembles it in child processes (llvm-objdump, ~3 s): done
+  # HERE, before this process touches the GPU — a fork of a process that holds a GPU context, and three
+  # idle seconds in the middle of the run, cost the legs behind it 10 % (profiles/r06_fast_mode_ab.txt).
+  lib_info = isa_audit() if rank == 0 else None
   if backend == 'gloo':
     local_rank = local_rank % max(1, torch.cuda.device_count())
   torch.cuda.set_device(local_rank)
@@ -416,7 +420,7 @@ def main():
         'traffic_source': profile_source('r*_pmc_hbm_traffic.json'),
         'note': '2*nrows*M*D FLOP per direction / HIP-event time of the counting pass alone '
                 '(cmhse_sim_rank_ex timer); rank 0\'s stripe when n_gpus > 1'}
-    out['library'] = isa_audit()       # cmhse_version() + the ISA audit of the library this run loaded
+    out['library'] = lib_info          # cmhse_version() + the ISA audit of the library this run loaded
     leg_seconds = out['leg_seconds'] = {}
 
     def leg(name, fn):

@@ -10,8 +10,8 @@
       selection on the product library (must pass).
 
 Mutants:
-  attn_eps_fwd   gru.hip: the masked softmax's `+ 0.0001f` (layers.py:158-162) -> `+ 0.0f`
-  attn_eps_bwd   bwd.hip: the same epsilon in the attention backward
+  attn_eps_fwd   gru_attention.hpp: the masked softmax's `+ 0.0001f` (layers.py:158-162) -> `+ 0.0f`
+  attn_eps_bwd   bwd_pool_kernels.hpp: the same epsilon in the attention backward
   norm_by_n      sim.hip / step_loss.hpp: nothing — `norm` is covered by values that differ by a factor n
                  (listed for completeness; not built)
 """
@@ -25,8 +25,8 @@ sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, 'build', 'mutants')
 
 MUTANTS = {
-    'attn_eps_fwd': ('gru.hip', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
-    'attn_eps_bwd': ('bwd.hip', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
+    'attn_eps_fwd': ('gru_attention.hpp', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
+    'attn_eps_bwd': ('bwd_pool_kernels.hpp', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
 }
 # the tests that must kill them (and pass on the product library)
 SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_golden.py', '-k',
@@ -66,7 +66,11 @@ def run():
                           '--tb=line'] + SELECT, cwd=REPO, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True)
     failed = [l for l in res.stdout.splitlines() if l.startswith('FAILED')]
+    errors = [l for l in res.stdout.splitlines() if l.startswith('ERROR')]
     tail = res.stdout.strip().splitlines()[-1] if res.stdout.strip() else ''
+    if errors:      # a mutant that does not even load (stale build, ABI drift) has killed nothing
+      print('=== %s: %d collection / setup ERRORS — rebuild the mutants (python tools/mutation_check.py build)' % (name, len(errors)))
+      failed = []
     results[name or 'product'] = (res.returncode, failed, tail)
     print('=== %s: rc %d  %s' % (name or 'product library', res.returncode, tail))
     for l in failed:
