@@ -10,6 +10,10 @@ grep -h "passed\|failed" $out/pytest_gpu.log | tail -2 | tee -a $out/summary.txt
 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?" | tee -a $out/summary.txt
 bash tools/collect_profiles.sh $R $N > $out/collect.log 2>&1
+# a rank's share of the split (8 / 4 / 2 ranks) under the whole split's plan, and the pass through the reference API
+for w in 8 4 2; do python tools/rank_share.py --world $w --steps 12 --warmup 3 2>/dev/null | tail -1; done > $out/rank_share.jsonl
+python tools/api_path_profile.py --passes 8 2>&1 | grep -v amdgpu.ids > $out/api_path.txt
+python tools/api_path_profile.py --passes 8 --host 1 2>&1 | grep -v amdgpu.ids >> $out/api_path.txt
 python - $out <<'PY' | tee -a $out/summary.txt
 import json, sys
 d = json.loads([l for l in open(sys.argv[1] + '/bench.json') if l.startswith('{')][0])
