@@ -675,16 +675,16 @@ class HostStage(object):
     if not todo:
       return
     self.copy.wait_stream(torch.cuda.current_stream(self.device))
-    self._send(todo)
+    self._send(todo, ops.PUSH_WORKGROUPS_LATE[0])
 
-  def _send(self, todo):
+  def _send(self, todo, workgroups=None):
     for k, t in todo:
       n = t.shape[0]
       dst = self.host[k][self.filled[k]:self.filled[k] + n]
       if PUSH_KERNEL[0]:
         tc = t.contiguous()
         self._keep.append(tc)
-        ops.push_rows(tc, dst, self.copy)
+        ops.push_rows(tc, dst, self.copy, workgroups)
       else:             # the runtime's copy: a chip-wide blit kernel on this image (A/B only)
         with torch.cuda.stream(self.copy):
           dst.copy_(t, non_blocking=True)

@@ -494,12 +494,15 @@ def pull_steps(sched, row_floats, copy_stream, chunk=8):
 
 PUSH_WORKGROUPS = [8]      # workgroups x wavefronts of cmhse_push_rows (tools/api_path_profile.py --push_wgs / --push_waves)
 PUSH_WAVES = [1]
+PUSH_WORKGROUPS_LATE = [32]   # ... for the two level-2 matrices, which leave under the ranking (no chain to disturb)
 
 
-def push_rows(src, dst_pinned, stream):
+def push_rows(src, dst_pinned, stream, workgroups=None):
   """cmhse_push_rows: contiguous device tensor `src` -> page-locked host tensor `dst_pinned` (same
   byte count) as a small kernel on `stream` (a torch stream).  Asynchronous: the caller orders
-  `stream` behind the producer of `src` and synchronises it before reading `dst_pinned`."""
+  `stream` behind the producer of `src` and synchronises it before reading `dst_pinned`.
+  `workgroups`: PUSH_WORKGROUPS by default (beside a step chain: few); more when nothing latency-
+  bound runs beside the copy."""
   _require_cuda(src, 'src')
   if dst_pinned.is_cuda or not dst_pinned.is_pinned():
     raise RuntimeError('push_rows: the destination must be page-locked host memory')
@@ -508,7 +511,8 @@ def push_rows(src, dst_pinned, stream):
   nbytes = src.numel() * src.element_size()
   if nbytes != dst_pinned.numel() * dst_pinned.element_size():
     raise ValueError('push_rows: byte counts differ')
-  rc = _lib.load().cmhse_push_rows(src.data_ptr(), dst_pinned.data_ptr(), nbytes, PUSH_WORKGROUPS[0],
+  rc = _lib.load().cmhse_push_rows(src.data_ptr(), dst_pinned.data_ptr(), nbytes,
+                                   PUSH_WORKGROUPS[0] if workgroups is None else int(workgroups),
                                    PUSH_WAVES[0], ctypes.c_void_p(stream.cuda_stream))
   _lib.check(rc, 'cmhse_push_rows')
 
