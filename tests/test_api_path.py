@@ -71,6 +71,34 @@ def test_staged_arrays_equal_the_device_matrices(small):
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('rnn_type,longer', [('attention', 'visual'), ('attention', 'text'), ('maxout', 'text'),
+                                             ('seq2seq', 'visual')])
+def test_staging_follows_whichever_tower_ends_first(rnn_type, longer):
+  """Each tower's level-1 rows leave for the host behind ITS ready event (cmhse_gru_job.out_ready_event):
+  recorded early for an attention-pooled tower whose chain ends while the other still steps — the
+  visual tower of an ActivityNet batch (long paragraphs), the text tower of a DiDeMo one (80-frame
+  clips, short sentences) — and at the end of the call otherwise (max / last pooling).  Either way the
+  arrays equal the device matrices bit for bit, at a width that runs the LDS-tiled kernels too."""
+  from cmhse_amd import evaluation as ev, ops
+  from cmhse_amd.model import VSE
+  opt = _opt(rnn_type=rnn_type, embed=128, img_dim=40)
+  torch.manual_seed(9)
+  model = VSE(opt)
+  if longer == 'visual':
+    spec = synthetic.ragged_spec(41, seed=3, max_clips=4, max_frames=33, max_words=3, max_video=40)
+  else:
+    spec = synthetic.ragged_spec(41, seed=3, max_clips=6, max_frames=5, max_words=17, max_video=7)
+  loader = synthetic.ListLoader(synthetic.make_batches(spec, 9, opt.img_dim, opt.vocab_size, seed=5))
+  for tiled in (False, True):
+    with ops.tuned(**(dict(tiny_max_seqs=0, mid_max_seqs=0) if tiled else {})):
+      cat, _, _ = ev.encode_data_device(opt, model, loader, logging=_quiet)
+      want = {k: cat[k].cpu().numpy() for k in ev.MATRICES}
+      got = ev.encode_data(opt, model, loader, 10, _quiet)
+    for k, a in zip(ev.MATRICES, got[:6]):
+      np.testing.assert_array_equal(a, want[k], err_msg='%s tiled=%s' % (k, tiled))
+  ev._forget_last_encode()
+
+
 def test_i2t_t2i_are_served_from_the_last_encode_bit_identically(small):
   """train.py:234-236 on the arrays encode_data returned: both calls are served from the ranking
   encode_data queued (2 hits), and equal — report, top-1, ranks — what the calls compute from
