@@ -616,6 +616,9 @@ MATRICES = ('vid_emb', 'para_emb', 'clip_emb', 'cap_emb', 'vid_ctx', 'para_ctx')
 PUSH_KERNEL = [True]     # device-to-host staging by cmhse_push_rows (a few waves) instead of hipMemcpyAsync
 
 
+_STAGE_EVENTS = []
+
+
 class HostStage(object):
   """The device-to-host side of encode_data: six page-locked float32 matrices (what the reference
   builds row by row with `.data.cpu()` + list.extend, evaluation.py:120-125,139-144) filled by
@@ -633,7 +636,8 @@ class HostStage(object):
     self.seen = set()
     self.copy = _copy_stream(device)
     self._keep = []      # the staged device tensors: their ids stay unique until wait()
-    self._events = []    # recycled between groups
+    self._events = _STAGE_EVENTS     # recycled between groups and passes (creating an event beside a
+                                     # busy GPU was seen to stall the host for milliseconds, ops.upload)
 
   def tower_events(self):
     """Two events (visual, text) for gru_pool_fwd_multi(ready_events=): recorded once here so that
@@ -760,7 +764,7 @@ def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_
     r_t, t_t = ops.sim_rank(cat['para_emb'], cat['vid_emb'])
     ranks_host = torch.empty((4, r_i.shape[0]), dtype=torch.int32, pin_memory=True)
     ranks_host.copy_(torch.stack([r_i, t_i, r_t, t_t]), non_blocking=True)
-    ranks_event = torch.cuda.Event()
+    ranks_event = _HOST_EVENTS.pop() if _HOST_EVENTS else torch.cuda.Event()
     ranks_event.record()
   _mark('ranking queued')
   finish_log()          # the per-batch 'Letest' meters (evaluation.py:129), behind everything queued
@@ -770,6 +774,7 @@ def encode_data(opt, model, data_loader, log_step=10, logging=print, contextual_
   arrays = {k: host[k].numpy() for k in MATRICES}
   if ranks_event is not None:
     ranks_event.synchronize()
+    _HOST_EVENTS.append(ranks_event)
     _mark('ranks on the host')
     _LAST_ENCODE[0] = dict(
         vid=weakref.ref(arrays['vid_emb'], _forget_last_encode),

@@ -125,7 +125,11 @@ def cpu_baseline(kind, wl, opt, model, spec, n_sample_batches, n_full, repeats=3
   t_full = t_enc * scale + t_score * scale * scale
   return {
       'value': n_full * n_full / t_full, 'unit': 'pairs/s', 'cores': best_n,
-      'kind': kind, 'host_cpu': _host_cpu_model(), 'host_logical_cpus': ncpu,
+      # "port" = a restatement of the reference's algorithm (oracle/), not the reference's own files (which
+      # cannot travel to the GPU box); `implementation` says which of the two restatements
+      'kind': 'port', 'implementation': ('oracle/cmhse_torch_cpu.py (torch CPU ops: nn.GRU over pack_padded_sequence)'
+                                         if kind == 'torch-cpu' else 'oracle/cmhse_oracle.py (NumPy / OpenBLAS)'),
+      'host_cpu': _host_cpu_model(), 'host_logical_cpus': ncpu,
       'videos_per_s': nv / t_enc, 'passes': repeats,
       'sample': ('%s = %d, the faster of {%s} on two loader batches of this %d-CPU host) on the first '
                  '%d videos (%d loader batches) of the same split: a 2-batch warm-up, median of %d timed '
