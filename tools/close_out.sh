@@ -12,6 +12,9 @@ echo "bench rc=$?" | tee -a $out/summary.txt
 bash tools/collect_profiles.sh $R $N > $out/collect.log 2>&1
 # a rank's share of the split (8 / 4 / 2 ranks) under the whole split's plan, and the pass through the reference API
 for w in 8 4 2; do python tools/rank_share.py --world $w --steps 12 --warmup 3 2>/dev/null | tail -1; done > $out/rank_share.jsonl
+# the 8-rank path at full size on THIS box's GPU(s) (gloo when there are fewer GPUs than ranks): a functional run; its CRC must be the single process's
+Q="--fast_steps 0 --train_steps 0 --host_steps 0 --cpu_batches 0 --rank_check 0 --cached_steps 0 --api_steps 0"
+timeout 900 python bench.py --gpus 8 --steps 2 --warmup 1 $Q > $out/bench_w8.json 2> $out/bench_w8.err
 python tools/api_path_profile.py --passes 8 2>&1 | grep -v amdgpu.ids > $out/api_path.txt
 python tools/api_path_profile.py --passes 8 --host 1 2>&1 | grep -v amdgpu.ids >> $out/api_path.txt
 python - $out <<'PY' | tee -a $out/summary.txt
@@ -25,4 +28,9 @@ print('train', {k: round(v['ms_per_step'], 2) for k, v in d.get('train_steps', {
 print('pcie', d.get('pcie_inclusive', {}).get('ms_per_step'))
 print('dropin_validate', {k: (round(v['ms_per_step'], 2), v.get('vs_device_pass') or v.get('vs_pcie_inclusive')) for k, v in d.get('dropin_validate', {}).items() if isinstance(v, dict)})
 print('fast_mode', {k: d.get('fast_mode', {}).get(k) for k in ('ms_per_step', 'max_abs_embedding_diff_vs_fp32', 'rank_rows_moved_on_correlated_embeddings')})
+try:
+  w8 = json.loads([l for l in open(sys.argv[1] + '/bench_w8.json') if l.startswith('{')][0])
+  print('8 ranks:', w8['config']['backend'], 'crc', w8['ranks_crc32'], 'equal to the single process:', w8['ranks_crc32'] == d['ranks_crc32'])
+except Exception as e:
+  print('8 ranks: no line', e)
 PY
