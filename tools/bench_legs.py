@@ -640,4 +640,8 @@ def dropin_validate_bench(opt, model, loaders, n_steps, crc_of):
                                        'and rank again'}}
   out['api'] = ('cmhse_amd/dropin: evaluation.encode_data -> NumPy 8-tuple -> evaluation.i2t -> evaluation.t2i '
                 '(the body of train.py:223-236)')
+  out['note'] = ('every timed pass encodes the split and ranks both directions ONCE, inside encode_data; i2t / t2i of the '
+                 'same pass report that ranking after comparing the arrays they are handed with the device copies '
+                 '(nothing is carried from one pass to the next: the next encode_data replaces the entry); `recompute` '
+                 'is the same pass with i2t / t2i uploading their arguments and ranking again')
   return out
