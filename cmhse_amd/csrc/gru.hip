@@ -1282,11 +1282,12 @@ extern "C" int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t*
   p.row_floats = row_floats;
   p.t0 = t0;
   p.t1 = t1;
-  // 32 single-wave workgroups, 8 x 16 B in flight per lane: 57 GB/s alone (the PCIe Gen5 x16 rate),
-  // and the smallest footprint that does it — beside the step kernel every resident pull wave
-  // takes a SIMD's free registers, i.e. one of that CU's three step-workgroup slots (sweep in
-  // profiles/r02_upload_pipeline.txt: 16 x 256 threads 358 ms / pass, 128 x 64 422, 32 x 64 330)
-  constexpr int cap = 32, thr = 64;
+  // "pull_waves" (32) single-wave workgroups, 8 x 16 B in flight per lane: 57 GB/s alone (the PCIe Gen5
+  // x16 rate).  Since round 6 a pull wave needs 48 registers and no scratch: it fits beside the two
+  // 232-register workgroups of the step chain on a CU instead of displacing one (gru_rows.hpp).
+  int cap = tunables().pull_waves.load(std::memory_order_relaxed);
+  cap = cap < 1 ? 1 : (cap > 1024 ? 1024 : cap);
+  constexpr int thr = 64;
   const unsigned grid = static_cast<unsigned>(n_active < cap ? n_active : cap);
   hipLaunchKernelGGL(pull_steps_kernel, dim3(grid), dim3(thr), 0,
                      static_cast<hipStream_t>(stream_), p);
@@ -1302,11 +1303,12 @@ extern "C" int cmhse_push_rows(const void* src, void* dst_pinned, size_t bytes, 
     return CMHSE_ERR_ARG;      // (rows of fp32 matrices out of the allocator: always 16-byte aligned)
   const size_t n16 = bytes >> 4;
   const int tail = static_cast<int>(bytes & 15u);
-  unsigned grid = static_cast<unsigned>(workgroups ? workgroups : 8);
-  const unsigned thr = 64u * static_cast<unsigned>(waves ? waves : 1);
-  const size_t need = (n16 + thr - 1) / thr;
+  // workgroups x waves single-wave workgroups (a wave of <= 48 registers fits beside the step chain's
+  // workgroups; wider workgroups would only tie four of them to one CU)
+  unsigned grid = static_cast<unsigned>(workgroups ? workgroups : 8) * static_cast<unsigned>(waves ? waves : 1);
+  const size_t need = (n16 + 511) / 512;
   if (need < grid) grid = static_cast<unsigned>(need ? need : 1);
-  hipLaunchKernelGGL(push_bytes_kernel, dim3(grid), dim3(thr), 0, static_cast<hipStream_t>(stream_),
+  hipLaunchKernelGGL(push_bytes_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream_),
                      static_cast<const float4*>(src), static_cast<float4*>(dst_pinned), n16,
                      static_cast<const unsigned char*>(src) + (n16 << 4),
                      static_cast<unsigned char*>(dst_pinned) + (n16 << 4), tail);

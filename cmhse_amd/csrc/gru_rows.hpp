@@ -65,34 +65,49 @@ struct PullParams {
   int32_t n_active, row_floats, t0, t1;
 };
 
-__global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p) {
-  const unsigned nthr = blockDim.x;
+// Both copy kernels below run BESIDE the step chain, whose 128-row workgroups hold 2 x 232 of a SIMD's
+// 512 vector registers: a copy wave that needs at most 48 fits into what is left and costs the chain
+// no workgroup slot; one that needs more (round 5's pull: 68 + 144 B of scratch for its `float4 v[8]`,
+// round 6's first push: 56) displaces a chain workgroup wherever it lands (the level-2 chain went
+// from 3.1 to 5.1 ms beside 32 such waves, profiles/r06_api_path.txt).  Hence: single-wave workgroups,
+// wave-uniform values forced into scalar registers, eight named 16-byte registers in flight per lane
+// with compile-time strides (one address register pair per direction) — 48 and 44 registers, no scratch.
+__device__ __forceinline__ uint64_t wave_uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// n16 16-byte units from src to dst (both 16-byte aligned, wave-uniform) by ONE wavefront.
+__device__ __forceinline__ void wave_copy16(uint64_t src, uint64_t dst, uint32_t n16) {
+  constexpr uint32_t chunk = 8 * 64;
+  const uint32_t nchunks = n16 / chunk;
+  const float4* sp = reinterpret_cast<const float4*>(src) + threadIdx.x;
+  float4* dp = reinterpret_cast<float4*>(dst) + threadIdx.x;
+  for (uint32_t c = 0; c < nchunks; ++c, sp += chunk, dp += chunk) {
+    const float4 v0 = sp[0], v1 = sp[64], v2 = sp[128], v3 = sp[192];
+    const float4 v4 = sp[256], v5 = sp[320], v6 = sp[384], v7 = sp[448];
+    dp[0] = v0; dp[64] = v1; dp[128] = v2; dp[192] = v3;
+    dp[256] = v4; dp[320] = v5; dp[384] = v6; dp[448] = v7;
+  }
+  for (uint32_t i = nchunks * chunk + threadIdx.x; i < n16; i += 64)
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+}
+
+__global__ __launch_bounds__(64) void pull_steps_kernel(const PullParams p) {
   for (int s = blockIdx.x; s < p.n_active; s += gridDim.x) {
-    const int len = p.lens[s];
+    const int len = __builtin_amdgcn_readfirstlane(p.lens[s]);
     const int te = (p.t1 < len) ? p.t1 : len;
     if (te <= p.t0) break;     // sorted longest first: every later sequence is shorter still
-    const size_t off = static_cast<size_t>(p.t0) * p.row_floats * 4u;
-    const size_t n = static_cast<size_t>(te - p.t0) * p.row_floats;
-    const rowaddr_t src = p.src_rows[s] + off, dst = p.dst_rows[s] + off;
+    const uint64_t off = static_cast<uint64_t>(p.t0) * p.row_floats * 4u;
+    const uint64_t n = static_cast<uint64_t>(te - p.t0) * p.row_floats;
+    const uint64_t src = wave_uniform64(p.src_rows[s]) + off, dst = wave_uniform64(p.dst_rows[s]) + off;
     if (((src | dst) & 15u) == 0 && (n & 3u) == 0) {
-      const float4* sp = reinterpret_cast<const float4*>(src);
-      float4* dp = reinterpret_cast<float4*>(dst);
-      const size_t n4 = n >> 2;
-      size_t i = threadIdx.x;
-      // eight 16-byte PCIe reads in flight per lane: few waves must keep the link busy, because
-      // every resident pull wave costs the MFMA-bound step kernel beside it a workgroup slot
-      for (; i + 7 * nthr < n4; i += 8 * nthr) {
-        float4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = sp[i + q * nthr];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dp[i + q * nthr] = v[q];
-      }
-      for (; i < n4; i += nthr) dp[i] = sp[i];
+      wave_copy16(src, dst, static_cast<uint32_t>(n >> 2));   // (one sequence's steps [t0, t1): far below 2^32 units)
     } else {
       const float* sp = reinterpret_cast<const float*>(src);
       float* dp = reinterpret_cast<float*>(dst);
-      for (size_t i = threadIdx.x; i < n; i += nthr) dp[i] = sp[i];
+      for (uint64_t i = threadIdx.x; i < n; i += 64) dp[i] = sp[i];
     }
   }
 }
@@ -105,21 +120,25 @@ __global__ __launch_bounds__(kThreads) void pull_steps_kernel(const PullParams p
 // 2 ms and the launches queued behind it by another (profiles/r06_api_path.txt).  PCIe writes are
 // posted: a few dozen waves keep the link full.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void push_bytes_kernel(const float4* __restrict__ src,
-                                                        float4* __restrict__ dst, size_t n16,
-                                                        const unsigned char* __restrict__ src_tail,
-                                                        unsigned char* __restrict__ dst_tail, int tail) {
-  const size_t nthr = static_cast<size_t>(gridDim.x) * blockDim.x;
-  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  for (; i + 7 * nthr < n16; i += 8 * nthr) {
-    float4 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = src[i + q * nthr];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) dst[i + q * nthr] = v[q];
+__global__ __launch_bounds__(64) void push_bytes_kernel(const float4* __restrict__ src,
+                                                       float4* __restrict__ dst, size_t n16,
+                                                       const unsigned char* __restrict__ src_tail,
+                                                       unsigned char* __restrict__ dst_tail, int tail) {
+  // wavefront w of G owns the chunks w, w + G, ... of 8 x 64 units; the first one also the ragged end
+  constexpr size_t chunk = 8 * 64;
+  const size_t nchunks = n16 / chunk;
+  for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const float4* sp = src + c * chunk + threadIdx.x;
+    float4* dp = dst + c * chunk + threadIdx.x;
+    const float4 v0 = sp[0], v1 = sp[64], v2 = sp[128], v3 = sp[192];
+    const float4 v4 = sp[256], v5 = sp[320], v6 = sp[384], v7 = sp[448];
+    dp[0] = v0; dp[64] = v1; dp[128] = v2; dp[192] = v3;
+    dp[256] = v4; dp[320] = v5; dp[384] = v6; dp[448] = v7;
   }
-  for (; i < n16; i += nthr) dst[i] = src[i];
-  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  if (blockIdx.x == 0) {
+    for (size_t i = nchunks * chunk + threadIdx.x; i < n16; i += 64) dst[i] = src[i];
+    if (static_cast<int>(threadIdx.x) < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  }
 }
 
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has

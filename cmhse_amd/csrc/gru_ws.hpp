@@ -66,7 +66,8 @@ struct GruWs {
   X(tn_rows_bm, 0)            /* tile height of the weight-gradient products: 128, 192, or 0 = by shape (tn_rows.hpp) */ \
   X(chain_min_steps, 2)       /* consecutive LDS-tiled inference steps from which they are ONE launch of gru_step_chain_kernel */ \
   X(early_xproj, 1)           /* 1: an inference call's hoisted projection starts on the side stream before the first step */ \
-  X(chain_tall_min_wgs, 256)  /* 64-row workgroups per step from which a step chain uses 128-row tiles */
+  X(chain_tall_min_wgs, 256)  /* 64-row workgroups per step from which a step chain uses 128-row tiles */ \
+  X(pull_waves, 32)           /* single-wave workgroups of one cmhse_pull_steps launch (host -> HBM over PCIe) */
 
 struct Tunables {
 #define CMHSE_TUNABLE_MEMBER_(name, dflt) std::atomic<int> name{dflt};

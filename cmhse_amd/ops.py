@@ -95,7 +95,7 @@ def tune(name, value=-1):
   are initialised from.  Names: tiny_max_seqs, mid_max_seqs, mid_units, mid_waves,
   tall_tile_min_wgs, mid_tall_min_seqs, bwd_mid_max_seqs, bwd_split_min_seqs, bwd_tail_min_steps,
   fwd_tail_min_steps, bwd_chunk_rows, xproj_chunk_rows, tn_rows_bm, chain_min_steps, early_xproj,
-  chain_tall_min_wgs, resident_timeout_ms (include/cmhse_hip.h)."""
+  chain_tall_min_wgs, pull_waves, resident_timeout_ms (include/cmhse_hip.h)."""
   ctx = TuneContext.current()
   if ctx is not None:
     return ctx.tune(name, value)

@@ -489,6 +489,7 @@ int cmhse_timer_tiled(void* timer, float* ms_host, double* flops_host, double* b
  *                             every product's row count (3H, H) is a whole number of them, else 128
  *                             (the row split into parts follows the tile count, i.e. the gradients
  *                             to fp32 rounding; profiles/r04_wgrad_rate.txt)
+ *   "pull_waves"          32  single-wave workgroups of one cmhse_pull_steps launch
  *   "multi_step_off"       0  (not a crossover, and per DEVICE rather than per context) 1 while the
  *                             multi-step kernels are switched off on the calling thread's current device
  *                             after an acknowledged timeout (cmhse_async_status below); readable, and

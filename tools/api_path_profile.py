@@ -30,12 +30,15 @@ def main():
   ap.add_argument('--push_wgs', type=int, default=8, help='workgroups of cmhse_push_rows')
   ap.add_argument('--push_waves', type=int, default=1, help='wavefronts per workgroup of cmhse_push_rows')
   ap.add_argument('--late_wgs', type=int, default=32, help='workgroups for the two level-2 matrices')
+  ap.add_argument('--pull_waves', type=int, default=0, help='cmhse_tune pull_waves (0 = default)')
   ap.add_argument('--brief', type=int, default=0)
   ap.add_argument('--blit', type=int, default=0, help='1: stage with hipMemcpyAsync instead (A/B)')
   args = ap.parse_args()
   ops.PUSH_WORKGROUPS[0] = args.push_wgs
   ops.PUSH_WAVES[0] = args.push_waves
   ops.PUSH_WORKGROUPS_LATE[0] = args.late_wgs
+  if args.pull_waves:
+    ops.tune('pull_waves', args.pull_waves)
   ev.PUSH_KERNEL[0] = not args.blit
   print('staging: %s' % ('hipMemcpyAsync' if args.blit else
                          'cmhse_push_rows, %d workgroups x %d waves' % (args.push_wgs, args.push_waves)))
