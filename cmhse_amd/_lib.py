@@ -81,6 +81,7 @@ SIGNATURES = {
     'cmhse_pull_steps': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                         c_int32, c_void_p]),
     'cmhse_push_rows': (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
+    'cmhse_rows_differ': (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     'cmhse_pad_rows': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p]),
     'cmhse_l2norm_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),

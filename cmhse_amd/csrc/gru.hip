@@ -1315,6 +1315,24 @@ extern "C" int cmhse_push_rows(const void* src, void* dst_pinned, size_t bytes, 
   return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
 }
 
+extern "C" int cmhse_rows_differ(const void* a, const void* b, size_t bytes, int32_t* flag, void* stream_) {
+  if (!flag || ((!a || !b) && bytes)) return CMHSE_ERR_ARG;
+  if (bytes == 0) return CMHSE_OK;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15u) return CMHSE_ERR_ARG;
+  const size_t n16 = bytes >> 4;
+  const int tail = static_cast<int>(bytes & 15u);
+  // nothing latency-bound runs beside this check: enough waves to keep the link full with four
+  // 16-byte reads in flight per lane
+  unsigned grid = 64;
+  const size_t need = (n16 + 255) / 256;
+  if (need < grid) grid = static_cast<unsigned>(need ? need : 1);
+  hipLaunchKernelGGL(rows_differ_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     static_cast<const uint4*>(a), static_cast<const uint4*>(b), n16,
+                     static_cast<const unsigned char*>(a) + (n16 << 4),
+                     static_cast<const unsigned char*>(b) + (n16 << 4), tail, flag);
+  return (hipGetLastError() == hipSuccess) ? CMHSE_OK : CMHSE_ERR_LAUNCH;
+}
+
 extern "C" int cmhse_pad_rows(const void* src, const int64_t* first_row, const int32_t* lens,
                               int32_t S, int32_t Tmax, int32_t row_bytes, void* dst, void* stream_) {
   if (!src || !first_row || !lens || !dst || S < 0 || Tmax < 0 || row_bytes <= 0 || row_bytes % 4 != 0)

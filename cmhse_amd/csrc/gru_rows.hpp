@@ -141,6 +141,39 @@ __global__ __launch_bounds__(64) void push_bytes_kernel(const float4* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Do two byte ranges hold the same bytes?  `a` may be page-locked HOST memory (read zero-copy over
+// PCIe), `b` is device memory: evaluation.i2t / t2i use it to check that the NumPy arrays they are
+// handed still hold what encode_data wrote before they report the ranking encode_data queued.  One
+// pass at the link's rate, nothing staged on the device; *flag is OR-ed with 1 on the first difference.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rows_differ_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                        size_t n16, const unsigned char* __restrict__ a_tail,
+                                                        const unsigned char* __restrict__ b_tail, int tail,
+                                                        int32_t* __restrict__ flag) {
+  constexpr size_t chunk = 4 * 64;
+  const size_t nchunks = n16 / chunk;
+  unsigned diff = 0;
+  for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const uint4* ap = a + c * chunk + threadIdx.x;
+    const uint4* bp = b + c * chunk + threadIdx.x;
+    const uint4 a0 = ap[0], a1 = ap[64], a2 = ap[128], a3 = ap[192];
+    const uint4 b0 = bp[0], b1 = bp[64], b2 = bp[128], b3 = bp[192];
+    diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w);
+    diff |= (a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w);
+    diff |= (a2.x ^ b2.x) | (a2.y ^ b2.y) | (a2.z ^ b2.z) | (a2.w ^ b2.w);
+    diff |= (a3.x ^ b3.x) | (a3.y ^ b3.y) | (a3.z ^ b3.z) | (a3.w ^ b3.w);
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = nchunks * chunk + threadIdx.x; i < n16; i += 64) {
+      const uint4 x = a[i], y = b[i];
+      diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    }
+    if (static_cast<int>(threadIdx.x) < tail) diff |= static_cast<unsigned>(a_tail[threadIdx.x] ^ b_tail[threadIdx.x]);
+  }
+  if (__builtin_amdgcn_ballot_w64(diff != 0) != 0 && threadIdx.x == 0) atomicOr(flag, 1);
+}
+
 // bf16x3 pre-split of a weight matrix W [R, K] (fp32, row stride K): row r of `out` has
 // split_ld(K) float units; per 16-k chunk 8 dwords of hi pairs then 8 dwords of lo pairs
 // (k beyond K zero-filled), see nt_phase_bf3.

@@ -517,6 +517,25 @@ def push_rows(src, dst_pinned, stream, workgroups=None):
   _lib.check(rc, 'cmhse_push_rows')
 
 
+def rows_differ(pairs):
+  """cmhse_rows_differ over [(a, b)]: a = page-locked host tensor (read in place over PCIe) or device
+  tensor, b = device tensor of the same byte count.  True when any pair differs in any byte.  One
+  small readback; synchronises the current stream."""
+  lib = _lib.load()
+  dev = pairs[0][1].device
+  flag = torch.zeros(1, dtype=torch.int32, device=dev)
+  for a, b in pairs:
+    _require_cuda(b, 'b')
+    if not (a.is_cuda or a.is_pinned()) or not a.is_contiguous() or not b.is_contiguous():
+      raise RuntimeError('rows_differ: `a` must be contiguous device or page-locked host memory')
+    na, nb = a.numel() * a.element_size(), b.numel() * b.element_size()
+    if na != nb:
+      return True
+    _lib.check(lib.cmhse_rows_differ(a.data_ptr(), b.data_ptr(), na, flag.data_ptr(), _stream()),
+               'cmhse_rows_differ')
+  return bool(flag.item())
+
+
 def _prepare_fwd(weights, pool_mode, lens, I, H, device, x_ptrs=None, tok_ptrs=None,
                  emb_table=None, h0_ptrs=None, out=None, save_for_backward=False,
                  constant_input=False, sched=None, step_events=None, side=True, step_plan=None):

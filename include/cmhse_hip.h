@@ -227,6 +227,13 @@ int cmhse_pull_steps(const uint64_t* src_rows_pinned, const uint64_t* dst_rows, 
 int cmhse_push_rows(const void* src, void* dst_pinned, size_t bytes, int32_t workgroups, int32_t waves,
                     void* stream);
 
+/* Do `bytes` bytes at `a` and at `b` differ?  `a`: device memory or page-locked host memory that the
+ * device can read (read in place, over PCIe); `b`: device memory; both 16-byte aligned.  ORs 1 into
+ * the device word *flag (zeroed by the caller) when they do.  evaluation.i2t / t2i (evaluation.py:
+ * 160-213) use it to make sure the NumPy arrays they are handed still hold what encode_data wrote
+ * before they report the ranking encode_data already queued on the device copies.  Asynchronous. */
+int cmhse_rows_differ(const void* a, const void* b, size_t bytes, int32_t* flag, void* stream);
+
 /* The padding half of the loader's collate_fn (activity_net/data.py:114-150, didemo_dev/data.py:
  * 133-165) as an index kernel: S ragged sequences stored back to back, row r of sequence s at
  * src + (first_row[s] + r) * row_bytes (frame features: row_bytes = 4 * img_dim; token ids: 8), are

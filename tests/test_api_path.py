@@ -178,3 +178,22 @@ def test_push_rows_moves_exactly_the_bytes(nbytes):
   assert bool((dst[nbytes:] == 7).all())
   with pytest.raises(RuntimeError):
     ops.push_rows(src, torch.empty(nbytes, dtype=torch.uint8), stream)        # pageable destination
+
+
+def test_rows_differ_sees_single_bits_anywhere():
+  """cmhse_rows_differ: pinned-host against device bytes, sizes with ragged ends, one flipped bit at
+  the first, a middle and the very last byte."""
+  from cmhse_amd import ops
+  dev = torch.device('cuda', 0)
+  for nbytes in (16, 4096 * 5 + 16 * 3, (1 << 20) + 16):
+    base = torch.randint(0, 256, (nbytes,), dtype=torch.uint8)
+    d = base.to(dev)
+    h = base.clone().pin_memory()
+    assert ops.rows_differ([(h, d)]) is False
+    assert ops.rows_differ([(d.clone(), d)]) is False            # device against device
+    for pos in (0, nbytes // 2 + 1, nbytes - 1):
+      h2 = base.clone()
+      h2[pos] ^= 0x10
+      assert ops.rows_differ([(h2.pin_memory(), d)]) is True, (nbytes, pos)
+    if nbytes > 16:
+      assert ops.rows_differ([(h, d), (h[:nbytes - 16].clone().pin_memory(), d)]) is True   # sizes differ

@@ -75,14 +75,26 @@ def main():
   for fn in (device_pass, api_pass):
     fn(); fn()
     torch.cuda.synchronize()
+  import gc
+  gc_log = []
+  gc.callbacks.append(lambda phase, info, _t=[0.0]: (_t.__setitem__(0, time.perf_counter()) if phase == 'start' else
+                                                      gc_log.append((info.get('generation'), (time.perf_counter() - _t[0]) * 1e3))))
   for name, fn in (('device pass', device_pass), ('api pass', api_pass)):
     ts = []
     for _ in range(args.passes):
       torch.cuda.synchronize()
+      del gc_log[:]
+      if name == 'api pass':
+        ev.TRACE = [('start', time.perf_counter())]
       t0 = time.perf_counter()
       fn()
       torch.cuda.synchronize()
       ts.append((time.perf_counter() - t0) * 1e3)
+      if name == 'api pass':
+        marks, ev.TRACE = ev.TRACE, None
+        if ts[-1] > 1.1 * min(ts):
+          print('  slow api pass %.1f ms: gc %s; phases %s' % (ts[-1], [(g, round(m, 1)) for g, m in gc_log if m > 1.0],
+                ['%s %.1f' % (b[0][:28], (b[1] - a[1]) * 1e3) for a, b in zip(marks[:-1], marks[1:]) if (b[1] - a[1]) > 2e-3]))
     print('%-12s ms per pass: %s  median %.2f' % (name, ' '.join('%.2f' % t for t in ts), float(np.median(ts))))
   if args.brief:
     return
