@@ -213,7 +213,9 @@ def main():
   # first: every rank derives the same assignment from the split's sizes alone
   costs = [parallel_eval.batch_cost(lc, lv, lw, lp, wl['img_dim'], 300, args.embed)
            for lc, lv, lw, lp in synthetic.batch_lengths(spec, wl['batch'])]
-  assignment = parallel_eval.assign_batches(costs, world)
+  _lens = synthetic.batch_lengths(spec, wl['batch'])
+  tail_from = parallel_eval.tail_horizon(np.concatenate([np.concatenate([lw, lp]) for _, _, lw, lp in _lens]))
+  assignment = parallel_eval.assign_batches(costs, world, tail_from=tail_from)
   batches = build_loader(spec, wl, device, assignment[rank])
   N = spec.n_videos
   quiet = lambda *a, **k: None
@@ -356,7 +358,8 @@ def main():
                    'rnn_type': args.rnn_type,
                    'step': 'encode_data + i2t + t2i over the split, ranks on the host and the '
                            'Recall@K / median-rank report computed (evaluation.py:173-184)',
-                   'sharding': 'loader batches dealt to ranks by GRU work (longest paragraph first), one all-gather of the embeddings, row-stripe scoring',
+                   'sharding': 'loader batches dealt to ranks by GRU work + the per-rank tail of its longest paragraph '
+                               '(parallel_eval.assign_batches), one all-gather of the embeddings, row-stripe scoring',
                    'schedule_cache': 'none: every timed pass rebuilds its packed schedules (sequence sort, '
                                      'step counts, pointer tables) as the reference does (layers.py:94-97); '
                                      '`cached_schedule_pass` times the opt-in that keeps them for a resident split',

@@ -4,10 +4,10 @@ The reference is single-GPU (train.py:101) and has no collective anywhere; this 
 data-parallel sharding the path offers: videos/paragraphs are independent units.
 
   1. the loader's batches are dealt to ranks by WORK, not by count (`assign_batches`): the cost of a
-     batch is its frame steps and word steps priced by the GRU step they feed, the batches are
-     placed longest-paragraph-first on the least-loaded rank, so the long few-sequence tails of the
-     text chain (which do not shrink with the world size) are spread over the ranks; rank r encodes
-     its batches with replicated weights;
+     batch is its frame steps and word steps priced by the GRU step they feed, plus — per RANK — the
+     few-sequence tail its longest paragraph brings (which does not shrink with the world size): the
+     batches with the few very long paragraphs share a rank that is dealt less work, the deal
+     minimises the slowest rank; rank r encodes its batches with replicated weights;
   2. ONE exchange step: all-gather of the L2-normalised [n_r, D] video and paragraph embeddings
      (RCCL over xGMI under backend "nccl"; `all_gather_into_tensor`, shards padded to the largest);
   3. rank r scores its own ROW STRIPE: V[stripe] . P^T for i2t and P[stripe] . V^T for t2i with the
@@ -54,10 +54,24 @@ def batch_cost(len_clip, len_vid, len_cap, len_par, img_dim, word_dim=300, hidde
   return work, int(np.max(len_par)) if len(len_par) else 0
 
 
-def assign_batches(costs, world):
-  """Deal batches to ranks: longest chain first (ties: most work first), each onto the rank with
-  the least work so far (ties: lowest rank).  `costs` = [(work, chain)] per batch.  Returns a list
-  of `world` ascending batch-index lists; deterministic, so every rank computes the same one."""
+# What ONE step of the text tower's few-sequence tail costs a rank, expressed in GRU FLOPs of its step
+# chain: ~21 us per dependent small-batch launch (a 608-video share: 363 tail steps in 7.7 ms) at the
+# ~125 TFLOP/s a share's chain runs at (profiles/r05_rank_share.txt).  Only its ORDER of magnitude
+# matters: it prices the tail a rank pays for its longest paragraph against the work it is dealt.
+TAIL_STEP_FLOPS = 2.6e9
+
+
+def tail_horizon(text_lens, threshold=1024):
+  """The time step from which the text tower of the WHOLE split runs on the small-batch kernels:
+  the number of leading steps with more than `threshold` (tiny_max_seqs) sequences still active over
+  all sentence and paragraph lengths.  A rank's tail is what its longest paragraph has beyond it."""
+  text_lens = np.asarray(text_lens, dtype=np.int64).reshape(-1)
+  if text_lens.size == 0:
+    return 0
+  return int((ops.step_counts(text_lens) > threshold).sum())
+
+
+def _lpt(costs, world):
   order = sorted(range(len(costs)), key=lambda i: (-costs[i][1], -costs[i][0], i))
   load = [0.0] * world
   out = [[] for _ in range(world)]
@@ -65,6 +79,81 @@ def assign_batches(costs, world):
     r = min(range(world), key=lambda q: (load[q], q))
     out[r].append(i)
     load[r] += max(costs[i][0], 1e-9)
+  return [sorted(o) for o in out]
+
+
+def assign_batches(costs, world, tail_from=None, tail_flops=TAIL_STEP_FLOPS):
+  """Deal batches to ranks.  `costs` = [(work, chain)] per batch: GRU FLOPs, longest paragraph.
+  Returns `world` ascending batch-index lists; deterministic, so every rank computes the same one.
+
+  A rank's pass is its step chain (its WORK at the matrix pipe's rate) followed by the text tower's
+  tail: one dependent small-batch launch per word its LONGEST paragraph has beyond `tail_from` (the
+  step from which the whole split's text tower is small-batch, tail_horizon()) — a cost per rank,
+  not per batch, that does not shrink with the world size (ActivityNet val: the longest paragraphs
+  have 309-435 words, a typical batch's longest 140; 363 tail steps are 7.7 of a 608-video share's
+  40 ms).  With `tail_from` the deal minimises max over ranks of work + tail_flops * tail steps:
+  the few batches with very long paragraphs go to the SAME rank, which is dealt that much less work,
+  instead of one to every rank (round 6; 8 ranks: 40.3 -> 36-37 ms per share,
+  profiles/r06_rank_share.txt).  Without it (a loader that only says how many videos a batch has):
+  longest chain first onto the least-loaded rank, as before.  Integer ranks do not depend on the
+  deal (step plan)."""
+  n = len(costs)
+  if tail_from is None or world <= 1 or n == 0:
+    return _lpt(costs, world)
+  key = (world, int(tail_from), float(tail_flops), tuple(costs))
+  if key in _DEALS:                      # (a validation loop deals the same split every epoch)
+    return [list(r) for r in _DEALS[key]]
+  out = _tail_aware_deal(costs, world, tail_from, tail_flops)
+  if len(_DEALS) >= 8:
+    _DEALS.pop(next(iter(_DEALS)))
+  _DEALS[key] = [tuple(r) for r in out]
+  return out
+
+
+_DEALS = {}
+
+
+def _tail_aware_deal(costs, world, tail_from, tail_flops):
+  n = len(costs)
+  tail = lambda chain: tail_flops * max(0, int(chain) - int(tail_from))
+  order = sorted(range(n), key=lambda i: (-costs[i][1], -costs[i][0], i))
+  total = float(sum(c[0] for c in costs))
+
+  def caps_for(limit):
+    """Ranks filled one after another with the batches in chain order (so the long paragraphs
+    share ranks) up to `limit` of work + tail each: the longest paragraph of every rank, or None when
+    the batches need more than `world` ranks."""
+    caps, load, cap = [], 0.0, None
+    for i in order:
+      w, chain = costs[i]
+      if cap is None:
+        cap, load = chain, 0.0
+      elif load + w > limit - tail(cap):
+        caps.append(cap)
+        if len(caps) >= world:
+          return None
+        cap, load = chain, 0.0
+      load += w
+    caps.append(cap)
+    return caps + [0] * (world - len(caps))
+
+  lo, hi = total / world, total + tail(costs[order[0]][1])
+  for _ in range(32):                    # bisection on the makespan of that contiguous packing
+    mid = 0.5 * (lo + hi)
+    if caps_for(mid) is None:
+      lo = mid
+    else:
+      hi = mid
+  caps = caps_for(hi)
+  # ... then the batches by work onto the least-loaded rank whose cap admits their longest paragraph
+  # (moving a batch to a rank that already pays for a longer paragraph is free)
+  load = [tail(c) for c in caps]
+  out = [[] for _ in range(world)]
+  for i in sorted(range(n), key=lambda i: (-costs[i][0], -costs[i][1], i)):
+    w, chain = costs[i]
+    r = min((q for q in range(world) if caps[q] >= chain), key=lambda q: (load[q], q))
+    out[r].append(i)
+    load[r] += max(w, 1e-9)
   return [sorted(o) for o in out]
 
 
@@ -80,6 +169,15 @@ def costs_of(batches, img_dim=None):
     I = img_dim if img_dim is not None else (int(b[0].shape[2]) if hasattr(b[0], 'shape') else 1024)
     out.append(batch_cost(np.asarray(b[4]), np.asarray(b[6]), np.asarray(b[5]), np.asarray(b[7]), I))
   return out
+
+
+def tail_horizon_of(batches):
+  """tail_horizon() of a loader's batches from their sentence / paragraph length members, or None
+  when any batch carries none (a stub: the deal must be a function of what all ranks see alike)."""
+  if any(b[5] is None or b[7] is None for b in batches):
+    return None
+  return tail_horizon(np.concatenate([np.asarray(b[5], dtype=np.int64).reshape(-1) for b in batches] +
+                                     [np.asarray(b[7], dtype=np.int64).reshape(-1) for b in batches]))
 
 
 def _default_encode(opt, model, batches, plan=None, step_plan=None):
@@ -250,7 +348,7 @@ def validate_sharded(opt, model, data_loader, group=None, encode_fn=None, rank_f
   me = dist.get_rank(group)
   batches = list(data_loader)
   if assignment is None:
-    assignment = assign_batches(costs_of(batches), world)
+    assignment = assign_batches(costs_of(batches), world, tail_from=tail_horizon_of(batches))
     _same_on_all_ranks(assignment, group, device)
   if encode_fn is None:
     if step_plan is None:

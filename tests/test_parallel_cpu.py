@@ -177,9 +177,9 @@ def test_shard_range_is_a_partition():
 
 
 def test_assign_batches_balances_work_and_spreads_the_long_chains():
-  """The deal is a partition, deterministic, balanced by work to within one batch, and puts the
-  batches with the longest paragraphs (the tails that do not shrink with the world size) on
-  different ranks."""
+  """Without a tail horizon (a loader that only says how many videos a batch has) the deal is a
+  partition, deterministic, balanced by work to within one batch, and puts the batches with the
+  longest paragraphs on different ranks (round 5's deal)."""
   from cmhse_amd import parallel_eval, synthetic
   spec = synthetic.anet_like_spec(4917, seed=0)
   costs = [parallel_eval.batch_cost(lc, lv, lw, lp, 2048)
@@ -195,6 +195,42 @@ def test_assign_batches_balances_work_and_spreads_the_long_chains():
     top = sorted(range(len(costs)), key=lambda i: -costs[i][1])[:world]
     owners = {r for r in range(world) for i in a[r] if i in top}
     assert len(owners) == world
+
+
+def test_tail_aware_deal_gathers_the_long_paragraphs_and_lowers_the_slowest_rank():
+  """With the split's tail horizon (round 6) a rank is priced work + TAIL_STEP_FLOPS x the words its
+  longest paragraph has beyond the horizon: the deal stays a deterministic partition, the outlier
+  paragraphs (309-435 words on this split; a typical batch's longest: 140) share ONE rank, which is
+  dealt less work, and the modelled finish time of the slowest rank drops by ~9 % at 8 ranks against
+  the work-only deal."""
+  from cmhse_amd import parallel_eval, synthetic
+  spec = synthetic.anet_like_spec(4917, seed=0)
+  lens = synthetic.batch_lengths(spec, 32)
+  costs = [parallel_eval.batch_cost(lc, lv, lw, lp, 2048) for lc, lv, lw, lp in lens]
+  horizon = parallel_eval.tail_horizon(np.concatenate([np.concatenate([lw, lp]) for _, _, lw, lp in lens]))
+  assert 40 <= horizon <= 120                       # (72 on this split: where 22 k text sequences drop to 1024 active)
+  K = parallel_eval.TAIL_STEP_FLOPS
+  finish = lambda deal: [sum(costs[i][0] for i in r) + K * max(0, max(costs[i][1] for i in r) - horizon) for r in deal]
+  for world in (2, 4, 8):
+    new = parallel_eval.assign_batches(costs, world, tail_from=horizon)
+    assert new == parallel_eval.assign_batches(list(costs), world, tail_from=horizon)        # (memoised or not)
+    assert sorted(i for r in new for i in r) == list(range(len(costs)))
+    old = parallel_eval.assign_batches(costs, world)
+    assert max(finish(new)) < max(finish(old))
+    longest = [max(costs[i][1] for i in r) for r in new]
+    assert longest == sorted(longest, reverse=True)
+    outliers = [i for i in range(len(costs)) if costs[i][1] >= 300]
+    assert len(outliers) == 5 and all(i in new[0] for i in outliers)
+    if world == 8:
+      assert max(finish(new)) < 0.93 * max(finish(old))
+      assert sum(costs[i][0] for i in new[0]) < 0.9 * max(sum(costs[i][0] for i in r) for r in new[1:])
+  # one rank, or no horizon: the old deal
+  assert parallel_eval.assign_batches(costs, 1, tail_from=horizon) == [list(range(len(costs)))]
+  # a split whose text tower never leaves the tiled regime pays no tail: the deal is balanced by work
+  short = [(c[0], 10) for c in costs]
+  d = parallel_eval.assign_batches(short, 4, tail_from=horizon)
+  load = [sum(short[i][0] for i in r) for r in d]
+  assert max(load) - min(load) <= max(c[0] for c in short) + 1e-6
 
 
 def test_batch_lengths_match_the_materialised_batches():
@@ -316,7 +352,8 @@ def _first_contact_worker(rank, world, port, out_dir):
   torch.set_num_threads(1)
   dist.init_process_group('gloo', rank=rank, world_size=world)
   spec, lens, costs = _full_split_lengths()
-  assignment = parallel_eval.assign_batches(costs, world)      # bench.py:197-199
+  horizon = parallel_eval.tail_horizon(np.concatenate([np.concatenate([lw, lp]) for _, _, lw, lp in lens]))
+  assignment = parallel_eval.assign_batches(costs, world, tail_from=horizon)      # bench.py's deal
   own = set(assignment[rank])
   a, b = synthetic.correlated_embeddings(N_FULL, D_FAKE, 2.0, seed=3)
   # the rank's loader as bench_common.build_loader makes it: own batches carry their length members
@@ -359,7 +396,7 @@ def _first_contact_worker(rank, world, port, out_dir):
 
 def test_eight_rank_first_contact_at_the_real_split_sizes(tmp_path, oracle):
   """8 gloo ranks over the N = 4917 split's LENGTHS (no features, fake embeddings keyed by the
-  global video index): every rank derives bench.py's by-work deal, holds a 544-704 video share,
+  global video index): every rank derives bench.py's deal (work + the tail of the rank's longest paragraph), holds a 480-704 video share,
   agrees on the whole split's step plan, all-gathers shards padded to the largest, scores its own
   [row0, row0 + nrows) stripe of the full 4917-row gallery, and the merged ranks / top-1 come out
   in loader order equal to the single-process oracle's."""
@@ -367,12 +404,14 @@ def test_eight_rank_first_contact_at_the_real_split_sizes(tmp_path, oracle):
   world = 8
   mp.spawn(_first_contact_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
   spec, lens, costs = _full_split_lengths()
-  assignment = parallel_eval.assign_batches(costs, world)
+  horizon = parallel_eval.tail_horizon(np.concatenate([np.concatenate([lw, lp]) for _, _, lw, lp in lens]))
+  assignment = parallel_eval.assign_batches(costs, world, tail_from=horizon)
   sizes = [min(N_FULL, b0 + B_FULL) - b0 for b0 in range(0, N_FULL, B_FULL)]
   counts = [sum(sizes[i] for i in assignment[r]) for r in range(world)]
-  assert sum(counts) == N_FULL and min(counts) >= 544 and max(counts) <= 704, counts
+  assert sum(counts) == N_FULL and min(counts) >= 480 and max(counts) <= 704, counts
   work = [sum(costs[i][0] for i in assignment[r]) for r in range(world)]
-  assert max(work) / min(work) < 1.06                 # the deal balances GRU work (to one batch), not video counts
+  assert max(work[1:]) / min(work[1:]) < 1.06         # the deal balances GRU work (to one batch), not video counts
+  assert work[0] < min(work[1:])                      # ... and the rank that pays for the longest paragraphs gets less of it
   # the whole split's plan from its lengths alone
   full = []
   for bi, (lc, lv, lw, lp) in enumerate(lens):

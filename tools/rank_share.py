@@ -49,6 +49,8 @@ def main():
   ap.add_argument('--workload', default='anet_icep_val', choices=sorted(WORKLOADS))
   ap.add_argument('--rnn_type', default='attention')
   ap.add_argument('--embed', type=int, default=1024)
+  ap.add_argument('--deal', default='tail', choices=['tail', 'lpt'],
+                  help="tail: the deal prices a rank's longest paragraph (round 6); lpt: work only, longest paragraph first (round 5)")
   ap.add_argument('--tune', default='', help='crossovers to move for the run: name=value,name=value (ops.tune)')
   args = ap.parse_args()
   for kv in [x for x in args.tune.split(',') if x]:
@@ -63,7 +65,8 @@ def main():
   spec = synthetic.anet_like_spec(wl['n_videos'], seed=0, dataset=wl['dataset'])
   lengths = synthetic.batch_lengths(spec, wl['batch'])
   costs = [parallel_eval.batch_cost(lc, lv, lw, lp, wl['img_dim'], 300, args.embed) for lc, lv, lw, lp in lengths]
-  assignment = parallel_eval.assign_batches(costs, args.world)
+  tail_from = parallel_eval.tail_horizon(np.concatenate([np.concatenate([lw, lp]) for _, _, lw, lp in lengths]))
+  assignment = parallel_eval.assign_batches(costs, args.world, tail_from=tail_from if args.deal == 'tail' else None)
   own = assignment[args.rank]
   batches = [b for i, b in enumerate(build_loader(spec, wl, dev, own)) if i in set(own)]
   step_plan = plan_of_lengths(lengths, spec.num_clips) if args.plan else None
@@ -98,7 +101,8 @@ def main():
   torch.cuda.synchronize()
   ms = (time.perf_counter() - t0) / args.steps * 1e3
   per = sorted((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
-  print(json.dumps({'world': args.world, 'rank': args.rank, 'plan': bool(args.plan), 'videos': n_own,
+  print(json.dumps({'world': args.world, 'rank': args.rank, 'deal': args.deal, 'plan': bool(args.plan), 'videos': n_own,
+                    'longest_paragraph': int(max(costs[i][1] for i in own)),
                     'stripe': '%d x %d' % (n_own, N), 'ms_per_pass': ms, 'pass_ms_min': per[0],
                     'pass_ms_median': per[len(per) // 2], 'pass_ms_max': per[-1], 'steps': args.steps,
                     'workload': args.workload, 'rnn_type': args.rnn_type, 'tune': args.tune,
