@@ -55,10 +55,12 @@ def batch_cost(len_clip, len_vid, len_cap, len_par, img_dim, word_dim=300, hidde
 
 
 # What ONE step of the text tower's few-sequence tail costs a rank, expressed in GRU FLOPs of its step
-# chain: ~21 us per dependent small-batch launch (a 608-video share: 363 tail steps in 7.7 ms) at the
-# ~125 TFLOP/s a share's chain runs at (profiles/r05_rank_share.txt).  Only its ORDER of magnitude
-# matters: it prices the tail a rank pays for its longest paragraph against the work it is dealt.
-TAIL_STEP_FLOPS = 2.6e9
+# chain.  Fitted to the measured shares of all ranks of an 8- and a 4-rank deal of the ICEP split
+# (24 points, profiles/r06_rank_share.txt): ms = 8.18 x TFLOP + 0.0105 x tail steps + 4.2, i.e. one
+# tail step (10.5 us: a dependent small-batch launch, partly hidden under the attention pass) is worth
+# 1.3 GFLOP of chain work at the 122 TFLOP/s a share's chain runs at.  It prices the tail a rank pays
+# for its longest paragraph against the work it is dealt.
+TAIL_STEP_FLOPS = 1.3e9
 
 
 def tail_horizon(text_lens, threshold=1024):
@@ -114,47 +116,41 @@ _DEALS = {}
 
 
 def _tail_aware_deal(costs, world, tail_from, tail_flops):
+  """min over deals of max over ranks of (work + tail_flops x tail steps of the rank's longest
+  paragraph), approximately: first-fit of the batches in order of their longest paragraph (so a rank's
+  FIRST batch fixes the tail it pays, every later batch fits under it for free, and the outliers end
+  up together on the first rank) into ranks of capacity T, the smallest T that needs no more than
+  `world` ranks found by bisection."""
   n = len(costs)
   tail = lambda chain: tail_flops * max(0, int(chain) - int(tail_from))
   order = sorted(range(n), key=lambda i: (-costs[i][1], -costs[i][0], i))
   total = float(sum(c[0] for c in costs))
 
-  def caps_for(limit):
-    """Ranks filled one after another with the batches in chain order (so the long paragraphs
-    share ranks) up to `limit` of work + tail each: the longest paragraph of every rank, or None when
-    the batches need more than `world` ranks."""
-    caps, load, cap = [], 0.0, None
+  def first_fit(limit):
+    load, out = [], []
     for i in order:
       w, chain = costs[i]
-      if cap is None:
-        cap, load = chain, 0.0
-      elif load + w > limit - tail(cap):
-        caps.append(cap)
-        if len(caps) >= world:
+      for r in range(len(load)):
+        if load[r] + w <= limit:
+          load[r] += w
+          out[r].append(i)
+          break
+      else:
+        if len(load) >= world or tail(chain) + w > limit:
           return None
-        cap, load = chain, 0.0
-      load += w
-    caps.append(cap)
-    return caps + [0] * (world - len(caps))
+        load.append(tail(chain) + w)
+        out.append([i])
+    return out + [[] for _ in range(world - len(out))]
 
-  lo, hi = total / world, total + tail(costs[order[0]][1])
-  for _ in range(32):                    # bisection on the makespan of that contiguous packing
+  lo = total / world
+  hi = total + tail(costs[order[0]][1])
+  for _ in range(32):
     mid = 0.5 * (lo + hi)
-    if caps_for(mid) is None:
+    if first_fit(mid) is None:
       lo = mid
     else:
       hi = mid
-  caps = caps_for(hi)
-  # ... then the batches by work onto the least-loaded rank whose cap admits their longest paragraph
-  # (moving a batch to a rank that already pays for a longer paragraph is free)
-  load = [tail(c) for c in caps]
-  out = [[] for _ in range(world)]
-  for i in sorted(range(n), key=lambda i: (-costs[i][0], -costs[i][1], i)):
-    w, chain = costs[i]
-    r = min((q for q in range(world) if caps[q] >= chain), key=lambda q: (load[q], q))
-    out[r].append(i)
-    load[r] += max(w, 1e-9)
-  return [sorted(o) for o in out]
+  return [sorted(r) for r in first_fit(hi)]
 
 
 def costs_of(batches, img_dim=None):
