@@ -11,7 +11,9 @@ python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 echo "bench rc=$?" | tee -a $out/summary.txt
 bash tools/collect_profiles.sh $R $N > $out/collect.log 2>&1
 # a rank's share of the split (8 / 4 / 2 ranks) under the whole split's plan, and the pass through the reference API
-for w in 8 4 2; do python tools/rank_share.py --world $w --steps 12 --warmup 3 2>/dev/null | tail -1; done > $out/rank_share.jsonl
+# (every rank of the deal and the whole split in one process: slowest rank, implied efficiency; both deals at 8 ranks)
+for w in 8 4 2; do python tools/rank_share.py --world $w --all_ranks 1 --steps 8 --warmup 2 2>/dev/null | tail -1; done > $out/rank_share.jsonl
+python tools/rank_share.py --world 8 --all_ranks 1 --deal lpt --steps 8 --warmup 2 2>/dev/null | tail -1 >> $out/rank_share.jsonl
 # the 8-rank path at full size on THIS box's GPU(s) (gloo when there are fewer GPUs than ranks): a functional run; its CRC must be the single process's
 Q="--fast_steps 0 --train_steps 0 --host_steps 0 --cpu_batches 0 --rank_check 0 --cached_steps 0 --api_steps 0"
 timeout 900 python bench.py --gpus 8 --steps 2 --warmup 1 $Q > $out/bench_w8.json 2> $out/bench_w8.err

@@ -39,7 +39,7 @@ def plan_of_lengths(lengths, num_clips):
   return dict(v1=ops.step_counts(v1), t1=ops.step_counts(t1), v2=ops.step_counts(v2), t2=ops.step_counts(v2))
 
 
-def main():
+def main(argv=None, quiet_print=False):
   ap = argparse.ArgumentParser()
   ap.add_argument('--world', type=int, default=8)
   ap.add_argument('--rank', type=int, default=0)
@@ -52,7 +52,32 @@ def main():
   ap.add_argument('--deal', default='tail', choices=['tail', 'lpt'],
                   help="tail: the deal prices a rank's longest paragraph (round 6); lpt: work only, longest paragraph first (round 5)")
   ap.add_argument('--tune', default='', help='crossovers to move for the run: name=value,name=value (ops.tune)')
-  args = ap.parse_args()
+  ap.add_argument('--all_ranks', type=int, default=0,
+                  help='1: every rank of the deal one after another in this process, then one summary line '
+                       '(slowest rank = what an N-GPU pass costs before communication) beside the whole split (world 1)')
+  args = ap.parse_args(argv)
+  if args.all_ranks:
+    base = list(argv if argv is not None else sys.argv[1:])
+
+    def strip(opts, name):      # drop `name value`
+      out, skip = [], False
+      for a in opts:
+        if skip:
+          skip = False
+          continue
+        if a == name:
+          skip = True
+          continue
+        out.append(a)
+      return out
+    base = strip(strip(strip(base, '--rank'), '--all_ranks'), '--world')
+    whole = main(base + ['--world', '1', '--rank', '0'], quiet_print=True)
+    rows = [main(base + ['--world', str(args.world), '--rank', str(r)], quiet_print=True) for r in range(args.world)]
+    slow = max(r['ms_per_pass'] for r in rows)
+    print(json.dumps({'world': args.world, 'deal': args.deal, 'whole_split_ms': whole['ms_per_pass'],
+                      'slowest_rank_ms': slow, 'implied_efficiency': whole['ms_per_pass'] / (args.world * slow),
+                      'ranks': [{k: r[k] for k in ('rank', 'videos', 'longest_paragraph', 'gru_tflop', 'ms_per_pass')} for r in rows]}))
+    return None
   for kv in [x for x in args.tune.split(',') if x]:
     k, v = kv.split('=')
     ops.tune(k, int(v))
@@ -101,12 +126,17 @@ def main():
   torch.cuda.synchronize()
   ms = (time.perf_counter() - t0) / args.steps * 1e3
   per = sorted((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
-  print(json.dumps({'world': args.world, 'rank': args.rank, 'deal': args.deal, 'plan': bool(args.plan), 'videos': n_own,
+  result = ({'world': args.world, 'rank': args.rank, 'deal': args.deal, 'plan': bool(args.plan), 'videos': n_own,
                     'longest_paragraph': int(max(costs[i][1] for i in own)),
                     'stripe': '%d x %d' % (n_own, N), 'ms_per_pass': ms, 'pass_ms_min': per[0],
                     'pass_ms_median': per[len(per) // 2], 'pass_ms_max': per[-1], 'steps': args.steps,
                     'workload': args.workload, 'rnn_type': args.rnn_type, 'tune': args.tune,
-                    'gru_tflop': float(sum(costs[i][0] for i in own)) / 1e12}))
+                    'gru_tflop': float(sum(costs[i][0] for i in own)) / 1e12})
+  del batches, V, P, model
+  torch.cuda.empty_cache()
+  if not quiet_print:
+    print(json.dumps(result))
+  return result
 
 
 if __name__ == '__main__':
