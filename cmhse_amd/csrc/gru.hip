@@ -525,7 +525,7 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
       break;
     case 2: {
       // staging-bound loop: the 128-row tile halves the weight bytes per MFMA
-      const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
+      const size_t smem = RingSmem<128, 3 * kGruBU>::kBytes;
       hipLaunchKernelGGL((gru_step_kernel<true, 2, true>), dim3(grid), dim3(kThreads), smem, stream, g);
       break;
     }
@@ -1143,7 +1143,13 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
       ep.row_begin = lo;
       ep.row_end = cut;
       const unsigned g1 = static_cast<unsigned>(((cut - lo + 127) / 128) * att_tiles);
-      hipLaunchKernelGGL((attn_energy_kernel<true, 2, true, true>), dim3(g1), dim3(kThreads), att_smem, stream, ep);
+      // three ring stages of 384 rows x 64 B: more than the 64 KiB a launch may ask for by default
+      constexpr size_t ring_smem = RingSmem<128, kAttBN>::kBytes;
+      // (per device; a host-side call, no synchronisation)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_energy_kernel<true, 2, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ring_smem)) != hipSuccess)
+        return CMHSE_ERR_LAUNCH;
+      hipLaunchKernelGGL((attn_energy_kernel<true, 2, true, true>), dim3(g1), dim3(kThreads), ring_smem, stream, ep);
     }
     if (hi > cut) {
       ep.row_begin = cut;

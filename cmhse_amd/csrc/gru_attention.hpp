@@ -64,7 +64,9 @@ __device__ __forceinline__ void attn_energy_tile(const AttnEnergyParams& p, cons
   int b_row0[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) b_row0[ns] = wn * (BN / 2) + 32 * ns;
-  if (BF3)
+  if constexpr (BF3 && ASPLIT)      // both operands pre-split: the LDS-DMA ring (rows past the edges are clamped, never stored)
+    nt_phase_bf3_ring<BM, BN, MSUB, NS, NS, NS - 1>(smem, ar, br, H, wm * 32 * MSUB, b_row0, acc);
+  else if constexpr (BF3)
     nt_phase_bf3<BM, BN, MSUB, NS, NS, NS - 1, ASPLIT>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);
   else
     nt_phase<BM, BN, MSUB, NS, NS, NS - 1, VEC>(smem, ar, av, br, bv, H, wm * 32 * MSUB, b_row0, acc);

@@ -196,10 +196,10 @@ __device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsi
 #ifdef TILE_TRACE_BUILD
   if (threadIdx.x == 0 && g_trace) g_trace[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memtime();
 #endif
-  if (BF3) {
+  if constexpr (BF3) {
     // pre-split A operands: xs, then hs_s of the previous step (or the pre-split initial states)
-    nt_phase_bf3<BM, BNR, MSUB, 3, 4, 2, true>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
-    if (have_h) nt_phase_bf3<BM, BNR, MSUB, 3, 4, 3, true>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);
+    nt_phase_bf3_ring<BM, BNR, MSUB, 3, 4, 2>(smem, ax, bx, I, a_row0, b_row0, acc);
+    if (have_h) nt_phase_bf3_ring<BM, BNR, MSUB, 3, 4, 3>(smem, ah, bh, H, a_row0, b_row0, acc);
   } else {
     nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (CHAIN) {

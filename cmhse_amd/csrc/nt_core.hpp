@@ -493,6 +493,180 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x3 on PRE-SPLIT operands through an LDS-DMA ring (round 6; the step kernels' loop).
+//
+// tools/tile_trace.py arms of nt_phase_bf3 (profiles/r06_fast_mode.txt): of the 292 us a pair of
+// co-resident level-1 tiles spends in its K loops, 62 go with the global loads and 20 more with the
+// ds_write pass; the MFMAs alone need 210.  At one third of the fp32 loop's matrix time per chunk the
+// register-staged prefetch of ONE chunk (1.2 us) no longer covers an HBM miss, and there are no
+// registers for a second one (230 VGPRs).  Here the operands go global -> LDS directly
+// (global_load_lds_dwordx4: no VGPR destination, no ds_write) into a ring of THREE stages, so the
+// load of chunk c + 2 is issued before the MFMAs of chunk c - 1 and is waited for two chunks later
+// with a counted vmcnt — never 0 inside the loop — and a raw s_barrier (a __syncthreads() would
+// drain the DMAs: cdna_hip_programming.md section 5, Pipelining across barriers).
+//
+// LDS image of a stage: [BM A rows | BNR B rows] x 64 B (one 16-k chunk of a pre-split row: 16 bf16
+// hi | 16 bf16 lo), row stride 64 B, NO padding — one wave-instruction writes 1 KiB = 16 whole rows
+// (lane i -> row i >> 2, 16-byte slot i & 3).  Bank conflicts of the fragment reads are removed by an
+// XOR swizzle instead: slot (q ^ ((row >> 2) & 3)) of a row holds its piece q, applied to the per-lane
+// SOURCE address of the DMA and to the ds_read_b128 address (rule 21: both sides).  The 16 lanes of a
+// ds_read_b128 group (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a 32-row sub-tile, one
+// piece) then cover the 64 banks exactly once.
+// Rows past the tile's edge are not masked: their base is clamped to a valid row by the caller and
+// they only feed outputs that are never stored; K needs no tail — pre-split rows are zero-padded to
+// whole chunks by their producers.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BNR>
+struct RingSmem {
+  static constexpr int kStages = 3;
+  static constexpr int kStageBytes = (BM + BNR) * 64;
+  static constexpr size_t kBytes = static_cast<size_t>(kStages) * kStageBytes;
+};
+
+typedef __attribute__((address_space(3))) char* lds_ptr_t;
+
+// N x (16 bytes per lane, global -> LDS): piece i of the wave goes to LDS byte address dst + 4096 i +
+// 16 lane (dst wave-uniform) from this lane's source address src[i] + off.  Inline asm on purpose: hipcc
+// puts an s_waitcnt vmcnt(0) in front of every ds_read that follows a __builtin_amdgcn_global_load_lds
+// it knows to be in flight, which is exactly the wait this ring exists to avoid; these loads are
+// invisible to its bookkeeping (the callers count them: vmcnt(N) before the barrier).  M0 (the LDS
+// destination base) is compiler-reserved: saved and restored inside the statement; s_nop 0 = the wait
+// state between an SALU write of M0 and the LDS-DMA that reads it.
+#define CMHSE_GLDS_FIRST_(D, S) "s_mov_b32 m0, " D "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " S ", off\n\t"
+#define CMHSE_GLDS_NEXT_(D, S, OFF) "s_add_i32 m0, " D ", " OFF "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " S ", off\n\t"
+template <int N>
+__device__ __forceinline__ void glds16_pieces(const rowaddr_t (&src)[N], rowaddr_t off, unsigned dst) {
+  static_assert(N == 5 || N == 6, "pieces per wave and chunk");
+  unsigned keep;
+  const rowaddr_t s0 = src[0] + off, s1 = src[1] + off, s2 = src[2] + off, s3 = src[3] + off, s4 = src[4] + off;
+  if constexpr (N == 5) {
+    asm volatile("s_mov_b32 %0, m0\n\t" CMHSE_GLDS_FIRST_("%6", "%1") CMHSE_GLDS_NEXT_("%6", "%2", "0x1000")
+                 CMHSE_GLDS_NEXT_("%6", "%3", "0x2000") CMHSE_GLDS_NEXT_("%6", "%4", "0x3000")
+                 CMHSE_GLDS_NEXT_("%6", "%5", "0x4000") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "s"(dst)
+                 : "memory", "scc");
+  } else {
+    const rowaddr_t s5 = src[5] + off;
+    asm volatile("s_mov_b32 %0, m0\n\t" CMHSE_GLDS_FIRST_("%7", "%1") CMHSE_GLDS_NEXT_("%7", "%2", "0x1000")
+                 CMHSE_GLDS_NEXT_("%7", "%3", "0x2000") CMHSE_GLDS_NEXT_("%7", "%4", "0x3000")
+                 CMHSE_GLDS_NEXT_("%7", "%5", "0x4000") CMHSE_GLDS_NEXT_("%7", "%6", "0x5000") "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "s"(dst)
+                 : "memory", "scc");
+  }
+}
+#undef CMHSE_GLDS_FIRST_
+#undef CMHSE_GLDS_NEXT_
+
+template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST>
+__device__ __forceinline__ void nt_phase_bf3_ring(float* smem, const rowaddr_t (&arow)[BM / 64],
+                                                  const rowaddr_t (&brow)[BNR / 64], int K, int a_row0,
+                                                  const int (&b_row0)[NSUB], f32x16 (&acc)[MSUB][NACC]) {
+  using RS = RingSmem<BM, BNR>;
+  constexpr int AP = BM / 64, BP = BNR / 64;
+  const int nchunks = (K + kBK - 1) / kBK;
+  if (nchunks == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* const base = reinterpret_cast<char*>(smem);
+  // this lane's 16-byte piece of the rows it stages (row = (tid >> 2) + 64 i, slot tid & 3)
+  const unsigned piece = static_cast<unsigned>(((tid & 3) ^ ((tid >> 4) & 3)) * 16);
+  // (a stage is [A rows | B rows], 64 rows = 4096 bytes per piece index: pieces 0 .. AP - 1 are A's)
+  rowaddr_t src[AP + BP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) src[i] = arow[i] + piece;
+#pragma unroll
+  for (int i = 0; i < BP; ++i) src[AP + i] = brow[i] + piece;
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)base)) + wave * 1024u;
+  auto dma = [&](int stage, int c) {
+    glds16_pieces<AP + BP>(src, static_cast<rowaddr_t>(c) * 64u, lds0 + static_cast<unsigned>(stage * RS::kStageBytes));
+  };
+  const int frow = lane & 31, half = lane >> 5, sw = (frow >> 2) & 3;
+  const int hi_off = frow * 64 + ((half ^ sw) * 16);
+  const int lo_off = frow * 64 + (((2 + half) ^ sw) * 16);
+  uint4 an[MSUB], aln[MSUB];
+  uint4 ah[MSUB], al[MSUB], bh[NSUB], bl[NSUB];
+  auto read_a = [&](int stage) {
+    const char* sb = base + stage * RS::kStageBytes + a_row0 * 64;
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+      an[ms] = *reinterpret_cast<const uint4*>(sb + ms * 2048 + hi_off);
+      aln[ms] = *reinterpret_cast<const uint4*>(sb + ms * 2048 + lo_off);
+    }
+  };
+  auto read_b = [&](int stage) {
+    const char* sb = base + stage * RS::kStageBytes + BM * 64;
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      bh[ns] = *reinterpret_cast<const uint4*>(sb + b_row0[ns] * 64 + hi_off);
+      bl[ns] = *reinterpret_cast<const uint4*>(sb + b_row0[ns] * 64 + lo_off);
+    }
+  };
+  auto take_a = [&]() {
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+      ah[ms] = an[ms];
+      al[ms] = aln[ms];
+    }
+  };
+  auto mfma_chunk = [&]() {
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+      const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[ms]);
+      const bf16x8 a_l = __builtin_bit_cast(bf16x8, al[ms]);
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        const bf16x8 b_h = __builtin_bit_cast(bf16x8, bh[ns]);
+        const bf16x8 b_l = __builtin_bit_cast(bf16x8, bl[ns]);
+        constexpr int kLast = LAST;
+        const int ai = (ns == NSUB - 1) ? kLast : ns;
+        acc[ms][ai] = mfma_bf16_16k(a_l, b_h, acc[ms][ai]);
+        acc[ms][ai] = mfma_bf16_16k(a_h, b_l, acc[ms][ai]);
+        acc[ms][ai] = mfma_bf16_16k(a_h, b_h, acc[ms][ai]);
+      }
+    }
+  };
+  // chunk c + 1 has landed (this wave's pieces: the AP + BP DMAs of chunk c + 2 may stay in flight;
+  // everybody's: the barrier) and this wave's fragment reads of chunk c have returned, so the stage
+  // of chunk c may be overwritten after the barrier
+#define CMHSE_RING_STEP_()                                        \
+  do {                                                            \
+    if (AP + BP == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");      \
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                   \
+    __builtin_amdgcn_s_barrier();                                 \
+  } while (0)
+  static_assert(AP + BP == 5 || AP + BP == 6, "counted vmcnt of the ring");
+  const int last = nchunks - 1;
+  dma(0, 0);
+  dma(1, last < 1 ? last : 1);
+  CMHSE_RING_STEP_();                  // chunk 0 landed
+  read_a(0);
+  read_b(0);
+  take_a();
+  dma(2, last < 2 ? last : 2);
+  CMHSE_RING_STEP_();                  // chunk 1 landed
+  int stage = 1;                       // stage of chunk c
+  for (int c = 1; c < nchunks; ++c) {
+    const int prev = (stage == 0) ? 2 : stage - 1;     // chunk c - 1's stage = chunk c + 2's
+    read_a(stage);
+    dma(prev, (c + 2 < last) ? c + 2 : last);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk();                      // chunk c - 1
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(stage);
+    take_a();
+    CMHSE_RING_STEP_();
+    stage = (stage == 2) ? 0 : stage + 1;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_chunk();                        // last chunk
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads of the last chunk
+  __builtin_amdgcn_s_barrier();        // ring free for the next phase
+#undef CMHSE_RING_STEP_
+}
+
 // Split-K building block of the latency-shaped kernels (gru_step_tiny_kernel, gru_bwd_step_kernel):
 // one 32x32 accumulator; NW (4 or 8) waves split K, this wave takes the 8-k blocks wave, wave+NW, ...; the A and B
 // fragments (row = lane&31, k = 8*kb + 4*(lane>>5) .. +3) go global -> registers directly in MFMA

@@ -111,6 +111,9 @@ def main():
   if '--sim' in sys.argv:
     return sim_trace(lib, dev, int(argv[0]) if argv else 4917)
   T = 2
+  ops.set_math_mode(os.environ.get('TRACE_MATH', 'fp32'))     # bf16x3: the fast mode's tiled step kernel
+  # per-step launches by default: the stamps are indexed by workgroup, and the last step's overwrite the first's
+  ops.tune('chain_min_steps', int(os.environ.get('TRACE_CHAIN_MIN_STEPS', '0')))
   x = torch.randn(S, T, I, device=dev)
   scale = float(os.environ.get('TRACE_DATA_SCALE', '1'))   # 0: all-zero operands (clock ceiling check)
   x *= scale
@@ -125,7 +128,7 @@ def main():
   if scale != 1.0:
     w = {k: v * scale for k, v in w.items()}
   n_wg = ((S + 63) // 64) * ((H + 63) // 64)
-  trace = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
+  trace = torch.zeros((2 * n_wg + 64) * 8, dtype=torch.int64, device=dev)
   ptrs = ops.padded_row_ptrs(x)
   reps = int(os.environ.get('TRACE_REPS', '3'))
   for it in range(reps):
@@ -134,7 +137,7 @@ def main():
     ops.gru_pool_fwd(w, pool, lens, I, H, dev, x_ptrs=ptrs)
     torch.cuda.synchronize()
   lib.cmhse_debug_set_trace(None)
-  tr = trace.cpu().numpy().reshape(n_wg, 8)
+  tr = trace.cpu().numpy().reshape(-1, 8)
   tr = tr[tr[:, 4] != 0]          # 128-row tiles launch half as many workgroups
   n_wg = len(tr)
   # unset: the launcher picks 128-row tiles for launches of >= 2048 64-row workgroups (gru_msub_for)
