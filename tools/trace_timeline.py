@@ -15,7 +15,7 @@ from collections import OrderedDict
 
 def short(name):
   for key in ['gru_step_tiny_kernel', 'gru_step_mid_kernel', 'gru_step_chain_kernel', 'gru_step_kernel', 'attn_energy_kernel',
-              'attn_pool_kernel', 'sim_kernel<1', 'sim_kernel<0', 'sim_kernel<2', 'l2norm_rows',
+              'attn_pool_kernel', 'split_rows_kernel', 'split_bf16x3_kernel', 'sim_kernel<1', 'sim_kernel<0', 'sim_kernel<2', 'l2norm_rows',
               'contrastive', 'xproj_kernel', 'top1_finalize', 'copyBuffer', 'fillBuffer']:
     if key in name:
       return key
@@ -23,8 +23,9 @@ def short(name):
 
 
 def main():
-  path = sys.argv[1]
-  back = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+  argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+  path = argv[0]
+  back = int(argv[1]) if len(argv) > 1 else 0
   rows = []
   for r in csv.DictReader(open(path)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']),
@@ -63,6 +64,22 @@ def main():
   for p in merged:
     print('%-24s %9.2f %9.2f %9.2f %6d' % (p['name'], (p['start'] - t0) / 1e6,
                                             (p['end'] - p['start']) / 1e6, p['busy'] / 1e6, p['n']))
+  if '--streams' in sys.argv:
+    # the same pass stream by stream: runs of one kernel name on one stream (what runs beside what)
+    print('\nper stream: runs of one kernel (start ms, end ms, busy ms, launches)')
+    for st_id in sorted(set(r[4] for r in sel)):
+      runs = []
+      for s, e, n, g, st in sel:
+        if st != st_id:
+          continue
+        if runs and runs[-1][0] == n and s - runs[-1][2] < 0.2e6:
+          runs[-1][2] = max(runs[-1][2], e); runs[-1][3] += e - s; runs[-1][4] += 1
+        else:
+          runs.append([n, s, e, e - s, 1])
+      print('  stream %d' % st_id)
+      for n, s, e, b, c in runs:
+        if e - s >= 0.05e6:
+          print('    %-24s %9.2f %9.2f %9.2f %6d' % (n, (s - t0) / 1e6, (e - t0) / 1e6, b / 1e6, c))
   tot = OrderedDict()
   for s, e, n, g, st in sel:
     a = tot.setdefault(n, [0, 0])
