@@ -277,7 +277,8 @@ def fast_mode_bench(opt, model, batches, N, n_steps):
     return {k: bool(ra[k] == rb[k]) for k in keys}
   return {'math': 'bf16x3: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x8_bf16_1k pairs, fp32 '
                   'accumulate (encoder GEMMs of steps with > 1024 active sequences and the '
-                  'attention projection); ranking kernel exact fp32',
+                  'attention projection; pre-split operands staged global -> LDS by global_load_lds_dwordx4 '
+                  'into a 3-stage ring); ranking kernel exact fp32',
           'contract': 'OUTSIDE the bit-identical-ranks contract: an opt-in (ops.set_math_mode), never `value`',
           'steps': n_steps, 'ms_per_step': dt * 1e3, 'value': float(N) * N / dt,
           'unit': 'pairs/s', 'max_abs_embedding_diff_vs_fp32': diff,
