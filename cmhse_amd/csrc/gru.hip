@@ -530,21 +530,18 @@ void launch_group(const GruStepGroup& g, int kind, unsigned grid, hipStream_t st
       break;
     }
     default:
-      // (vec shapes stage through the LDS-DMA ring, the scalar-load shapes through registers)
       if (msub == 2) {
+        const size_t smem = TileSmem<128, 3 * kGruBU>::kBytes;
         if (vec)
-          hipLaunchKernelGGL((gru_step_kernel<true, 2, false>), dim3(grid), dim3(kThreads),
-                             (RingSmem<128, 3 * kGruBU>::kBytes), stream, g);
+          hipLaunchKernelGGL((gru_step_kernel<true, 2, false>), dim3(grid), dim3(kThreads), smem, stream, g);
         else
-          hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads),
-                             (TileSmem<128, 3 * kGruBU>::kBytes), stream, g);
+          hipLaunchKernelGGL((gru_step_kernel<false, 2, false>), dim3(grid), dim3(kThreads), smem, stream, g);
       } else {
+        const size_t smem = TileSmem<64, 3 * kGruBU>::kBytes;
         if (vec)
-          hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads),
-                             (RingSmem<64, 3 * kGruBU>::kBytes), stream, g);
+          hipLaunchKernelGGL((gru_step_kernel<true, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
         else
-          hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads),
-                             (TileSmem<64, 3 * kGruBU>::kBytes), stream, g);
+          hipLaunchKernelGGL((gru_step_kernel<false, 1, false>), dim3(grid), dim3(kThreads), smem, stream, g);
       }
   }
 }
@@ -759,10 +756,10 @@ static void launch_chain(FwdJob* jobs, int n, int t, const ChainPlan& c, Timer* 
 #define CHAIN_LAUNCH_(V, M, SMEM) \
   hipLaunchKernelGGL((gru_step_chain_kernel<V, M>), dim3(cgrid), dim3(kThreads), SMEM, c.stream, cg)
   if (bm == 128) {
-    if (cvec) CHAIN_LAUNCH_(true, 2, (RingSmem<128, 3 * kGruBU>::kBytes));
+    if (cvec) CHAIN_LAUNCH_(true, 2, (TileSmem<128, 3 * kGruBU>::kBytes));
     else CHAIN_LAUNCH_(false, 2, (TileSmem<128, 3 * kGruBU>::kBytes));
   } else {
-    if (cvec) CHAIN_LAUNCH_(true, 1, (RingSmem<64, 3 * kGruBU>::kBytes));
+    if (cvec) CHAIN_LAUNCH_(true, 1, (TileSmem<64, 3 * kGruBU>::kBytes));
     else CHAIN_LAUNCH_(false, 1, (TileSmem<64, 3 * kGruBU>::kBytes));
   }
 #undef CHAIN_LAUNCH_

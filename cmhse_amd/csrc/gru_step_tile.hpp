@@ -200,17 +200,10 @@ __device__ __forceinline__ void gru_step_tile(const GruStepParams& p, const unsi
     // pre-split A operands: xs, then hs_s of the previous step (or the pre-split initial states)
     nt_phase_bf3_ring<BM, BNR, MSUB, 3, 4, 2>(smem, ax, bx, I, a_row0, b_row0, acc);
     if (have_h) nt_phase_bf3_ring<BM, BNR, MSUB, 3, 4, 3>(smem, ah, bh, H, a_row0, b_row0, acc);
-  } else if constexpr (VEC) {
-    // operands global -> LDS by LDS-DMA (nt_phase_ring: the MFMAs of nt_phase, in its order)
-    nt_phase_ring<BM, BNR, MSUB, 3, 4, 2>(smem, ax, bx, I, a_row0, b_row0, acc);
-    if (CHAIN) {
-      // the previous step's rows of this row tile: complete (written through by their tiles)?
-      if (dep.wait != nullptr && !flag_wait(dep.sync, dep.wait, dep.need)) return;
-    }
-    if (have_h) nt_phase_ring<BM, BNR, MSUB, 3, 4, 3>(smem, ah, bh, H, a_row0, b_row0, acc);
   } else {
     nt_phase<BM, BNR, MSUB, 3, 4, 2, VEC>(smem, ax, av, bx, bv, I, a_row0, b_row0, acc);
     if (CHAIN) {
+      // the previous step's rows of this row tile: complete (written through by their tiles)?
       if (dep.wait != nullptr && !flag_wait(dep.sync, dep.wait, dep.need)) return;
     }
     if (have_h) nt_phase<BM, BNR, MSUB, 3, 4, 3, VEC>(smem, ah, av, bh, bv, H, a_row0, b_row0, acc);

@@ -527,185 +527,38 @@ struct RingSmem {
 typedef __attribute__((address_space(3))) char* lds_ptr_t;
 
 // N x (16 bytes per lane, global -> LDS): piece i of the wave goes to LDS byte address dst + 4096 i +
-// 16 lane (dst wave-uniform) from this lane's source address src[i].  Inline asm on purpose: hipcc
+// 16 lane (dst wave-uniform) from this lane's source address src[i] + off.  Inline asm on purpose: hipcc
 // puts an s_waitcnt vmcnt(0) in front of every ds_read that follows a __builtin_amdgcn_global_load_lds
-// it knows to be in flight, which is exactly the wait the rings exist to avoid; these loads are
+// it knows to be in flight, which is exactly the wait this ring exists to avoid; these loads are
 // invisible to its bookkeeping (the callers count them: vmcnt(N) before the barrier).  M0 (the LDS
 // destination base) is compiler-reserved: saved and restored inside the statement; s_nop 0 = the wait
 // state between an SALU write of M0 and the LDS-DMA that reads it.
 #define CMHSE_GLDS_FIRST_(D, S) "s_mov_b32 m0, " D "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " S ", off\n\t"
 #define CMHSE_GLDS_NEXT_(D, S, OFF) "s_add_i32 m0, " D ", " OFF "\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " S ", off\n\t"
 template <int N>
-__device__ __forceinline__ void glds16_pieces(const rowaddr_t (&src)[N], unsigned dst) {
-  static_assert(N >= 4 && N <= 6, "pieces per wave and chunk");
+__device__ __forceinline__ void glds16_pieces(const rowaddr_t (&src)[N], rowaddr_t off, unsigned dst) {
+  static_assert(N == 5 || N == 6, "pieces per wave and chunk");
   unsigned keep;
-  if constexpr (N == 4) {
-    asm volatile("s_mov_b32 %0, m0\n\t" CMHSE_GLDS_FIRST_("%5", "%1") CMHSE_GLDS_NEXT_("%5", "%2", "0x1000")
-                 CMHSE_GLDS_NEXT_("%5", "%3", "0x2000") CMHSE_GLDS_NEXT_("%5", "%4", "0x3000") "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(dst)
-                 : "memory", "scc");
-  } else if constexpr (N == 5) {
+  const rowaddr_t s0 = src[0] + off, s1 = src[1] + off, s2 = src[2] + off, s3 = src[3] + off, s4 = src[4] + off;
+  if constexpr (N == 5) {
     asm volatile("s_mov_b32 %0, m0\n\t" CMHSE_GLDS_FIRST_("%6", "%1") CMHSE_GLDS_NEXT_("%6", "%2", "0x1000")
                  CMHSE_GLDS_NEXT_("%6", "%3", "0x2000") CMHSE_GLDS_NEXT_("%6", "%4", "0x3000")
                  CMHSE_GLDS_NEXT_("%6", "%5", "0x4000") "s_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "s"(dst)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "s"(dst)
                  : "memory", "scc");
   } else {
+    const rowaddr_t s5 = src[5] + off;
     asm volatile("s_mov_b32 %0, m0\n\t" CMHSE_GLDS_FIRST_("%7", "%1") CMHSE_GLDS_NEXT_("%7", "%2", "0x1000")
                  CMHSE_GLDS_NEXT_("%7", "%3", "0x2000") CMHSE_GLDS_NEXT_("%7", "%4", "0x3000")
                  CMHSE_GLDS_NEXT_("%7", "%5", "0x4000") CMHSE_GLDS_NEXT_("%7", "%6", "0x5000") "s_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "s"(dst)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "s"(dst)
                  : "memory", "scc");
   }
 }
 #undef CMHSE_GLDS_FIRST_
 #undef CMHSE_GLDS_NEXT_
-
-// counted wait of a ring step: this wave's N newest LDS-DMAs may stay in flight, its LDS reads have returned
-template <int N>
-__device__ __forceinline__ void ring_wait() {
-  static_assert(N >= 4 && N <= 6, "pieces per wave and chunk");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-}
-
-// 16 zero bytes: what a lane whose piece of the LAST chunk lies past the end of its (unpadded fp32)
-// row stages instead, and the dummy loads that keep the vmcnt count uniform past the last chunk
-static __device__ __attribute__((aligned(16))) const float g_zero_piece[4] = {0.f, 0.f, 0.f, 0.f};
-
-// ---------------------------------------------------------------------------------------------
-// The exact-fp32 loop (nt_phase, VEC shapes) on the same LDS-DMA ring.  Same MFMAs in the same order
-// on every accumulator (chunk by chunk, 8-k block 0 then 1, k sub-step 0..3), so the results are
-// bit-identical to nt_phase; what changes is how the operands reach LDS.  Timing-only arms of
-// nt_phase on a level-1 step (S = 22419, I = 2048; profiles/r06_fp32_ring.txt): a launch of 3134 us is
-// 2942-2974 without its global loads and 2839-2844 without loads and LDS writes — the register
-// staging costs the exact path 9 % although its loop keeps the matrix pipe "busy" — and the clock
-// rises from 2.28 to 2.38 GHz without it.
-//   * a chunk of a row = 16 floats = 64 B = four 16-byte pieces; lane (row, half) of an MFMA fragment
-//     reads piece 2 kb + half of 8-k block kb; slot (q ^ ((row >> 2) & 3)) holds piece q
-//   * fp32 rows are NOT padded: in the last chunk a lane whose piece starts at k >= K stages 16 zero
-//     bytes instead (K % 4 == 0: a piece is inside or outside as a whole) — the same zeros nt_phase
-//     masks in, for A and for B
-//   * rows past the tile's edge are clamped by the caller, never masked: they feed outputs that are
-//     never stored
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST>
-__device__ __forceinline__ void nt_phase_ring(float* smem, const rowaddr_t (&arow)[BM / 64],
-                                              const rowaddr_t (&brow)[BNR / 64], int K, int a_row0,
-                                              const int (&b_row0)[NSUB], f32x16 (&acc)[MSUB][NACC]) {
-  using RS = RingSmem<BM, BNR>;
-  constexpr int AP = BM / 64, BP = BNR / 64, NP = AP + BP;
-  const int nchunks = (K + kBK - 1) / kBK;
-  if (nchunks == 0) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const char* const base = reinterpret_cast<const char*>(smem);
-  const int q = (tid & 3) ^ ((tid >> 4) & 3);   // the piece this lane stages (row = (tid >> 2) + 64 i, slot tid & 3)
-  rowaddr_t src[NP];                            // running: this lane's piece of the next chunk to issue
-#pragma unroll
-  for (int i = 0; i < AP; ++i) src[i] = arow[i] + static_cast<rowaddr_t>(q * 16);
-#pragma unroll
-  for (int i = 0; i < BP; ++i) src[AP + i] = brow[i] + static_cast<rowaddr_t>(q * 16);
-  const int last = nchunks - 1;
-  const bool ktail = (K & (kBK - 1)) != 0;
-  const bool tail_in = last * kBK + q * 4 < K;
-  const rowaddr_t zero = row_addr(g_zero_piece);
-  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)base)) + wave * 1024u;
-  int issued = 0;                               // chunks issued so far
-  auto dma = [&](int stage) {
-    const unsigned dst = lds0 + static_cast<unsigned>(stage * RS::kStageBytes);
-    if (issued < last || (issued == last && !ktail)) {
-      glds16_pieces<NP>(src, dst);
-#pragma unroll
-      for (int i = 0; i < NP; ++i) src[i] += 64u;
-    } else {
-      rowaddr_t s[NP];
-#pragma unroll
-      for (int i = 0; i < NP; ++i) s[i] = (issued == last && tail_in) ? src[i] : zero;
-      glds16_pieces<NP>(s, dst);
-    }
-    ++issued;
-  };
-  const int frow = lane & 31, half = lane >> 5, sw = (frow >> 2) & 3;
-  const int k0_off = frow * 64 + ((half ^ sw) * 16);
-  const int k1_off = frow * 64 + (((2 + half) ^ sw) * 16);
-  float4 f0a[MSUB], f0b[NSUB], f1a[MSUB], f1b[NSUB];
-  auto read_frags = [&](int stage_bytes, int kb, float4(&fa)[MSUB], float4(&fb)[NSUB]) {
-    const char* sa = base + stage_bytes + a_row0 * 64 + (kb ? k1_off : k0_off);
-#pragma unroll
-    for (int ms = 0; ms < MSUB; ++ms) fa[ms] = *reinterpret_cast<const float4*>(sa + ms * 2048);
-    const char* sb = base + stage_bytes + BM * 64 + (kb ? k1_off : k0_off);
-#pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns) fb[ns] = *reinterpret_cast<const float4*>(sb + b_row0[ns] * 64);
-  };
-  auto mfma_block = [&](const float4(&fa)[MSUB], const float4(&fb)[NSUB]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int ms = 0; ms < MSUB; ++ms) {
-        const float av = (j == 0) ? fa[ms].x : (j == 1) ? fa[ms].y : (j == 2) ? fa[ms].z : fa[ms].w;
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) {
-          const float bv = (j == 0) ? fb[ns].x : (j == 1) ? fb[ns].y : (j == 2) ? fb[ns].z : fb[ns].w;
-          constexpr int kLast = LAST;
-          const int ai = (ns == NSUB - 1) ? kLast : ns;
-          acc[ms][ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ms][ai], 0, 0, 0);
-        }
-      }
-    }
-  };
-  // a ring step: chunk c + 1 has landed (this wave's pieces: the NP DMAs of chunk c + 2 may stay in
-  // flight; everybody's: the barrier) and this wave's fragment reads of chunk c have returned, so
-  // chunk c's stage may be overwritten after the barrier
-  auto ring_step = [&]() {
-    ring_wait<NP>();
-    __builtin_amdgcn_s_barrier();
-  };
-  // chunk c lives in stage ST; F1 holds 8-k block 1 of chunk c - 1
-  auto iter = [&](auto stc) {
-    constexpr int ST = decltype(stc)::value;
-    read_frags(ST * RS::kStageBytes, 0, f0a, f0b);
-    dma((ST + 2) % 3);                 // chunk c + 2 over chunk c - 1
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(f1a, f1b);              // (c - 1, block 1)
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(ST * RS::kStageBytes, 1, f1a, f1b);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(f0a, f0b);              // (c, block 0)
-    ring_step();
-  };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>;
-  dma(0);
-  dma(1);
-  ring_step();                         // chunk 0 landed
-  read_frags(0, 0, f0a, f0b);
-  read_frags(0, 1, f1a, f1b);
-  dma(2);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_block(f0a, f0b);                // (0, block 0)
-  ring_step();                         // chunk 1 landed
-  int c = 1;
-  for (; c + 3 <= nchunks; c += 3) {
-    iter(S1{});
-    iter(S2{});
-    iter(S0{});
-  }
-  if (c < nchunks) {
-    iter(S1{});
-    ++c;
-  }
-  if (c < nchunks) iter(S2{});
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_block(f1a, f1b);                // (last, block 1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy loads past the last chunk
-  __builtin_amdgcn_s_barrier();        // ring free for the next phase
-}
 
 template <int BM, int BNR, int MSUB, int NSUB, int NACC, int LAST>
 __device__ __forceinline__ void nt_phase_bf3_ring(float* smem, const rowaddr_t (&arow)[BM / 64],
@@ -728,10 +581,7 @@ __device__ __forceinline__ void nt_phase_bf3_ring(float* smem, const rowaddr_t (
   for (int i = 0; i < BP; ++i) src[AP + i] = brow[i] + piece;
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)base)) + wave * 1024u;
   auto dma = [&](int stage, int c) {
-    rowaddr_t s[AP + BP];
-#pragma unroll
-    for (int i = 0; i < AP + BP; ++i) s[i] = src[i] + static_cast<rowaddr_t>(c) * 64u;
-    glds16_pieces<AP + BP>(s, lds0 + static_cast<unsigned>(stage * RS::kStageBytes));
+    glds16_pieces<AP + BP>(src, static_cast<rowaddr_t>(c) * 64u, lds0 + static_cast<unsigned>(stage * RS::kStageBytes));
   };
   const int frow = lane & 31, half = lane >> 5, sw = (frow >> 2) & 3;
   const int hi_off = frow * 64 + ((half ^ sw) * 16);
@@ -781,11 +631,13 @@ __device__ __forceinline__ void nt_phase_bf3_ring(float* smem, const rowaddr_t (
   // chunk c + 1 has landed (this wave's pieces: the AP + BP DMAs of chunk c + 2 may stay in flight;
   // everybody's: the barrier) and this wave's fragment reads of chunk c have returned, so the stage
   // of chunk c may be overwritten after the barrier
-#define CMHSE_RING_STEP_()          \
-  do {                              \
-    ring_wait<AP + BP>();           \
-    __builtin_amdgcn_s_barrier();   \
+#define CMHSE_RING_STEP_()                                        \
+  do {                                                            \
+    if (AP + BP == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");      \
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                   \
+    __builtin_amdgcn_s_barrier();                                 \
   } while (0)
+  static_assert(AP + BP == 5 || AP + BP == 6, "counted vmcnt of the ring");
   const int last = nchunks - 1;
   dma(0, 0);
   dma(1, last < 1 ? last : 1);
