@@ -71,7 +71,7 @@ from cmhse_amd.model import VSE  # noqa: E402
 # (tools/bench_legs.py); re-exported here because the tools and the full-size tests import them from bench
 from bench_common import (BF16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS, WORKLOADS, build_loader,  # noqa: E402,F401
                           device_batch, gru_flops_per_step, make_opt)
-from bench_legs import (TRAIN_CONFIGS, cpu_baseline, dropin_validate_bench, fast_mode_bench,  # noqa: E402,F401
+from bench_legs import (TRAIN_CONFIGS, cpu_baseline, dropin_validate_bench, fast_mode_bench, power_probe,  # noqa: E402,F401
                         isa_audit, measured_clock_ghz, profile_source,
                         measured_step_latency_us, measured_traffic, rank_check, rank_noise_floor,
                         train_bench, train_step_work)
@@ -144,6 +144,9 @@ def main():
   ap.add_argument('--fast_steps', type=int, default=5,
                   help='also time this many passes in the opt-in bf16x3 math mode (0 = skip).  Reported as the '
                        'fenced `fast_mode` object: the mode is outside the bit-identical-ranks contract and never `value`')
+  ap.add_argument('--power_steps', type=int, default=4,
+                  help='extra passes per math mode beside which socket power and shader clock are sampled in-process '
+                       '(the `power` object; 0 = off)')
   ap.add_argument('--train_steps', type=int, default=10,
                   help='also time this many VSE.train_emb steps per BASELINE training config (0 = skip)')
   ap.add_argument('--train_configs', default='anet_c3d_tau0,anet_icep_tau0,anet_icep_recon,didemo_icep_recon',
@@ -455,6 +458,16 @@ def main():
       leg('cached_schedule_pass', cached)
     if world == 1 and args.fast_steps > 0:
       leg('fast_mode', lambda: fast_mode_bench(opt, model, batches, N, args.fast_steps))
+    if world == 1 and args.power_steps > 0:
+      def power_leg():
+        def fast():
+          ops.set_math_mode('bf16x3')
+          try:
+            step()
+          finally:
+            ops.set_math_mode('fp32')
+        return power_probe({'exact_fp32': step, 'bf16x3': fast}, args.power_steps, device)
+      leg('power', power_leg)
     if world == 1 and args.train_steps > 0:
       # the BASELINE training configurations (configs[1..3]) as driver-timed train_emb steps —
       # timed while the GPU is still at its working clocks (right behind the validation passes:

@@ -218,6 +218,61 @@ def rank_noise_floor(wl, opt, model, spec, n_sample_batches, n_full):
   }
 
 
+def power_probe(passes, n_steps, device, interval_s=0.05):
+  """Socket power and shader clock WHILE the pass loops: a thread samples torch.cuda.power_draw() /
+  clock_rate() (amdsmi, in-process: no child process, see profiles/r06_fast_mode_ab.txt) beside
+  `n_steps` extra passes of every mode in `passes` {name: callable}.  Runs behind the timed legs and is
+  not part of any of them.  Context for roofline.frac: the pass runs at the package power limit, and the
+  clock it holds there — not the loop's MFMA occupancy — is what separates it from the nominal peak
+  (profiles/r06_fast_mode.txt item 4, r06_fp32_ring.txt)."""
+  import threading
+  out = {'source': 'amdsmi via torch.cuda.power_draw / clock_rate, sampled in-process every %d ms beside %d extra '
+                   'passes per mode; not part of any timed leg' % (int(interval_s * 1e3), n_steps)}
+  try:
+    torch.cuda.power_draw(device)
+    torch.cuda.clock_rate(device)
+  except Exception as e:    # noqa: BLE001
+    return {'available': False, 'error': '%s: %s' % (type(e).__name__, e)}
+  try:
+    import amdsmi
+    h = torch.cuda._get_amdsmi_handler(device)
+    cap = amdsmi.amdsmi_get_power_cap_info(h)
+    out['power_cap_w'] = float(cap['power_cap']) / 1e6 if float(cap['power_cap']) > 1e4 else float(cap['power_cap'])
+  except Exception:         # noqa: BLE001
+    out['power_cap_w'] = None
+  for name, fn in passes.items():
+    fn()
+    torch.cuda.synchronize()
+    samples, stop = [], threading.Event()
+
+    def sample():
+      while not stop.is_set():
+        try:
+          samples.append((float(torch.cuda.power_draw(device)), float(torch.cuda.clock_rate(device))))
+        except Exception:   # noqa: BLE001
+          pass
+        stop.wait(interval_s)
+    th = threading.Thread(target=sample, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    for _ in range(n_steps):
+      fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+    stop.set()
+    th.join()
+    w = [x[0] for x in samples[1:]] or [x[0] for x in samples]   # (the first sample predates the load)
+    c = [x[1] for x in samples[1:]] or [x[1] for x in samples]
+    scale = 1e-3 if w and max(w) > 1e4 else 1.0                   # mW (the API's unit) or W
+    out[name] = {'ms_per_step_while_sampled': dt * 1e3, 'samples': len(w),
+                 'socket_w_mean': scale * sum(w) / len(w) if w else None,
+                 'socket_w_max': scale * max(w) if w else None,
+                 'sclk_mhz_mean': sum(c) / len(c) if c else None,
+                 'sclk_mhz_min': min(c) if c else None}
+  out['available'] = True
+  return out
+
+
 def fast_mode_bench(opt, model, batches, N, n_steps):
   """Supplementary: the same validation pass with CMHSE_MATH_BF16X3 (3-term bf16 hi/lo split on
   the bf16 matrix pipe, fp32 accumulate, for the large encoder GEMMs; ranking stays exact fp32),
