@@ -546,6 +546,16 @@ def main():
         leg('cpu_baseline_numpy', lambda: cpu_baseline('port', wl, opt, model, spec, args.cpu_batches, N))
       # the exact path's own distance from the oracle on the same sample, rank by rank
       leg('rank_noise_floor', lambda: rank_noise_floor(wl, opt, model, spec, args.cpu_batches, N))
+    pw = out.get('power') if isinstance(out.get('power'), dict) else None
+    if pw and pw.get('available') and pw.get('exact_fp32', {}).get('sclk_mhz_mean'):
+      # context only (`frac` stays priced against the nominal peak): the matrix peak at the shader clock the
+      # box held under this pass — boxes differ by 5 % in what their power limit leaves
+      sclk = pw['exact_fp32']['sclk_mhz_mean']
+      rf = out['roofline']
+      rf['sclk_mhz_under_load'] = sclk
+      rf['peak_at_that_clock'] = rf['peak'] * sclk / 2400.0
+      rf['frac_at_that_clock'] = rf['achieved'] / rf['peak_at_that_clock']
+      rf['sclk_source'] = 'the `power` leg of this run (amdsmi, in-process); nominal 2400 MHz'
     print(json.dumps(out))
     sys.stdout.flush()
   if world > 1:

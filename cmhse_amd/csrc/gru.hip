@@ -346,8 +346,9 @@ int prepare_job(const cmhse_seq_batch* b, const cmhse_gru_weights* w, int32_t po
   p.n_tiles = (b->H + kGruBU - 1) / kGruBU;
   // dwordx4 operand loads need K % 4 == 0 in both phases (row bases are then 4-float multiples)
   job->vec = (b->I % 4 == 0) && (b->H % 4 == 0);
-  // bf16x3 serves the LDS-tiled kernels only (the latency-shaped tiny kernel stays exact fp32)
-  job->bf3 = bf3 && job->vec && (job->kind_count[0] > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
+  // bf16x3 serves the LDS-tiled kernels of inference calls only (the latency-shaped tiny kernel stays
+  // exact fp32; a training call's backward consumes what the exact forward saved)
+  job->bf3 = bf3 && !save && job->vec && (job->kind_count[0] > tiny_max_seqs() || pool_mode == CMHSE_POOL_ATTN);
   // steps with few active sequences: mid-size kernel on a hoisted input projection
   job->t_mid = b->Tmax;
   p.gx = nullptr;

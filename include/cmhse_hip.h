@@ -62,8 +62,12 @@ enum {
   CMHSE_SAVE_FOR_BACKWARD = 0x100,
   /* OR-ed into pool_mode: run the large GEMMs of the call on the bf16 matrix pipe with a 3-term
    * hi/lo split (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate): ~2^-17 relative error per
-   * product, ~1e-6 on the embeddings (parity bar 1e-4), ~5x the matrix rate of exact fp32.
-   * Default (flag clear) is exact fp32. */
+   * product, ~1e-6 on the embeddings (parity bar 1e-4); 2.7x less matrix time per product than exact
+   * fp32 on the v_mfma_f32_32x32x8_bf16_1k pairs this library restricts itself to, 1.8x per validation
+   * pass.  Inference calls only (ignored with CMHSE_SAVE_FOR_BACKWARD); applies to the steps with more
+   * than `tiny_max_seqs` active sequences and to the attention projection of their rows; those
+   * kernels stage pre-split operands by LDS-DMA and use 60 KB (steps) / 72 KB (projection) of LDS per
+   * workgroup.  Outside the bit-identical-ranks contract.  Default (flag clear) is exact fp32. */
   CMHSE_MATH_BF16X3 = 0x200,
   /* OR-ed into the pool_mode of a cmhse_gru_job / cmhse_gru_bwd_job that has its own `stream`: the
    * call does NOT order its own stream argument behind that stream when it returns.  The job's

@@ -498,3 +498,40 @@ def test_small_batch_step_shapes_are_bit_identical(dev, S, H, tune):
   for o in outs[1:]:
     for a, b in zip(outs[0], o):
       assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('I,H', [(300, 1024), (2048, 1024), (36, 96)])
+def test_bf16x3_ring_is_deterministic_over_many_runs(dev, I, H):
+  """The bf16x3 loops stage operands by LDS-DMA into a 3-stage ring ordered by counted vmcnt waits and
+  raw barriers (nt_phase_bf3_ring): a read placed one step too early would pass a single comparison
+  whenever the DMA happens to land first.  Screen for that: 25 runs of an attention-pooled encoder whose
+  step launches co-reside two workgroups per CU (19 / 128 / 3 chunks in the input phase), every output
+  bit-identical to the first run's, with a competing exact-fp32 call between the runs."""
+  from cmhse_amd import layers, ops
+  torch.manual_seed(11)
+  S, T = 2600, 4
+  layer = layers.Attention(I, H).to(dev)
+  rng = np.random.RandomState(5)
+  lens = np.sort(rng.randint(2, T + 1, size=S))[::-1].copy()
+  lens[0] = T
+  x = torch.randn(S, T, I, device=dev)
+  lens_t = torch.from_numpy(lens)
+  other = layers.Maxout(I, H).to(dev)
+  try:
+    ops.set_math_mode('bf16x3')
+    with torch.no_grad():
+      first = layer(x, lens_t).clone()
+    for _ in range(25):
+      ops.set_math_mode('fp32')
+      with torch.no_grad():
+        other(x, lens_t)
+      ops.set_math_mode('bf16x3')
+      with torch.no_grad():
+        again = layer(x, lens_t)
+      assert torch.equal(again, first)
+  finally:
+    ops.set_math_mode('fp32')
+  with torch.no_grad():
+    exact = layer(x, lens_t)
+  assert not torch.equal(exact, first), 'bf16x3 mode did not engage'
+  assert float((exact - first).abs().max()) < 5e-5

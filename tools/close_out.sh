@@ -15,7 +15,7 @@ bash tools/collect_profiles.sh $R $N > $out/collect.log 2>&1
 for w in 8 4 2; do python tools/rank_share.py --world $w --all_ranks 1 --steps 8 --warmup 2 2>/dev/null | tail -1; done > $out/rank_share.jsonl
 python tools/rank_share.py --world 8 --all_ranks 1 --deal lpt --steps 8 --warmup 2 2>/dev/null | tail -1 >> $out/rank_share.jsonl
 # the 8-rank path at full size on THIS box's GPU(s) (gloo when there are fewer GPUs than ranks): a functional run; its CRC must be the single process's
-Q="--fast_steps 0 --train_steps 0 --host_steps 0 --cpu_batches 0 --rank_check 0 --cached_steps 0 --api_steps 0"
+Q="--fast_steps 0 --power_steps 0 --train_steps 0 --host_steps 0 --cpu_batches 0 --rank_check 0 --cached_steps 0 --api_steps 0"
 timeout 900 python bench.py --gpus 8 --steps 2 --warmup 1 $Q > $out/bench_w8.json 2> $out/bench_w8.err
 python tools/api_path_profile.py --passes 8 2>&1 | grep -v amdgpu.ids > $out/api_path.txt
 python tools/api_path_profile.py --passes 8 --host 1 2>&1 | grep -v amdgpu.ids >> $out/api_path.txt

@@ -8,10 +8,10 @@ R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 D=$R/gpurun_out/$OUT
 mkdir -p $D
-B="bench.py --steps 7 --warmup 2 --cpu_batches 0 --train_steps 0 --host_steps 0 --rank_check 0 --cached_steps 0 --api_steps 0 --fast_steps 0"
+B="bench.py --steps 7 --warmup 2 --cpu_batches 0 --train_steps 0 --host_steps 0 --rank_check 0 --cached_steps 0 --api_steps 0 --fast_steps 0 --power_steps 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 $R/$B > $D/bench_under_rocprof.json 2>/dev/null
-B2="bench.py --steps 2 --warmup 1 --cpu_batches 0 --train_steps 0 --host_steps 0 --rank_check 0 --cached_steps 0 --api_steps 0 --fast_steps 0"
+B2="bench.py --steps 2 --warmup 1 --cpu_batches 0 --train_steps 0 --host_steps 0 --rank_check 0 --cached_steps 0 --api_steps 0 --fast_steps 0 --power_steps 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/pmc_FETCH_SIZE -- python3 $R/$B2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/pmc_WRITE_SIZE -- python3 $R/$B2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $D/pmc_SQ -- python3 $R/$B2 > $D/pmc_SQ.log 2>&1
