@@ -12,8 +12,7 @@
 Mutants:
   attn_eps_fwd   gru_attention.hpp: the masked softmax's `+ 0.0001f` (layers.py:158-162) -> `+ 0.0f`
   attn_eps_bwd   bwd_pool_kernels.hpp: the same epsilon in the attention backward
-  norm_by_n      sim.hip / step_loss.hpp: nothing — `norm` is covered by values that differ by a factor n
-                 (listed for completeness; not built)
+  norm_by_n, gru_bhn_outside_r(_tiled), rank_counts_ties, l2norm_eps   (round 6, second batch) see MUTANTS
 """
 import os
 import shutil
@@ -27,10 +26,25 @@ OUT = os.path.join(REPO, 'build', 'mutants')
 MUTANTS = {
     'attn_eps_fwd': ('gru_attention.hpp', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
     'attn_eps_bwd': ('bwd_pool_kernels.hpp', 's_den = d + 0.0001f;', 's_den = d + 0.0f;'),
+    # loss.py:114-115: `norm` divides by n * m, not by n
+    'norm_by_n': ('sim.hip', 'loss = loss / static_cast<float>(static_cast<int64_t>(p.n) * p.n);',
+                  'loss = loss / static_cast<float>(p.n);'),
+    # nn.GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)) — b_hn INSIDE the reset gate's product
+    # (the mid-size step kernel, the one the golden-sized batches run on)
+    'gru_bhn_outside_r': ('gru_small_batch.hpp', 'const float ng = tanhf_(e_gx[q][2] + e_b[q][2] + rg * ghn);',
+                          'const float ng = tanhf_(e_gx[q][2] + e_b[q][2] + rg * hn_ + e_b[q][3]);'),
+    # ... and the LDS-tiled step (batches of more than 1024 sequences)
+    'gru_bhn_outside_r_tiled': ('gru_step_tile.hpp', 'const float ng = tanhf_(acc[ms][2][r] + b_in + rg * ghn);',
+                                'const float ng = tanhf_(acc[ms][2][r] + b_in + rg * acc[ms][3][r] + b_hn);'),
+    # evaluation.py:92-95 / 131-134 via the documented tie rule: strict '>' for the rank
+    'rank_counts_ties': ('sim.hip', 'valid && j != gi && v > dii', 'valid && j != gi && v >= dii'),
+    # F.normalize's eps (model.py l2norm of the encoder outputs): a zero row stays zero, x / max(|x|, 1e-12)
+    'l2norm_eps': ('gru_rows.hpp', 's_inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);', 's_inv = 1.0f / sqrtf(t);'),
 }
 # the tests that must kill them (and pass on the product library)
-SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_golden.py', '-k',
-          'epsilon or test_layers_vs_golden or test_layer_backward_vs_golden or test_model_vs_golden']
+SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_golden.py', 'tests/test_gpu_gru.py', 'tests/test_gpu_scoring.py', '-k',
+          'epsilon or test_layers_vs_golden or test_layer_backward_vs_golden or test_model_vs_golden or norm or '
+          'test_gru_pool_vs_oracle or tie or zero or l2norm']
 
 
 def build():
