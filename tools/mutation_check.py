@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mutation check of the parity tests: do they notice a kernel that drops a reference quirk?
 
-  python tools/mutation_check.py build        (build container: hipcc, no GPU needed)
+  python tools/mutation_check.py build [name ...]   (build container: hipcc, no GPU needed)
       copies cmhse_amd/csrc to build/mutants/<name>/, applies ONE source edit per mutant, and builds
       build/mutants/libcmhse_<name>.so (same ABI; the product sources and library are untouched).
   python tools/mutation_check.py run          (GPU box)
@@ -38,19 +38,25 @@ MUTANTS = {
                                 'const float ng = tanhf_(acc[ms][2][r] + b_in + rg * acc[ms][3][r] + b_hn);'),
     # evaluation.py:92-95 / 131-134 via the documented tie rule: strict '>' for the rank
     'rank_counts_ties': ('sim.hip', 'valid && j != gi && v > dii', 'valid && j != gi && v >= dii'),
+    # loss.py:100-103: the diagonal of both cost matrices is masked to zero
+    'loss_diag_not_masked': ('sim.hip', 'if (j == i) c = 0.f;', ''),
+    # loss.py:106-111: max_violation keeps the hardest negative per row / column only
+    'max_violation_sums': ('sim.hip', 'total += p.max_violation ? static_cast<double>(mx) : sum;', 'total += sum;'),
     # F.normalize's eps (model.py l2norm of the encoder outputs): a zero row stays zero, x / max(|x|, 1e-12)
     'l2norm_eps': ('gru_rows.hpp', 's_inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);', 's_inv = 1.0f / sqrtf(t);'),
 }
 # the tests that must kill them (and pass on the product library)
 SELECT = ['tests/test_quirks_tight.py', 'tests/test_gpu_golden.py', 'tests/test_gpu_gru.py', 'tests/test_gpu_scoring.py', '-k',
           'epsilon or test_layers_vs_golden or test_layer_backward_vs_golden or test_model_vs_golden or norm or '
-          'test_gru_pool_vs_oracle or tie or zero or l2norm']
+          'test_gru_pool_vs_oracle or tie or zero or l2norm or test_contrastive_vs_oracle']
 
 
-def build():
+def build(only=()):
   from cmhse_amd import build as b
   os.makedirs(OUT, exist_ok=True)
   for name, (fname, old, new) in MUTANTS.items():
+    if only and name not in only:
+      continue
     root = os.path.join(OUT, name)
     shutil.rmtree(root, ignore_errors=True)
     src = os.path.join(root, 'cmhse_amd', 'csrc')          # (the sources include ../../include/cmhse_hip.h)
@@ -98,4 +104,4 @@ def run():
 
 
 if __name__ == '__main__':
-  sys.exit(build() if sys.argv[1:] == ['build'] else run())
+  sys.exit(build(sys.argv[2:]) if sys.argv[1:2] == ['build'] else run())
