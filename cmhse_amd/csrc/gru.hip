@@ -1098,8 +1098,9 @@ int launch_attention(FwdJob& job, hipStream_t stream, int64_t row_end, bool pool
   char* wsb = job.wsb;
   const int64_t sum_T = job.sum_T;
   const int att_tiles = (b->H + kAttBN - 1) / kAttBN;
-  // tile height of the projection: 64 rows (128 measured equal on the full split: 285.0 against
-  // 285.8 ms per pass)
+  // tile height of the projection: 64 rows (128 measured equal on the full split in round 2: 285.0
+  // against 285.8 ms per pass; again in round 6, beside the text tower's tail on the side stream:
+  // 271.0-273.4 with 64 rows against 273.3-275.1 with 128, three runs each on one box)
   constexpr int msub = 1;
   float* e_part = reinterpret_cast<float*>(wsb + L.e_part);
   AttnEnergyParams ep;
