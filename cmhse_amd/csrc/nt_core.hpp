@@ -494,13 +494,16 @@ __device__ __forceinline__ void nt_phase_bf3(float* smem, const rowaddr_t (&arow
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16x3 on PRE-SPLIT operands through an LDS-DMA ring (round 6; the step kernels' loop).
+// bf16x3 on PRE-SPLIT operands through an LDS-DMA ring (round 6; the loop of the bf16x3 step kernel and
+// of the attention projection of pre-split rows).
 //
 // tools/tile_trace.py arms of nt_phase_bf3 (profiles/r06_fast_mode.txt): of the 292 us a pair of
 // co-resident level-1 tiles spends in its K loops, 62 go with the global loads and 20 more with the
-// ds_write pass; the MFMAs alone need 210.  At one third of the fp32 loop's matrix time per chunk the
-// register-staged prefetch of ONE chunk (1.2 us) no longer covers an HBM miss, and there are no
-// registers for a second one (230 VGPRs).  Here the operands go global -> LDS directly
+// ds_write pass; the MFMAs alone need 210.  The register-staged prefetch runs ONE chunk ahead (1.2 us at a
+// third of the fp32 loop's matrix time per chunk) and there are no registers for a second (230 VGPRs).
+// With the ring the same pair needs 259 us, and its own arms show nothing left to wait for (no vmcnt
+// wait, no barrier, L2-resident sources: all the same time): what remains above the matrix floor is the
+// operand traffic itself.  Here the operands go global -> LDS directly
 // (global_load_lds_dwordx4: no VGPR destination, no ds_write) into a ring of THREE stages, so the
 // load of chunk c + 2 is issued before the MFMAs of chunk c - 1 and is waited for two chunks later
 // with a counted vmcnt — never 0 inside the loop — and a raw s_barrier (a __syncthreads() would
