@@ -415,7 +415,7 @@ def encode_group(model, group, contextual_model=True, device=None, plan=None, st
     v_ptrs = ops.seq_row_ptrs_many(clips_l + vids_l)
     t_ptrs = ops.seq_row_ptrs_many(caps_l + pars_l)
     # The visual chain (<= 80 frames) ends long before the text chain (paragraphs of hundreds of
-    # tokens, a handful of sequences per step by then): the text tail continues on a high-priority
+    # tokens, a handful of sequences per step by then): the text tail continues on a separate (own hardware queue; ops.stream_set)
     # side stream while the visual attention pass runs on this one, instead of after it.
     tail = _tail_stream(device) if EARLY_POOL[0] else None
     v_lens, t_lens = np.concatenate(len_clip + len_vid), np.concatenate(len_cap + len_par)
